@@ -1,0 +1,83 @@
+"""Deterministic synthetic scenes (SURVEY.md section 8(d) generator).
+
+The reference ships no data (``get_data.sh`` needs the network) and never renders more than
+52 363 isotropic points, so the benchmark configs of BASELINE.json (1e5 / 1e6 / 5e6 Gaussians)
+use this generator: a frozen numpy ``RandomState`` stream, Gaussians placed inside the view
+frustum of a COLMAP PINHOLE camera posed like Treehill image 100 (``part_1.ipynb:179``).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+# Treehill image 100 pose, as printed in the reference notebook part_1.ipynb:179.
+TREEHILL_QVEC = (0.96282662, -0.23562335, 0.12748722, 0.0345476)
+TREEHILL_TVEC = (0.0530637, 0.87330016, 3.58750122)
+
+
+def _rotation(qvec) -> np.ndarray:
+    w, x, y, z = (np.asarray(qvec, dtype=np.float64) / np.linalg.norm(qvec))
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def make_scene(n: int, width: int, height: int, seed: int = 0, behind_fraction: float = 0.0,
+               qvec=TREEHILL_QVEC, tvec=TREEHILL_TVEC) -> Dict[str, np.ndarray]:
+    """Returns float32 arrays ``points (n,3)``, ``colors_0_255 (n,3)``, ``scales (n,3)`` (linear),
+    ``quaternions (n,4)`` (w,x,y,z, unnormalised), ``opacity (n,1)`` (logit) plus the camera
+    ``qvec, tvec, fx, fy, cx, cy, width, height``.
+
+    Draw order: z, u, v, sigma(n,3), q(n,4), opacity(n,1), rgb(n,3).  ``behind_fraction`` > 0
+    additionally moves that share of the points behind the z >= 0.2 cull plane (drawn last, so
+    the default stream is unchanged).
+    """
+    rs = np.random.RandomState(seed)
+    fx = fy = 0.75 * width
+    tanx, tany = width / (2 * fx), height / (2 * fy)
+    z = rs.uniform(2.0, 10.0, n)
+    u = rs.uniform(-1.0, 1.0, n)
+    v = rs.uniform(-1.0, 1.0, n)
+    sigma_px = rs.lognormal(np.log(1.5), 0.5, (n, 3))
+    quats = rs.normal(0.0, 1.0, (n, 4))
+    opacity = rs.normal(0.0, 2.0, (n, 1))
+    rgb = rs.uniform(0.0, 255.0, (n, 3))
+    if behind_fraction > 0.0:
+        behind = rs.uniform(0.0, 1.0, n) < behind_fraction
+        z = np.where(behind, -z * 0.5 + 0.15, z)
+    p_cam = np.stack([u * tanx * np.abs(z), v * tany * np.abs(z), z], axis=1)
+    R, t = _rotation(qvec), np.asarray(tvec, dtype=np.float64)
+    # camera = R @ world + t  =>  world = R^T (camera - t)
+    world = (p_cam - t[None, :]) @ R
+    scales = sigma_px * np.abs(z)[:, None] / fx
+    f = np.float32
+    return dict(
+        points=world.astype(f), colors_0_255=rgb.astype(f), scales=scales.astype(f),
+        quaternions=quats.astype(f), opacity=opacity.astype(f),
+        qvec=np.asarray(qvec, dtype=np.float64), tvec=np.asarray(tvec, dtype=np.float64),
+        fx=np.float64(fx), fy=np.float64(fy), cx=np.float64(width / 2), cy=np.float64(height / 2),
+        width=np.int64(width), height=np.int64(height),
+    )
+
+
+def write_colmap_text(path: str, scene: Dict[str, np.ndarray], image_id: int = 1,
+                      name: str = "synthetic.jpg") -> None:
+    """Writes the two COLMAP text files a ``GaussianScene`` needs (cameras.txt, images.txt)."""
+    import os
+
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "cameras.txt"), "w") as fid:
+        fid.write("# Camera list with one line of data per camera:\n")
+        fid.write("1 PINHOLE %d %d %r %r %r %r\n" % (
+            int(scene["width"]), int(scene["height"]), float(scene["fx"]), float(scene["fy"]),
+            float(scene["cx"]), float(scene["cy"])))
+    with open(os.path.join(path, "images.txt"), "w") as fid:
+        fid.write("# Image list with two lines of data per image:\n")
+        q, t = scene["qvec"], scene["tvec"]
+        fid.write("%d %r %r %r %r %r %r %r 1 %s\n" % (
+            image_id, float(q[0]), float(q[1]), float(q[2]), float(q[3]),
+            float(t[0]), float(t[1]), float(t[2]), name))
+        fid.write("1.0 2.0 -1\n")

@@ -1,0 +1,134 @@
+"""Golden-vector capture: runs the REFERENCE ITSELF and stores inputs + outputs as fixtures.
+
+Runs only in the build container (it needs /root/reference, which never travels to the GPU
+box).  The reference's Python is imported, never copied: this script writes *data* -- inputs
+and the reference's outputs -- to tests/golden/*.npz.  Recipe: stub
+the absent third-party ``plyfile`` module (only used for an IO side effect of the
+``Gaussians`` constructor, splat/gaussians.py:18), write a synthetic COLMAP text model, build
+``Gaussians``, overwrite its plain-tensor attributes with the fixture values, call
+``GaussianScene.preprocess`` and ``GaussianScene.render_image``.
+
+    python oracle/capture_golden.py            # all fixtures (the 256x256 one takes ~3 min)
+    python oracle/capture_golden.py small      # only those whose name contains "small"
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+import time
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REFERENCE = "/root/reference"
+OUT_DIR = os.path.join(ROOT, "tests", "golden")
+
+# name -> generator arguments.  tile: tile_size passed to render_image.
+FIXTURES = {
+    "small_64x48_n300": dict(n=300, width=64, height=48, seed=3, tile=16),
+    "small_80x64_n120_tile8": dict(n=120, width=80, height=64, seed=5, tile=8),
+    "cull_96x80_n400": dict(n=400, width=96, height=80, seed=7, tile=16, behind_fraction=0.25),
+    "c1_256x256_n2000": dict(n=2000, width=256, height=256, seed=0, tile=16),
+}
+
+
+def _import_reference():
+    stub = types.ModuleType("plyfile")
+
+    class PlyData:  # noqa: D401 - minimal stand-in for an absent IO dependency
+        def __init__(self, *a, **k):
+            pass
+
+        def write(self, *a, **k):
+            pass
+
+        @staticmethod
+        def read(*a, **k):
+            raise RuntimeError("plyfile is stubbed")
+
+    class PlyElement:
+        @staticmethod
+        def describe(*a, **k):
+            return None
+
+    stub.PlyData, stub.PlyElement = PlyData, PlyElement
+    sys.modules["plyfile"] = stub
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REFERENCE)
+    import torch  # noqa: F401
+    from splat.gaussian_scene import GaussianScene
+    from splat.gaussians import Gaussians
+
+    return GaussianScene, Gaussians
+
+
+def capture(name: str, spec: dict, GaussianScene, Gaussians) -> None:
+    import torch
+
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene, write_colmap_text
+
+    spec = dict(spec)
+    tile = spec.pop("tile")
+    sc = make_scene(**spec)
+    with tempfile.TemporaryDirectory() as tmp:
+        write_colmap_text(os.path.join(tmp, "colmap"), sc)
+        with torch.no_grad():
+            g = Gaussians(torch.from_numpy(sc["points"]), torch.from_numpy(sc["colors_0_255"]), model_path=tmp)
+            g.points = torch.from_numpy(sc["points"]).float()
+            g.scales = torch.from_numpy(sc["scales"]).float()
+            g.quaternions = torch.from_numpy(sc["quaternions"]).float()
+            g.opacity = torch.from_numpy(sc["opacity"]).float()
+            scene = GaussianScene(os.path.join(tmp, "colmap"), g)
+            cam = scene.images[1]
+            from splat.utils import in_view_frustum
+
+            in_view = in_view_frustum(points=g.points, view_matrix=cam.world2view)
+            cov3d = g.get_3d_covariance_matrix()
+            pre = scene.preprocess(1)
+            # the reference does not return its permutation; recover it from depths.
+            hom = torch.cat([g.points[in_view], torch.ones(int(in_view.sum()), 1)], dim=1)
+            depth_unsorted = (hom @ cam.world2view)[:, 2]
+            perm = torch.argsort(depth_unsorted)
+            assert torch.equal(depth_unsorted[perm], pre.depths), "argsort is not reproducible"
+            t0 = time.time()
+            image = scene.render_image(1, tile_size=tile)
+            dt = time.time() - t0
+    idx = np.nonzero(in_view.numpy())[0]
+    out = dict(sc)
+    out.update(
+        tile=np.int64(tile),
+        colors=g.colors.detach().numpy(),
+        world2view=cam.world2view.numpy(), projection_matrix=cam.projection_matrix.numpy(),
+        full_proj_transform=cam.full_proj_transform.numpy(),
+        tan_fovX=cam.tan_fovX.numpy(), tan_fovY=cam.tan_fovY.numpy(),
+        f_x=cam.f_x.numpy(), f_y=cam.f_y.numpy(),
+        in_view=in_view.numpy(), covariance_3d=cov3d.numpy(),
+        order=idx[perm.numpy()].astype(np.int64),
+        pre_points=pre.points.numpy(), pre_colors=pre.colors.detach().numpy(),
+        pre_covariance_2d=pre.covariance_2d.numpy(), pre_depths=pre.depths.numpy(),
+        pre_inverse_covariance_2d=pre.inverse_covariance_2d.numpy(), pre_radius=pre.radius.numpy(),
+        pre_points_xy=pre.points_xy.numpy(), pre_min_x=pre.min_x.numpy(), pre_min_y=pre.min_y.numpy(),
+        pre_max_x=pre.max_x.numpy(), pre_max_y=pre.max_y.numpy(),
+        pre_sigmoid_opacity=pre.sigmoid_opacity.numpy(),
+        image=image.numpy(), reference_render_seconds=np.float64(dt),
+    )
+    os.makedirs(OUT_DIR, exist_ok=True)
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%s: N=%d in_view=%d image=%s ref_render=%.1fs -> %s (%.0f KB)" % (
+        name, sc["points"].shape[0], idx.size, tuple(image.shape), dt, path, os.path.getsize(path) / 1024))
+
+
+def main() -> None:
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    GaussianScene, Gaussians = _import_reference()
+    for name, spec in FIXTURES.items():
+        if only in name:
+            capture(name, spec, GaussianScene, Gaussians)
+
+
+if __name__ == "__main__":
+    main()

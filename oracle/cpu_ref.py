@@ -1,0 +1,373 @@
+"""CPU restatement (numpy float32) of the reference's pure-Python forward rasteriser.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it,
+and only as the checker.  The product path (``intro_to_gaussian_splatting_amd``) never
+imports this module and fails loudly when its HIP library is missing.
+
+Parity status: PINNED.  ``oracle/capture_golden.py`` imports the reference itself
+(``/root/reference/splat``) in the build container and stores its inputs, every
+``PreprocessedScene`` field, the depth permutation and the rendered image under
+``tests/golden/``; ``tests/test_oracle_golden.py`` checks this restatement against them.
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+All arithmetic is float32 with an explicit left-to-right operation order and no fused
+multiply-add; the C restatement (``oracle/raster_cpu.c``) and the HIP projection kernel use
+this same order so that depths, radii and bounding boxes are bit-identical between them.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, NamedTuple, Optional
+
+import numpy as np
+
+f32 = np.float32
+
+# Constants the reference hard-codes ("Config / flags").
+MIN_Z = f32(0.2)            # splat/utils.py:294
+FOV_CLAMP = f32(1.3)        # splat/utils.py:336-337
+DET_FLOOR = f32(1e-3)       # splat/utils.py:387
+EIG_FLOOR = f32(0.1)        # splat/utils.py:414
+SIGMA_EXTENT = f32(3.0)     # splat/utils.py:421
+STOP_T = f32(0.000001)      # splat/gaussian_scene.py:153
+ZNEAR = f32(0.001)          # splat/image.py:47
+ZFAR = f32(100.0)           # splat/image.py:46
+
+
+class Camera(NamedTuple):
+    """Already-computed float32 camera constants (what ``GsxCamera`` carries)."""
+
+    world2view: np.ndarray   # (4,4) row-vector form, splat/image.py:51-53
+    full_proj: np.ndarray    # (4,4) splat/image.py:61-65
+    tan_fovx: np.float32     # splat/image.py:42
+    tan_fovy: np.float32     # splat/image.py:43
+    fx: np.float32           # splat/image.py:28
+    fy: np.float32           # splat/image.py:29
+    width: int               # splat/image.py:38
+    height: int              # splat/image.py:37
+
+
+class Preprocessed(NamedTuple):
+    """Depth-sorted stage-1 output; field names follow splat/schema.py:13-25."""
+
+    points: np.ndarray                  # (Nv,2) == points_xy
+    colors: np.ndarray                  # (Nv,3)
+    covariance_2d: np.ndarray           # (Nv,2,2)
+    depths: np.ndarray                  # (Nv,)
+    inverse_covariance_2d: np.ndarray   # (Nv,2,2)
+    radius: np.ndarray                  # (Nv,)
+    points_xy: np.ndarray               # (Nv,2)
+    min_x: np.ndarray
+    min_y: np.ndarray
+    max_x: np.ndarray
+    max_y: np.ndarray
+    sigmoid_opacity: np.ndarray         # (Nv,1)
+    order: np.ndarray                   # (Nv,) original Gaussian index of each sorted row
+
+
+# --------------------------------------------------------------------------- camera
+
+def rotation_from_quaternion(q: np.ndarray) -> np.ndarray:
+    """(N,4) (w,x,y,z) -> (N,3,3).  splat/utils.py:132-155 (normalises first)."""
+    q = np.asarray(q, dtype=f32)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    norm = np.sqrt(w * w + x * x + y * y + z * z)
+    w, x, y, z = w / norm, x / norm, y / norm, z / norm
+    one, two = f32(1.0), f32(2.0)
+    R = np.empty((q.shape[0], 3, 3), dtype=f32)
+    R[:, 0, 0] = one - two * (y * y + z * z)
+    R[:, 0, 1] = two * (x * y - w * z)
+    R[:, 0, 2] = two * (x * z + w * y)
+    R[:, 1, 0] = two * (x * y + w * z)
+    R[:, 1, 1] = one - two * (x * x + z * z)
+    R[:, 1, 2] = two * (y * z - w * x)
+    R[:, 2, 0] = two * (x * z - w * y)
+    R[:, 2, 1] = two * (y * z + w * x)
+    R[:, 2, 2] = one - two * (x * x + y * y)
+    return R
+
+
+def build_camera(qvec, tvec, fx, fy, width: int, height: int) -> Camera:
+    """COLMAP PINHOLE pose/intrinsics -> camera constants.
+
+    splat/image.py:28-66 with splat/utils.py:158-159 (focal2fov), :162-172
+    (getWorld2View), :189-225 (getProjectionMatrix).  The principal point is ignored by
+    the render path.  ``math.atan``/``math.tan`` run in double on float32 operands exactly
+    as the reference does.
+    """
+    fx32, fy32 = f32(fx), f32(fy)
+    w32, h32 = f32(width), f32(height)
+    R = rotation_from_quaternion(np.asarray(qvec, dtype=f32)[None, :])[0]
+    E = np.zeros((4, 4), dtype=f32)
+    E[:3, :3] = R
+    E[:3, 3] = np.asarray(tvec, dtype=f32)
+    E[3, 3] = f32(1.0)
+    V = np.ascontiguousarray(E.T)
+
+    fovx = f32(2.0 * math.atan(float(w32 / (f32(2.0) * fx32))))
+    fovy = f32(2.0 * math.atan(float(h32 / (f32(2.0) * fy32))))
+    tanx = np.tan(fovx / f32(2.0), dtype=f32)
+    tany = np.tan(fovy / f32(2.0), dtype=f32)
+
+    thx = f32(math.tan(float(fovx / f32(2.0))))
+    thy = f32(math.tan(float(fovy / f32(2.0))))
+    top = thy * ZNEAR
+    bottom = -top
+    right = thx * ZNEAR
+    left = -right
+    P = np.zeros((4, 4), dtype=f32)
+    P[0, 0] = f32(2.0) * ZNEAR / (right - left)
+    P[1, 1] = f32(2.0) * ZNEAR / (top - bottom)
+    P[0, 2] = (right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[3, 2] = f32(1.0)
+    P[2, 2] = f32(1.0) * ZFAR / (ZFAR - ZNEAR)
+    P[2, 3] = -(ZFAR * ZNEAR) / (ZFAR - ZNEAR)
+    Pt = np.ascontiguousarray(P.T)
+    F = np.zeros((4, 4), dtype=f32)
+    for i in range(4):
+        for j in range(4):
+            acc = V[i, 0] * Pt[0, j]
+            for k in range(1, 4):
+                acc = f32(acc + V[i, k] * Pt[k, j])
+            F[i, j] = acc
+    return Camera(V, F, f32(tanx), f32(tany), fx32, fy32, int(width), int(height))
+
+
+# --------------------------------------------------------------------------- stage 1
+
+def _row4(p: np.ndarray, M: np.ndarray, col: int) -> np.ndarray:
+    """Column ``col`` of ``[p,1] @ M`` with left-to-right accumulation."""
+    return ((p[:, 0] * M[0, col] + p[:, 1] * M[1, col]) + p[:, 2] * M[2, col]) + M[3, col]
+
+
+def covariance_3d(scales: np.ndarray, quats: np.ndarray) -> np.ndarray:
+    """Sigma = (R S)(R S)^T.  splat/gaussians.py:54-69 (F.normalize then build_rotation)."""
+    q = np.asarray(quats, dtype=f32)
+    n1 = np.sqrt(((q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1]) + q[:, 2] * q[:, 2]) + q[:, 3] * q[:, 3])
+    n1 = np.maximum(n1, f32(1e-12))
+    R = rotation_from_quaternion(q / n1[:, None])
+    s = np.asarray(scales, dtype=f32)
+    M = R * s[:, None, :]
+    S = np.empty_like(M)
+    for i in range(3):
+        for j in range(3):
+            S[:, i, j] = (M[:, i, 0] * M[:, j, 0] + M[:, i, 1] * M[:, j, 1]) + M[:, i, 2] * M[:, j, 2]
+    return S
+
+
+def _mm3(A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """Batched 3x3 product, each entry accumulated k=0,1,2 left to right."""
+    if B.ndim == 2:
+        B = np.broadcast_to(B, A.shape)
+    C = np.empty_like(A)
+    for i in range(3):
+        for j in range(3):
+            C[:, i, j] = (A[:, i, 0] * B[:, 0, j] + A[:, i, 1] * B[:, 1, j]) + A[:, i, 2] * B[:, 2, j]
+    return C
+
+
+def covariance_2d(points: np.ndarray, cov3d: np.ndarray, cam: Camera) -> np.ndarray:
+    """EWA projection of Sigma.  splat/utils.py:320-354."""
+    V = cam.world2view
+    tx, ty, tz = _row4(points, V, 0), _row4(points, V, 1), _row4(points, V, 2)
+    limx = FOV_CLAMP * cam.tan_fovx
+    limy = FOV_CLAMP * cam.tan_fovy
+    x = np.minimum(np.maximum(tx / tz, -limx), limx) * tz
+    y = np.minimum(np.maximum(ty / tz, -limy), limy) * tz
+    n = points.shape[0]
+    J = np.zeros((n, 3, 3), dtype=f32)
+    J[:, 0, 0] = cam.fx / tz
+    J[:, 0, 2] = -(cam.fx * x) / (tz * tz)
+    J[:, 1, 1] = cam.fy / tz
+    J[:, 1, 2] = -(cam.fy * y) / (tz * tz)
+    Wm = np.ascontiguousarray(V[:3, :3].T)
+    A = _mm3(J, Wm)
+    B = _mm3(A, cov3d)
+    C = _mm3(B, np.ascontiguousarray(Wm.T))
+    D = _mm3(C, np.ascontiguousarray(np.transpose(J, (0, 2, 1))))
+    return np.ascontiguousarray(D[:, :2, :2])
+
+
+def inverted_covariance(c2: np.ndarray) -> np.ndarray:
+    """splat/utils.py:368-393 (determinant floored at 1e-3; entries divided one by one)."""
+    det = c2[:, 0, 0] * c2[:, 1, 1] - c2[:, 0, 1] * c2[:, 1, 0]
+    det = np.maximum(det, DET_FLOOR)
+    inv = np.empty_like(c2)
+    inv[:, 0, 0] = c2[:, 1, 1] / det
+    inv[:, 1, 1] = c2[:, 0, 0] / det
+    inv[:, 0, 1] = -c2[:, 0, 1] / det
+    inv[:, 1, 0] = -c2[:, 1, 0] / det
+    return inv
+
+
+def extent_radius(c2: np.ndarray) -> np.ndarray:
+    """splat/utils.py:409-423: r = ceil(3 sqrt(lambda_max)), discriminant floored at 0.1."""
+    mid = f32(0.5) * (c2[:, 0, 0] + c2[:, 1, 1])
+    det = c2[:, 0, 0] * c2[:, 1, 1] - c2[:, 0, 1] * c2[:, 0, 1]
+    m = np.maximum(mid * mid - det, EIG_FLOOR)
+    root = np.sqrt(m)
+    lam = np.maximum(mid + root, mid - root)
+    return np.ceil(SIGMA_EXTENT * np.sqrt(lam))
+
+
+def sigmoid(x: np.ndarray) -> np.ndarray:
+    x = np.asarray(x, dtype=f32)
+    return (f32(1.0) / (f32(1.0) + np.exp(-x))).astype(f32)
+
+
+def preprocess(points, colors, scales, quats, opacity_logit, cam: Camera,
+               order: Optional[np.ndarray] = None) -> Preprocessed:
+    """Stage 1.  splat/gaussian_scene.py:70-144.
+
+    ``colors`` are the stored colours (already divided by 256, splat/gaussians.py:20-22).
+    Depth order is ascending view-space z with ties broken by original index (the
+    reference's ``torch.argsort`` leaves ties implementation-defined);
+    ``order`` overrides the permutation (original indices of in-view Gaussians) so a
+    fixture can pin the reference's own permutation.
+    """
+    points = np.asarray(points, dtype=f32)
+    V, F = cam.world2view, cam.full_proj
+    zv = _row4(points, V, 2)
+    in_view = zv >= MIN_Z                                   # splat/utils.py:293-310
+    idx = np.nonzero(in_view)[0]
+    p = points[idx]
+    cov3 = covariance_3d(np.asarray(scales, f32), np.asarray(quats, f32))[idx]
+
+    depth = _row4(p, V, 2)
+    cw = _row4(p, F, 3)
+    ndc_x = _row4(p, F, 0) / cw
+    ndc_y = _row4(p, F, 1) / cw
+    # splat/utils.py:313-317: (v + 1) * (dim - 1) * 0.5
+    x_pix = (ndc_x + f32(1.0)) * (f32(cam.width) - f32(1.0)) * f32(0.5)
+    y_pix = (ndc_y + f32(1.0)) * (f32(cam.height) - f32(1.0)) * f32(0.5)
+    xy = np.stack([x_pix, y_pix], axis=1).astype(f32)
+
+    c2 = covariance_2d(p, cov3, cam)
+    inv = inverted_covariance(c2)
+    r = extent_radius(c2)
+    min_x, max_x = np.floor(x_pix - r), np.ceil(x_pix + r)
+    min_y, max_y = np.floor(y_pix - r), np.ceil(y_pix + r)
+
+    if order is None:
+        perm = np.lexsort((idx, depth.view(np.uint32)))     # depth >= 0.2 > 0: bits are monotone
+    else:
+        lookup = -np.ones(points.shape[0], dtype=np.int64)
+        lookup[idx] = np.arange(idx.size)
+        perm = lookup[np.asarray(order, dtype=np.int64)]
+        assert (perm >= 0).all() and perm.size == idx.size
+    cols = np.asarray(colors, dtype=f32)[idx]
+    op = np.asarray(opacity_logit, dtype=f32).reshape(-1, 1)[idx]
+    return Preprocessed(
+        points=xy[perm], colors=cols[perm], covariance_2d=c2[perm], depths=depth[perm],
+        inverse_covariance_2d=inv[perm], radius=r[perm], points_xy=xy[perm],
+        min_x=min_x[perm], min_y=min_y[perm], max_x=max_x[perm], max_y=max_y[perm],
+        sigmoid_opacity=sigmoid(op[perm]), order=idx[perm],
+    )
+
+
+# --------------------------------------------------------------------------- stage 2
+
+def tile_origins(extent: int, tile: int):
+    """``range(0, extent - tile, tile)``: the last tile row/column is never rendered.
+    splat/gaussian_scene.py:208,214."""
+    return range(0, extent - tile, tile)
+
+
+def tile_list(pre, x0: int, y0: int, tile: int) -> np.ndarray:
+    """Indices (depth order) binned into the tile at (x0,y0).  splat/gaussian_scene.py:209-218."""
+    m = (pre.min_x <= f32(x0 + tile)) & (pre.max_x >= f32(x0)) & \
+        (pre.min_y <= f32(y0 + tile)) & (pre.max_y >= f32(y0))
+    return np.nonzero(m)[0]
+
+
+def render_pixel_scalar(px: int, py: int, means, colors, sig_op, inv) -> np.ndarray:
+    """One pixel, scalar loop.  splat/gaussian_scene.py:146-171 + splat/utils.py:357-365.
+
+    ``sig_op`` is already sigmoid(opacity); the reference applies sigmoid again (:164).
+    """
+    T = f32(1.0)
+    C = np.zeros(3, dtype=f32)
+    fx_, fy_ = f32(px), f32(py)
+    half = f32(-0.5)
+    for k in range(means.shape[0]):
+        d0 = half * (means[k, 0] - fx_)
+        d1 = half * (means[k, 1] - fy_)
+        t0 = f32(d0 * inv[k, 0, 0] + d1 * inv[k, 1, 0])
+        t1 = f32(d0 * inv[k, 0, 1] + d1 * inv[k, 1, 1])
+        e0 = means[k, 0] - fx_
+        e1 = means[k, 1] - fy_
+        power = f32(t0 * e0 + t1 * e1)
+        w = np.exp(power, dtype=f32)
+        o2 = f32(1.0) / (f32(1.0) + np.exp(-sig_op[k], dtype=f32))
+        alpha = f32(w * o2)
+        test = f32(T * (f32(1.0) - alpha))
+        if test < STOP_T:
+            return C
+        C = C + f32(T * alpha) * colors[k]
+        T = test
+    return C
+
+
+def render_tile_vector(x0: int, y0: int, tile: int, means, colors, sig_op, inv) -> np.ndarray:
+    """All tile*tile pixels of one tile at once (same arithmetic as render_pixel_scalar).
+    Returns (tile, tile, 3) indexed [x - x0, y - y0].  splat/gaussian_scene.py:173-198."""
+    xs = (np.arange(x0, x0 + tile, dtype=np.int64)).astype(f32)
+    ys = (np.arange(y0, y0 + tile, dtype=np.int64)).astype(f32)
+    PX, PY = np.meshgrid(xs, ys, indexing="ij")
+    T = np.ones((tile, tile), dtype=f32)
+    C = np.zeros((tile, tile, 3), dtype=f32)
+    live = np.ones((tile, tile), dtype=bool)
+    half = f32(-0.5)
+    o2 = sigmoid(sig_op.reshape(-1))
+    for k in range(means.shape[0]):
+        e0 = means[k, 0] - PX
+        e1 = means[k, 1] - PY
+        d0 = half * e0
+        d1 = half * e1
+        t0 = d0 * inv[k, 0, 0] + d1 * inv[k, 1, 0]
+        t1 = d0 * inv[k, 0, 1] + d1 * inv[k, 1, 1]
+        w = np.exp(t0 * e0 + t1 * e1)
+        alpha = w * o2[k]
+        test = T * (f32(1.0) - alpha)
+        live &= ~(test < STOP_T)
+        if not live.any():
+            break
+        contrib = (T * alpha)[..., None] * colors[k][None, None, :]
+        C = np.where(live[..., None], C + contrib, C)
+        T = np.where(live, test, T)
+    return C
+
+
+def render_image(pre, width: int, height: int, tile: int = 16, scalar: bool = False,
+                 window=None, stats: Optional[Dict] = None) -> np.ndarray:
+    """Stage 2.  splat/gaussian_scene.py:200-238.  Returns (W,H,3) float32 indexed [x,y];
+    pixels of the never-rendered last tile row/column stay 0.
+
+    ``window=(tx0,tx1,ty0,ty1)`` restricts rendering to a tile-index window (used by the
+    bounded CPU-baseline sample in bench.py); ``stats['pairs']`` counts list entries x pixels.
+    """
+    image = np.zeros((width, height, 3), dtype=f32)
+    pairs = 0
+    for ix, x0 in enumerate(tile_origins(width, tile)):
+        if window is not None and not (window[0] <= ix < window[1]):
+            continue
+        for iy, y0 in enumerate(tile_origins(height, tile)):
+            if window is not None and not (window[2] <= iy < window[3]):
+                continue
+            sel = tile_list(pre, x0, y0, tile)
+            if sel.size == 0:
+                continue
+            pairs += sel.size * tile * tile
+            m, c = pre.points[sel], pre.colors[sel]
+            o, q = pre.sigmoid_opacity[sel].reshape(-1), pre.inverse_covariance_2d[sel]
+            if scalar:
+                for px in range(x0, x0 + tile):
+                    for py in range(y0, y0 + tile):
+                        image[px, py] = render_pixel_scalar(px, py, m, c, o, q)
+            else:
+                image[x0:x0 + tile, y0:y0 + tile] = render_tile_vector(x0, y0, tile, m, c, o, q)
+    if stats is not None:
+        stats["pairs"] = pairs
+    return image

@@ -1,0 +1,318 @@
+/*
+ * C restatement of the reference's CPU forward rasteriser (float32, multi-threaded).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Built by oracle/Makefile into oracle/liboracle.so and loaded with
+ * ctypes from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- as the
+ * checker / reported CPU baseline, never as part of the product path.
+ *
+ * Parity status: PINNED through tests/test_oracle_golden.py (golden vectors produced by the
+ * reference itself, oracle/capture_golden.py).
+ *
+ * Same arithmetic, same explicit left-to-right operation order as oracle/cpu_ref.py and as the
+ * HIP projection kernel; compile with -ffp-contract=off (see Makefile) so no FMA is formed and
+ * depths / radii / bounding boxes are bit-identical across the three.
+ *
+ * Reference lines restated (paths relative to /root/reference):
+ *   orc_preprocess   splat/gaussian_scene.py:70-144, splat/gaussians.py:54-69,
+ *                    splat/utils.py:132-155, 293-317, 320-354, 368-393, 409-423
+ *   orc_render       splat/gaussian_scene.py:146-171 (render_pixel), :173-198 (render_tile),
+ *                    :200-238 (render_image tile loop / binning), splat/utils.py:357-365
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    float V[16];      /* world2view, row-vector form (splat/image.py:51-53)   */
+    float F[16];      /* full_proj_transform (splat/image.py:61-65)            */
+    float tan_fovx, tan_fovy, fx, fy;
+    int32_t width, height;
+} OrcCamera;
+
+static inline float row4(const float *p, const float *M, int col) {
+    return ((p[0] * M[0 * 4 + col] + p[1] * M[1 * 4 + col]) + p[2] * M[2 * 4 + col]) + M[3 * 4 + col];
+}
+
+static void mm3(const float *A, const float *B, float *C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            C[i * 3 + j] = (A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j]) + A[i * 3 + 2] * B[2 * 3 + j];
+}
+
+static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+/* One Gaussian of stage 1.  Returns 0 when culled (z_view < 0.2). */
+static int project_one(const OrcCamera *cam, const float *p, const float *s, const float *q,
+                       float *xy, float *c2, float *depth, float *inv, float *radius, float *bbox) {
+    const float *V = cam->V, *F = cam->F;
+    float tz = row4(p, V, 2);
+    if (!(tz >= 0.2f)) return 0;                       /* utils.py:293-310 */
+    /* Sigma3D: F.normalize then build_rotation's own normalisation (gaussians.py:59-69) */
+    float n1 = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+    n1 = fmaxf(n1, 1e-12f);
+    float a0 = q[0] / n1, a1 = q[1] / n1, a2 = q[2] / n1, a3 = q[3] / n1;
+    float n2 = sqrtf(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
+    float w = a0 / n2, x = a1 / n2, y = a2 / n2, z = a3 / n2;
+    float R[9];
+    R[0] = 1.0f - 2.0f * (y * y + z * z);
+    R[1] = 2.0f * (x * y - w * z);
+    R[2] = 2.0f * (x * z + w * y);
+    R[3] = 2.0f * (x * y + w * z);
+    R[4] = 1.0f - 2.0f * (x * x + z * z);
+    R[5] = 2.0f * (y * z - w * x);
+    R[6] = 2.0f * (x * z - w * y);
+    R[7] = 2.0f * (y * z + w * x);
+    R[8] = 1.0f - 2.0f * (x * x + y * y);
+    float M[9], S[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[i * 3 + j] = R[i * 3 + j] * s[j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            S[i * 3 + j] = (M[i * 3 + 0] * M[j * 3 + 0] + M[i * 3 + 1] * M[j * 3 + 1]) + M[i * 3 + 2] * M[j * 3 + 2];
+
+    /* pixel position (gaussian_scene.py:87-97, utils.py:313-317) */
+    float cw = row4(p, F, 3);
+    float ndcx = row4(p, F, 0) / cw, ndcy = row4(p, F, 1) / cw;
+    float xp = (ndcx + 1.0f) * ((float)cam->width - 1.0f) * 0.5f;
+    float yp = (ndcy + 1.0f) * ((float)cam->height - 1.0f) * 0.5f;
+
+    /* EWA 2D covariance (utils.py:320-354) */
+    float tx = row4(p, V, 0), ty = row4(p, V, 1);
+    float limx = 1.3f * cam->tan_fovx, limy = 1.3f * cam->tan_fovy;
+    float cx = fminf(fmaxf(tx / tz, -limx), limx) * tz;
+    float cy = fminf(fmaxf(ty / tz, -limy), limy) * tz;
+    float J[9] = {0}, Wm[9], Wt[9], Jt[9], A[9], B[9], C[9], D[9];
+    J[0] = cam->fx / tz;
+    J[2] = -(cam->fx * cx) / (tz * tz);
+    J[4] = cam->fy / tz;
+    J[5] = -(cam->fy * cy) / (tz * tz);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Wm[i * 3 + j] = V[j * 4 + i];            /* V[:3,:3]^T */
+            Wt[i * 3 + j] = V[i * 4 + j];
+            Jt[i * 3 + j] = J[j * 3 + i];
+        }
+    mm3(J, Wm, A); mm3(A, S, B); mm3(B, Wt, C); mm3(C, Jt, D);
+    float ca = D[0], cb = D[1], cc = D[3], cd = D[4];
+
+    /* inverse (utils.py:368-393) */
+    float det = ca * cd - cb * cc;
+    det = fmaxf(det, 1e-3f);
+    inv[0] = cd / det; inv[1] = -cb / det; inv[2] = -cc / det; inv[3] = ca / det;
+
+    /* radius (utils.py:409-423) */
+    float mid = 0.5f * (ca + cd);
+    float det2 = ca * cd - cb * cb;
+    float m = fmaxf(mid * mid - det2, 0.1f);
+    float root = sqrtf(m);
+    float lam = fmaxf(mid + root, mid - root);
+    float r = ceilf(3.0f * sqrtf(lam));
+
+    xy[0] = xp; xy[1] = yp;
+    c2[0] = ca; c2[1] = cb; c2[2] = cc; c2[3] = cd;
+    *depth = tz; *radius = r;
+    bbox[0] = floorf(xp - r); bbox[1] = ceilf(xp + r);   /* min_x, max_x */
+    bbox[2] = floorf(yp - r); bbox[3] = ceilf(yp + r);   /* min_y, max_y */
+    return 1;
+}
+
+/* stable LSD radix sort of (key,val) pairs by 32-bit key */
+static void radix_sort_pairs(uint32_t *key, int64_t *val, int64_t n) {
+    uint32_t *k2 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
+    int64_t *v2 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    for (int pass = 0; pass < 4; ++pass) {
+        int64_t hist[257] = {0};
+        int sh = pass * 8;
+        for (int64_t i = 0; i < n; ++i) hist[((key[i] >> sh) & 255u) + 1]++;
+        for (int b = 0; b < 256; ++b) hist[b + 1] += hist[b];
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t d = hist[(key[i] >> sh) & 255u]++;
+            k2[d] = key[i]; v2[d] = val[i];
+        }
+        uint32_t *tk = key; key = k2; k2 = tk;
+        int64_t *tv = val; val = v2; v2 = tv;
+    }
+    free(k2); free(v2);   /* 4 passes: data is back in the caller's arrays */
+}
+
+/*
+ * Stage 1 for n Gaussians.  Outputs are depth-sorted (ties by original index) and compacted to
+ * *n_vis rows; every output array must hold n rows.  order[i] = original index of sorted row i.
+ */
+int orc_preprocess(const OrcCamera *cam, const float *points, const float *colors, const float *scales,
+                   const float *quats, const float *opacity, int64_t n,
+                   float *xy, float *colors_out, float *cov2d, float *depths, float *inv_cov, float *radius,
+                   float *min_x, float *max_x, float *min_y, float *max_y, float *sig_op,
+                   int64_t *order, int64_t *n_vis) {
+    size_t cap = (size_t)(n > 0 ? n : 1);
+    float *t_xy = malloc(cap * 2 * 4), *t_c2 = malloc(cap * 4 * 4), *t_inv = malloc(cap * 4 * 4);
+    float *t_r = malloc(cap * 4), *t_bb = malloc(cap * 4 * 4);
+    uint32_t *key = malloc(cap * 4);
+    int64_t *val = malloc(cap * 8);
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        float d;
+        if (project_one(cam, points + 3 * i, scales + 3 * i, quats + 4 * i, t_xy + 2 * m, t_c2 + 4 * m, &d,
+                        t_inv + 4 * m, t_r + m, t_bb + 4 * m)) {
+            memcpy(&key[m], &d, 4);       /* d >= 0.2 > 0: IEEE bits are monotone in d */
+            val[m] = m;                   /* position in the compacted arrays */
+            order[m] = i;
+            ++m;
+        }
+    }
+    int64_t *orig = malloc(cap * 8);
+    memcpy(orig, order, (size_t)m * 8);
+    radix_sort_pairs(key, val, m);
+    for (int64_t i = 0; i < m; ++i) {
+        int64_t j = val[i], g = orig[j];
+        order[i] = g;
+        memcpy(&depths[i], &key[i], 4);
+        xy[2 * i] = t_xy[2 * j]; xy[2 * i + 1] = t_xy[2 * j + 1];
+        for (int c = 0; c < 4; ++c) { cov2d[4 * i + c] = t_c2[4 * j + c]; inv_cov[4 * i + c] = t_inv[4 * j + c]; }
+        for (int c = 0; c < 3; ++c) colors_out[3 * i + c] = colors[3 * g + c];
+        radius[i] = t_r[j];
+        min_x[i] = t_bb[4 * j]; max_x[i] = t_bb[4 * j + 1]; min_y[i] = t_bb[4 * j + 2]; max_y[i] = t_bb[4 * j + 3];
+        sig_op[i] = sigmoidf_(opacity[g]);               /* gaussian_scene.py:143 */
+    }
+    *n_vis = m;
+    free(t_xy); free(t_c2); free(t_inv); free(t_r); free(t_bb); free(key); free(val); free(orig);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------ stage 2 */
+
+typedef struct {
+    int W, H, tile, ntx, nty;
+    const float *means, *colors, *inv, *op2;
+    const int64_t *tile_start;   /* ntx*nty+1 */
+    const int32_t *tile_items;
+    float *image;                /* (W,H,3) indexed [x,y] */
+    int wx0, wx1, wy0, wy1;      /* tile-index window */
+    int next;                    /* work counter (tile id) */
+    int64_t pairs;
+    pthread_mutex_t mu;
+} RenderJob;
+
+static void render_one_tile(RenderJob *jb, int tix, int tiy) {
+    int T = jb->tile, x0 = tix * T, y0 = tiy * T, H = jb->H;
+    int64_t b = jb->tile_start[tix * jb->nty + tiy], e = jb->tile_start[tix * jb->nty + tiy + 1];
+    if (b == e) return;                                    /* gaussian_scene.py:219-220 */
+    for (int px = x0; px < x0 + T; ++px)
+        for (int py = y0; py < y0 + T; ++py) {
+            float Tw = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+            float fx_ = (float)px, fy_ = (float)py;
+            for (int64_t k = b; k < e; ++k) {              /* render_pixel, :146-171 */
+                int32_t g = jb->tile_items[k];
+                const float *Q = jb->inv + 4 * (int64_t)g;
+                float e0 = jb->means[2 * (int64_t)g] - fx_, e1 = jb->means[2 * (int64_t)g + 1] - fy_;
+                float d0 = -0.5f * e0, d1 = -0.5f * e1;     /* utils.py:363-364 */
+                float t0 = d0 * Q[0] + d1 * Q[2];
+                float t1 = d0 * Q[1] + d1 * Q[3];
+                float w = expf(t0 * e0 + t1 * e1);
+                float alpha = w * jb->op2[g];               /* second sigmoid, :164 */
+                float test = Tw * (1.0f - alpha);
+                if (test < 0.000001f) break;                /* return before accumulating, :166 */
+                float ta = Tw * alpha;
+                const float *c = jb->colors + 3 * (int64_t)g;
+                C0 += ta * c[0]; C1 += ta * c[1]; C2 += ta * c[2];
+                Tw = test;
+            }
+            float *o = jb->image + ((int64_t)px * H + py) * 3;
+            o[0] = C0; o[1] = C1; o[2] = C2;
+        }
+}
+
+static void *render_worker(void *arg) {
+    RenderJob *jb = (RenderJob *)arg;
+    int nwx = jb->wx1 - jb->wx0, nwy = jb->wy1 - jb->wy0;
+    int64_t local_pairs = 0;
+    for (;;) {
+        int id = __atomic_fetch_add(&jb->next, 1, __ATOMIC_RELAXED);
+        if (id >= nwx * nwy) break;
+        int tix = jb->wx0 + id / nwy, tiy = jb->wy0 + id % nwy;
+        int64_t len = jb->tile_start[tix * jb->nty + tiy + 1] - jb->tile_start[tix * jb->nty + tiy];
+        local_pairs += len * jb->tile * jb->tile;
+        render_one_tile(jb, tix, tiy);
+    }
+    pthread_mutex_lock(&jb->mu);
+    jb->pairs += local_pairs;
+    pthread_mutex_unlock(&jb->mu);
+    return NULL;
+}
+
+/* NaN compares false in the reference's masks: map it to an empty range (lo > hi). */
+static inline int clamp_lo(double v, int lo, int hi) { return !(v == v) ? hi + 1 : (v < lo ? lo : (v > hi ? hi : (int)v)); }
+static inline int clamp_hi(double v, int lo, int hi) { return !(v == v) ? lo - 1 : (v < lo ? lo : (v > hi ? hi : (int)v)); }
+
+/*
+ * Stage 2 on depth-sorted stage-1 arrays (the argument list of the reference's native boundary,
+ * splat/c/render.cu:90-101, with CPU semantics).  image: (W,H,3) float32 indexed [x,y], zeroed
+ * here.  window = {tx0,tx1,ty0,ty1} in tile indices or NULL for the whole frame.
+ * pairs_out: (list length x tile^2) summed over rendered tiles.  instances_out: total list length
+ * over ALL tiles (the D of SURVEY.md section 8).
+ */
+int orc_render(int H, int W, int tile, const float *means, const float *colors, const float *inv_cov,
+               const float *min_x, const float *max_x, const float *min_y, const float *max_y,
+               const float *sig_op, int64_t n, float *image, int nthreads, const int32_t *window,
+               int64_t *pairs_out, int64_t *instances_out) {
+    if (tile <= 0 || W <= 0 || H <= 0) return -1;
+    memset(image, 0, (size_t)W * H * 3 * sizeof(float));
+    /* range(0, W - tile, tile) has ceil((W - tile)/tile) entries (gaussian_scene.py:208,214) */
+    int ntx = W > tile ? (W - tile + tile - 1) / tile : 0;
+    int nty = H > tile ? (H - tile + tile - 1) / tile : 0;
+    if (pairs_out) *pairs_out = 0;
+    if (instances_out) *instances_out = 0;
+    if (ntx == 0 || nty == 0 || n == 0) return 0;
+    int64_t ntiles = (int64_t)ntx * nty;
+    int64_t *start = calloc((size_t)ntiles + 1, 8);
+    int32_t *rect = malloc((size_t)n * 4 * 4);
+    float *op2 = malloc((size_t)n * 4);
+    /* tile test (gaussian_scene.py:209-217): min <= x0 + T and max >= x0, x0 = t*T */
+    for (int64_t i = 0; i < n; ++i) {
+        double T = tile;
+        int lx = clamp_lo(ceil(((double)min_x[i] - T) / T), 0, ntx), hx = clamp_hi(floor((double)max_x[i] / T), -1, ntx - 1);
+        int ly = clamp_lo(ceil(((double)min_y[i] - T) / T), 0, nty), hy = clamp_hi(floor((double)max_y[i] / T), -1, nty - 1);
+        if (lx > hx || ly > hy) { lx = 0; hx = -1; ly = 0; hy = -1; }
+        rect[4 * i] = lx; rect[4 * i + 1] = hx; rect[4 * i + 2] = ly; rect[4 * i + 3] = hy;
+        for (int a = lx; a <= hx; ++a)
+            for (int b = ly; b <= hy; ++b) start[(int64_t)a * nty + b + 1]++;
+        op2[i] = sigmoidf_(sig_op[i]);
+    }
+    for (int64_t t = 0; t < ntiles; ++t) start[t + 1] += start[t];
+    int64_t D = start[ntiles];
+    int32_t *items = malloc((size_t)(D > 0 ? D : 1) * 4);
+    int64_t *fill = malloc((size_t)ntiles * 8);
+    memcpy(fill, start, (size_t)ntiles * 8);
+    for (int64_t i = 0; i < n; ++i)          /* ascending i == depth order is preserved per tile */
+        for (int a = rect[4 * i]; a <= rect[4 * i + 1]; ++a)
+            for (int b = rect[4 * i + 2]; b <= rect[4 * i + 3]; ++b) items[fill[(int64_t)a * nty + b]++] = (int32_t)i;
+
+    RenderJob jb;
+    memset(&jb, 0, sizeof jb);
+    jb.W = W; jb.H = H; jb.tile = tile; jb.ntx = ntx; jb.nty = nty;
+    jb.means = means; jb.colors = colors; jb.inv = inv_cov; jb.op2 = op2;
+    jb.tile_start = start; jb.tile_items = items; jb.image = image;
+    jb.wx0 = 0; jb.wx1 = ntx; jb.wy0 = 0; jb.wy1 = nty;
+    if (window) {
+        jb.wx0 = window[0] < 0 ? 0 : window[0]; jb.wx1 = window[1] > ntx ? ntx : window[1];
+        jb.wy0 = window[2] < 0 ? 0 : window[2]; jb.wy1 = window[3] > nty ? nty : window[3];
+    }
+    pthread_mutex_init(&jb.mu, NULL);
+    if (jb.wx1 > jb.wx0 && jb.wy1 > jb.wy0) {
+        if (nthreads < 1) nthreads = 1;
+        if (nthreads > 256) nthreads = 256;
+        pthread_t th[256];
+        for (int t = 1; t < nthreads; ++t) pthread_create(&th[t], NULL, render_worker, &jb);
+        render_worker(&jb);
+        for (int t = 1; t < nthreads; ++t) pthread_join(th[t], NULL);
+    }
+    pthread_mutex_destroy(&jb.mu);
+    if (pairs_out) *pairs_out = jb.pairs;
+    if (instances_out) *instances_out = D;
+    free(start); free(rect); free(op2); free(items); free(fill);
+    return 0;
+}
+
+int orc_version(void) { return 1; }
