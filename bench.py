@@ -1,0 +1,238 @@
+"""Headline benchmark: Mpixels/s of one forward raster on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one whole forward render (projection -> depth sort -> tile binning -> compositing,
+Gaussian parameters already resident in HBM) of the named synthetic workload; the default is the
+configuration the metric is quoted on: 1M Gaussians at 1920x1080 (C3, SURVEY.md section 8(d)
+generator, seed 0, since the Treehill .ply is not available offline).  With N > 1 the SAME frame
+is sharded as strips of tile rows across the ranks (every rank holds the full Gaussian set and
+runs the projection; binning, sorting and compositing cover only its strip) and the frame is
+gathered on rank 0 over RCCL: total work is fixed, so "scaling" is "strong".
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the dominant kernel (tile compositing): algorithmic bytes per launch over its
+                average duration, measured live with HIP events on the launch stream;
+  cpu_baseline  the oracle's C restatement timed on this host's cores on a bounded sample of
+                the same workload (rank 0, N = 1 only), plus the scalar Python restatement on
+                one tile (the stand-in for the reference's pure-Python loop);
+  max_abs_dpixel  max |GPU - CPU| over the sampled window (parity, target <= 1e-4).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians, strips  # noqa: E402
+from intro_to_gaussian_splatting_amd.synthetic import make_scene, write_colmap_text  # noqa: E402
+
+WORKLOADS = {
+    # name: (n, width, height, description)
+    "c1": (2_000, 256, 256, "C1 stand-in: synthetic 2k Gaussians, 256x256"),
+    "c2": (100_000, 1920, 1080, "C2: synthetic 100k Gaussians, 1920x1080"),
+    "c3": (1_000_000, 1920, 1080, "C3: synthetic 1M Gaussians, 1920x1080 (metric config)"),
+    "c4": (5_000_000, 3840, 2160, "C4: synthetic 5M Gaussians, 3840x2160"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (unpacked VALU)
+VALU_OPS_PER_PAIR = 20         # instructions per (pixel, Gaussian) evaluation incl. v_exp
+
+
+def build_scene(workload: str, device: str):
+    n, w, h, _ = WORKLOADS[workload]
+    sc = make_scene(n, w, h, seed=0)
+    with tempfile.TemporaryDirectory() as tmp:
+        write_colmap_text(tmp, sc)
+        g = Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"],
+                                  sc["opacity"], device=device)
+        scene = GaussianScene(tmp, g)
+    return sc, scene
+
+
+def cpu_baseline(sc, scene, gpu_frame: torch.Tensor, budget_s: float = 20.0):
+    """Times the oracle on this host (bounded sample) and checks the GPU frame against it."""
+    from oracle import c_oracle, cpu_ref
+
+    im = scene.images[1]
+    c = im.gsx_camera()
+    cam = cpu_ref.Camera(im.world2view.cpu().numpy(), im.full_proj_transform.cpu().numpy(), np.float32(c.tan_fovx),
+                         np.float32(c.tan_fovy), np.float32(c.fx), np.float32(c.fy), c.width, c.height)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    pre = c_oracle.preprocess(sc["points"], scene.gaussians.colors.cpu().numpy(), sc["scales"], sc["quaternions"],
+                              sc["opacity"], cam)
+    t_pre = time.perf_counter() - t0
+    w, h, tile = c.width, c.height, 16
+    ntx, nty = strips.tiles_along(w, tile), strips.tiles_along(h, tile)
+    # probe an 8x8-tile window in the middle of the frame, then size the sample to the budget
+    px, py = max(0, ntx // 2 - 4), max(0, nty // 2 - 4)
+    probe = (px, min(ntx, px + 8), py, min(nty, py + 8))
+    t0 = time.perf_counter()
+    _, probe_pairs, _ = c_oracle.render(pre, w, h, tile, nthreads=cores, window=probe)
+    t_probe = max(time.perf_counter() - t0, 1e-6)
+    n_probe = (probe[1] - probe[0]) * (probe[3] - probe[2])
+    est_full = t_probe * (ntx * nty) / max(n_probe, 1)
+    if est_full <= 1.5 * budget_s:
+        window, label = (0, ntx, 0, nty), "whole frame"
+    else:
+        cols = max(8, min(ntx, int(ntx * budget_s / est_full)))
+        x0 = max(0, ntx // 2 - cols // 2)
+        window = (x0, min(ntx, x0 + cols), 0, nty)
+        label = "tile columns [%d,%d) of %d (all %d tile rows)" % (window[0], window[1], ntx, nty)
+    t0 = time.perf_counter()
+    ref, pairs, inst = c_oracle.render(pre, w, h, tile, nthreads=cores, window=window)
+    t_render = time.perf_counter() - t0
+    n_tiles = (window[1] - window[0]) * (window[3] - window[2])
+    frac = n_tiles / max(ntx * nty, 1)
+    sample_px = n_tiles * tile * tile
+    # the projection is whole-frame work; charge the sample its share
+    mpix = sample_px / (t_render + t_pre * frac) / 1e6
+    x0, x1, y0, y1 = window[0] * tile, window[1] * tile, window[2] * tile, window[3] * tile
+    err = float(np.abs(gpu_frame[x0:x1, y0:y1].cpu().numpy() - ref[x0:x1, y0:y1]).max()) if n_tiles else 0.0
+
+    # the reference's own loop is single-threaded pure Python: time the scalar restatement on one tile
+    tx, ty = ntx // 2, nty // 2
+    st = {}
+    t0 = time.perf_counter()
+    cpu_ref.render_image(pre, w, h, tile, scalar=True, window=(tx, tx + 1, ty, ty + 1), stats=st)
+    t_py = time.perf_counter() - t0
+    py_pairs = max(st.get("pairs", 0), 1)
+    us_per_pair = t_py / py_pairs * 1e6
+    total_pairs = inst * tile * tile
+    py_mpix = (ntx * nty * tile * tile) / (us_per_pair * 1e-6 * max(total_pairs, 1)) / 1e6
+    return {
+        "value": round(mpix, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        "sample": "oracle/raster_cpu.c (C restatement, %d threads) on %s: %.2f s render + %.2f s projection share; "
+                  "%d (pixel,Gaussian) pairs" % (cores, label, t_render, t_pre * frac, pairs),
+        "seconds": round(t_render + t_pre * frac, 3),
+        "python_port": {"us_per_pair": round(us_per_pair, 3), "pairs": int(py_pairs), "cores": 1,
+                        "extrapolated_mpixels_per_s": float("%.3g" % py_mpix),
+                        "sample": "oracle/cpu_ref.py scalar loop on tile (%d,%d)" % (tx, ty)},
+    }, err, int(inst)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+
+    n, width, height, desc = WORKLOADS[args.workload]
+    sc, scene = build_scene(args.workload, str(device))
+    tile, layout = 16, "wh3"
+
+    def render_strip(window, out, origin):
+        scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=window, out=out, out_origin=origin)
+
+    def step():
+        if world == 1:
+            return scene.render_image_hip(1, tile_size=tile, layout=layout)
+        return strips.render_sharded(render_strip, width, height, tile, layout, device)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    frame = None
+    for _ in range(args.warmup):
+        frame = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    mpix = width * height / (ms_per_step * 1e-3) / 1e6
+
+    # per-stage HIP-event times of this rank's share (live, same process, separate loop)
+    stage = {}
+    stats = {}
+    reps = max(3, min(args.steps, 10))
+    window = None
+    if world > 1:
+        per, plan = strips.strip_plan(strips.tiles_along(width, tile), world)
+        window = (plan[rank][0], plan[rank][1], 0, strips.tiles_along(height, tile))
+    for _ in range(reps):
+        stats = {}
+        scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=window, stats=stats, timing=True)
+        for k, v in stats.get("stage_ms", {}).items():
+            stage[k] = stage.get(k, 0.0) + v / reps
+
+    if rank == 0:
+        d, nvis = int(stats["n_instances"]), int(stats["n_visible"])
+        my_tiles = int(stats["n_tiles"])
+        blend_ms = stage.get("blend", 0.0)
+        # algorithmic bytes of one compositing launch: per tile instance one 4-B rank id and
+        # one 36-B record; per rendered pixel one 12-B RGB store
+        blend_bytes = 40.0 * d + 12.0 * my_tiles * tile * tile
+        achieved = blend_bytes / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
+        frame_bytes = 56.0 * n + 40.0 * nvis + 60.0 * d + 12.0 * width * height      # SURVEY.md 8(d) B_alg
+        pairs = 256.0 * d
+        valu = pairs * VALU_OPS_PER_PAIR / (blend_ms * 1e-3) / FP32_LANE_OPS_PER_S if blend_ms > 0 else 0.0
+        out = {
+            "metric": "Mpixels/sec forward raster (1M Gaussians, 1080p) + max |dpixel| vs CPU ref",
+            "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "n_gaussians": n, "width": width, "height": height, "tile": tile,
+                       "semantics": "ref_cpu", "layout": layout, "n_visible": nvis, "tile_instances": d,
+                       "parallelism": "1 GPU" if world == 1 else "%d column strips + RCCL gather" % world},
+            "fps": round(1e3 / ms_per_step, 2),
+            "roofline": {"bound": "hbm", "kernel": "blend_tile16_kernel", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None, "bytes_per_launch": blend_bytes, "avg_ms": round(blend_ms, 4),
+                         "valu_frac": round(valu, 4),
+                         "note": "compositing under reference CPU semantics is VALU-bound (256 evaluations per "
+                                 "36-B record); valu_frac = 256*D*%d lane-ops / t / unpacked FP32 VALU peak"
+                                 % VALU_OPS_PER_PAIR},
+            "frame_roofline": {"bytes": frame_bytes, "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                               "unit": "GB/s", "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, err, inst = cpu_baseline(sc, scene, frame)
+            out["cpu_baseline"] = base
+            out["max_abs_dpixel"] = err
+            out["parity_ok"] = bool(err <= 1e-4 and inst == d)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

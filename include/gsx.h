@@ -1,0 +1,178 @@
+/*
+ * gsx.h -- C ABI of libgsx.so, the MI355X (gfx950) forward Gaussian-splat rasteriser.
+ *
+ * This is the drop-in boundary for the hot path of dcaustin33/intro_to_gaussian_splatting:
+ * plain pointers and sizes, no torch types, no C++ exceptions.  Every entry point cites the
+ * reference interface it replaces (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - All array pointers are DEVICE pointers to contiguous float32 (or the stated integer type)
+ *     on the current HIP device, unless the name ends in `_host`.
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *     Calls that report a host-side count (n_visible / n_instances) synchronise that stream
+ *     once; nothing else blocks.
+ *   - The library never allocates, frees or retains device memory: the caller owns inputs,
+ *     outputs and the workspace (size from gsx_workspace_bytes).
+ *   - Return value: GSX_OK (0) or a negative GsxStatus; gsx_last_error() gives a thread-local
+ *     message for the last failing call on the calling thread.
+ */
+#ifndef GSX_H_
+#define GSX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSX_VERSION 100 /* major*10000 + minor*100 + patch */
+
+typedef enum GsxStatus {
+    GSX_OK = 0,
+    GSX_ERR_INVALID_ARGUMENT = -1,
+    GSX_ERR_WORKSPACE_TOO_SMALL = -2, /* stats->n_instances holds the count that is needed */
+    GSX_ERR_HIP = -3,                 /* a HIP runtime call or kernel launch failed        */
+    GSX_ERR_UNSUPPORTED = -4
+} GsxStatus;
+
+/* Compositing semantics. */
+typedef enum GsxSemantics {
+    /* splat/gaussian_scene.py:146-238: sigmoid applied twice, no alpha clamp, stop when
+     * T(1-alpha) < 1e-6 before accumulating, every binned Gaussian evaluated at every pixel of
+     * the tile, last tile row/column never rendered, pixel centres at integers. */
+    GSX_SEM_REF_CPU = 0,
+    /* splat/c/render.cu:21-87: single sigmoid, alpha clamped to 0.99, stop at 0.001, per-pixel
+     * inclusive bbox cull, int-truncated means, all tiles rendered. */
+    GSX_SEM_REF_CUDA = 1
+} GsxSemantics;
+
+/* Memory layout of the output frame. */
+typedef enum GsxLayout {
+    GSX_LAYOUT_WH3 = 0, /* out[x][y][c], what render_image returns (gaussian_scene.py:206) */
+    GSX_LAYOUT_HW3 = 1  /* out[y][x][c], what render_image_cuda returns (render.cu:116)     */
+} GsxLayout;
+
+/*
+ * Already-computed float32 camera constants, i.e. the attributes of the reference's
+ * GaussianImage that preprocess() reads (splat/image.py:28-66).  Matrices are row-major and in
+ * the reference's row-vector convention (p_row @ M).
+ */
+typedef struct GsxCamera {
+    float world2view[16]; /* splat/image.py:51-53  */
+    float full_proj[16];  /* splat/image.py:61-65  */
+    float tan_fovx;       /* splat/image.py:42     */
+    float tan_fovy;       /* splat/image.py:43     */
+    float fx;             /* splat/image.py:28     */
+    float fy;             /* splat/image.py:29     */
+    int32_t width;        /* splat/image.py:38     */
+    int32_t height;       /* splat/image.py:37     */
+} GsxCamera;
+
+/*
+ * Options.  gsx_default_params() fills the reference's behaviour; a NULL params pointer means
+ * the defaults.  The tile window selects which tiles this call renders (multi-GPU strips):
+ * tiles [tile_x0, tile_x1) x [tile_y0, tile_y1); tile_x1 / tile_y1 <= 0 means "to the end".
+ * `out` always addresses a buffer of out_w x out_h pixels whose pixel (0,0) is frame pixel
+ * (out_x0, out_y0); out_w / out_h <= 0 means the whole frame.
+ */
+typedef struct GsxParams {
+    int32_t semantics; /* GsxSemantics, default GSX_SEM_REF_CPU */
+    int32_t layout;    /* GsxLayout, default GSX_LAYOUT_WH3     */
+    int32_t tile_x0, tile_x1, tile_y0, tile_y1;
+    int32_t out_x0, out_y0, out_w, out_h;
+    int32_t flags; /* GSX_FLAG_* */
+    int32_t reserved[5];
+} GsxParams;
+
+/* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call
+ * then waits for the frame to finish).  Off by default: timing is measurement, not product. */
+#define GSX_FLAG_TIMING 1
+
+/* Indices into GsxFrameStats.stage_ms (milliseconds). */
+enum {
+    GSX_STAGE_DEPTH_SORT = 0, /* depth keys + radix sort of N keys            */
+    GSX_STAGE_PROJECT = 1,    /* projection / record packing                    */
+    GSX_STAGE_SCAN = 2,       /* tile-count scan + the host read-back of D      */
+    GSX_STAGE_BIN = 3,        /* frame clear, key emit, tile sort, tile ranges  */
+    GSX_STAGE_BLEND = 4,      /* the compositing kernel alone                   */
+    GSX_STAGE_TOTAL = 5
+};
+
+/* Host-side counts of one frame (N_vis and D). */
+typedef struct GsxFrameStats {
+    int64_t n_visible;   /* Gaussians that pass the z_view >= 0.2 cull         */
+    int64_t n_instances; /* (Gaussian, tile) pairs binned inside the tile window */
+    int64_t n_tiles;     /* tiles inside the window                             */
+    int64_t reserved;
+    float stage_ms[8];   /* filled only with GSX_FLAG_TIMING                     */
+} GsxFrameStats;
+
+int gsx_version(void);
+const char *gsx_last_error(void);
+void gsx_default_params(GsxParams *params);
+
+/*
+ * Bytes of device workspace needed by any entry point below for up to `n` Gaussians, a
+ * width x height frame, tile size `tile` and at most `max_instances` (Gaussian, tile) pairs.
+ * Returns 0 on invalid arguments.
+ */
+size_t gsx_workspace_bytes(int64_t n, int32_t width, int32_t height, int32_t tile, int64_t max_instances);
+
+/*
+ * Stage 1.  Replaces GaussianScene.preprocess (splat/gaussian_scene.py:70-144) with
+ * Gaussians.get_3d_covariance_matrix (splat/gaussians.py:54-69) and the helpers of
+ * splat/utils.py:293-423 fused in.  Inputs are the Gaussians attributes (splat/gaussians.py:19-33):
+ * means3d (n,3), scales (n,3) linear, quats (n,4) (w,x,y,z), opacity_logit (n,1), colors (n,3).
+ * Outputs are the PreprocessedScene fields (splat/schema.py:13-25), each with room for n rows,
+ * depth-sorted (ascending view z, ties by original index); rows >= *n_visible_host are unspecified.
+ * order (n) int32: original index of each sorted row (may be NULL).  Synchronises `stream`.
+ */
+int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
+                   const float *opacity_logit, const float *colors, int64_t n,
+                   float *points_xy, float *colors_out, float *covariance_2d, float *depths,
+                   float *inverse_covariance_2d, float *radius, float *min_x, float *max_x,
+                   float *min_y, float *max_y, float *sigmoid_opacity, int32_t *order,
+                   int64_t *n_visible_host, const GsxParams *params, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/*
+ * Stage 2 on stage-1 arrays.  Argument-for-argument mirror of the reference's native entry
+ * point `torch::Tensor render_image(int image_height, int image_width, int tile_size, point_means,
+ * point_colors, inverse_covariance_2d, min_x, max_x, min_y, max_y, opacity)`
+ * (splat/c/render.cu:90-101, declared at splat/gaussian_scene.py:244-257), with the output
+ * buffer caller-allocated instead of returned.  Rows must be in compositing (depth) order.
+ * `opacity` is PreprocessedScene.sigmoid_opacity (n,1).  Under GSX_SEM_REF_CPU this computes what
+ * GaussianScene.render_image (splat/gaussian_scene.py:200-238) computes from the same arrays.
+ * out_image is fully written (pixels outside rendered tiles are set to 0).
+ */
+int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t tile_size,
+                            const float *point_means, const float *point_colors,
+                            const float *inverse_covariance_2d, const float *min_x, const float *max_x,
+                            const float *min_y, const float *max_y, const float *opacity, int64_t n,
+                            float *out_image, const GsxParams *params, GsxFrameStats *stats_host,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Whole hot path: projection -> depth order -> tile binning -> compositing.  Replaces
+ * GaussianScene.render_image (splat/gaussian_scene.py:200-238) and, with GSX_SEM_REF_CUDA /
+ * GSX_LAYOUT_HW3, GaussianScene.render_image_cuda (splat/gaussian_scene.py:263-285).
+ * stats_host may be NULL.  Synchronises `stream` once (to learn n_instances).
+ */
+int gsx_render_forward(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
+                       const float *opacity_logit, const float *colors, int64_t n, int32_t tile_size,
+                       float *out_image, const GsxParams *params, GsxFrameStats *stats_host,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Debug helper on the same projection: replaces GaussianScene.render_points_image
+ * (splat/gaussian_scene.py:44-51, splat/image.py:72-89).  Writes (x_pix, y_pix, ndc_z) for every
+ * Gaussian in input order into points_out (n,3) and 1/0 into in_view_out (n) (uint8).
+ */
+int gsx_project_points(const GsxCamera *camera, const float *means3d, int64_t n, float *points_out,
+                       uint8_t *in_view_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSX_H_ */

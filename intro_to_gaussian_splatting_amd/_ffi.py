@@ -1,0 +1,99 @@
+"""ctypes binding of libgsx.so (the C ABI declared in include/gsx.h).
+
+The library is built ahead of time by ``__graft_entry__.build()`` /
+``make -C intro_to_gaussian_splatting_amd/csrc`` and lives next to this file.  There is no CPU
+fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_float, c_int32, c_int64, c_size_t, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsx.so")
+
+GSX_OK = 0
+GSX_ERR_INVALID_ARGUMENT = -1
+GSX_ERR_WORKSPACE_TOO_SMALL = -2
+GSX_ERR_HIP = -3
+GSX_ERR_UNSUPPORTED = -4
+
+GSX_SEM_REF_CPU = 0
+GSX_SEM_REF_CUDA = 1
+GSX_LAYOUT_WH3 = 0
+GSX_LAYOUT_HW3 = 1
+GSX_FLAG_TIMING = 1
+STAGE_NAMES = ("depth_sort", "project", "scan", "bin", "blend", "total")
+
+
+class GsxCamera(ctypes.Structure):
+    _fields_ = [("world2view", c_float * 16), ("full_proj", c_float * 16),
+                ("tan_fovx", c_float), ("tan_fovy", c_float), ("fx", c_float), ("fy", c_float),
+                ("width", c_int32), ("height", c_int32)]
+
+
+class GsxParams(ctypes.Structure):
+    _fields_ = [("semantics", c_int32), ("layout", c_int32),
+                ("tile_x0", c_int32), ("tile_x1", c_int32), ("tile_y0", c_int32), ("tile_y1", c_int32),
+                ("out_x0", c_int32), ("out_y0", c_int32), ("out_w", c_int32), ("out_h", c_int32),
+                ("flags", c_int32), ("reserved", c_int32 * 5)]
+
+
+class GsxFrameStats(ctypes.Structure):
+    _fields_ = [("n_visible", c_int64), ("n_instances", c_int64), ("n_tiles", c_int64), ("reserved", c_int64),
+                ("stage_ms", c_float * 8)]
+
+
+# name -> (restype, argtypes); every symbol include/gsx.h declares.
+_FP = c_void_p  # device float*
+SIGNATURES = {
+    "gsx_version": (ctypes.c_int, []),
+    "gsx_last_error": (ctypes.c_char_p, []),
+    "gsx_default_params": (None, [POINTER(GsxParams)]),
+    "gsx_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int64]),
+    "gsx_preprocess": (ctypes.c_int, [POINTER(GsxCamera)] + [_FP] * 5 + [c_int64] + [_FP] * 11 +
+                       [c_void_p, POINTER(c_int64), POINTER(GsxParams), c_void_p, c_size_t, c_void_p]),
+    "gsx_render_preprocessed": (ctypes.c_int, [c_int32, c_int32, c_int32] + [_FP] * 8 + [c_int64, _FP,
+                                POINTER(GsxParams), POINTER(GsxFrameStats), c_void_p, c_size_t, c_void_p]),
+    "gsx_render_forward": (ctypes.c_int, [POINTER(GsxCamera)] + [_FP] * 5 + [c_int64, c_int32, _FP,
+                           POINTER(GsxParams), POINTER(GsxFrameStats), c_void_p, c_size_t, c_void_p]),
+    "gsx_project_points": (ctypes.c_int, [POINTER(GsxCamera), _FP, c_int64, _FP, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libgsx.so once; raises RuntimeError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libgsx.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C intro_to_gaussian_splatting_amd/csrc` (needs hipcc, targets gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class GsxError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__("libgsx error %d: %s" % (code, message))
+        self.code = code
+
+
+def check(code: int) -> None:
+    if code != GSX_OK:
+        raise GsxError(code, load().gsx_last_error().decode("utf-8", "replace"))
+
+
+def default_params() -> GsxParams:
+    p = GsxParams()
+    load().gsx_default_params(ctypes.byref(p))
+    return p

@@ -1,0 +1,365 @@
+// C ABI of libgsx.so (see include/gsx.h): argument validation, workspace carving and the
+// stream-ordered launch sequence.  No device memory is allocated here and nothing is retained
+// between calls; errors are returned as codes with a thread-local message.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gsx_internal.h"
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define GSX_HIP(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(GSX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
+
+// Number of tiles along an axis.  REF_CPU iterates range(0, extent - tile, tile)
+// (splat/gaussian_scene.py:208,214): the last row/column is never rendered.
+// REF_CUDA covers the frame (splat/c/render.cu:119-120).
+inline int32_t tiles_along(int32_t extent, int32_t tile, int semantics) {
+    if (semantics == GSX_SEM_REF_CPU) return extent > tile ? (extent - tile + tile - 1) / tile : 0;
+    return (extent + tile - 1) / tile;
+}
+
+struct Carve {
+    size_t keys0, keys1, vals0, vals1;      // n x u32: depth keys / original indices (ping-pong)
+    size_t rec, rect, counts, offsets;      // per depth rank
+    size_t tkeys0, tkeys1, tvals0, tvals1;  // cap x u32: tile ids / depth ranks (ping-pong)
+    size_t ranges, counters, temp, temp_bytes, total;
+};
+
+Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes) {
+    Carve c;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off = align_up(off + bytes);
+        return at;
+    };
+    size_t nn = (size_t)(n > 0 ? n : 1), cc = (size_t)(cap > 0 ? cap : 1);
+    c.keys0 = take(nn * 4); c.keys1 = take(nn * 4); c.vals0 = take(nn * 4); c.vals1 = take(nn * 4);
+    c.rec = take(nn * sizeof(gsx::Record));
+    c.rect = take(nn * sizeof(gsx::TileRect));
+    c.counts = take((nn + 1) * 4);
+    c.offsets = take((nn + 1) * 4);
+    c.tkeys0 = take(cc * 4); c.tkeys1 = take(cc * 4); c.tvals0 = take(cc * 4); c.tvals1 = take(cc * 4);
+    c.ranges = take((size_t)(max_tiles > 0 ? max_tiles : 1) * sizeof(uint2));
+    c.counters = take(64);
+    c.temp = take(temp_bytes);
+    c.temp_bytes = temp_bytes;
+    c.total = off;
+    return c;
+}
+
+int64_t max_tiles_of(int32_t width, int32_t height, int32_t tile) {
+    return (int64_t)((width + tile - 1) / tile) * ((height + tile - 1) / tile);
+}
+
+// Largest instance capacity whose carve fits `bytes` (temp size depends weakly on capacity).
+int64_t capacity_for(size_t bytes, int64_t n, int64_t max_tiles) {
+    Carve fixed = carve(n, 1, max_tiles, gsx::binning_temp_bytes(n, 1));
+    if (fixed.total > bytes) return -1;
+    int64_t cap = (int64_t)((bytes - fixed.total) / 16);
+    for (int it = 0; it < 16 && cap > 0; ++it) {
+        Carve c = carve(n, cap, max_tiles, gsx::binning_temp_bytes(n, cap));
+        if (c.total <= bytes) return cap;
+        int64_t over = (int64_t)((c.total - bytes + 15) / 16) + 64;
+        cap = cap > over ? cap - over : 0;
+    }
+    return 0;
+}
+
+struct Plan {
+    gsx::TileGrid grid;
+    gsx::OutDesc out;
+    int semantics;
+    bool timing;
+};
+
+// Optional per-stage timing with HIP events on the launch stream (GSX_FLAG_TIMING).
+struct StageTimer {
+    bool on = false;
+    hipStream_t s = nullptr;
+    hipEvent_t ev[8];
+    int n = 0;
+    void begin(bool enable, hipStream_t stream) {
+        on = enable;
+        s = stream;
+        mark();
+    }
+    void mark() {
+        if (!on || n >= 8) return;
+        if (hipEventCreate(&ev[n]) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(ev[n], s);
+        ++n;
+    }
+    // marks: 0 start | 1 depth+sort | 2 project | 3 scan+readback | 4 bin | 5 blend
+    void finish(GsxFrameStats *st) {
+        if (n > 0) (void)hipEventSynchronize(ev[n - 1]);
+        if (st) {
+            for (int i = 0; i < 8; ++i) st->stage_ms[i] = 0.0f;
+            for (int i = 1; i < n; ++i) {
+                float ms = 0.0f;
+                (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+                st->stage_ms[i - 1] = ms;
+            }
+            if (n > 1) {
+                float ms = 0.0f;
+                (void)hipEventElapsedTime(&ms, ev[0], ev[n - 1]);
+                st->stage_ms[GSX_STAGE_TOTAL] = ms;
+            }
+        }
+        for (int i = 0; i < n; ++i) (void)hipEventDestroy(ev[i]);
+        n = 0;
+    }
+    ~StageTimer() { finish(nullptr); }
+};
+
+int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, const GsxParams *params, Plan &p) {
+    GsxParams d;
+    gsx_default_params(&d);
+    if (params) d = *params;
+    if (width <= 0 || height <= 0) return fail(GSX_ERR_INVALID_ARGUMENT, "image size %dx%d is not positive", width, height);
+    if (tile <= 0 || tile > 1024) return fail(GSX_ERR_INVALID_ARGUMENT, "tile size %d out of range [1,1024]", tile);
+    if (d.semantics != GSX_SEM_REF_CPU)
+        return fail(GSX_ERR_UNSUPPORTED, "semantics %d not implemented (only GSX_SEM_REF_CPU)", d.semantics);
+    if (d.layout != GSX_LAYOUT_WH3 && d.layout != GSX_LAYOUT_HW3) return fail(GSX_ERR_INVALID_ARGUMENT, "unknown layout %d", d.layout);
+    if (!out_image) return fail(GSX_ERR_INVALID_ARGUMENT, "out_image is NULL");
+    p.semantics = d.semantics;
+    p.timing = (d.flags & GSX_FLAG_TIMING) != 0;
+    gsx::TileGrid &g = p.grid;
+    g.tile = tile;
+    g.ntx = tiles_along(width, tile, d.semantics);
+    g.nty = tiles_along(height, tile, d.semantics);
+    if (g.ntx > 65535 || g.nty > 65535) return fail(GSX_ERR_UNSUPPORTED, "more than 65535 tiles along an axis");
+    g.wx0 = d.tile_x0 < 0 ? 0 : d.tile_x0;
+    g.wy0 = d.tile_y0 < 0 ? 0 : d.tile_y0;
+    g.wx1 = (d.tile_x1 <= 0 || d.tile_x1 > g.ntx) ? g.ntx : d.tile_x1;
+    g.wy1 = (d.tile_y1 <= 0 || d.tile_y1 > g.nty) ? g.nty : d.tile_y1;
+    if (g.wx0 > g.wx1) g.wx0 = g.wx1;
+    if (g.wy0 > g.wy1) g.wy0 = g.wy1;
+    gsx::OutDesc &o = p.out;
+    o.ptr = out_image;
+    o.x0 = d.out_w > 0 ? d.out_x0 : 0;
+    o.y0 = d.out_h > 0 ? d.out_y0 : 0;
+    o.w = d.out_w > 0 ? d.out_w : width;
+    o.h = d.out_h > 0 ? d.out_h : height;
+    if (d.layout == GSX_LAYOUT_WH3) {
+        o.stride_x = (int64_t)o.h * 3;
+        o.stride_y = 3;
+    } else {
+        o.stride_x = 3;
+        o.stride_y = (int64_t)o.w * 3;
+    }
+    if (g.count() > 0) {
+        // every rendered tile must lie inside the output buffer
+        int64_t px0 = (int64_t)g.wx0 * tile, px1 = (int64_t)g.wx1 * tile, py0 = (int64_t)g.wy0 * tile, py1 = (int64_t)g.wy1 * tile;
+        if (px0 < o.x0 || px1 > (int64_t)o.x0 + o.w || py0 < o.y0 || py1 > (int64_t)o.y0 + o.h)
+            return fail(GSX_ERR_INVALID_ARGUMENT, "tile window [%d,%d)x[%d,%d) does not fit the %dx%d output buffer at (%d,%d)",
+                        g.wx0, g.wx1, g.wy0, g.wy1, o.w, o.h, o.x0, o.y0);
+    }
+    return GSX_OK;
+}
+
+inline int key_bits_for(int64_t n_tiles) {
+    int b = 1;
+    while (((int64_t)1 << b) < n_tiles) ++b;
+    return b;
+}
+
+// Steps shared by both render entry points once records / rects / counts exist (rank order).
+int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t cap, int64_t n_visible_known,
+                  GsxFrameStats *stats, StageTimer &tm, hipStream_t s) {
+    uint32_t *counts = (uint32_t *)(ws + c.counts), *offsets = (uint32_t *)(ws + c.offsets);
+    uint32_t *counters = (uint32_t *)(ws + c.counters);
+    void *temp = ws + c.temp;
+    GSX_HIP(gsx::scan_counts(temp, c.temp_bytes, counts, offsets, n + 1, s));
+    uint32_t host[2] = {0, 0};
+    GSX_HIP(hipMemcpyAsync(&host[0], offsets + n, 4, hipMemcpyDeviceToHost, s));
+    if (n_visible_known < 0) GSX_HIP(hipMemcpyAsync(&host[1], counters, 4, hipMemcpyDeviceToHost, s));
+    GSX_HIP(hipStreamSynchronize(s));
+    tm.mark();  // 3: scan + read-back
+    const int64_t d = host[0];
+    if (stats) {
+        stats->n_visible = n_visible_known < 0 ? (int64_t)host[1] : n_visible_known;
+        stats->n_instances = d;
+        stats->n_tiles = p.grid.count();
+        stats->reserved = 0;
+    }
+    const size_t out_bytes = (size_t)p.out.w * p.out.h * 3 * sizeof(float);
+    GSX_HIP(hipMemsetAsync(p.out.ptr, 0, out_bytes, s));
+    if (d > cap)
+        return fail(GSX_ERR_WORKSPACE_TOO_SMALL, "frame needs %lld tile instances, workspace holds %lld", (long long)d,
+                    (long long)cap);
+    if (d == 0 || p.grid.count() == 0) return GSX_OK;
+    uint32_t *tk = (uint32_t *)(ws + c.tkeys0), *tk2 = (uint32_t *)(ws + c.tkeys1);
+    uint32_t *tv = (uint32_t *)(ws + c.tvals0), *tv2 = (uint32_t *)(ws + c.tvals1);
+    GSX_HIP(gsx::launch_emit((const gsx::TileRect *)(ws + c.rect), offsets, n, p.grid, tk, tv, s));
+    GSX_HIP(gsx::sort_pairs(temp, c.temp_bytes, tk, tk2, tv, tv2, d, key_bits_for(p.grid.count()), s));
+    uint2 *ranges = (uint2 *)(ws + c.ranges);
+    GSX_HIP(gsx::launch_tile_ranges(tk, d, ranges, p.grid.count(), s));
+    tm.mark();  // 4: bin
+    GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), tv, ranges, p.grid, p.out, p.semantics, s));
+    tm.mark();  // 5: blend
+    tm.finish(stats);
+    return GSX_OK;
+}
+
+int check_workspace(void *workspace, size_t bytes, int64_t n, int64_t max_tiles, Carve &c, int64_t &cap) {
+    if (!workspace) return fail(GSX_ERR_INVALID_ARGUMENT, "workspace is NULL");
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0) return fail(GSX_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
+    cap = capacity_for(bytes, n, max_tiles);
+    if (cap < 0)
+        return fail(GSX_ERR_WORKSPACE_TOO_SMALL, "workspace of %zu bytes cannot hold %lld Gaussians", bytes, (long long)n);
+    c = carve(n, cap, max_tiles, gsx::binning_temp_bytes(n, cap));
+    return GSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsx_version(void) { return GSX_VERSION; }
+
+const char *gsx_last_error(void) { return g_error; }
+
+void gsx_default_params(GsxParams *params) {
+    if (!params) return;
+    memset(params, 0, sizeof *params);
+    params->semantics = GSX_SEM_REF_CPU;
+    params->layout = GSX_LAYOUT_WH3;
+}
+
+size_t gsx_workspace_bytes(int64_t n, int32_t width, int32_t height, int32_t tile, int64_t max_instances) {
+    if (n < 0 || width <= 0 || height <= 0 || tile <= 0 || max_instances < 0) return 0;
+    if (n >= (int64_t)1 << 31 || max_instances >= (int64_t)1 << 31) return 0;
+    size_t temp = gsx::binning_temp_bytes(n, max_instances);
+    if (temp == 0) return 0;
+    return carve(n, max_instances, max_tiles_of(width, height, tile), temp).total;
+}
+
+int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
+                   const float *opacity_logit, const float *colors, int64_t n, float *points_xy, float *colors_out,
+                   float *covariance_2d, float *depths, float *inverse_covariance_2d, float *radius, float *min_x,
+                   float *max_x, float *min_y, float *max_y, float *sigmoid_opacity, int32_t *order,
+                   int64_t *n_visible_host, const GsxParams *params, void *workspace, size_t workspace_bytes,
+                   void *stream) {
+    (void)params;
+    hipStream_t s = (hipStream_t)stream;
+    if (!camera) return fail(GSX_ERR_INVALID_ARGUMENT, "camera is NULL");
+    if (n < 0 || n >= (int64_t)1 << 31) return fail(GSX_ERR_INVALID_ARGUMENT, "n = %lld out of range", (long long)n);
+    if (n_visible_host) *n_visible_host = 0;
+    if (n == 0) return GSX_OK;
+    if (!means3d || !scales || !quats || !opacity_logit || !colors) return fail(GSX_ERR_INVALID_ARGUMENT, "an input array is NULL");
+    if (!points_xy || !colors_out || !covariance_2d || !depths || !inverse_covariance_2d || !radius || !min_x || !max_x ||
+        !min_y || !max_y || !sigmoid_opacity)
+        return fail(GSX_ERR_INVALID_ARGUMENT, "an output array is NULL");
+    Carve c;
+    int64_t cap;
+    int rc = check_workspace(workspace, workspace_bytes, n, 1, c, cap);
+    if (rc != GSX_OK) return rc;
+    char *ws = (char *)workspace;
+    uint32_t *k0 = (uint32_t *)(ws + c.keys0), *k1 = (uint32_t *)(ws + c.keys1);
+    uint32_t *v0 = (uint32_t *)(ws + c.vals0), *v1 = (uint32_t *)(ws + c.vals1);
+    uint32_t *counters = (uint32_t *)(ws + c.counters);
+    GSX_HIP(hipMemsetAsync(counters, 0, 64, s));
+    GSX_HIP(gsx::launch_depth_keys(*camera, means3d, n, k0, v0, counters, s));
+    GSX_HIP(gsx::sort_pairs(ws + c.temp, c.temp_bytes, k0, k1, v0, v1, n, 32, s));
+    gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
+    gsx::StageOneOut out{points_xy, colors_out, covariance_2d, depths, inverse_covariance_2d, radius,
+                         min_x, max_x, min_y, max_y, sigmoid_opacity, order};
+    GSX_HIP(gsx::launch_project_full(*camera, in, k0, v0, n, out, s));
+    uint32_t nv = 0;
+    GSX_HIP(hipMemcpyAsync(&nv, counters, 4, hipMemcpyDeviceToHost, s));
+    GSX_HIP(hipStreamSynchronize(s));
+    if (n_visible_host) *n_visible_host = nv;
+    return GSX_OK;
+}
+
+int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t tile_size, const float *point_means,
+                            const float *point_colors, const float *inverse_covariance_2d, const float *min_x,
+                            const float *max_x, const float *min_y, const float *max_y, const float *opacity,
+                            int64_t n, float *out_image, const GsxParams *params, GsxFrameStats *stats_host,
+                            void *workspace, size_t workspace_bytes, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    Plan p;
+    int rc = make_plan(image_width, image_height, tile_size, out_image, params, p);
+    if (rc != GSX_OK) return rc;
+    if (n < 0 || n >= (int64_t)1 << 31) return fail(GSX_ERR_INVALID_ARGUMENT, "n = %lld out of range", (long long)n);
+    if (n > 0 && (!point_means || !point_colors || !inverse_covariance_2d || !min_x || !max_x || !min_y || !max_y || !opacity))
+        return fail(GSX_ERR_INVALID_ARGUMENT, "an input array is NULL");
+    Carve c;
+    int64_t cap;
+    rc = check_workspace(workspace, workspace_bytes, n, max_tiles_of(image_width, image_height, tile_size), c, cap);
+    if (rc != GSX_OK) return rc;
+    char *ws = (char *)workspace;
+    StageTimer tm;
+    tm.begin(p.timing, s);
+    tm.mark();  // 1: (no depth sort on this entry point)
+    GSX_HIP(hipMemsetAsync(ws + c.counts + (size_t)n * 4, 0, 4, s));
+    gsx::PreprocessedIn in{point_means, point_colors, inverse_covariance_2d, min_x, max_x, min_y, max_y, opacity};
+    GSX_HIP(gsx::launch_pack_preprocessed(in, n, p.grid, p.semantics, (gsx::Record *)(ws + c.rec),
+                                          (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts), s));
+    tm.mark();  // 2: pack
+    return bin_and_blend(p, c, ws, n, cap, n, stats_host, tm, s);
+}
+
+int gsx_render_forward(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
+                       const float *opacity_logit, const float *colors, int64_t n, int32_t tile_size,
+                       float *out_image, const GsxParams *params, GsxFrameStats *stats_host, void *workspace,
+                       size_t workspace_bytes, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!camera) return fail(GSX_ERR_INVALID_ARGUMENT, "camera is NULL");
+    Plan p;
+    int rc = make_plan(camera->width, camera->height, tile_size, out_image, params, p);
+    if (rc != GSX_OK) return rc;
+    if (n < 0 || n >= (int64_t)1 << 31) return fail(GSX_ERR_INVALID_ARGUMENT, "n = %lld out of range", (long long)n);
+    if (n > 0 && (!means3d || !scales || !quats || !opacity_logit || !colors)) return fail(GSX_ERR_INVALID_ARGUMENT, "an input array is NULL");
+    Carve c;
+    int64_t cap;
+    rc = check_workspace(workspace, workspace_bytes, n, max_tiles_of(camera->width, camera->height, tile_size), c, cap);
+    if (rc != GSX_OK) return rc;
+    char *ws = (char *)workspace;
+    uint32_t *k0 = (uint32_t *)(ws + c.keys0), *k1 = (uint32_t *)(ws + c.keys1);
+    uint32_t *v0 = (uint32_t *)(ws + c.vals0), *v1 = (uint32_t *)(ws + c.vals1);
+    uint32_t *counters = (uint32_t *)(ws + c.counters);
+    StageTimer tm;
+    tm.begin(p.timing, s);
+    GSX_HIP(hipMemsetAsync(counters, 0, 64, s));
+    GSX_HIP(hipMemsetAsync(ws + c.counts + (size_t)n * 4, 0, 4, s));
+    GSX_HIP(gsx::launch_depth_keys(*camera, means3d, n, k0, v0, counters, s));
+    GSX_HIP(gsx::sort_pairs(ws + c.temp, c.temp_bytes, k0, k1, v0, v1, n, 32, s));
+    tm.mark();  // 1: depth keys + sort
+    gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
+    GSX_HIP(gsx::launch_project_pack(*camera, in, k0, v0, n, p.grid, p.semantics, (gsx::Record *)(ws + c.rec),
+                                     (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts), s));
+    tm.mark();  // 2: project
+    return bin_and_blend(p, c, ws, n, cap, -1, stats_host, tm, s);
+}
+
+int gsx_project_points(const GsxCamera *camera, const float *means3d, int64_t n, float *points_out,
+                       uint8_t *in_view_out, void *stream) {
+    if (!camera) return fail(GSX_ERR_INVALID_ARGUMENT, "camera is NULL");
+    if (n < 0) return fail(GSX_ERR_INVALID_ARGUMENT, "n is negative");
+    if (n > 0 && (!means3d || !points_out || !in_view_out)) return fail(GSX_ERR_INVALID_ARGUMENT, "an array is NULL");
+    GSX_HIP(gsx::launch_project_points(*camera, means3d, n, points_out, in_view_out, (hipStream_t)stream));
+    return GSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,318 @@
+// Stage 1 on gfx950: 3D -> 2D EWA projection, conic, extent, bounding box, tile rectangle.
+//
+// THIS TRANSLATION UNIT IS COMPILED WITH -ffp-contract=off.  The float32 operation order below
+// is the contract shared with the CPU restatement used by the parity tests: with no FMA
+// formed and correctly rounded divide/sqrt (hipcc's default for HIP), view depth, radius and
+// bounding box -- the quantities whose rounding decides sort order and tile membership -- come
+// out bit-identical on both sides.
+//
+// Reference behaviour restated here (paths relative to the reference repository):
+//   splat/gaussian_scene.py:70-144  preprocess
+//   splat/gaussians.py:54-69        Sigma = (R S)(R S)^T
+//   splat/utils.py:132-155          quaternion -> rotation (normalises again)
+//   splat/utils.py:293-310          z_view >= 0.2 cull
+//   splat/utils.py:313-317          NDC -> pixel, (v + 1)(dim - 1)/2
+//   splat/utils.py:320-354          EWA 2D covariance, clamp at 1.3 tan(fov/2)
+//   splat/utils.py:368-393          inverse with determinant floored at 1e-3
+//   splat/utils.py:409-423          r = ceil(3 sqrt(lambda_max)), discriminant floored at 0.1
+//   splat/gaussian_scene.py:209-217 tile membership test (min <= x0 + T and max >= x0)
+#include "gsx_internal.h"
+
+namespace gsx {
+namespace {
+
+constexpr int kBlock = 256;
+
+struct Projected {
+    float x, y;            // pixel position
+    float ca, cb, cc, cd;  // 2D covariance [[ca, cb], [cc, cd]]
+    float q00, q01, q10, q11;
+    float radius, depth;
+    float min_x, max_x, min_y, max_y;
+};
+
+// Column `col` of [p,1] @ M, accumulated left to right.
+__device__ __forceinline__ float row4(float p0, float p1, float p2, const float *M, int col) {
+    return ((p0 * M[0 + col] + p1 * M[4 + col]) + p2 * M[8 + col]) + M[12 + col];
+}
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// Everything of stage 1 for one visible Gaussian.  Rows 2 of J (all zero) and the structural
+// zeros J01, J10 are skipped: adding an exact zero does not change a float32 sum.
+__device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1, float p2, float tz,
+                                        float s0, float s1, float s2, float qw, float qx, float qy, float qz,
+                                        Projected &o) {
+    const float *V = cam.world2view, *F = cam.full_proj;
+    // Sigma3D
+    float n1 = sqrtf(((qw * qw + qx * qx) + qy * qy) + qz * qz);
+    n1 = fmaxf(n1, 1e-12f);
+    float a0 = qw / n1, a1 = qx / n1, a2 = qy / n1, a3 = qz / n1;
+    float n2 = sqrtf(((a0 * a0 + a1 * a1) + a2 * a2) + a3 * a3);
+    float w = a0 / n2, x = a1 / n2, y = a2 / n2, z = a3 / n2;
+    float R[3][3];
+    R[0][0] = 1.0f - 2.0f * (y * y + z * z);
+    R[0][1] = 2.0f * (x * y - w * z);
+    R[0][2] = 2.0f * (x * z + w * y);
+    R[1][0] = 2.0f * (x * y + w * z);
+    R[1][1] = 1.0f - 2.0f * (x * x + z * z);
+    R[1][2] = 2.0f * (y * z - w * x);
+    R[2][0] = 2.0f * (x * z - w * y);
+    R[2][1] = 2.0f * (y * z + w * x);
+    R[2][2] = 1.0f - 2.0f * (x * x + y * y);
+    float M[3][3], S[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        M[i][0] = R[i][0] * s0;
+        M[i][1] = R[i][1] * s1;
+        M[i][2] = R[i][2] * s2;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) S[i][j] = (M[i][0] * M[j][0] + M[i][1] * M[j][1]) + M[i][2] * M[j][2];
+
+    // pixel position
+    float cw = row4(p0, p1, p2, F, 3);
+    float ndcx = row4(p0, p1, p2, F, 0) / cw;
+    float ndcy = row4(p0, p1, p2, F, 1) / cw;
+    o.x = (ndcx + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
+    o.y = (ndcy + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
+
+    // EWA
+    float tx = row4(p0, p1, p2, V, 0), ty = row4(p0, p1, p2, V, 1);
+    float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
+    float cx = fminf(fmaxf(tx / tz, -limx), limx) * tz;
+    float cy = fminf(fmaxf(ty / tz, -limy), limy) * tz;
+    float j00 = cam.fx / tz;
+    float j02 = -(cam.fx * cx) / (tz * tz);
+    float j11 = cam.fy / tz;
+    float j12 = -(cam.fy * cy) / (tz * tz);
+    // A = J @ Wm, Wm[i][j] = V[j*4+i]
+    float A[2][3], B[2][3], C[2][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        A[0][j] = j00 * V[j * 4 + 0] + j02 * V[j * 4 + 2];
+        A[1][j] = j11 * V[j * 4 + 1] + j12 * V[j * 4 + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) B[i][j] = (A[i][0] * S[0][j] + A[i][1] * S[1][j]) + A[i][2] * S[2][j];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[i][j] = (B[i][0] * V[0 * 4 + j] + B[i][1] * V[1 * 4 + j]) + B[i][2] * V[2 * 4 + j];
+    o.ca = C[0][0] * j00 + C[0][2] * j02;
+    o.cb = C[0][1] * j11 + C[0][2] * j12;
+    o.cc = C[1][0] * j00 + C[1][2] * j02;
+    o.cd = C[1][1] * j11 + C[1][2] * j12;
+
+    float det = o.ca * o.cd - o.cb * o.cc;
+    det = fmaxf(det, 1e-3f);
+    o.q00 = o.cd / det;
+    o.q01 = -o.cb / det;
+    o.q10 = -o.cc / det;
+    o.q11 = o.ca / det;
+
+    float mid = 0.5f * (o.ca + o.cd);
+    float det2 = o.ca * o.cd - o.cb * o.cb;
+    float m = fmaxf(mid * mid - det2, 0.1f);
+    float root = sqrtf(m);
+    float lam = fmaxf(mid + root, mid - root);
+    o.radius = ceilf(3.0f * sqrtf(lam));
+    o.depth = tz;
+    o.min_x = floorf(o.x - o.radius);
+    o.max_x = ceilf(o.x + o.radius);
+    o.min_y = floorf(o.y - o.radius);
+    o.max_y = ceilf(o.y + o.radius);
+}
+
+// Tile index range along one axis for the reference's test `mn <= t*T + T and mx >= t*T`
+// (gaussian_scene.py:209-217), clamped to the window [w0, w1).  Exact for every finite input;
+// NaN compares false in the reference, i.e. the Gaussian is in no tile.
+__device__ __forceinline__ void axis_range(float mn, float mx, int T, int w0, int w1, int &lo, int &hi) {
+    if (!(mn == mn) || !(mx == mx)) {
+        lo = 1;
+        hi = 0;
+        return;
+    }
+    const float big = 1073741824.0f;  // 2^30
+    int imn = (int)ceilf(fminf(fmaxf(mn, -big), big));
+    int imx = (int)floorf(fminf(fmaxf(mx, -big), big));
+    // smallest t with t*T + T >= imn  <=>  t >= (imn - T) / T ; largest t with t*T <= imx
+    int a = imn - T;
+    lo = a >= 0 ? (a + T - 1) / T : -((-a) / T);
+    hi = imx >= 0 ? imx / T : -((-imx + T - 1) / T);
+    lo = lo < w0 ? w0 : lo;
+    hi = hi > w1 - 1 ? w1 - 1 : hi;
+}
+
+__device__ __forceinline__ uint32_t tile_rect(float mnx, float mxx, float mny, float mxy, const TileGrid &g,
+                                              TileRect &r) {
+    int lx, hx, ly, hy;
+    axis_range(mnx, mxx, g.tile, g.wx0, g.wx1, lx, hx);
+    axis_range(mny, mxy, g.tile, g.wy0, g.wy1, ly, hy);
+    if (lx > hx || ly > hy) {
+        r.x0 = 1; r.x1 = 0; r.y0 = 1; r.y1 = 0;
+        return 0u;
+    }
+    r.x0 = (uint16_t)lx; r.x1 = (uint16_t)hx; r.y0 = (uint16_t)ly; r.y1 = (uint16_t)hy;
+    return (uint32_t)(hx - lx + 1) * (uint32_t)(hy - ly + 1);
+}
+
+// ------------------------------------------------------------------------------------ kernels
+
+// One thread per Gaussian: view depth -> sortable key.  z >= 0.2 > 0, so the IEEE bits of z are
+// monotone in z; culled Gaussians get the largest key and sort to the end.
+__global__ void __launch_bounds__(kBlock) depth_keys_kernel(GsxCamera cam, const float *__restrict__ means3d,
+                                                            int64_t n, uint32_t *__restrict__ keys,
+                                                            uint32_t *__restrict__ vals,
+                                                            uint32_t *__restrict__ n_visible) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool vis = false;
+    if (i < n) {
+        float tz = row4(means3d[3 * i], means3d[3 * i + 1], means3d[3 * i + 2], cam.world2view, 2);
+        vis = tz >= 0.2f;
+        keys[i] = vis ? __float_as_uint(tz) : kCulledKey;
+        vals[i] = (uint32_t)i;
+    }
+    unsigned long long m = __ballot(vis);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_visible, (uint32_t)__popcll(m));
+}
+
+// One thread per depth rank: gather the Gaussian, project it, write the compositing record, its
+// tile rectangle and tile count.
+__global__ void __launch_bounds__(kBlock)
+    project_pack_kernel(GsxCamera cam, GaussiansIn in, const uint32_t *__restrict__ sorted_keys,
+                        const uint32_t *__restrict__ sorted_idx, int64_t n, TileGrid grid, int semantics,
+                        Record *__restrict__ rec, TileRect *__restrict__ rect, uint32_t *__restrict__ counts) {
+    int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    uint32_t key = sorted_keys[r];
+    if (key == kCulledKey) {
+        TileRect e;
+        e.x0 = 1; e.x1 = 0; e.y0 = 1; e.y1 = 0;
+        rect[r] = e;
+        counts[r] = 0u;
+        return;
+    }
+    int64_t g = sorted_idx[r];
+    const float *p = in.means3d + 3 * g, *s = in.scales + 3 * g, *q = in.quats + 4 * g, *c = in.colors + 3 * g;
+    Projected o;
+    project(cam, p[0], p[1], p[2], __uint_as_float(key), s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
+    float op = sigmoidf(in.opacity_logit[g]);                  // gaussian_scene.py:143
+    if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);       // gaussian_scene.py:164 (second sigmoid)
+    Record out;
+    out.a = make_float4(o.x, o.y, o.q00, o.q01);
+    out.b = make_float4(o.q10, o.q11, op, o.radius);
+    out.c = make_float4(c[0], c[1], c[2], o.depth);
+    rec[r] = out;
+    TileRect tr;
+    counts[r] = tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, tr);
+    rect[r] = tr;
+}
+
+// Same projection, all PreprocessedScene fields (the reference's stage-1 API surface).
+__global__ void __launch_bounds__(kBlock)
+    project_full_kernel(GsxCamera cam, GaussiansIn in, const uint32_t *__restrict__ sorted_keys,
+                        const uint32_t *__restrict__ sorted_idx, int64_t n, StageOneOut out) {
+    int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    uint32_t key = sorted_keys[r];
+    if (key == kCulledKey) return;
+    int64_t g = sorted_idx[r];
+    const float *p = in.means3d + 3 * g, *s = in.scales + 3 * g, *q = in.quats + 4 * g, *c = in.colors + 3 * g;
+    Projected o;
+    project(cam, p[0], p[1], p[2], __uint_as_float(key), s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
+    out.points_xy[2 * r] = o.x;
+    out.points_xy[2 * r + 1] = o.y;
+    out.colors[3 * r] = c[0];
+    out.colors[3 * r + 1] = c[1];
+    out.colors[3 * r + 2] = c[2];
+    out.cov2d[4 * r] = o.ca; out.cov2d[4 * r + 1] = o.cb; out.cov2d[4 * r + 2] = o.cc; out.cov2d[4 * r + 3] = o.cd;
+    out.depths[r] = o.depth;
+    out.inv_cov[4 * r] = o.q00; out.inv_cov[4 * r + 1] = o.q01; out.inv_cov[4 * r + 2] = o.q10; out.inv_cov[4 * r + 3] = o.q11;
+    out.radius[r] = o.radius;
+    out.min_x[r] = o.min_x; out.max_x[r] = o.max_x; out.min_y[r] = o.min_y; out.max_y[r] = o.max_y;
+    out.sig_op[r] = sigmoidf(in.opacity_logit[g]);
+    if (out.order) out.order[r] = (int32_t)g;
+}
+
+// Stage-1 arrays handed in by the caller (the reference's native argument list) -> records.
+__global__ void __launch_bounds__(kBlock)
+    pack_preprocessed_kernel(PreprocessedIn in, int64_t n, TileGrid grid, int semantics, Record *__restrict__ rec,
+                             TileRect *__restrict__ rect, uint32_t *__restrict__ counts) {
+    int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    float op = in.opacity[r];
+    if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);
+    float mnx = in.min_x[r], mxx = in.max_x[r], mny = in.min_y[r], mxy = in.max_y[r];
+    Record out;
+    out.a = make_float4(in.means[2 * r], in.means[2 * r + 1], in.inv_cov[4 * r], in.inv_cov[4 * r + 1]);
+    out.b = make_float4(in.inv_cov[4 * r + 2], in.inv_cov[4 * r + 3], op, 0.5f * (mxx - mnx));
+    out.c = make_float4(in.colors[3 * r], in.colors[3 * r + 1], in.colors[3 * r + 2], 0.0f);
+    rec[r] = out;
+    TileRect tr;
+    counts[r] = tile_rect(mnx, mxx, mny, mxy, grid, tr);
+    rect[r] = tr;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    project_points_kernel(GsxCamera cam, const float *__restrict__ means3d, int64_t n, float *__restrict__ pts,
+                          uint8_t *__restrict__ in_view) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float p0 = means3d[3 * i], p1 = means3d[3 * i + 1], p2 = means3d[3 * i + 2];
+    float tz = row4(p0, p1, p2, cam.world2view, 2);
+    const float *F = cam.full_proj;
+    float cw = row4(p0, p1, p2, F, 3);
+    float nx = row4(p0, p1, p2, F, 0) / cw, ny = row4(p0, p1, p2, F, 1) / cw, nz = row4(p0, p1, p2, F, 2) / cw;
+    pts[3 * i] = (nx + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
+    pts[3 * i + 1] = (ny + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
+    pts[3 * i + 2] = nz;
+    in_view[i] = tz >= 0.2f ? 1 : 0;
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+hipError_t launch_depth_keys(const GsxCamera &cam, const float *means3d, int64_t n, uint32_t *keys,
+                             uint32_t *vals, uint32_t *n_visible, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    depth_keys_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, means3d, n, keys, vals, n_visible);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_pack(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
+                               const uint32_t *sorted_idx, int64_t n, const TileGrid &grid, int semantics,
+                               Record *rec, TileRect *rect, uint32_t *counts, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    project_pack_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, sorted_keys, sorted_idx, n, grid, semantics, rec,
+                                                         rect, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
+                               const uint32_t *sorted_idx, int64_t n, const StageOneOut &out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    project_full_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, sorted_keys, sorted_idx, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_preprocessed(const PreprocessedIn &in, int64_t n, const TileGrid &grid, int semantics,
+                                    Record *rec, TileRect *rect, uint32_t *counts, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    pack_preprocessed_kernel<<<blocks_for(n), kBlock, 0, s>>>(in, n, grid, semantics, rec, rect, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_points(const GsxCamera &cam, const float *means3d, int64_t n, float *points_out,
+                                 uint8_t *in_view, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    project_points_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, means3d, n, points_out, in_view);
+    return hipGetLastError();
+}
+
+}  // namespace gsx

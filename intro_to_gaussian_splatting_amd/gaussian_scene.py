@@ -1,0 +1,243 @@
+"""``GaussianScene``: the reference's render surface (splat/gaussian_scene.py:25-285) on MI355X.
+
+Host code stays Python and PyTorch-ROCm tensors hold the Gaussian parameters; every stage of
+the hot path -- projection, depth ordering, tile binning, compositing -- runs in libgsx.so (HIP,
+gfx950) through the C ABI of include/gsx.h.  There is no CPU path in this module: without the
+library or without a GPU the render methods raise.
+
+Surface kept from the reference:
+  ``GaussianScene(colmap_path, gaussians)``, ``.images[idx]``, ``.gaussians``,
+  ``.preprocess(idx) -> PreprocessedScene``            (gaussian_scene.py:70-144)
+  ``.render_image(idx, tile_size=16) -> (W,H,3)``      (gaussian_scene.py:200-238, CPU semantics)
+  ``.render_points_image(idx)``                        (gaussian_scene.py:44-51)
+Added: ``.render_image_hip`` (explicit layout / tile window / stats), ``.render_preprocessed``
+(the argument list of the reference's native ``render_image``, splat/c/render.cu:90-101).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _ffi
+from .colmap import read_camera_file, read_image_file
+from .gaussians import Gaussians
+from .image import GaussianImage
+from .schema import PreprocessedScene
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _check_f32(name: str, t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    if t.device != device:
+        raise ValueError("%s is on %s, expected %s" % (name, t.device, device))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Workspace:
+    """Caller-owned device scratch for libgsx (the library never allocates)."""
+
+    def __init__(self) -> None:
+        self.buffers: Dict[torch.device, torch.Tensor] = {}
+
+    def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
+        buf = self.buffers.get(device)
+        if buf is None or buf.numel() < nbytes:
+            self.buffers[device] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return buf
+
+
+_WORKSPACE = _Workspace()
+
+
+def _stream_handle(device: torch.device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu(device: torch.device) -> None:
+    if device.type != "cuda":
+        raise RuntimeError(
+            "the Gaussian tensors are on %s: this renderer runs only as HIP kernels on an AMD GPU "
+            "(torch device 'cuda'); there is no CPU fallback" % device)
+
+
+def render_preprocessed(height: int, width: int, tile_size: int, point_means: torch.Tensor,
+                        point_colors: torch.Tensor, inverse_covariance_2d: torch.Tensor, min_x: torch.Tensor,
+                        max_x: torch.Tensor, min_y: torch.Tensor, max_y: torch.Tensor, opacity: torch.Tensor,
+                        layout: str = "wh3", instances_hint: int = 0,
+                        stats: Optional[dict] = None) -> torch.Tensor:
+    """Stage 2 on depth-sorted stage-1 arrays: the reference's native entry point
+    ``render_image(image_height, image_width, tile_size, point_means, point_colors,
+    inverse_covariance_2d, min_x, max_x, min_y, max_y, opacity)`` (splat/c/render.cu:90-101) with the
+    CPU path's compositing semantics.  Returns (W,H,3) for layout "wh3", (H,W,3) for "hw3"."""
+    lib = _ffi.load()
+    dev = point_means.device
+    _require_gpu(dev)
+    n = int(point_means.shape[0])
+    args = [_check_f32(k, v, dev) for k, v in (
+        ("point_means", point_means), ("point_colors", point_colors),
+        ("inverse_covariance_2d", inverse_covariance_2d), ("min_x", min_x), ("max_x", max_x),
+        ("min_y", min_y), ("max_y", max_y), ("opacity", opacity))]
+    params = _ffi.default_params()
+    params.layout = _ffi.GSX_LAYOUT_WH3 if layout == "wh3" else _ffi.GSX_LAYOUT_HW3
+    shape = (width, height, 3) if layout == "wh3" else (height, width, 3)
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    st = _ffi.GsxFrameStats()
+    cap = max(int(instances_hint), 8 * n + 4096)
+    with torch.cuda.device(dev):
+        for _ in range(3):
+            nbytes = lib.gsx_workspace_bytes(n, width, height, tile_size, cap)
+            if nbytes == 0:
+                raise _ffi.GsxError(_ffi.GSX_ERR_INVALID_ARGUMENT, "gsx_workspace_bytes rejected the sizes")
+            ws = _WORKSPACE.get(dev, nbytes)
+            rc = lib.gsx_render_preprocessed(height, width, tile_size, *[_ptr(a) for a in args], n, _ptr(out),
+                                             ctypes.byref(params), ctypes.byref(st), _ptr(ws), ws.numel(),
+                                             _stream_handle(dev))
+            if rc != _ffi.GSX_ERR_WORKSPACE_TOO_SMALL:
+                break
+            cap = int(st.n_instances * 1.25) + 4096
+    _ffi.check(rc)
+    if stats is not None:
+        stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles)
+    return out
+
+
+class GaussianScene:
+    def __init__(self, colmap_path: str, gaussians: Gaussians) -> None:
+        cameras = read_camera_file(colmap_path)
+        images = read_image_file(colmap_path)
+        self.images: Dict[int, GaussianImage] = {}
+        for idx, image in images.items():
+            self.images[idx] = GaussianImage(camera=cameras[image.camera_id], image=image,
+                                             device=gaussians.device)
+        self.gaussians = gaussians
+        self._instances_hint = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _inputs(self):
+        g = self.gaussians
+        dev = g.points.device
+        _require_gpu(dev)
+        n = int(g.points.shape[0])
+        tensors = [
+            _check_f32("points", g.points.reshape(n, 3), dev),
+            _check_f32("scales", g.scales.reshape(n, 3), dev),
+            _check_f32("quaternions", g.quaternions.reshape(n, 4), dev),
+            _check_f32("opacity", g.opacity.reshape(n, 1), dev),
+            _check_f32("colors", g.colors.reshape(n, 3), dev),
+        ]
+        return dev, n, tensors
+
+    # ------------------------------------------------------------------ stage 1
+    def preprocess(self, image_idx: int) -> PreprocessedScene:
+        """Projection + depth sort on the GPU (gsx_preprocess); fields as splat/schema.py:13-25."""
+        lib = _ffi.load()
+        dev, n, tensors = self._inputs()
+        cam = self.images[image_idx].gsx_camera()
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        xy, col, c2, dep, inv, rad = f(n, 2), f(n, 3), f(n, 2, 2), f(n), f(n, 2, 2), f(n)
+        mnx, mxx, mny, mxy, sop = f(n), f(n), f(n), f(n), f(n, 1)
+        order = torch.empty(n, dtype=torch.int32, device=dev)
+        nvis = ctypes.c_int64(0)
+        with torch.cuda.device(dev):
+            nbytes = lib.gsx_workspace_bytes(n, cam.width, cam.height, 16, 1)
+            ws = _WORKSPACE.get(dev, nbytes)
+            rc = lib.gsx_preprocess(ctypes.byref(cam), *[_ptr(t) for t in tensors], n,
+                                    *[_ptr(t) for t in (xy, col, c2, dep, inv, rad, mnx, mxx, mny, mxy, sop)],
+                                    _ptr(order), ctypes.byref(nvis), None, _ptr(ws), ws.numel(), _stream_handle(dev))
+        _ffi.check(rc)
+        m = nvis.value
+        self.last_order = order[:m]
+        return PreprocessedScene(points=xy[:m], colors=col[:m], covariance_2d=c2[:m], depths=dep[:m],
+                                 inverse_covariance_2d=inv[:m], radius=rad[:m], points_xy=xy[:m],
+                                 min_x=mnx[:m], min_y=mny[:m], max_x=mxx[:m], max_y=mxy[:m],
+                                 sigmoid_opacity=sop[:m])
+
+    # ------------------------------------------------------------------ whole path
+    def render_image_hip(self, image_idx: int, tile_size: int = 16, layout: str = "wh3",
+                         tile_window: Optional[Tuple[int, int, int, int]] = None,
+                         out: Optional[torch.Tensor] = None, out_origin: Tuple[int, int] = (0, 0),
+                         stats: Optional[dict] = None, timing: bool = False) -> torch.Tensor:
+        """Full forward render in libgsx (gsx_render_forward).
+
+        layout "wh3" -> (W,H,3) indexed [x,y] like ``render_image``; "hw3" -> (H,W,3).
+        tile_window (tx0,tx1,ty0,ty1) renders only those tiles (row/column strips for multi-GPU);
+        ``out`` may then be a strip-sized buffer whose pixel (0,0) is frame pixel ``out_origin``.
+        ``timing`` asks the library for per-stage HIP-event times (``stats["stage_ms"]``); the call
+        then waits for the frame.
+        """
+        lib = _ffi.load()
+        dev, n, tensors = self._inputs()
+        cam = self.images[image_idx].gsx_camera()
+        width, height = cam.width, cam.height
+        params = _ffi.default_params()
+        params.layout = _ffi.GSX_LAYOUT_WH3 if layout == "wh3" else _ffi.GSX_LAYOUT_HW3
+        if timing:
+            params.flags |= _ffi.GSX_FLAG_TIMING
+        if tile_window is not None:
+            params.tile_x0, params.tile_x1, params.tile_y0, params.tile_y1 = [int(v) for v in tile_window]
+        if out is None:
+            shape = (width, height, 3) if layout == "wh3" else (height, width, 3)
+            out = torch.empty(shape, dtype=torch.float32, device=dev)
+        else:
+            _check_f32("out", out, dev)
+            if not out.is_contiguous():
+                raise ValueError("out must be contiguous")
+            ow, oh = (out.shape[0], out.shape[1]) if layout == "wh3" else (out.shape[1], out.shape[0])
+            params.out_x0, params.out_y0, params.out_w, params.out_h = int(out_origin[0]), int(out_origin[1]), int(ow), int(oh)
+        st = _ffi.GsxFrameStats()
+        cap = max(self._instances_hint, 8 * n + 4096)
+        with torch.cuda.device(dev):
+            for _ in range(3):
+                nbytes = lib.gsx_workspace_bytes(n, width, height, tile_size, cap)
+                if nbytes == 0:
+                    raise _ffi.GsxError(_ffi.GSX_ERR_INVALID_ARGUMENT, "gsx_workspace_bytes rejected the sizes")
+                ws = _WORKSPACE.get(dev, nbytes)
+                rc = lib.gsx_render_forward(ctypes.byref(cam), *[_ptr(t) for t in tensors], n, tile_size, _ptr(out),
+                                            ctypes.byref(params), ctypes.byref(st), _ptr(ws), ws.numel(),
+                                            _stream_handle(dev))
+                if rc != _ffi.GSX_ERR_WORKSPACE_TOO_SMALL:
+                    break
+                cap = int(st.n_instances * 1.25) + 4096
+        _ffi.check(rc)
+        self._instances_hint = max(self._instances_hint, int(st.n_instances * 1.1))
+        if stats is not None:
+            stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles)
+            if timing:
+                stats["stage_ms"] = {k: float(st.stage_ms[i]) for i, k in enumerate(_ffi.STAGE_NAMES)}
+        return out
+
+    def render_image(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:
+        """(W,H,3) float32 indexed [x,y]; same result as the reference's pure-Python
+        ``render_image`` (gaussian_scene.py:200-238), computed on the GPU."""
+        return self.render_image_hip(image_idx, tile_size=tile_size, layout="wh3")
+
+    render = render_image  # the name BASELINE.json's north star uses
+
+    def render_preprocessed(self, image_idx: int, pre: PreprocessedScene, tile_size: int = 16,
+                            layout: str = "wh3", stats: Optional[dict] = None) -> torch.Tensor:
+        cam = self.images[image_idx].gsx_camera()
+        return render_preprocessed(cam.height, cam.width, tile_size, pre.points, pre.colors,
+                                   pre.inverse_covariance_2d, pre.min_x, pre.max_x, pre.min_y, pre.max_y,
+                                   pre.sigmoid_opacity, layout=layout, stats=stats)
+
+    # ------------------------------------------------------------------ debug helper
+    def render_points_image(self, image_idx: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Projected (x_pix, y_pix, ndc_z) of the in-view points and their colours
+        (gaussian_scene.py:44-51, image.py:72-89)."""
+        lib = _ffi.load()
+        dev, n, tensors = self._inputs()
+        cam = self.images[image_idx].gsx_camera()
+        pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        vis = torch.empty(n, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.gsx_project_points(ctypes.byref(cam), _ptr(tensors[0]), n, _ptr(pts), _ptr(vis),
+                                        _stream_handle(dev))
+        _ffi.check(rc)
+        keep = vis.bool()
+        return pts[keep], self.gaussians.colors[keep]

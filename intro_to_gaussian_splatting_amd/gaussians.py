@@ -1,0 +1,51 @@
+"""Gaussian parameter container with the reference's attribute layout (splat/gaussians.py:9-33).
+
+``points (N,3)``, ``colors (N,3)`` = rgb/256, ``scales (N,3)`` linear (no exp), ``quaternions
+(N,4)`` (w,x,y,z), ``opacity (N,1)`` logit -- float32 PyTorch-ROCm tensors resident in HBM.
+Differences from the reference, on purpose: the constructor has no file side effect (the
+reference writes ``point_cloud.ply``, gaussians.py:17-18) and never tracks gradients (the
+reference's path is forward-only).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+
+class Gaussians:
+    def __init__(self, points: torch.Tensor, colors: torch.Tensor, model_path: str = ".",
+                 device: Optional[str] = None) -> None:
+        dev = torch.device(device) if device is not None else torch.device(
+            "cuda" if torch.cuda.is_available() else "cpu")
+        self.device = dev
+        self.model_path = model_path
+        n = points.shape[0]
+        f32 = torch.float32
+        self.points = torch.as_tensor(points).detach().to(dev, f32).contiguous()
+        self.colors = (torch.as_tensor(colors).detach().to(f32) / 256).to(dev).contiguous()
+        self.scales = torch.full((n, 3), 0.001, dtype=f32, device=dev)          # gaussians.py:23
+        self.quaternions = torch.zeros((n, 4), dtype=f32, device=dev)           # gaussians.py:29-30
+        self.quaternions[:, 0] = 1.0
+        p = 0.9999 * torch.ones((n, 1), dtype=f32)                             # gaussians.py:31-33
+        self.opacity = torch.log(p / (1 - p)).to(dev)
+
+    def __len__(self) -> int:
+        return int(self.points.shape[0])
+
+    def to(self, device) -> "Gaussians":
+        dev = torch.device(device)
+        for name in ("points", "colors", "scales", "quaternions", "opacity"):
+            setattr(self, name, getattr(self, name).to(dev).contiguous())
+        self.device = dev
+        return self
+
+    @classmethod
+    def from_arrays(cls, points, colors_0_255, scales, quaternions, opacity_logit, device=None) -> "Gaussians":
+        """Builds a container and overwrites the constructor's defaults with explicit values."""
+        g = cls(torch.as_tensor(points), torch.as_tensor(colors_0_255), device=device)
+        f32 = torch.float32
+        g.scales = torch.as_tensor(scales).to(g.device, f32).reshape(-1, 3).contiguous()
+        g.quaternions = torch.as_tensor(quaternions).to(g.device, f32).reshape(-1, 4).contiguous()
+        g.opacity = torch.as_tensor(opacity_logit).to(g.device, f32).reshape(-1, 1).contiguous()
+        return g

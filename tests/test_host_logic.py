@@ -1,0 +1,118 @@
+"""Host-side Python of the package: camera constants, COLMAP reader, containers, generator,
+strip plan.  CPU only; nothing here renders."""
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians, colmap, strips
+from intro_to_gaussian_splatting_amd.image import GaussianImage
+from intro_to_gaussian_splatting_amd.synthetic import make_scene, write_colmap_text
+
+
+def _camera_from_fixture(g):
+    cam = colmap.Camera(1, "PINHOLE", int(g["width"]), int(g["height"]),
+                        np.array([float(g["fx"]), float(g["fy"]), float(g["cx"]), float(g["cy"])]))
+    img = colmap.Image(1, np.asarray(g["qvec"]), np.asarray(g["tvec"]), 1, "x.jpg")
+    return GaussianImage(cam, img, device="cpu")
+
+
+def test_camera_constants_bit_equal_to_reference(golden):
+    g = golden
+    im = _camera_from_fixture(g)
+    assert np.array_equal(im.world2view.numpy(), g["world2view"])
+    assert np.array_equal(im.projection_matrix.numpy(), g["projection_matrix"])
+    assert np.array_equal(im.full_proj_transform.numpy(), g["full_proj_transform"])
+    assert np.array_equal(im.tan_fovX.numpy(), g["tan_fovX"]) and np.array_equal(im.tan_fovY.numpy(), g["tan_fovY"])
+    assert np.array_equal(im.f_x.numpy(), g["f_x"]) and np.array_equal(im.f_y.numpy(), g["f_y"])
+    c = im.gsx_camera()
+    assert np.array_equal(np.array(c.world2view[:], np.float32), g["world2view"].reshape(-1))
+    assert np.array_equal(np.array(c.full_proj[:], np.float32), g["full_proj_transform"].reshape(-1))
+    assert (c.width, c.height) == (int(g["width"]), int(g["height"]))
+    assert np.float32(c.tan_fovx) == g["tan_fovX"][0] and np.float32(c.fx) == g["f_x"][0]
+
+
+def test_colmap_text_and_binary_readers_agree(tmp_path):
+    sc = make_scene(10, 320, 200, seed=1)
+    txt = tmp_path / "txt"
+    write_colmap_text(str(txt), sc, image_id=7, name="frame.jpg")
+    cams, imgs = colmap.read_camera_file(str(txt)), colmap.read_image_file(str(txt))
+    assert cams[1].model == "PINHOLE" and (cams[1].width, cams[1].height) == (320, 200)
+    assert np.allclose(cams[1].params, [240.0, 240.0, 160.0, 100.0])
+    assert imgs[7].name == "frame.jpg" and imgs[7].camera_id == 1
+    assert np.array_equal(imgs[7].qvec, sc["qvec"]) and np.array_equal(imgs[7].tvec, sc["tvec"])
+    # the same model in COLMAP's binary format (cameras.bin / images.bin take precedence)
+    b = tmp_path / "bin"
+    os.makedirs(b)
+    with open(b / "cameras.bin", "wb") as f:
+        f.write(struct.pack("<Q", 1))
+        f.write(struct.pack("<iiQQ", 1, 1, 320, 200))
+        f.write(struct.pack("<dddd", 240.0, 240.0, 160.0, 100.0))
+    with open(b / "images.bin", "wb") as f:
+        f.write(struct.pack("<Q", 1))
+        f.write(struct.pack("<idddddddi", 7, *sc["qvec"], *sc["tvec"], 1))
+        f.write(b"frame.jpg\x00")
+        f.write(struct.pack("<Q", 2))
+        f.write(struct.pack("<ddqddq", 1.0, 2.0, -1, 3.0, 4.0, 5))
+    cams_b, imgs_b = colmap.read_camera_file(str(b)), colmap.read_image_file(str(b))
+    assert cams_b[1].model == cams[1].model and np.array_equal(cams_b[1].params, cams[1].params)
+    assert imgs_b[7].name == "frame.jpg" and np.array_equal(imgs_b[7].qvec, imgs[7].qvec)
+    with pytest.raises(ValueError):
+        colmap.read_camera_file(str(tmp_path / "nothing"))
+
+
+def test_gaussians_defaults_follow_the_reference():
+    pts = torch.rand(5, 3)
+    rgb = torch.tensor([[0.0, 128.0, 255.0]] * 5)
+    g = Gaussians(pts, rgb, device="cpu")
+    assert g.points.dtype == torch.float32 and g.colors.shape == (5, 3)
+    assert torch.equal(g.colors[0], torch.tensor([0.0, 0.5, 255.0 / 256.0]))
+    assert torch.all(g.scales == 0.001) and g.scales.shape == (5, 3)
+    assert torch.equal(g.quaternions, torch.tensor([[1.0, 0, 0, 0]] * 5))
+    assert g.opacity.shape == (5, 1)
+    assert abs(torch.sigmoid(g.opacity[0, 0]).item() - 0.9999) < 1e-6
+    assert len(g) == 5
+
+
+def test_scene_construction_and_cpu_tensors_are_rejected(tmp_path):
+    sc = make_scene(50, 64, 48, seed=2)
+    write_colmap_text(str(tmp_path), sc)
+    g = Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"], sc["opacity"],
+                              device="cpu")
+    scene = GaussianScene(str(tmp_path), g)
+    assert list(scene.images) == [1] and scene.gaussians is g
+    assert scene.images[1].width.item() == 64.0 and scene.images[1].name == "synthetic.jpg"
+    # the product path has no CPU fallback: CPU-resident Gaussians must raise, not render
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        scene.render_image(1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        scene.preprocess(1)
+
+
+def test_synthetic_generator_is_frozen():
+    a, b = make_scene(1000, 256, 256, seed=0), make_scene(1000, 256, 256, seed=0)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    g = load_golden("c1_256x256_n2000")
+    c = make_scene(2000, 256, 256, seed=0)
+    for k in ("points", "scales", "quaternions", "opacity", "colors_0_255"):
+        assert np.array_equal(c[k], g[k]), k   # the committed fixture came from this generator
+    d = make_scene(1000, 256, 256, seed=0, behind_fraction=0.3)
+    assert np.array_equal(d["scales"][:, 0] > 0, np.ones(1000, bool))
+
+
+def test_strip_plan_covers_every_tile_once():
+    for n_tiles in (0, 1, 2, 7, 67, 119, 239):
+        for world in (1, 2, 3, 4, 8):
+            per, plan = strips.strip_plan(n_tiles, world)
+            assert len(plan) == world
+            covered = [t for a, b in plan for t in range(a, b)]
+            assert covered == list(range(n_tiles))
+            assert all(b - a <= per for a, b in plan)
+            assert all(a == min(r * per, n_tiles) for r, (a, b) in enumerate(plan))
+    assert strips.tiles_along(1920, 16) == 119 and strips.tiles_along(1080, 16) == 67
+    assert strips.tiles_along(16, 16) == 0 and strips.tiles_along(17, 16) == 1
+    assert strips.tiles_along(3840, 16) == 239 and strips.tiles_along(2160, 16) == 134

@@ -1,0 +1,79 @@
+"""The N>1 path on CPU: two gloo ranks run the package's strip partition + frame gather
+(intro_to_gaussian_splatting_amd/strips.py) with the oracle standing in for the per-strip
+renderer, and the gathered frame must equal the single-process frame bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden_preprocessed, load_golden
+from intro_to_gaussian_splatting_amd import strips
+from oracle import c_oracle
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_strip_renderer(pre, width, height, tile, layout):
+    def render(window, out, origin):
+        img, _, _ = c_oracle.render(pre, width, height, tile, nthreads=1, window=window)   # (W,H,3)
+        if layout == "hw3":
+            img = np.ascontiguousarray(img.transpose(1, 0, 2))
+        lead0 = origin[0] if layout == "wh3" else origin[1]
+        out.copy_(torch.from_numpy(img[lead0:lead0 + out.shape[0]]))
+    return render
+
+
+def _worker(rank, world, port, name, layout, all_ranks, result_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden(name)
+        w, h, t = int(g["width"]), int(g["height"]), int(g["tile"])
+        fn = _oracle_strip_renderer(golden_preprocessed(g), w, h, t, layout)
+        frame = strips.render_sharded(fn, w, h, t, layout, torch.device("cpu"), all_ranks=all_ranks)
+        if frame is not None:
+            np.save(os.path.join(result_dir, "frame_%d.npy" % rank), frame.numpy())
+        else:
+            assert rank != 0 and not all_ranks
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,layout,all_ranks", [
+    ("c1_256x256_n2000", "wh3", False),
+    ("c1_256x256_n2000", "hw3", True),
+    ("cull_96x80_n400", "wh3", True),
+    ("small_64x48_n300", "hw3", False),
+])
+def test_two_rank_strips_equal_single_frame(tmp_path, name, layout, all_ranks):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), name, layout, all_ranks, str(tmp_path)), nprocs=world, join=True)
+    g = load_golden(name)
+    ref = g["image"] if layout == "wh3" else g["image"].transpose(1, 0, 2)
+    full, _, _ = c_oracle.render(golden_preprocessed(g), int(g["width"]), int(g["height"]), int(g["tile"]))
+    full = full if layout == "wh3" else full.transpose(1, 0, 2)
+    ranks = [0, 1] if all_ranks else [0]
+    for r in ranks:
+        frame = np.load(tmp_path / ("frame_%d.npy" % r))
+        assert frame.shape == ref.shape
+        assert np.array_equal(frame, full)                     # strips == one-process render, bit for bit
+        assert np.max(np.abs(frame - ref)) <= 1e-6             # and both match the reference's image
+    if not all_ranks:
+        assert not (tmp_path / "frame_1.npy").exists()
+
+
+def test_single_process_path_without_process_group():
+    g = load_golden("small_64x48_n300")
+    w, h, t = int(g["width"]), int(g["height"]), int(g["tile"])
+    fn = _oracle_strip_renderer(golden_preprocessed(g), w, h, t, "wh3")
+    frame = strips.render_sharded(fn, w, h, t, "wh3", torch.device("cpu"))
+    full, _, _ = c_oracle.render(golden_preprocessed(g), w, h, t)
+    assert np.array_equal(frame.numpy(), full)
