@@ -91,8 +91,8 @@ typedef struct GsxParams {
 
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
 enum {
-    GSX_STAGE_DEPTH_SORT = 0, /* depth keys + radix sort of N keys            */
-    GSX_STAGE_PROJECT = 1,    /* projection / record packing                    */
+    GSX_STAGE_PROJECT = 0,    /* projection, depth keys, record packing         */
+    GSX_STAGE_DEPTH_SORT = 1, /* stable sort of N depth keys                    */
     GSX_STAGE_SCAN = 2,       /* tile-count scan + the host read-back of D      */
     GSX_STAGE_BIN = 3,        /* frame clear, key emit, tile sort, tile ranges  */
     GSX_STAGE_BLEND = 4,      /* the compositing kernel alone                   */

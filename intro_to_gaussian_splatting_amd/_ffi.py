@@ -24,7 +24,7 @@ GSX_SEM_REF_CUDA = 1
 GSX_LAYOUT_WH3 = 0
 GSX_LAYOUT_HW3 = 1
 GSX_FLAG_TIMING = 1
-STAGE_NAMES = ("depth_sort", "project", "scan", "bin", "blend", "total")
+STAGE_NAMES = ("project", "depth_sort", "scan", "bin", "blend", "total")
 
 
 class GsxCamera(ctypes.Structure):

@@ -109,7 +109,7 @@ struct StageTimer {
         (void)hipEventRecord(ev[n], s);
         ++n;
     }
-    // marks: 0 start | 1 depth+sort | 2 project | 3 scan+readback | 4 bin | 5 blend
+    // marks: 0 start | 1 project (+keys) | 2 depth sort | 3 scan+readback | 4 bin | 5 blend
     void finish(GsxFrameStats *st) {
         if (n > 0) (void)hipEventSynchronize(ev[n - 1]);
         if (st) {
@@ -177,19 +177,14 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     return GSX_OK;
 }
 
-inline int key_bits_for(int64_t n_tiles) {
-    int b = 1;
-    while (((int64_t)1 << b) < n_tiles) ++b;
-    return b;
-}
-
 // Steps shared by both render entry points once records / rects / counts exist (rank order).
-int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t cap, int64_t n_visible_known,
-                  GsxFrameStats *stats, StageTimer &tm, hipStream_t s) {
+// `order` = Gaussian index of each depth rank (nullptr: rows are already in compositing order).
+int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t cap, const uint32_t *order,
+                  int64_t n_visible_known, GsxFrameStats *stats, StageTimer &tm, hipStream_t s) {
     uint32_t *counts = (uint32_t *)(ws + c.counts), *offsets = (uint32_t *)(ws + c.offsets);
     uint32_t *counters = (uint32_t *)(ws + c.counters);
     void *temp = ws + c.temp;
-    GSX_HIP(gsx::scan_counts(temp, c.temp_bytes, counts, offsets, n + 1, s));
+    GSX_HIP(gsx::scan_counts(temp, c.temp_bytes, counts, order, offsets, n, s));
     uint32_t host[2] = {0, 0};
     GSX_HIP(hipMemcpyAsync(&host[0], offsets + n, 4, hipMemcpyDeviceToHost, s));
     if (n_visible_known < 0) GSX_HIP(hipMemcpyAsync(&host[1], counters, 4, hipMemcpyDeviceToHost, s));
@@ -208,14 +203,13 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
         return fail(GSX_ERR_WORKSPACE_TOO_SMALL, "frame needs %lld tile instances, workspace holds %lld", (long long)d,
                     (long long)cap);
     if (d == 0 || p.grid.count() == 0) return GSX_OK;
-    uint32_t *tk = (uint32_t *)(ws + c.tkeys0), *tk2 = (uint32_t *)(ws + c.tkeys1);
-    uint32_t *tv = (uint32_t *)(ws + c.tvals0), *tv2 = (uint32_t *)(ws + c.tvals1);
-    GSX_HIP(gsx::launch_emit((const gsx::TileRect *)(ws + c.rect), offsets, n, p.grid, tk, tv, s));
-    GSX_HIP(gsx::sort_pairs(temp, c.temp_bytes, tk, tk2, tv, tv2, d, key_bits_for(p.grid.count()), s));
     uint2 *ranges = (uint2 *)(ws + c.ranges);
-    GSX_HIP(gsx::launch_tile_ranges(tk, d, ranges, p.grid.count(), s));
+    const uint32_t *sorted_vals = nullptr;
+    GSX_HIP(gsx::bin_instances(temp, c.temp_bytes, (const gsx::TileRect *)(ws + c.rect), order, offsets, n, d, p.grid,
+                               ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0), (uint32_t *)(ws + c.tvals1),
+                               ranges, &sorted_vals, s));
     tm.mark();  // 4: bin
-    GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), tv, ranges, p.grid, p.out, p.semantics, s));
+    GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), sorted_vals, ranges, p.grid, p.out, p.semantics, s));
     tm.mark();  // 5: blend
     tm.finish(stats);
     return GSX_OK;
@@ -279,8 +273,9 @@ int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *s
     uint32_t *v0 = (uint32_t *)(ws + c.vals0), *v1 = (uint32_t *)(ws + c.vals1);
     uint32_t *counters = (uint32_t *)(ws + c.counters);
     GSX_HIP(hipMemsetAsync(counters, 0, 64, s));
-    GSX_HIP(gsx::launch_depth_keys(*camera, means3d, n, k0, v0, counters, s));
-    GSX_HIP(gsx::sort_pairs(ws + c.temp, c.temp_bytes, k0, k1, v0, v1, n, 32, s));
+    GSX_HIP(gsx::launch_depth_keys(*camera, means3d, n, k0, v0, s));
+    GSX_HIP(gsx::sort_by_depth(ws + c.temp, c.temp_bytes, k0, k1, v0, v1, n, s));
+    GSX_HIP(gsx::launch_count_visible(k0, n, counters, s));
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
     gsx::StageOneOut out{points_xy, colors_out, covariance_2d, depths, inverse_covariance_2d, radius,
                          min_x, max_x, min_y, max_y, sigmoid_opacity, order};
@@ -312,12 +307,11 @@ int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t t
     StageTimer tm;
     tm.begin(p.timing, s);
     tm.mark();  // 1: (no depth sort on this entry point)
-    GSX_HIP(hipMemsetAsync(ws + c.counts + (size_t)n * 4, 0, 4, s));
     gsx::PreprocessedIn in{point_means, point_colors, inverse_covariance_2d, min_x, max_x, min_y, max_y, opacity};
     GSX_HIP(gsx::launch_pack_preprocessed(in, n, p.grid, p.semantics, (gsx::Record *)(ws + c.rec),
                                           (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts), s));
     tm.mark();  // 2: pack
-    return bin_and_blend(p, c, ws, n, cap, n, stats_host, tm, s);
+    return bin_and_blend(p, c, ws, n, cap, nullptr, n, stats_host, tm, s);
 }
 
 int gsx_render_forward(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
@@ -342,15 +336,14 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     StageTimer tm;
     tm.begin(p.timing, s);
     GSX_HIP(hipMemsetAsync(counters, 0, 64, s));
-    GSX_HIP(hipMemsetAsync(ws + c.counts + (size_t)n * 4, 0, 4, s));
-    GSX_HIP(gsx::launch_depth_keys(*camera, means3d, n, k0, v0, counters, s));
-    GSX_HIP(gsx::sort_pairs(ws + c.temp, c.temp_bytes, k0, k1, v0, v1, n, 32, s));
-    tm.mark();  // 1: depth keys + sort
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
-    GSX_HIP(gsx::launch_project_pack(*camera, in, k0, v0, n, p.grid, p.semantics, (gsx::Record *)(ws + c.rec),
+    GSX_HIP(gsx::launch_project_pack(*camera, in, n, p.grid, p.semantics, k0, v0, (gsx::Record *)(ws + c.rec),
                                      (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts), s));
-    tm.mark();  // 2: project
-    return bin_and_blend(p, c, ws, n, cap, -1, stats_host, tm, s);
+    tm.mark();  // 1: project (+ depth keys)
+    GSX_HIP(gsx::sort_by_depth(ws + c.temp, c.temp_bytes, k0, k1, v0, v1, n, s));
+    GSX_HIP(gsx::launch_count_visible(k0, n, counters, s));
+    tm.mark();  // 2: depth sort
+    return bin_and_blend(p, c, ws, n, cap, v0, -1, stats_host, tm, s);
 }
 
 int gsx_project_points(const GsxCamera *camera, const float *means3d, int64_t n, float *points_out,

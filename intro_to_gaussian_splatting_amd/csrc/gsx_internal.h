@@ -10,8 +10,9 @@ namespace gsx {
 
 constexpr uint32_t kCulledKey = 0xFFFFFFFFu;  // depth key of a Gaussian behind the z >= 0.2 plane
 
-// Stage-1 -> stage-2 record, 48 B, three 16-B loads.  Indexed by depth rank.
-//   a = (x_pix, y_pix, Q00, Q01)   b = (Q10, Q11, opacity factor, radius)   c = (r, g, b, depth)
+// Stage-1 -> stage-2 record, 48 B, three 16-B loads, indexed by the Gaussian's index (original
+// index on the whole-path entry, row index on the stage-2 entry).  With Q'' = Q * (-1/2 log2 e):
+//   a = (x_pix, y_pix, Q''00, Q''01 + Q''10)   b = (Q''11, opacity factor, r, g)   c = (b, depth, -, -)
 struct __attribute__((aligned(16))) Record {
     float4 a, b, c;
 };
@@ -54,10 +55,13 @@ struct PreprocessedIn {  // argument list of splat/c/render.cu:90-101
 
 // ---- gsx_project.hip (compiled with -ffp-contract=off)
 hipError_t launch_depth_keys(const GsxCamera &cam, const float *means3d, int64_t n, uint32_t *keys,
-                             uint32_t *vals, uint32_t *n_visible, hipStream_t s);
-hipError_t launch_project_pack(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
-                               const uint32_t *sorted_idx, int64_t n, const TileGrid &grid, int semantics,
-                               Record *rec, TileRect *rect, uint32_t *counts, hipStream_t s);
+                             uint32_t *vals, hipStream_t s);
+hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t *n_visible, hipStream_t s);
+// Original order: depth keys + identity values for the sort, records / rects / counts indexed by
+// the ORIGINAL Gaussian index.
+hipError_t launch_project_pack(const GsxCamera &cam, const GaussiansIn &in, int64_t n, const TileGrid &grid,
+                               int semantics, uint32_t *keys, uint32_t *vals, Record *rec, TileRect *rect,
+                               uint32_t *counts, hipStream_t s);
 hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
                                const uint32_t *sorted_idx, int64_t n, const StageOneOut &out, hipStream_t s);
 hipError_t launch_pack_preprocessed(const PreprocessedIn &in, int64_t n, const TileGrid &grid, int semantics,
@@ -67,16 +71,21 @@ hipError_t launch_project_points(const GsxCamera &cam, const float *means3d, int
 
 // ---- gsx_binning.hip
 size_t binning_temp_bytes(int64_t n, int64_t cap);
-// Stable LSD radix sort of (key, value) pairs on key bits [0, end_bit).  The two buffers of
-// each pair are ping-ponged; on return keys_cur / vals_cur point at the sorted data.
-hipError_t sort_pairs(void *temp, size_t temp_bytes, uint32_t *&keys_cur, uint32_t *&keys_alt, uint32_t *&vals_cur,
-                      uint32_t *&vals_alt, int64_t n, int end_bit, hipStream_t s);
-hipError_t scan_counts(void *temp, size_t temp_bytes, const uint32_t *counts, uint32_t *offsets, int64_t n_plus_1,
-                       hipStream_t s);
-hipError_t launch_emit(const TileRect *rect, const uint32_t *offsets, int64_t n, const TileGrid &grid,
-                       uint32_t *tile_keys, uint32_t *tile_vals, hipStream_t s);
-hipError_t launch_tile_ranges(const uint32_t *sorted_tile_keys, int64_t d, uint2 *ranges, int64_t n_tiles,
-                              hipStream_t s);
+// Stable radix sort of (depth key, index) pairs, all 32 key bits.  The two buffers of each pair
+// are ping-ponged; on return keys_cur / vals_cur point at the sorted data.
+hipError_t sort_by_depth(void *temp, size_t temp_bytes, uint32_t *&keys_cur, uint32_t *&keys_alt, uint32_t *&vals_cur,
+                         uint32_t *&vals_alt, int64_t n, hipStream_t s);
+// offsets[r] = sum over ranks r' < r of counts[order[r']] for r in [0, n]; order == nullptr means
+// the identity (rows already in compositing order).
+hipError_t scan_counts(void *temp, size_t temp_bytes, const uint32_t *counts, const uint32_t *order,
+                       uint32_t *offsets, int64_t n, hipStream_t s);
+// Emits one (tile id, Gaussian index) pair per covered tile in rank order, stable-sorts them by
+// tile id and fills ranges[t] = [first, last) for every tile of the window.  keys0/keys1/vals0/
+// vals1 hold d 32-bit words each; *sorted_vals points at the sorted Gaussian indices.
+hipError_t bin_instances(void *temp, size_t temp_bytes, const TileRect *rect, const uint32_t *order,
+                         const uint32_t *offsets, int64_t n, int64_t d, const TileGrid &grid, void *keys0,
+                         void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges, const uint32_t **sorted_vals,
+                         hipStream_t s);
 
 // ---- gsx_blend.hip
 hipError_t launch_blend(const Record *rec, const uint32_t *sorted_vals, const uint2 *ranges, const TileGrid &grid,

@@ -163,54 +163,71 @@ __device__ __forceinline__ uint32_t tile_rect(float mnx, float mxx, float mny, f
 
 // ------------------------------------------------------------------------------------ kernels
 
-// One thread per Gaussian: view depth -> sortable key.  z >= 0.2 > 0, so the IEEE bits of z are
-// monotone in z; culled Gaussians get the largest key and sort to the end.
+// One thread per Gaussian: view depth -> sortable key (stage-1 API path).  z >= 0.2 > 0, so the
+// IEEE bits of z are monotone in z; culled Gaussians get the largest key and sort to the end.
 __global__ void __launch_bounds__(kBlock) depth_keys_kernel(GsxCamera cam, const float *__restrict__ means3d,
                                                             int64_t n, uint32_t *__restrict__ keys,
-                                                            uint32_t *__restrict__ vals,
-                                                            uint32_t *__restrict__ n_visible) {
+                                                            uint32_t *__restrict__ vals) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    bool vis = false;
-    if (i < n) {
-        float tz = row4(means3d[3 * i], means3d[3 * i + 1], means3d[3 * i + 2], cam.world2view, 2);
-        vis = tz >= 0.2f;
-        keys[i] = vis ? __float_as_uint(tz) : kCulledKey;
-        vals[i] = (uint32_t)i;
-    }
-    unsigned long long m = __ballot(vis);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_visible, (uint32_t)__popcll(m));
+    if (i >= n) return;
+    float tz = row4(means3d[3 * i], means3d[3 * i + 1], means3d[3 * i + 2], cam.world2view, 2);
+    keys[i] = tz >= 0.2f ? __float_as_uint(tz) : kCulledKey;
+    vals[i] = (uint32_t)i;
 }
 
-// One thread per depth rank: gather the Gaussian, project it, write the compositing record, its
-// tile rectangle and tile count.
+// The number of visible Gaussians is where the culled keys start in the sorted key array: one
+// writer, no atomics (a shared counter costs ~12 ns per wave-level atomic, 180 us at N = 1M).
 __global__ void __launch_bounds__(kBlock)
-    project_pack_kernel(GsxCamera cam, GaussiansIn in, const uint32_t *__restrict__ sorted_keys,
-                        const uint32_t *__restrict__ sorted_idx, int64_t n, TileGrid grid, int semantics,
-                        Record *__restrict__ rec, TileRect *__restrict__ rect, uint32_t *__restrict__ counts) {
+    count_visible_kernel(const uint32_t *__restrict__ sorted_keys, int64_t n, uint32_t *__restrict__ n_visible) {
     int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
-    uint32_t key = sorted_keys[r];
-    if (key == kCulledKey) {
+    if (sorted_keys[r] != kCulledKey && (r == n - 1 || sorted_keys[r + 1] == kCulledKey)) *n_visible = (uint32_t)(r + 1);
+}
+
+// Opacity factor and conic as the compositing kernel consumes them.
+//   op  : sigmoid(opacity), applied twice under the CPU semantics (gaussian_scene.py:143 and :164)
+//   Q'' : Q * (-1/2 log2 e), so that the weight is exp2(d Q'' d^T); the -1/2 is exact, log2 e costs
+//         one rounding per entry (relative 6e-8, far inside the 1e-4 pixel tolerance)
+__device__ __forceinline__ void pack_record(float x, float y, float q00, float q01, float q10, float q11, float op,
+                                            float cr, float cg, float cb, float depth, Record &out) {
+    const float k = -0.5f * 1.44269504088896340736f;
+    out.a = make_float4(x, y, q00 * k, (q01 + q10) * k);
+    out.b = make_float4(q11 * k, op, cr, cg);
+    out.c = make_float4(cb, depth, 0.0f, 0.0f);
+}
+
+// One thread per Gaussian, ORIGINAL order (coalesced reads of the parameter arrays, coalesced
+// writes): depth key for the sort, compositing record, tile rectangle and tile count.
+__global__ void __launch_bounds__(kBlock)
+    project_pack_kernel(GsxCamera cam, GaussiansIn in, int64_t n, TileGrid grid, int semantics,
+                        uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, Record *__restrict__ rec,
+                        TileRect *__restrict__ rect, uint32_t *__restrict__ counts) {
+    int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n) return;
+    const float *p = in.means3d + 3 * g;
+    float p0 = p[0], p1 = p[1], p2 = p[2];
+    float tz = row4(p0, p1, p2, cam.world2view, 2);
+    vals[g] = (uint32_t)g;
+    if (!(tz >= 0.2f)) {                                        // utils.py:293-310
         TileRect e;
         e.x0 = 1; e.x1 = 0; e.y0 = 1; e.y1 = 0;
-        rect[r] = e;
-        counts[r] = 0u;
+        keys[g] = kCulledKey;
+        rect[g] = e;
+        counts[g] = 0u;
         return;
     }
-    int64_t g = sorted_idx[r];
-    const float *p = in.means3d + 3 * g, *s = in.scales + 3 * g, *q = in.quats + 4 * g, *c = in.colors + 3 * g;
+    keys[g] = __float_as_uint(tz);
+    const float *s = in.scales + 3 * g, *q = in.quats + 4 * g, *c = in.colors + 3 * g;
     Projected o;
-    project(cam, p[0], p[1], p[2], __uint_as_float(key), s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
-    float op = sigmoidf(in.opacity_logit[g]);                  // gaussian_scene.py:143
-    if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);       // gaussian_scene.py:164 (second sigmoid)
+    project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
+    float op = sigmoidf(in.opacity_logit[g]);
+    if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);
     Record out;
-    out.a = make_float4(o.x, o.y, o.q00, o.q01);
-    out.b = make_float4(o.q10, o.q11, op, o.radius);
-    out.c = make_float4(c[0], c[1], c[2], o.depth);
-    rec[r] = out;
+    pack_record(o.x, o.y, o.q00, o.q01, o.q10, o.q11, op, c[0], c[1], c[2], o.depth, out);
+    rec[g] = out;
     TileRect tr;
-    counts[r] = tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, tr);
-    rect[r] = tr;
+    counts[g] = tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, tr);
+    rect[g] = tr;
 }
 
 // Same projection, all PreprocessedScene fields (the reference's stage-1 API surface).
@@ -249,9 +266,8 @@ __global__ void __launch_bounds__(kBlock)
     if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);
     float mnx = in.min_x[r], mxx = in.max_x[r], mny = in.min_y[r], mxy = in.max_y[r];
     Record out;
-    out.a = make_float4(in.means[2 * r], in.means[2 * r + 1], in.inv_cov[4 * r], in.inv_cov[4 * r + 1]);
-    out.b = make_float4(in.inv_cov[4 * r + 2], in.inv_cov[4 * r + 3], op, 0.5f * (mxx - mnx));
-    out.c = make_float4(in.colors[3 * r], in.colors[3 * r + 1], in.colors[3 * r + 2], 0.0f);
+    pack_record(in.means[2 * r], in.means[2 * r + 1], in.inv_cov[4 * r], in.inv_cov[4 * r + 1], in.inv_cov[4 * r + 2],
+                in.inv_cov[4 * r + 3], op, in.colors[3 * r], in.colors[3 * r + 1], in.colors[3 * r + 2], 0.0f, out);
     rec[r] = out;
     TileRect tr;
     counts[r] = tile_rect(mnx, mxx, mny, mxy, grid, tr);
@@ -279,18 +295,23 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBl
 }  // namespace
 
 hipError_t launch_depth_keys(const GsxCamera &cam, const float *means3d, int64_t n, uint32_t *keys,
-                             uint32_t *vals, uint32_t *n_visible, hipStream_t s) {
+                             uint32_t *vals, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    depth_keys_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, means3d, n, keys, vals, n_visible);
+    depth_keys_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, means3d, n, keys, vals);
     return hipGetLastError();
 }
 
-hipError_t launch_project_pack(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
-                               const uint32_t *sorted_idx, int64_t n, const TileGrid &grid, int semantics,
-                               Record *rec, TileRect *rect, uint32_t *counts, hipStream_t s) {
+hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t *n_visible, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    project_pack_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, sorted_keys, sorted_idx, n, grid, semantics, rec,
-                                                         rect, counts);
+    count_visible_kernel<<<blocks_for(n), kBlock, 0, s>>>(sorted_keys, n, n_visible);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_pack(const GsxCamera &cam, const GaussiansIn &in, int64_t n, const TileGrid &grid,
+                               int semantics, uint32_t *keys, uint32_t *vals, Record *rec, TileRect *rect,
+                               uint32_t *counts, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    project_pack_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, n, grid, semantics, keys, vals, rec, rect, counts);
     return hipGetLastError();
 }
 
