@@ -48,7 +48,11 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (unpacked VALU)
-VALU_OPS_PER_PAIR = 20         # instructions per (pixel, Gaussian) evaluation incl. v_exp
+# VALU lane-ops the compositing loop issues per (pixel, Gaussian) pair, counted in the gfx950 ISA of
+# blend_tile16_kernel: per record and lane (4 pixels) 23 unpacked + 10 packed
+# (2 lane-ops each) + 4 v_exp_f32 = 47, i.e. 11.75 per pair.
+VALU_OPS_PER_PAIR = 11.75
+PMC_FILE = os.path.join(ROOT, "profiles", "r1_pmc_c3.json")
 
 
 def build_scene(workload: str, device: str):
@@ -122,6 +126,15 @@ def cpu_baseline(sc, scene, gpu_frame: torch.Tensor, budget_s: float = 20.0):
                         "extrapolated_mpixels_per_s": float("%.3g" % py_mpix),
                         "sample": "oracle/cpu_ref.py scalar loop on tile (%d,%d)" % (tx, ty)},
     }, err, int(inst)
+
+
+def pmc_traffic(workload: str, world: int):
+    """HBM-side bytes per compositing launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes (MI355X_MICROARCH.md: FETCH_SIZE doubled on gfx950); recorded for C3 on 1 GPU."""
+    if workload != "c3" or world != 1 or not os.path.exists(PMC_FILE):
+        return None
+    with open(PMC_FILE) as f:
+        return json.load(f)["blend_traffic_bytes_per_launch"]["total"]
 
 
 def main() -> None:
@@ -214,10 +227,11 @@ def main() -> None:
             "fps": round(1e3 / ms_per_step, 2),
             "roofline": {"bound": "hbm", "kernel": "blend_tile16_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "bytes_per_launch": blend_bytes, "avg_ms": round(blend_ms, 4),
-                         "valu_frac": round(valu, 4),
+                         "traffic": pmc_traffic(args.workload, world), "bytes_per_launch": blend_bytes,
+                         "avg_ms": round(blend_ms, 4), "valu_frac": round(valu, 4),
                          "note": "compositing under reference CPU semantics is VALU-bound (256 evaluations per "
-                                 "36-B record); valu_frac = 256*D*%d lane-ops / t / unpacked FP32 VALU peak"
+                                 "36-B record); valu_frac = 256*D*%.2f lane-ops / t / unpacked FP32 VALU peak; "
+                                 "traffic = HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_c3.json)"
                                  % VALU_OPS_PER_PAIR},
             "frame_roofline": {"bytes": frame_bytes, "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                                "unit": "GB/s", "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},

@@ -31,8 +31,8 @@
 // operation is an explicit fmaf, so the result does not depend on how the compiler would have
 // contracted each template instance: both output layouts give bit-identical pixels.  With
 // Q'' = -1/2 log2(e) Q (packed by the projection kernels), e = mean - pixel:
-//     w = exp2(e0^2 Q''00 + e0 e1 (Q''01 + Q''10) + e1^2 Q''11)       (v_exp_f32, no range reduction)
-// which is the reference's exp(-1/2 e Q e^T) with the four products re-associated; the
+//     alpha = exp2(e0^2 Q''00 + e0 e1 (Q''01 + Q''10) + e1^2 Q''11 + log2 op)    (one v_exp_f32)
+// which is the reference's exp(-1/2 e Q e^T) * op with the four products re-associated; the
 // difference is a few ulp of the largest product, like the reference's own float32 rounding.
 // T(1 - alpha) is evaluated as T - T alpha (1 ulp).
 #include "gsx_internal.h"
@@ -50,8 +50,8 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
     return start + i;
 }
 
-struct Splat {  // one record, unpacked (wave-uniform values)
-    float mx, my, q00, qs, q11, op, cr, cg, cb;
+struct Splat {  // one record, unpacked (wave-uniform values); lop = log2(opacity factor)
+    float mx, my, q00, qs, q11, lop, cr, cg, cb;
 };
 
 __device__ __forceinline__ Splat read_splat(const float4 (*sh)[64], uint32_t k) {
@@ -67,13 +67,13 @@ template <int NPX>
 __device__ __forceinline__ void composite(float e_s, const float (&e_p)[NPX], float q_ss, float qs, float q_pp,
                                           const Splat &g, float (&T)[NPX], float (&c0)[NPX], float (&c1)[NPX],
                                           float (&c2)[NPX]) {
-    const float a0 = (e_s * e_s) * q_ss;
+    const float a0 = __builtin_fmaf(e_s * e_s, q_ss, g.lop);  // opacity rides in the exponent
     const float b0 = e_s * qs;
     float ta[NPX], test[NPX];
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
         const float pw = __builtin_fmaf(e_p[j], __builtin_fmaf(e_p[j], q_pp, b0), a0);
-        const float alpha = __builtin_amdgcn_exp2f(pw) * g.op;
+        const float alpha = __builtin_amdgcn_exp2f(pw);
         ta[j] = T[j] * alpha;
         test[j] = T[j] - ta[j];
     }

@@ -12,7 +12,7 @@ constexpr uint32_t kCulledKey = 0xFFFFFFFFu;  // depth key of a Gaussian behind 
 
 // Stage-1 -> stage-2 record, 48 B, three 16-B loads, indexed by the Gaussian's index (original
 // index on the whole-path entry, row index on the stage-2 entry).  With Q'' = Q * (-1/2 log2 e):
-//   a = (x_pix, y_pix, Q''00, Q''01 + Q''10)   b = (Q''11, opacity factor, r, g)   c = (b, depth, -, -)
+//   a = (x_pix, y_pix, Q''00, Q''01 + Q''10)   b = (Q''11, log2(opacity factor), r, g)   c = (b, depth, -, -)
 struct __attribute__((aligned(16))) Record {
     float4 a, b, c;
 };

@@ -185,14 +185,15 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // Opacity factor and conic as the compositing kernel consumes them.
-//   op  : sigmoid(opacity), applied twice under the CPU semantics (gaussian_scene.py:143 and :164)
+//   op  : sigmoid(opacity), applied twice under the CPU semantics (gaussian_scene.py:143 and :164);
+//         stored as log2(op) so that alpha = exp2(d Q'' d^T + log2 op) needs no multiply
 //   Q'' : Q * (-1/2 log2 e), so that the weight is exp2(d Q'' d^T); the -1/2 is exact, log2 e costs
 //         one rounding per entry (relative 6e-8, far inside the 1e-4 pixel tolerance)
 __device__ __forceinline__ void pack_record(float x, float y, float q00, float q01, float q10, float q11, float op,
                                             float cr, float cg, float cb, float depth, Record &out) {
     const float k = -0.5f * 1.44269504088896340736f;
     out.a = make_float4(x, y, q00 * k, (q01 + q10) * k);
-    out.b = make_float4(q11 * k, op, cr, cg);
+    out.b = make_float4(q11 * k, log2f(op), cr, cg);
     out.c = make_float4(cb, depth, 0.0f, 0.0f);
 }
 
