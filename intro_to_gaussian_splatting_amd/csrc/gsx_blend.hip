@@ -35,6 +35,8 @@
 // which is the reference's exp(-1/2 e Q e^T) * op with the four products re-associated; the
 // difference is a few ulp of the largest product, like the reference's own float32 rounding.
 // T(1 - alpha) is evaluated as T - T alpha (1 ulp).
+#include <stdlib.h>
+
 #include "gsx_internal.h"
 
 namespace gsx {
@@ -99,6 +101,55 @@ __device__ __forceinline__ void composite(float e_s, const float (&e_p)[NPX], fl
     }
 }
 
+// ---- packed-math form of the same arithmetic (two pixels per VGPR pair) ----------------------
+// On gfx950 a v_pk_{fma,mul,add}_f32 retires two float32 operations per lane in the issue time of
+// one unpacked VALU instruction (measured: 4.4 cycles per VALU instruction on average in this
+// loop, packed and unpacked alike), so the lane's 4 pixels are kept as two float2 and every
+// per-pixel operation except v_exp_f32 is issued packed.  Same operations, same order, same
+// bits as composite<4>.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_exp2(v2f p) { return v2f{__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)}; }
+__device__ __forceinline__ v2f splat2(float v) { return v2f{v, v}; }
+
+// alpha of one record at the lane's 4 pixels (pairs a = (y0,y1), b = (y2,y3)); independent of T.
+// A = (x, y, Q''00, Q''01+Q''10), q11 = Q''11, lop = log2(opacity factor).
+__device__ __forceinline__ void alphas(float4 A, float q11, float lop, float cx, v2f cya, v2f cyb, v2f &al_a,
+                                       v2f &al_b) {
+    const float e_x = A.x - cx;
+    const float a0 = __builtin_fmaf(e_x * e_x, A.z, lop);
+    const float b0 = e_x * A.w;
+    const v2f ea = splat2(A.y) - cya, eb = splat2(A.y) - cyb;
+    al_a = pk_exp2(pk_fma(ea, pk_fma(ea, splat2(q11), splat2(b0)), splat2(a0)));
+    al_b = pk_exp2(pk_fma(eb, pk_fma(eb, splat2(q11), splat2(b0)), splat2(a0)));
+}
+
+#define GSX_ACCUMULATE(ta_a, ta_b, cr, cg, cb)          \
+    do {                                                \
+        c0a = pk_fma(ta_a, splat2(cr), c0a);            \
+        c1a = pk_fma(ta_a, splat2(cg), c1a);            \
+        c2a = pk_fma(ta_a, splat2(cb), c2a);            \
+        c0b = pk_fma(ta_b, splat2(cr), c0b);            \
+        c1b = pk_fma(ta_b, splat2(cg), c1b);            \
+        c2b = pk_fma(ta_b, splat2(cb), c2b);            \
+    } while (0)
+
+// Exact saturation rule for one pixel pair (the rare path): a pixel whose T(1-alpha) drops below
+// the threshold does not receive this Gaussian and stays at T = 0.
+__device__ __forceinline__ void checked_pair(v2f alpha, v2f &T, v2f &ta) {
+    ta = T * alpha;
+    v2f t = T - ta;
+    const bool s0 = t.x < kStopRefCpu, s1 = t.y < kStopRefCpu;
+    ta.x = s0 ? 0.0f : ta.x;
+    ta.y = s1 ? 0.0f : ta.y;
+    t.x = s0 ? 0.0f : t.x;
+    t.y = s1 ? 0.0f : t.y;
+    T = t;
+}
+
+__device__ __forceinline__ float min4(v2f a, v2f b) { return fminf(fminf(a.x, a.y), fminf(b.x, b.y)); }
+
 // Fast path, tile = 16: one wave per tile, 4 pixels per lane.  A lane owns pixels
 // (x, y..y+3): x is the coordinate its pixels share, so the x-only terms of the exponent are
 // computed once per record.  The assignment (and therefore every bit of the result) is the same
@@ -106,6 +157,8 @@ __device__ __forceinline__ void composite(float e_s, const float (&e_p)[NPX], fl
 //   GSX_LAYOUT_WH3  out[x][y][c]: the lane's 4 pixels are 48 contiguous bytes (3 x dwordx4);
 //   GSX_LAYOUT_HW3  out[y][x][c]: 4 stores of 12 B; the 16 lanes that share a y write 192
 //                   contiguous bytes per store instruction.
+// VARIANT 0: scalar-form composite<4>; VARIANT 1: packed form, two records per saturation test.
+template <int VARIANT>
 __global__ void __launch_bounds__(64)
     blend_tile16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                         const uint2 *__restrict__ ranges, TileGrid g, OutDesc out) {
@@ -121,32 +174,83 @@ __global__ void __launch_bounds__(64)
     float cy[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) cy[j] = (float)(py0 + j);
+    const v2f cya = v2f{cy[0], cy[1]}, cyb = v2f{cy[2], cy[3]};
 
     float T[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     float c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
+    v2f Ta = splat2(1.0f), Tb = splat2(1.0f);  // packed state: pairs (y0,y1) and (y2,y3)
+    v2f c0a = splat2(0.0f), c1a = c0a, c2a = c0a, c0b = c0a, c1b = c0a, c2b = c0a;
 
+    bool checked = false;  // wave-uniform: some pixel of this tile has saturated
     const uint2 rg = ranges[t];
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
-        const uint32_t nb = min(64u, rg.y - base);
+        const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
         if ((uint32_t)lane < nb) {
-            const Record *p = rec + vals[base + lane];
-            sh[0][lane] = p->a;
-            sh[1][lane] = p->b;
-            sh[2][lane] = p->c;
+            const Record *q = rec + vals[base + lane];
+            sh[0][lane] = q->a;
+            sh[1][lane] = q->b;
+            sh[2][lane] = q->c;
         }
         __syncthreads();
-        for (uint32_t k = 0; k < nb; ++k) {
-            const Splat s = read_splat(sh, k);
-            // e = mean - pixel, the pixel coordinate formed first, as the reference does
-            const float e_x = s.mx - cx;
-            float e_y[4];
+        if (VARIANT == 0) {
+            for (uint32_t k = 0; k < nb; ++k) {
+                const Splat s = read_splat(sh, k);
+                // e = mean - pixel, the pixel coordinate formed first, as the reference does
+                const float e_x = s.mx - cx;
+                float e_y[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e_y[j] = s.my - cy[j];
-            composite<4>(e_x, e_y, s.q00, s.qs, s.q11, s, T, c0, c1, c2);
+                for (int j = 0; j < 4; ++j) e_y[j] = s.my - cy[j];
+                composite<4>(e_x, e_y, s.q00, s.qs, s.q11, s, T, c0, c1, c2);
+            }
+        } else {
+            // Common path: two records per trip, ONE wave-level saturation test, no per-pixel
+            // selects.  The first time any pixel of the tile saturates the wave leaves this loop
+            // (before committing the pair) and finishes the tile on the checked path below; a
+            // saturated pixel has T = 0 and would trip the test on every record anyway.
+            uint32_t k = 0;
+            if (!checked) {
+                for (; k + 1 < nb; k += 2) {
+                    const float4 A0 = sh[0][k], B0 = sh[1][k], A1 = sh[0][k + 1], B1 = sh[1][k + 1];
+                    const float cb0 = sh[2][k].x, cb1 = sh[2][k + 1].x;
+                    v2f aa0, ab0, aa1, ab1;
+                    alphas(A0, B0.x, B0.y, cx, cya, cyb, aa0, ab0);
+                    alphas(A1, B1.x, B1.y, cx, cya, cyb, aa1, ab1);
+                    const v2f ta0a = Ta * aa0, ta0b = Tb * ab0;
+                    const v2f t1a = Ta - ta0a, t1b = Tb - ta0b;
+                    const v2f ta1a = t1a * aa1, ta1b = t1b * ab1;
+                    const v2f t2a = t1a - ta1a, t2b = t1b - ta1b;
+                    if (__builtin_expect(__any(fminf(min4(t1a, t1b), min4(t2a, t2b)) < kStopRefCpu), 0)) {
+                        checked = true;
+                        break;
+                    }
+                    GSX_ACCUMULATE(ta0a, ta0b, B0.z, B0.w, cb0);
+                    GSX_ACCUMULATE(ta1a, ta1b, B1.z, B1.w, cb1);
+                    Ta = t2a;
+                    Tb = t2b;
+                }
+            }
+            for (; k < nb; ++k) {  // tail record of the batch, or the checked path
+                const float4 A0 = sh[0][k], B0 = sh[1][k];
+                const float cb0 = sh[2][k].x;
+                v2f aa0, ab0, ta0a, ta0b;
+                alphas(A0, B0.x, B0.y, cx, cya, cyb, aa0, ab0);
+                checked_pair(aa0, Ta, ta0a);
+                checked_pair(ab0, Tb, ta0b);
+                GSX_ACCUMULATE(ta0a, ta0b, B0.z, B0.w, cb0);
+            }
         }
         __syncthreads();
-        const bool live = (T[0] > 0.0f) | (T[1] > 0.0f) | (T[2] > 0.0f) | (T[3] > 0.0f);
+        bool live;
+        if (VARIANT == 0)
+            live = (T[0] > 0.0f) | (T[1] > 0.0f) | (T[2] > 0.0f) | (T[3] > 0.0f);
+        else
+            live = (Ta.x > 0.0f) | (Ta.y > 0.0f) | (Tb.x > 0.0f) | (Tb.y > 0.0f);
         if (__ballot(live) == 0ull) break;
+    }
+    if (VARIANT != 0) {
+        c0[0] = c0a.x; c0[1] = c0a.y; c0[2] = c0b.x; c0[3] = c0b.y;
+        c1[0] = c1a.x; c1[1] = c1a.y; c1[2] = c1b.x; c1[3] = c1b.y;
+        c2[0] = c2a.x; c2[1] = c2a.y; c2[2] = c2b.x; c2[3] = c2b.y;
     }
 
     float *o = out.ptr + (int64_t)(px - out.x0) * out.stride_x + (int64_t)(py0 - out.y0) * out.stride_y;
@@ -220,7 +324,15 @@ hipError_t launch_blend(const Record *rec, const uint32_t *sorted_vals, const ui
     const int64_t nt = grid.count();
     if (nt <= 0) return hipSuccess;
     if (grid.tile == 16) {
-        blend_tile16_kernel<<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out);
+        // GSX_BLEND_VARIANT: measurement knob for A/B runs of the compositing loop (default 1)
+        static const int variant = [] {
+            const char *e = getenv("GSX_BLEND_VARIANT");
+            return e ? atoi(e) : 1;
+        }();
+        if (variant == 0)
+            blend_tile16_kernel<0><<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out);
+        else
+            blend_tile16_kernel<1><<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out);
     } else {
         blend_generic_kernel<<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out);
     }
