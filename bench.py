@@ -144,6 +144,11 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="frames in flight: consecutive frames alternate over this many HIP streams, so one "
+                         "frame's latency-bound sorts overlap another's VALU-bound compositing (1 GPU only)")
+    ap.add_argument("--sync-frames", action="store_true",
+                    help="read the instance count back inside every frame instead of speculating on it")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,9 +171,22 @@ def main() -> None:
         scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=window, out=out, out_origin=origin)
 
     def step():
+        # 1 GPU: speculative frames (GSX_FLAG_NO_SYNC) -- the pair list is sized by the previous
+        # frame's instance count, so nothing waits for the device inside a frame; the counts are
+        # confirmed after the timed region (confirm_frames) and a miss invalidates the run.
         if world == 1:
-            return scene.render_image_hip(1, tile_size=tile, layout=layout)
+            if len(streams) > 1:
+                st = streams[step.count % len(streams)]
+                step.count += 1
+                with torch.cuda.stream(st):
+                    return scene.render_image_hip(1, tile_size=tile, layout=layout, out=outs[st],
+                                                  no_sync=not args.sync_frames)
+            return scene.render_image_hip(1, tile_size=tile, layout=layout, no_sync=not args.sync_frames)
         return strips.render_sharded(render_strip, width, height, tile, layout, device)
+
+    step.count = 0
+    streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if (world == 1 and args.streams > 1) else []
+    outs = {st: torch.empty((width, height, 3), dtype=torch.float32, device=device) for st in streams}
 
     def fence():
         if world > 1:
@@ -179,17 +197,33 @@ def main() -> None:
     for _ in range(args.warmup):
         frame = step()
     fence()
+    if world == 1:
+        scene.confirm_frames()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame = step()
     fence()
     elapsed = time.perf_counter() - t0
+    respeculated = scene.confirm_frames() if world == 1 else 0
+    if respeculated:
+        raise SystemExit("speculative frames missed their instance hint %d times: timing invalid" % respeculated)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     mpix = width * height / (ms_per_step * 1e-3) / 1e6
+
+    # frame latency with ONE frame in flight (same process, same scene), for reference
+    latency_ms = None
+    if world == 1 and len(streams) > 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            scene.render_image_hip(1, tile_size=tile, layout=layout, no_sync=not args.sync_frames)
+        torch.cuda.synchronize()
+        latency_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        scene.confirm_frames()
 
     # per-stage HIP-event times of this rank's share (live, same process, separate loop)
     stage = {}
@@ -223,6 +257,10 @@ def main() -> None:
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "n_gaussians": n, "width": width, "height": height, "tile": tile,
                        "semantics": "ref_cpu", "layout": layout, "n_visible": nvis, "tile_instances": d,
+                       "frames_in_flight": max(1, len(streams)),
+                       "ms_per_frame_one_in_flight": None if latency_ms is None else round(latency_ms, 4),
+                       "frame_sync": "host reads instance count every frame" if (args.sync_frames or world > 1)
+                       else "speculative (GSX_FLAG_NO_SYNC), counts confirmed after the timed region",
                        "parallelism": "1 GPU" if world == 1 else "%d column strips + RCCL gather" % world},
             "fps": round(1e3 / ms_per_step, 2),
             "roofline": {"bound": "hbm", "kernel": "blend_tile16_kernel", "achieved": round(achieved, 2),

@@ -81,13 +81,25 @@ typedef struct GsxParams {
     int32_t layout;    /* GsxLayout, default GSX_LAYOUT_WH3     */
     int32_t tile_x0, tile_x1, tile_y0, tile_y1;
     int32_t out_x0, out_y0, out_w, out_h;
-    int32_t flags; /* GSX_FLAG_* */
-    int32_t reserved[5];
+    int32_t flags;          /* GSX_FLAG_* */
+    int32_t instances_hint; /* with GSX_FLAG_NO_SYNC: upper bound of n_instances, > 0 */
+    int32_t reserved[4];
 } GsxParams;
 
 /* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call
  * then waits for the frame to finish).  Off by default: timing is measurement, not product. */
 #define GSX_FLAG_TIMING 1
+
+/* Speculative frame: enqueue everything without waiting for the device.  The (Gaussian, tile) pair
+ * list is sized by params->instances_hint (normally the n_instances of the previous frame of the
+ * same scene) instead of the count read back from the device, so the call returns as soon as the
+ * launches are queued.  stats_host must then be PINNED host memory that stays valid until the
+ * stream has passed this frame: n_visible / n_instances arrive by an asynchronous copy
+ * (stats_host->reserved == 1 says so); read them after synchronising the stream.  If n_instances
+ * turns out larger than instances_hint, pairs were dropped and the frame must be rendered again
+ * (without the flag, or with a larger hint).  Ignored (normal, synchronising path) when the hint
+ * exceeds the workspace capacity or the window has more than 65535 tiles. */
+#define GSX_FLAG_NO_SYNC 2
 
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
 enum {

@@ -90,6 +90,7 @@ struct Plan {
     gsx::OutDesc out;
     int semantics;
     bool timing;
+    int64_t hint;  // > 0: speculative frame, no host synchronisation (GSX_FLAG_NO_SYNC)
 };
 
 // Optional per-stage timing with HIP events on the launch stream (GSX_FLAG_TIMING).
@@ -143,6 +144,9 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     if (!out_image) return fail(GSX_ERR_INVALID_ARGUMENT, "out_image is NULL");
     p.semantics = d.semantics;
     p.timing = (d.flags & GSX_FLAG_TIMING) != 0;
+    p.hint = (d.flags & GSX_FLAG_NO_SYNC) ? (int64_t)d.instances_hint : 0;
+    if ((d.flags & GSX_FLAG_NO_SYNC) && d.instances_hint <= 0)
+        return fail(GSX_ERR_INVALID_ARGUMENT, "GSX_FLAG_NO_SYNC needs instances_hint > 0");
     gsx::TileGrid &g = p.grid;
     g.tile = tile;
     g.ntx = tiles_along(width, tile, d.semantics);
@@ -177,6 +181,35 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     return GSX_OK;
 }
 
+// Zero the pixels of the output buffer that no tile of the window covers (the compositing kernel
+// writes every pixel of every tile it owns, empty tiles included): up to four rectangles instead
+// of a whole-frame memset (25 MB at 1080p).
+int clear_outside_window(const Plan &p, hipStream_t s) {
+    const gsx::OutDesc &o = p.out;
+    const int T = p.grid.tile;
+    // window in buffer-local pixel coordinates along (slow, fast) memory axes
+    const bool wh3 = o.stride_y < o.stride_x;  // x is the slow axis
+    const int64_t slow_n = wh3 ? o.w : o.h, fast_n = wh3 ? o.h : o.w;
+    int64_t ws0 = (int64_t)(wh3 ? p.grid.wx0 : p.grid.wy0) * T - (wh3 ? o.x0 : o.y0);
+    int64_t ws1 = (int64_t)(wh3 ? p.grid.wx1 : p.grid.wy1) * T - (wh3 ? o.x0 : o.y0);
+    int64_t wf0 = (int64_t)(wh3 ? p.grid.wy0 : p.grid.wx0) * T - (wh3 ? o.y0 : o.x0);
+    int64_t wf1 = (int64_t)(wh3 ? p.grid.wy1 : p.grid.wx1) * T - (wh3 ? o.y0 : o.x0);
+    const size_t px = 3 * sizeof(float), pitch = (size_t)fast_n * px;
+    char *base = (char *)o.ptr;
+    auto rect = [&](int64_t s0, int64_t s1, int64_t f0, int64_t f1) -> hipError_t {
+        if (s1 <= s0 || f1 <= f0) return hipSuccess;
+        if (f0 == 0 && f1 == fast_n)  // whole rows: one contiguous block
+            return hipMemsetAsync(base + (size_t)s0 * pitch, 0, (size_t)(s1 - s0) * pitch, s);
+        return hipMemset2DAsync(base + (size_t)s0 * pitch + (size_t)f0 * px, pitch, 0, (size_t)(f1 - f0) * px,
+                                (size_t)(s1 - s0), s);
+    };
+    GSX_HIP(rect(0, ws0, 0, fast_n));
+    GSX_HIP(rect(ws1, slow_n, 0, fast_n));
+    GSX_HIP(rect(ws0, ws1, 0, wf0));
+    GSX_HIP(rect(ws0, ws1, wf1, fast_n));
+    return GSX_OK;
+}
+
 // Steps shared by both render entry points once records / rects / counts exist (rank order).
 // `order` = Gaussian index of each depth rank (nullptr: rows are already in compositing order).
 int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t cap, const uint32_t *order,
@@ -185,28 +218,51 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
     uint32_t *counters = (uint32_t *)(ws + c.counters);
     void *temp = ws + c.temp;
     GSX_HIP(gsx::scan_counts(temp, c.temp_bytes, counts, order, offsets, n, s));
-    uint32_t host[2] = {0, 0};
-    GSX_HIP(hipMemcpyAsync(&host[0], offsets + n, 4, hipMemcpyDeviceToHost, s));
-    if (n_visible_known < 0) GSX_HIP(hipMemcpyAsync(&host[1], counters, 4, hipMemcpyDeviceToHost, s));
-    GSX_HIP(hipStreamSynchronize(s));
-    tm.mark();  // 3: scan + read-back
-    const int64_t d = host[0];
-    if (stats) {
-        stats->n_visible = n_visible_known < 0 ? (int64_t)host[1] : n_visible_known;
-        stats->n_instances = d;
-        stats->n_tiles = p.grid.count();
-        stats->reserved = 0;
+    // Speculative frame: the pair list is sized by the caller's hint (normally the previous frame's
+    // count), nothing waits for the device.  Needs 16-bit tile ids (the padding key is 0xFFFF).
+    const bool speculative = p.hint > 0 && p.hint <= cap && p.grid.count() <= 65535 && !p.timing;
+    int64_t d = 0;
+    if (speculative) {
+        d = p.hint;
+        if (stats) {
+            int64_t *dev2 = (int64_t *)(counters + 8);
+            GSX_HIP(gsx::publish_counts(counters, offsets + n, n_visible_known, dev2, s));
+            // stats must be pinned host memory; the two counts land when the stream gets here
+            GSX_HIP(hipMemcpyAsync(stats, dev2, 16, hipMemcpyDeviceToHost, s));
+            stats->n_tiles = p.grid.count();
+            stats->reserved = 1;  // 1 = counts are delivered asynchronously
+        }
+        tm.mark();
+    } else {
+        uint32_t host[2] = {0, 0};
+        GSX_HIP(hipMemcpyAsync(&host[0], offsets + n, 4, hipMemcpyDeviceToHost, s));
+        if (n_visible_known < 0) GSX_HIP(hipMemcpyAsync(&host[1], counters, 4, hipMemcpyDeviceToHost, s));
+        GSX_HIP(hipStreamSynchronize(s));
+        tm.mark();  // 3: scan + read-back
+        d = host[0];
+        if (stats) {
+            stats->n_visible = n_visible_known < 0 ? (int64_t)host[1] : n_visible_known;
+            stats->n_instances = d;
+            stats->n_tiles = p.grid.count();
+            stats->reserved = 0;
+        }
     }
     const size_t out_bytes = (size_t)p.out.w * p.out.h * 3 * sizeof(float);
-    GSX_HIP(hipMemsetAsync(p.out.ptr, 0, out_bytes, s));
-    if (d > cap)
+    if (d > cap) {
+        GSX_HIP(hipMemsetAsync(p.out.ptr, 0, out_bytes, s));
         return fail(GSX_ERR_WORKSPACE_TOO_SMALL, "frame needs %lld tile instances, workspace holds %lld", (long long)d,
                     (long long)cap);
-    if (d == 0 || p.grid.count() == 0) return GSX_OK;
+    }
+    if (d == 0 || p.grid.count() == 0) {
+        GSX_HIP(hipMemsetAsync(p.out.ptr, 0, out_bytes, s));
+        return GSX_OK;
+    }
+    int rc = clear_outside_window(p, s);
+    if (rc != GSX_OK) return rc;
     uint2 *ranges = (uint2 *)(ws + c.ranges);
     const uint32_t *sorted_vals = nullptr;
-    GSX_HIP(gsx::bin_instances(temp, c.temp_bytes, (const gsx::TileRect *)(ws + c.rect), order, offsets, n, d, p.grid,
-                               ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0), (uint32_t *)(ws + c.tvals1),
+    GSX_HIP(gsx::bin_instances(temp, c.temp_bytes, (const gsx::TileRect *)(ws + c.rect), order, offsets, n, d,
+                               speculative, p.grid, ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0), (uint32_t *)(ws + c.tvals1),
                                ranges, &sorted_vals, s));
     tm.mark();  // 4: bin
     GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), sorted_vals, ranges, p.grid, p.out, p.semantics, s));

@@ -32,7 +32,9 @@ constexpr uint32_t kSerialMax = 16;
 
 template <typename Key>
 __device__ __forceinline__ void emit_one(const TileRect &r, uint32_t k, const TileGrid &g, uint32_t value,
-                                         uint32_t base, Key *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                         uint32_t base, uint32_t limit, Key *__restrict__ keys,
+                                         uint32_t *__restrict__ vals) {
+    if (base + k >= limit) return;  // speculative mode: the instance count exceeded the caller's hint
     uint32_t h = (uint32_t)(r.y1 - r.y0 + 1);
     uint32_t tx = r.x0 + k / h, ty = r.y0 + k % h;
     keys[base + k] = (Key)((tx - (uint32_t)g.wx0) * (uint32_t)g.nwy() + (ty - (uint32_t)g.wy0));
@@ -42,8 +44,8 @@ __device__ __forceinline__ void emit_one(const TileRect &r, uint32_t k, const Ti
 template <typename Key>
 __global__ void __launch_bounds__(kBlock)
     emit_kernel(const TileRect *__restrict__ rect, const uint32_t *__restrict__ order,
-                const uint32_t *__restrict__ offsets, int64_t n, TileGrid g, Key *__restrict__ keys,
-                uint32_t *__restrict__ vals) {
+                const uint32_t *__restrict__ offsets, int64_t n, TileGrid g, uint32_t limit,
+                Key *__restrict__ keys, uint32_t *__restrict__ vals) {
     int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     TileRect tr;
     tr.x0 = 1; tr.x1 = 0; tr.y0 = 1; tr.y1 = 0;
@@ -55,7 +57,7 @@ __global__ void __launch_bounds__(kBlock)
         if (cnt) tr = rect[gi];
     }
     if (cnt <= kSerialMax)
-        for (uint32_t k = 0; k < cnt; ++k) emit_one(tr, k, g, gi, base, keys, vals);
+        for (uint32_t k = 0; k < cnt; ++k) emit_one(tr, k, g, gi, base, limit, keys, vals);
     unsigned long long big = __ballot(cnt > kSerialMax);
     const int lane = threadIdx.x & 63;
     while (big) {
@@ -68,20 +70,29 @@ __global__ void __launch_bounds__(kBlock)
         br.y1 = (uint16_t)__shfl((int)tr.y1, src);
         uint32_t bbase = (uint32_t)__shfl((int)base, src), bcnt = (uint32_t)__shfl((int)cnt, src);
         uint32_t bgi = (uint32_t)__shfl((int)gi, src);
-        for (uint32_t k = lane; k < bcnt; k += 64) emit_one(br, k, g, bgi, bbase, keys, vals);
+        for (uint32_t k = lane; k < bcnt; k += 64) emit_one(br, k, g, bgi, bbase, limit, keys, vals);
     }
 }
 
 // ranges[t] = [first, last+1) of tile t inside the tile-sorted pair list; untouched (zeroed by
 // the caller) for tiles with no entries.
-template <typename Key>
+// PADDED: the pair list was sized by the caller's hint and padded with all-ones keys.
+template <typename Key, bool PADDED>
 __global__ void __launch_bounds__(kBlock)
     tile_ranges_kernel(const Key *__restrict__ keys, int64_t d, uint2 *__restrict__ ranges) {
     int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= d) return;
-    uint32_t t = keys[j];
+    const Key t = keys[j];
+    if (PADDED && t == (Key)~(Key)0) return;
     if (j == 0 || keys[j - 1] != t) ranges[t].x = (uint32_t)j;
     if (j == d - 1 || keys[j + 1] != t) ranges[t].y = (uint32_t)(j + 1);
+}
+
+// Device-side frame counts in the layout of the first two GsxFrameStats fields.
+__global__ void publish_counts_kernel(const uint32_t *__restrict__ n_visible, const uint32_t *__restrict__ total,
+                                      int64_t n_visible_known, int64_t *__restrict__ out2) {
+    out2[0] = n_visible_known >= 0 ? n_visible_known : (int64_t)*n_visible;
+    out2[1] = (int64_t)*total;
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
@@ -152,38 +163,55 @@ hipError_t scan_counts(void *temp, size_t temp_bytes, const uint32_t *counts, co
 // every tile's [first, last) range.  Tile ids fit 16 bits for any frame up to 65535 tiles (4K has
 // 32 026), which halves the key traffic of the sort; larger frames use 32-bit ids.
 // keys0 / keys1 / vals0 / vals1 each hold `d` 32-bit words.  *sorted_vals = the sorted values.
+// padded: `d` is the caller's hint, not the true count (which only the device knows): the key
+// buffer is pre-filled with all-ones keys that sort behind every tile, and pairs past `d` are dropped.
 template <typename Key>
 hipError_t bin_impl(void *temp, size_t temp_bytes, const TileRect *rect, const uint32_t *order,
-                    const uint32_t *offsets, int64_t n, int64_t d, const TileGrid &grid, void *keys0, void *keys1,
-                    uint32_t *vals0, uint32_t *vals1, uint2 *ranges, int key_bits, const uint32_t **sorted_vals,
-                    hipStream_t s) {
+                    const uint32_t *offsets, int64_t n, int64_t d, bool padded, const TileGrid &grid, void *keys0,
+                    void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges, int key_bits,
+                    const uint32_t **sorted_vals, hipStream_t s) {
     Key *kc = (Key *)keys0, *ka = (Key *)keys1;
     uint32_t *vc = vals0, *va = vals1;
-    emit_kernel<Key><<<blocks_for(n), kBlock, 0, s>>>(rect, order, offsets, n, grid, kc, vc);
-    hipError_t e = hipGetLastError();
+    hipError_t e;
+    if (padded) {
+        e = hipMemsetAsync(kc, 0xFF, sizeof(Key) * (size_t)d, s);
+        if (e != hipSuccess) return e;
+        key_bits = (int)sizeof(Key) * 8;
+    }
+    emit_kernel<Key><<<blocks_for(n), kBlock, 0, s>>>(rect, order, offsets, n, grid, (uint32_t)d, kc, vc);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     e = sort_impl<rocprim::default_config>(temp, temp_bytes, kc, ka, vc, va, d, key_bits, s);
     if (e != hipSuccess) return e;
-    tile_ranges_kernel<Key><<<blocks_for(d), kBlock, 0, s>>>(kc, d, ranges);
+    if (padded)
+        tile_ranges_kernel<Key, true><<<blocks_for(d), kBlock, 0, s>>>(kc, d, ranges);
+    else
+        tile_ranges_kernel<Key, false><<<blocks_for(d), kBlock, 0, s>>>(kc, d, ranges);
     *sorted_vals = vc;
     return hipGetLastError();
 }
 
 hipError_t bin_instances(void *temp, size_t temp_bytes, const TileRect *rect, const uint32_t *order,
-                         const uint32_t *offsets, int64_t n, int64_t d, const TileGrid &grid, void *keys0,
-                         void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges, const uint32_t **sorted_vals,
-                         hipStream_t s) {
+                         const uint32_t *offsets, int64_t n, int64_t d, bool padded, const TileGrid &grid,
+                         void *keys0, void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges,
+                         const uint32_t **sorted_vals, hipStream_t s) {
     const int64_t nt = grid.count();
     hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)nt, s);
     *sorted_vals = vals0;
     if (e != hipSuccess || d == 0 || n == 0) return e;
     int bits = 1;
     while (((int64_t)1 << bits) < nt) ++bits;
-    if (nt <= 65536)
-        return bin_impl<uint16_t>(temp, temp_bytes, rect, order, offsets, n, d, grid, keys0, keys1, vals0, vals1,
-                                  ranges, bits, sorted_vals, s);
-    return bin_impl<uint32_t>(temp, temp_bytes, rect, order, offsets, n, d, grid, keys0, keys1, vals0, vals1, ranges,
-                              bits, sorted_vals, s);
+    if (nt <= 65535)
+        return bin_impl<uint16_t>(temp, temp_bytes, rect, order, offsets, n, d, padded, grid, keys0, keys1, vals0,
+                                  vals1, ranges, bits, sorted_vals, s);
+    return bin_impl<uint32_t>(temp, temp_bytes, rect, order, offsets, n, d, padded, grid, keys0, keys1, vals0, vals1,
+                              ranges, bits, sorted_vals, s);
+}
+
+hipError_t publish_counts(const uint32_t *n_visible, const uint32_t *total, int64_t n_visible_known, int64_t *out2,
+                          hipStream_t s) {
+    publish_counts_kernel<<<1, 1, 0, s>>>(n_visible, total, n_visible_known, out2);
+    return hipGetLastError();
 }
 
 }  // namespace gsx

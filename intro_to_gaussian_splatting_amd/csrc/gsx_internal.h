@@ -82,10 +82,16 @@ hipError_t scan_counts(void *temp, size_t temp_bytes, const uint32_t *counts, co
 // Emits one (tile id, Gaussian index) pair per covered tile in rank order, stable-sorts them by
 // tile id and fills ranges[t] = [first, last) for every tile of the window.  keys0/keys1/vals0/
 // vals1 hold d 32-bit words each; *sorted_vals points at the sorted Gaussian indices.
+// padded = speculative mode: d is an upper bound supplied by the caller, the true count stays on
+// the device (offsets[n]); pairs beyond d are dropped.
 hipError_t bin_instances(void *temp, size_t temp_bytes, const TileRect *rect, const uint32_t *order,
-                         const uint32_t *offsets, int64_t n, int64_t d, const TileGrid &grid, void *keys0,
-                         void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges, const uint32_t **sorted_vals,
-                         hipStream_t s);
+                         const uint32_t *offsets, int64_t n, int64_t d, bool padded, const TileGrid &grid,
+                         void *keys0, void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges,
+                         const uint32_t **sorted_vals, hipStream_t s);
+// out2[0] = n_visible, out2[1] = n_instances as int64 (device memory), for an asynchronous copy
+// into the first two fields of a GsxFrameStats.
+hipError_t publish_counts(const uint32_t *n_visible, const uint32_t *total, int64_t n_visible_known, int64_t *out2,
+                          hipStream_t s);
 
 // ---- gsx_blend.hip
 hipError_t launch_blend(const Record *rec, const uint32_t *sorted_vals, const uint2 *ranges, const TileGrid &grid,

@@ -43,16 +43,19 @@ class _Workspace:
     """Caller-owned device scratch for libgsx (the library never allocates)."""
 
     def __init__(self) -> None:
-        self.buffers: Dict[torch.device, torch.Tensor] = {}
+        self.buffers: Dict[tuple, torch.Tensor] = {}
 
     def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
-        buf = self.buffers.get(device)
+        # one buffer per (device, stream): frames in flight on different streams must not share scratch
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        buf = self.buffers.get(key)
         if buf is None or buf.numel() < nbytes:
-            self.buffers[device] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.buffers[key] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return buf
 
 
 _WORKSPACE = _Workspace()
+_PINNED_SLOTS = 256
 
 
 def _stream_handle(device: torch.device) -> ctypes.c_void_p:
@@ -116,7 +119,11 @@ class GaussianScene:
             self.images[idx] = GaussianImage(camera=cameras[image.camera_id], image=image,
                                              device=gaussians.device)
         self.gaussians = gaussians
-        self._instances_hint = 0
+        self._instances_hint = 0      # workspace sizing: largest instance count seen (+10 %)
+        self._last_instances = 0      # instance count of the latest full frame (speculative hint)
+        self._pending = []            # speculative frames awaiting confirm_frames()
+        self._pinned_pool = None
+        self._pinned_next = 0
 
     # ------------------------------------------------------------------ helpers
     def _inputs(self):
@@ -162,7 +169,8 @@ class GaussianScene:
     def render_image_hip(self, image_idx: int, tile_size: int = 16, layout: str = "wh3",
                          tile_window: Optional[Tuple[int, int, int, int]] = None,
                          out: Optional[torch.Tensor] = None, out_origin: Tuple[int, int] = (0, 0),
-                         stats: Optional[dict] = None, timing: bool = False) -> torch.Tensor:
+                         stats: Optional[dict] = None, timing: bool = False,
+                         no_sync: bool = False) -> torch.Tensor:
         """Full forward render in libgsx (gsx_render_forward).
 
         layout "wh3" -> (W,H,3) indexed [x,y] like ``render_image``; "hw3" -> (H,W,3).
@@ -170,6 +178,11 @@ class GaussianScene:
         ``out`` may then be a strip-sized buffer whose pixel (0,0) is frame pixel ``out_origin``.
         ``timing`` asks the library for per-stage HIP-event times (``stats["stage_ms"]``); the call
         then waits for the frame.
+        ``no_sync`` (GSX_FLAG_NO_SYNC) enqueues the frame without waiting for the device: the pair
+        list is sized by the instance count of this scene's previous frame (+6 %); the counts arrive
+        later in pinned memory and ``confirm_frames()`` must be called (it synchronises) before the
+        images are trusted -- it re-renders, synchronously, any frame whose count exceeded the hint.
+        The first frame of a scene (no hint yet) always takes the synchronising path.
         """
         lib = _ffi.load()
         dev, n, tensors = self._inputs()
@@ -190,8 +203,21 @@ class GaussianScene:
                 raise ValueError("out must be contiguous")
             ow, oh = (out.shape[0], out.shape[1]) if layout == "wh3" else (out.shape[1], out.shape[0])
             params.out_x0, params.out_y0, params.out_w, params.out_h = int(out_origin[0]), int(out_origin[1]), int(ow), int(oh)
-        st = _ffi.GsxFrameStats()
         cap = max(self._instances_hint, 8 * n + 4096)
+        speculative = bool(no_sync and not timing and self._last_instances > 0 and tile_window is None)
+        if speculative:
+            hint = int(self._last_instances * 1.06) + 1024
+            cap = max(cap, hint)
+            params.flags |= _ffi.GSX_FLAG_NO_SYNC
+            params.instances_hint = hint
+            if len(self._pending) >= _PINNED_SLOTS:
+                self.confirm_frames()
+            pinned = self._pinned_slot()
+            st_ref = ctypes.cast(ctypes.c_void_p(pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats))
+            st = st_ref.contents
+        else:
+            st = _ffi.GsxFrameStats()
+            st_ref = ctypes.byref(st)
         with torch.cuda.device(dev):
             for _ in range(3):
                 nbytes = lib.gsx_workspace_bytes(n, width, height, tile_size, cap)
@@ -199,18 +225,54 @@ class GaussianScene:
                     raise _ffi.GsxError(_ffi.GSX_ERR_INVALID_ARGUMENT, "gsx_workspace_bytes rejected the sizes")
                 ws = _WORKSPACE.get(dev, nbytes)
                 rc = lib.gsx_render_forward(ctypes.byref(cam), *[_ptr(t) for t in tensors], n, tile_size, _ptr(out),
-                                            ctypes.byref(params), ctypes.byref(st), _ptr(ws), ws.numel(),
+                                            ctypes.byref(params), st_ref, _ptr(ws), ws.numel(),
                                             _stream_handle(dev))
                 if rc != _ffi.GSX_ERR_WORKSPACE_TOO_SMALL:
                     break
                 cap = int(st.n_instances * 1.25) + 4096
         _ffi.check(rc)
+        if speculative and st.reserved == 1:
+            # counts are still in flight: remember what has to be confirmed
+            self._pending.append((pinned, hint, image_idx, tile_size, layout, out))
+            if stats is not None:
+                stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
+            return out
         self._instances_hint = max(self._instances_hint, int(st.n_instances * 1.1))
+        if tile_window is None:
+            self._last_instances = int(st.n_instances)
         if stats is not None:
             stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles)
             if timing:
                 stats["stage_ms"] = {k: float(st.stage_ms[i]) for i, k in enumerate(_ffi.STAGE_NAMES)}
         return out
+
+    def _pinned_slot(self) -> torch.Tensor:
+        """One 64-byte slot of a pinned ring (pinning memory per frame would dominate the frame)."""
+        if self._pinned_pool is None:
+            self._pinned_pool = torch.zeros((_PINNED_SLOTS, ctypes.sizeof(_ffi.GsxFrameStats)),
+                                            dtype=torch.uint8).pin_memory()
+        slot = self._pinned_pool[self._pinned_next % _PINNED_SLOTS]
+        self._pinned_next += 1
+        slot.zero_()
+        return slot
+
+    def confirm_frames(self) -> int:
+        """Synchronises and validates every frame rendered with ``no_sync=True`` since the last call.
+        A frame whose true instance count exceeded its hint (pairs were dropped) is rendered again
+        on the synchronising path into the same output tensor.  Returns the number of re-renders."""
+        if not self._pending:
+            return 0
+        torch.cuda.synchronize(self.gaussians.points.device)
+        redone = 0
+        pending, self._pending = self._pending, []
+        for pinned, hint, image_idx, tile_size, layout, out in pending:
+            st = ctypes.cast(ctypes.c_void_p(pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents
+            self._last_instances = int(st.n_instances)
+            if st.n_instances > hint:
+                redone += 1
+                full = self.render_image_hip(image_idx, tile_size=tile_size, layout=layout)
+                out.copy_(full)
+        return redone
 
     def render_image(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:
         """(W,H,3) float32 indexed [x,y]; same result as the reference's pure-Python

@@ -349,6 +349,47 @@ def test_workspace_growth_retry(tmp_path):
     assert np.max(np.abs(img.cpu().numpy() - ref)) <= PIXEL_TOL
 
 
+def test_speculative_frames_equal_synchronised_frames(tmp_path):
+    """GSX_FLAG_NO_SYNC: pair list sized by the previous frame's count, counts confirmed later."""
+    _need_gpu()
+    g = load_golden("c1_256x256_n2000")
+    scene = _scene_from_golden(tmp_path, g)
+    ref = scene.render_image_hip(1)                       # synchronising path; learns the count
+    st = {}
+    a = scene.render_image_hip(1, no_sync=True, stats=st)
+    assert st.get("speculative") is True
+    b = scene.render_image_hip(1, no_sync=True, layout="hw3")
+    assert scene.confirm_frames() == 0
+    assert torch.equal(a, ref) and torch.equal(b.permute(1, 0, 2), ref)
+    # a hint that is too small drops pairs on the device; confirm_frames notices and re-renders
+    scene._last_instances = 1000
+    c = scene.render_image_hip(1, no_sync=True)
+    assert scene.confirm_frames() == 1
+    assert torch.equal(c, ref)
+    assert scene._last_instances == 7379
+
+
+def test_frames_in_flight_on_several_streams(tmp_path):
+    """Frames of the same scene enqueued on different HIP streams (own scratch per stream) overlap
+    on the GPU and must still be the single-stream frame, bit for bit."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    sc = make_scene(200_000, 640, 480, seed=5)
+    scene = _scene_from_arrays(tmp_path, sc)
+    ref = scene.render_image_hip(1)
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(3)]
+    outs = [torch.empty_like(ref) for _ in range(9)]
+    torch.cuda.synchronize()
+    for i, out in enumerate(outs):
+        with torch.cuda.stream(streams[i % 3]):
+            scene.render_image_hip(1, out=out, no_sync=(i % 2 == 0))
+    torch.cuda.synchronize()
+    assert scene.confirm_frames() == 0
+    for out in outs:
+        assert torch.equal(out, ref)
+
+
 def test_points_projection_helper(tmp_path):
     _need_gpu()
     g = load_golden("cull_96x80_n400")
