@@ -39,7 +39,7 @@ inline int32_t tiles_along(int32_t extent, int32_t tile, int semantics) {
 
 struct Carve {
     size_t keys0, keys1, vals0, vals1;      // n x u32: depth keys / original indices (ping-pong)
-    size_t rec, rect, counts, offsets;      // per depth rank
+    size_t rec, rect, counts, offsets, bbox;  // per Gaussian
     size_t tkeys0, tkeys1, tvals0, tvals1;  // cap x u32: tile ids / depth ranks (ping-pong)
     size_t ranges, counters, temp, temp_bytes, total;
 };
@@ -58,6 +58,7 @@ Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes) {
     c.rect = take(nn * sizeof(gsx::TileRect));
     c.counts = take((nn + 1) * 4);
     c.offsets = take((nn + 1) * 4);
+    c.bbox = take(nn * sizeof(float4));
     c.tkeys0 = take(cc * 4); c.tkeys1 = take(cc * 4); c.tvals0 = take(cc * 4); c.tvals1 = take(cc * 4);
     c.ranges = take((size_t)(max_tiles > 0 ? max_tiles : 1) * sizeof(uint2));
     c.counters = take(64);
@@ -138,8 +139,8 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     if (params) d = *params;
     if (width <= 0 || height <= 0) return fail(GSX_ERR_INVALID_ARGUMENT, "image size %dx%d is not positive", width, height);
     if (tile <= 0 || tile > 1024) return fail(GSX_ERR_INVALID_ARGUMENT, "tile size %d out of range [1,1024]", tile);
-    if (d.semantics != GSX_SEM_REF_CPU)
-        return fail(GSX_ERR_UNSUPPORTED, "semantics %d not implemented (only GSX_SEM_REF_CPU)", d.semantics);
+    if (d.semantics != GSX_SEM_REF_CPU && d.semantics != GSX_SEM_REF_CUDA)
+        return fail(GSX_ERR_UNSUPPORTED, "unknown semantics %d", d.semantics);
     if (d.layout != GSX_LAYOUT_WH3 && d.layout != GSX_LAYOUT_HW3) return fail(GSX_ERR_INVALID_ARGUMENT, "unknown layout %d", d.layout);
     if (!out_image) return fail(GSX_ERR_INVALID_ARGUMENT, "out_image is NULL");
     p.semantics = d.semantics;
@@ -151,6 +152,8 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     g.tile = tile;
     g.ntx = tiles_along(width, tile, d.semantics);
     g.nty = tiles_along(height, tile, d.semantics);
+    g.width = width;
+    g.height = height;
     if (g.ntx > 65535 || g.nty > 65535) return fail(GSX_ERR_UNSUPPORTED, "more than 65535 tiles along an axis");
     g.wx0 = d.tile_x0 < 0 ? 0 : d.tile_x0;
     g.wy0 = d.tile_y0 < 0 ? 0 : d.tile_y0;
@@ -174,6 +177,8 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     if (g.count() > 0) {
         // every rendered tile must lie inside the output buffer
         int64_t px0 = (int64_t)g.wx0 * tile, px1 = (int64_t)g.wx1 * tile, py0 = (int64_t)g.wy0 * tile, py1 = (int64_t)g.wy1 * tile;
+        px1 = px1 > width ? width : px1;   // partial edge tiles (REF_CUDA) end at the frame border
+        py1 = py1 > height ? height : py1;
         if (px0 < o.x0 || px1 > (int64_t)o.x0 + o.w || py0 < o.y0 || py1 > (int64_t)o.y0 + o.h)
             return fail(GSX_ERR_INVALID_ARGUMENT, "tile window [%d,%d)x[%d,%d) does not fit the %dx%d output buffer at (%d,%d)",
                         g.wx0, g.wx1, g.wy0, g.wy1, o.w, o.h, o.x0, o.y0);
@@ -191,9 +196,11 @@ int clear_outside_window(const Plan &p, hipStream_t s) {
     const bool wh3 = o.stride_y < o.stride_x;  // x is the slow axis
     const int64_t slow_n = wh3 ? o.w : o.h, fast_n = wh3 ? o.h : o.w;
     int64_t ws0 = (int64_t)(wh3 ? p.grid.wx0 : p.grid.wy0) * T - (wh3 ? o.x0 : o.y0);
-    int64_t ws1 = (int64_t)(wh3 ? p.grid.wx1 : p.grid.wy1) * T - (wh3 ? o.x0 : o.y0);
+    int64_t ws1 = (int64_t)(wh3 ? p.grid.wx1 : p.grid.wy1) * T;
+    int64_t wf1 = (int64_t)(wh3 ? p.grid.wy1 : p.grid.wx1) * T;
+    ws1 = (ws1 > (wh3 ? p.grid.width : p.grid.height) ? (wh3 ? p.grid.width : p.grid.height) : ws1) - (wh3 ? o.x0 : o.y0);
+    wf1 = (wf1 > (wh3 ? p.grid.height : p.grid.width) ? (wh3 ? p.grid.height : p.grid.width) : wf1) - (wh3 ? o.y0 : o.x0);
     int64_t wf0 = (int64_t)(wh3 ? p.grid.wy0 : p.grid.wx0) * T - (wh3 ? o.y0 : o.x0);
-    int64_t wf1 = (int64_t)(wh3 ? p.grid.wy1 : p.grid.wx1) * T - (wh3 ? o.y0 : o.x0);
     const size_t px = 3 * sizeof(float), pitch = (size_t)fast_n * px;
     char *base = (char *)o.ptr;
     auto rect = [&](int64_t s0, int64_t s1, int64_t f0, int64_t f1) -> hipError_t {
@@ -265,7 +272,8 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
                                speculative, p.grid, ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0), (uint32_t *)(ws + c.tvals1),
                                ranges, &sorted_vals, s));
     tm.mark();  // 4: bin
-    GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), sorted_vals, ranges, p.grid, p.out, p.semantics, s));
+    GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals, ranges,
+                              p.grid, p.out, p.semantics, s));
     tm.mark();  // 5: blend
     tm.finish(stats);
     return GSX_OK;
@@ -365,7 +373,8 @@ int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t t
     tm.mark();  // 1: (no depth sort on this entry point)
     gsx::PreprocessedIn in{point_means, point_colors, inverse_covariance_2d, min_x, max_x, min_y, max_y, opacity};
     GSX_HIP(gsx::launch_pack_preprocessed(in, n, p.grid, p.semantics, (gsx::Record *)(ws + c.rec),
-                                          (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts), s));
+                                          (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts),
+                                          p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 2: pack
     return bin_and_blend(p, c, ws, n, cap, nullptr, n, stats_host, tm, s);
 }
@@ -394,7 +403,8 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     GSX_HIP(hipMemsetAsync(counters, 0, 64, s));
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
     GSX_HIP(gsx::launch_project_pack(*camera, in, n, p.grid, p.semantics, k0, v0, (gsx::Record *)(ws + c.rec),
-                                     (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts), s));
+                                     (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts),
+                                     p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 1: project (+ depth keys)
     GSX_HIP(gsx::sort_by_depth(ws + c.temp, c.temp_bytes, k0, k1, v0, v1, n, s));
     GSX_HIP(gsx::launch_count_visible(k0, n, counters, s));

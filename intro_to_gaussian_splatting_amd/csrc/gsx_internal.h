@@ -24,6 +24,7 @@ struct __attribute__((aligned(16))) Record {
 struct TileGrid {
     int32_t tile, ntx, nty;
     int32_t wx0, wx1, wy0, wy1;
+    int32_t width, height;  // frame size in pixels (REF_CUDA has partial edge tiles)
     __host__ __device__ int32_t nwx() const { return wx1 - wx0; }
     __host__ __device__ int32_t nwy() const { return wy1 - wy0; }
     __host__ __device__ int64_t count() const { return (int64_t)nwx() * nwy(); }
@@ -59,13 +60,15 @@ hipError_t launch_depth_keys(const GsxCamera &cam, const float *means3d, int64_t
 hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t *n_visible, hipStream_t s);
 // Original order: depth keys + identity values for the sort, records / rects / counts indexed by
 // the ORIGINAL Gaussian index.
+// bbox (REF_CUDA only, else may be null): (min_x, max_x, min_y, max_y) per Gaussian for the
+// per-pixel cull of splat/c/render.cu:55-60.
 hipError_t launch_project_pack(const GsxCamera &cam, const GaussiansIn &in, int64_t n, const TileGrid &grid,
                                int semantics, uint32_t *keys, uint32_t *vals, Record *rec, TileRect *rect,
-                               uint32_t *counts, hipStream_t s);
+                               uint32_t *counts, float4 *bbox, hipStream_t s);
 hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
                                const uint32_t *sorted_idx, int64_t n, const StageOneOut &out, hipStream_t s);
 hipError_t launch_pack_preprocessed(const PreprocessedIn &in, int64_t n, const TileGrid &grid, int semantics,
-                                    Record *rec, TileRect *rect, uint32_t *counts, hipStream_t s);
+                                    Record *rec, TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s);
 hipError_t launch_project_points(const GsxCamera &cam, const float *means3d, int64_t n, float *points_out,
                                  uint8_t *in_view, hipStream_t s);
 
@@ -94,7 +97,7 @@ hipError_t publish_counts(const uint32_t *n_visible, const uint32_t *total, int6
                           hipStream_t s);
 
 // ---- gsx_blend.hip
-hipError_t launch_blend(const Record *rec, const uint32_t *sorted_vals, const uint2 *ranges, const TileGrid &grid,
-                        const OutDesc &out, int semantics, hipStream_t s);
+hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
+                        const TileGrid &grid, const OutDesc &out, int semantics, hipStream_t s);
 
 }  // namespace gsx

@@ -148,11 +148,41 @@ __device__ __forceinline__ void axis_range(float mn, float mx, int T, int w0, in
     hi = hi > w1 - 1 ? w1 - 1 : hi;
 }
 
+// REF_CUDA: a Gaussian matters to the pixels p with mn <= p <= mx (splat/c/render.cu:55-60), i.e. to
+// the tiles holding an integer pixel of [ceil(mn), floor(mx)] inside the frame.
+__device__ __forceinline__ void axis_range_pixels(float mn, float mx, int T, int extent, int w0, int w1, int &lo,
+                                                  int &hi) {
+    if (!(mn == mn) || !(mx == mx)) {
+        lo = 1;
+        hi = 0;
+        return;
+    }
+    const float big = 1073741824.0f;
+    int p0 = (int)ceilf(fminf(fmaxf(mn, -big), big));
+    int p1 = (int)floorf(fminf(fmaxf(mx, -big), big));
+    p0 = p0 < 0 ? 0 : p0;
+    p1 = p1 > extent - 1 ? extent - 1 : p1;
+    if (p0 > p1) {
+        lo = 1;
+        hi = 0;
+        return;
+    }
+    lo = p0 / T;
+    hi = p1 / T;
+    lo = lo < w0 ? w0 : lo;
+    hi = hi > w1 - 1 ? w1 - 1 : hi;
+}
+
 __device__ __forceinline__ uint32_t tile_rect(float mnx, float mxx, float mny, float mxy, const TileGrid &g,
-                                              TileRect &r) {
+                                              int semantics, TileRect &r) {
     int lx, hx, ly, hy;
-    axis_range(mnx, mxx, g.tile, g.wx0, g.wx1, lx, hx);
-    axis_range(mny, mxy, g.tile, g.wy0, g.wy1, ly, hy);
+    if (semantics == GSX_SEM_REF_CUDA) {
+        axis_range_pixels(mnx, mxx, g.tile, g.width, g.wx0, g.wx1, lx, hx);
+        axis_range_pixels(mny, mxy, g.tile, g.height, g.wy0, g.wy1, ly, hy);
+    } else {
+        axis_range(mnx, mxx, g.tile, g.wx0, g.wx1, lx, hx);
+        axis_range(mny, mxy, g.tile, g.wy0, g.wy1, ly, hy);
+    }
     if (lx > hx || ly > hy) {
         r.x0 = 1; r.x1 = 0; r.y0 = 1; r.y1 = 0;
         return 0u;
@@ -189,9 +219,22 @@ __global__ void __launch_bounds__(kBlock)
 //         stored as log2(op) so that alpha = exp2(d Q'' d^T + log2 op) needs no multiply
 //   Q'' : Q * (-1/2 log2 e), so that the weight is exp2(d Q'' d^T); the -1/2 is exact, log2 e costs
 //         one rounding per entry (relative 6e-8, far inside the 1e-4 pixel tolerance)
-__device__ __forceinline__ void pack_record(float x, float y, float q00, float q01, float q10, float q11, float op,
-                                            float cr, float cg, float cb, float depth, Record &out) {
+// REF_CUDA (splat/c/render.cu:5-19, 61-68): the mean is truncated to int by the device function's
+// signature and the quadratic form is a dx^2 + 2 b dx dy + c dy^2 with b = Q01 only.
+__device__ __forceinline__ float trunc_to_int(float v) {
+    const float big = 2147483520.0f;
+    return (float)(int)fminf(fmaxf(v, -big), big);
+}
+
+__device__ __forceinline__ void pack_record(int semantics, float x, float y, float q00, float q01, float q10,
+                                            float q11, float op, float cr, float cg, float cb, float depth,
+                                            Record &out) {
     const float k = -0.5f * 1.44269504088896340736f;
+    if (semantics == GSX_SEM_REF_CUDA) {
+        x = trunc_to_int(x);
+        y = trunc_to_int(y);
+        q10 = q01;
+    }
     out.a = make_float4(x, y, q00 * k, (q01 + q10) * k);
     out.b = make_float4(q11 * k, log2f(op), cr, cg);
     out.c = make_float4(cb, depth, 0.0f, 0.0f);
@@ -202,7 +245,7 @@ __device__ __forceinline__ void pack_record(float x, float y, float q00, float q
 __global__ void __launch_bounds__(kBlock)
     project_pack_kernel(GsxCamera cam, GaussiansIn in, int64_t n, TileGrid grid, int semantics,
                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, Record *__restrict__ rec,
-                        TileRect *__restrict__ rect, uint32_t *__restrict__ counts) {
+                        TileRect *__restrict__ rect, uint32_t *__restrict__ counts, float4 *__restrict__ bbox) {
     int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= n) return;
     const float *p = in.means3d + 3 * g;
@@ -224,10 +267,11 @@ __global__ void __launch_bounds__(kBlock)
     float op = sigmoidf(in.opacity_logit[g]);
     if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);
     Record out;
-    pack_record(o.x, o.y, o.q00, o.q01, o.q10, o.q11, op, c[0], c[1], c[2], o.depth, out);
+    pack_record(semantics, o.x, o.y, o.q00, o.q01, o.q10, o.q11, op, c[0], c[1], c[2], o.depth, out);
     rec[g] = out;
+    if (bbox) bbox[g] = make_float4(o.min_x, o.max_x, o.min_y, o.max_y);
     TileRect tr;
-    counts[g] = tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, tr);
+    counts[g] = tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, semantics, tr);
     rect[g] = tr;
 }
 
@@ -260,18 +304,20 @@ __global__ void __launch_bounds__(kBlock)
 // Stage-1 arrays handed in by the caller (the reference's native argument list) -> records.
 __global__ void __launch_bounds__(kBlock)
     pack_preprocessed_kernel(PreprocessedIn in, int64_t n, TileGrid grid, int semantics, Record *__restrict__ rec,
-                             TileRect *__restrict__ rect, uint32_t *__restrict__ counts) {
+                             TileRect *__restrict__ rect, uint32_t *__restrict__ counts, float4 *__restrict__ bbox) {
     int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
     float op = in.opacity[r];
     if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);
     float mnx = in.min_x[r], mxx = in.max_x[r], mny = in.min_y[r], mxy = in.max_y[r];
     Record out;
-    pack_record(in.means[2 * r], in.means[2 * r + 1], in.inv_cov[4 * r], in.inv_cov[4 * r + 1], in.inv_cov[4 * r + 2],
-                in.inv_cov[4 * r + 3], op, in.colors[3 * r], in.colors[3 * r + 1], in.colors[3 * r + 2], 0.0f, out);
+    pack_record(semantics, in.means[2 * r], in.means[2 * r + 1], in.inv_cov[4 * r], in.inv_cov[4 * r + 1],
+                in.inv_cov[4 * r + 2], in.inv_cov[4 * r + 3], op, in.colors[3 * r], in.colors[3 * r + 1],
+                in.colors[3 * r + 2], 0.0f, out);
     rec[r] = out;
+    if (bbox) bbox[r] = make_float4(mnx, mxx, mny, mxy);
     TileRect tr;
-    counts[r] = tile_rect(mnx, mxx, mny, mxy, grid, tr);
+    counts[r] = tile_rect(mnx, mxx, mny, mxy, grid, semantics, tr);
     rect[r] = tr;
 }
 
@@ -310,9 +356,10 @@ hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t
 
 hipError_t launch_project_pack(const GsxCamera &cam, const GaussiansIn &in, int64_t n, const TileGrid &grid,
                                int semantics, uint32_t *keys, uint32_t *vals, Record *rec, TileRect *rect,
-                               uint32_t *counts, hipStream_t s) {
+                               uint32_t *counts, float4 *bbox, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    project_pack_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, n, grid, semantics, keys, vals, rec, rect, counts);
+    project_pack_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, n, grid, semantics, keys, vals, rec, rect, counts,
+                                                         bbox);
     return hipGetLastError();
 }
 
@@ -324,9 +371,9 @@ hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, cons
 }
 
 hipError_t launch_pack_preprocessed(const PreprocessedIn &in, int64_t n, const TileGrid &grid, int semantics,
-                                    Record *rec, TileRect *rect, uint32_t *counts, hipStream_t s) {
+                                    Record *rec, TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    pack_preprocessed_kernel<<<blocks_for(n), kBlock, 0, s>>>(in, n, grid, semantics, rec, rect, counts);
+    pack_preprocessed_kernel<<<blocks_for(n), kBlock, 0, s>>>(in, n, grid, semantics, rec, rect, counts, bbox);
     return hipGetLastError();
 }
 

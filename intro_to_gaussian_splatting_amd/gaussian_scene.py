@@ -56,6 +56,7 @@ class _Workspace:
 
 _WORKSPACE = _Workspace()
 _PINNED_SLOTS = 256
+_SEMANTICS = {"ref_cpu": _ffi.GSX_SEM_REF_CPU, "ref_cuda": _ffi.GSX_SEM_REF_CUDA}
 
 
 def _stream_handle(device: torch.device) -> ctypes.c_void_p:
@@ -73,11 +74,12 @@ def render_preprocessed(height: int, width: int, tile_size: int, point_means: to
                         point_colors: torch.Tensor, inverse_covariance_2d: torch.Tensor, min_x: torch.Tensor,
                         max_x: torch.Tensor, min_y: torch.Tensor, max_y: torch.Tensor, opacity: torch.Tensor,
                         layout: str = "wh3", instances_hint: int = 0,
-                        stats: Optional[dict] = None) -> torch.Tensor:
+                        stats: Optional[dict] = None, semantics: str = "ref_cpu") -> torch.Tensor:
     """Stage 2 on depth-sorted stage-1 arrays: the reference's native entry point
     ``render_image(image_height, image_width, tile_size, point_means, point_colors,
     inverse_covariance_2d, min_x, max_x, min_y, max_y, opacity)`` (splat/c/render.cu:90-101) with the
-    CPU path's compositing semantics.  Returns (W,H,3) for layout "wh3", (H,W,3) for "hw3"."""
+    CPU path's compositing semantics (``semantics="ref_cuda"``: the CUDA kernel's own semantics,
+    SURVEY.md Appendix B).  Returns (W,H,3) for layout "wh3", (H,W,3) for "hw3"."""
     lib = _ffi.load()
     dev = point_means.device
     _require_gpu(dev)
@@ -88,6 +90,7 @@ def render_preprocessed(height: int, width: int, tile_size: int, point_means: to
         ("min_y", min_y), ("max_y", max_y), ("opacity", opacity))]
     params = _ffi.default_params()
     params.layout = _ffi.GSX_LAYOUT_WH3 if layout == "wh3" else _ffi.GSX_LAYOUT_HW3
+    params.semantics = _SEMANTICS[semantics]
     shape = (width, height, 3) if layout == "wh3" else (height, width, 3)
     out = torch.empty(shape, dtype=torch.float32, device=dev)
     st = _ffi.GsxFrameStats()
@@ -170,7 +173,7 @@ class GaussianScene:
                          tile_window: Optional[Tuple[int, int, int, int]] = None,
                          out: Optional[torch.Tensor] = None, out_origin: Tuple[int, int] = (0, 0),
                          stats: Optional[dict] = None, timing: bool = False,
-                         no_sync: bool = False) -> torch.Tensor:
+                         no_sync: bool = False, semantics: str = "ref_cpu") -> torch.Tensor:
         """Full forward render in libgsx (gsx_render_forward).
 
         layout "wh3" -> (W,H,3) indexed [x,y] like ``render_image``; "hw3" -> (H,W,3).
@@ -190,6 +193,7 @@ class GaussianScene:
         width, height = cam.width, cam.height
         params = _ffi.default_params()
         params.layout = _ffi.GSX_LAYOUT_WH3 if layout == "wh3" else _ffi.GSX_LAYOUT_HW3
+        params.semantics = _SEMANTICS[semantics]
         if timing:
             params.flags |= _ffi.GSX_FLAG_TIMING
         if tile_window is not None:
@@ -204,7 +208,8 @@ class GaussianScene:
             ow, oh = (out.shape[0], out.shape[1]) if layout == "wh3" else (out.shape[1], out.shape[0])
             params.out_x0, params.out_y0, params.out_w, params.out_h = int(out_origin[0]), int(out_origin[1]), int(ow), int(oh)
         cap = max(self._instances_hint, 8 * n + 4096)
-        speculative = bool(no_sync and not timing and self._last_instances > 0 and tile_window is None)
+        speculative = bool(no_sync and not timing and self._last_instances > 0 and tile_window is None
+                           and semantics == "ref_cpu")
         if speculative:
             hint = int(self._last_instances * 1.06) + 1024
             cap = max(cap, hint)
@@ -238,7 +243,7 @@ class GaussianScene:
                 stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
             return out
         self._instances_hint = max(self._instances_hint, int(st.n_instances * 1.1))
-        if tile_window is None:
+        if tile_window is None and semantics == "ref_cpu":
             self._last_instances = int(st.n_instances)
         if stats is not None:
             stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles)
@@ -280,6 +285,16 @@ class GaussianScene:
         return self.render_image_hip(image_idx, tile_size=tile_size, layout="wh3")
 
     render = render_image  # the name BASELINE.json's north star uses
+
+    def render_image_cuda(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:
+        """(H,W,3) float32 indexed [y,x] with the semantics of the reference's CUDA kernel
+        (``render_image_cuda``, splat/gaussian_scene.py:263-285 -> splat/c/render.cu): same flow as the
+        reference -- ``preprocess`` then the native entry point on its arrays."""
+        pre = self.preprocess(image_idx)
+        cam = self.images[image_idx].gsx_camera()
+        return render_preprocessed(cam.height, cam.width, tile_size, pre.points, pre.colors,
+                                   pre.inverse_covariance_2d, pre.min_x, pre.max_x, pre.min_y, pre.max_y,
+                                   pre.sigmoid_opacity, layout="hw3", semantics="ref_cuda")
 
     def render_preprocessed(self, image_idx: int, pre: PreprocessedScene, tile_size: int = 16,
                             layout: str = "wh3", stats: Optional[dict] = None) -> torch.Tensor:

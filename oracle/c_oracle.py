@@ -98,3 +98,19 @@ def render(pre, width: int, height: int, tile: int = 16, nthreads: Optional[int]
                           int(nthreads), win, ctypes.byref(pairs), ctypes.byref(inst))
     assert rc == 0
     return image, pairs.value, inst.value
+
+
+def render_cuda_semantics(pre, width: int, height: int, nthreads: Optional[int] = None) -> np.ndarray:
+    """The reference's CUDA-kernel semantics (splat/c/render.cu) on the CPU; returns (H,W,3)."""
+    f = lambda a: np.ascontiguousarray(np.asarray(a, np.float32))  # noqa: E731
+    means, colors, inv = f(pre.points), f(pre.colors), f(pre.inverse_covariance_2d)
+    mnx, mxx, mny, mxy, sop = f(pre.min_x), f(pre.max_x), f(pre.min_y), f(pre.max_y), f(pre.sigmoid_opacity)
+    image = np.zeros((height, width, 3), np.float32)
+    if nthreads is None:
+        nthreads = os.cpu_count() or 1
+    fn = lib().orc_render_cuda_semantics
+    fn.restype = ctypes.c_int
+    rc = fn(int(height), int(width), _fp(means), _fp(colors), _fp(inv), _fp(mnx), _fp(mxx), _fp(mny), _fp(mxy),
+            _fp(sop), ctypes.c_int64(means.shape[0]), _fp(image), int(nthreads))
+    assert rc == 0
+    return image

@@ -123,3 +123,36 @@ def test_empty_and_all_culled_scenes():
     pts = np.repeat(behind.astype(np.float32), 7, axis=0)
     pre = cpu_ref.preprocess(pts, g["colors"][:7], g["scales"][:7], g["quaternions"][:7], g["opacity"][:7], cam)
     assert pre.points.shape[0] == 0
+
+
+def test_cuda_semantics_restatement_against_numpy():
+    """oracle/raster_cpu.c::orc_render_cuda_semantics vs an independent numpy statement of
+    splat/c/render.cu:21-87 (unpinned by the reference itself: its kernel cannot run here)."""
+    g = load_golden("small_64x48_n300")
+    pre = golden_preprocessed(g)
+    w, h = int(g["width"]), int(g["height"])
+    img = c_oracle.render_cuda_semantics(pre, w, h, nthreads=2)
+    f32 = np.float32
+    PX, PY = np.meshgrid(np.arange(w), np.arange(h))           # (h, w)
+    T = np.ones((h, w), f32)
+    C = np.zeros((h, w, 3), f32)
+    live = np.ones((h, w), bool)
+    op = pre.sigmoid_opacity.reshape(-1)
+    for i in range(pre.points.shape[0]):
+        inside = (PX >= pre.min_x[i]) & (PX <= pre.max_x[i]) & (PY >= pre.min_y[i]) & (PY <= pre.max_y[i]) & live
+        dx = (PX - int(pre.points[i, 0])).astype(f32)
+        dy = (PY - int(pre.points[i, 1])).astype(f32)
+        q = pre.inverse_covariance_2d[i]
+        power = dx * q[0, 0] * dx + f32(2) * dx * dy * q[0, 1] + dy * dy * q[1, 1]
+        alpha = np.minimum(f32(0.99), op[i] * np.exp(f32(-0.5) * power))
+        test = T * (f32(1) - alpha)
+        stop = inside & (test < f32(0.001))
+        live &= ~stop
+        acc = inside & ~stop
+        C[acc] += (T * alpha)[acc][:, None] * pre.colors[i][None, :]
+        T[acc] = test[acc]
+    assert img.shape == (h, w, 3)
+    assert np.max(np.abs(img - C)) <= 2e-6
+    # differs from the CPU path by construction (single sigmoid, clamp, per-pixel cull, edge tiles)
+    cpu_sem, _, _ = c_oracle.render(pre, w, h, 16)
+    assert np.max(np.abs(img.transpose(1, 0, 2) - cpu_sem)) > 0.05
