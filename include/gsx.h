@@ -184,6 +184,17 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
 int gsx_project_points(const GsxCamera *camera, const float *means3d, int64_t n, float *points_out,
                        uint8_t *in_view_out, void *stream);
 
+/*
+ * Build extension (no counterpart in the reference, whose colour is the stored rgb/256,
+ * splat/gaussians.py:20-22): view-dependent colour from real spherical harmonics of degree 0..3 in
+ * the published 3D Gaussian Splatting convention, colour = max(0, 0.5 + sum_k Y_k(d) sh[k]) with
+ * d = normalize(mean - camera centre).  sh is (n, (degree+1)^2, 3); camera_center_host is 3 floats
+ * in HOST memory (GaussianImage.camera_center, splat/image.py:66); colors_out (n,3) then feeds the
+ * `colors` argument of gsx_render_forward.
+ */
+int gsx_sh_to_rgb(const float *means3d, const float *sh, int32_t degree, int64_t n,
+                  const float *camera_center_host, float *colors_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -412,6 +412,16 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     return bin_and_blend(p, c, ws, n, cap, v0, -1, stats_host, tm, s);
 }
 
+int gsx_sh_to_rgb(const float *means3d, const float *sh, int32_t degree, int64_t n, const float *camera_center_host,
+                  float *colors_out, void *stream) {
+    if (degree < 0 || degree > 3) return fail(GSX_ERR_INVALID_ARGUMENT, "SH degree %d outside [0,3]", degree);
+    if (n < 0) return fail(GSX_ERR_INVALID_ARGUMENT, "n is negative");
+    if (!camera_center_host) return fail(GSX_ERR_INVALID_ARGUMENT, "camera_center_host is NULL");
+    if (n > 0 && (!means3d || !sh || !colors_out)) return fail(GSX_ERR_INVALID_ARGUMENT, "an array is NULL");
+    GSX_HIP(gsx::launch_sh_to_rgb(means3d, sh, degree, n, camera_center_host, colors_out, (hipStream_t)stream));
+    return GSX_OK;
+}
+
 int gsx_project_points(const GsxCamera *camera, const float *means3d, int64_t n, float *points_out,
                        uint8_t *in_view_out, void *stream) {
     if (!camera) return fail(GSX_ERR_INVALID_ARGUMENT, "camera is NULL");

@@ -96,6 +96,10 @@ hipError_t bin_instances(void *temp, size_t temp_bytes, const TileRect *rect, co
 hipError_t publish_counts(const uint32_t *n_visible, const uint32_t *total, int64_t n_visible_known, int64_t *out2,
                           hipStream_t s);
 
+// ---- gsx_sh.hip
+hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, int64_t n, const float *center,
+                            float *colors, hipStream_t s);
+
 // ---- gsx_blend.hip
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, hipStream_t s);

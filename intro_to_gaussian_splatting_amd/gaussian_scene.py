@@ -129,17 +129,38 @@ class GaussianScene:
         self._pinned_next = 0
 
     # ------------------------------------------------------------------ helpers
-    def _inputs(self):
+    def _colors(self, image_idx: int) -> torch.Tensor:
+        """``gaussians.colors`` like the reference, or -- build extension -- the view-dependent colour
+        of this camera evaluated on the GPU from ``gaussians.sh`` (gsx_sh_to_rgb)."""
+        g = self.gaussians
+        if getattr(g, "sh", None) is None:
+            return g.colors
+        lib = _ffi.load()
+        dev = g.points.device
+        _require_gpu(dev)
+        n = int(g.points.shape[0])
+        k = (int(g.sh_degree) + 1) ** 2
+        pts = _check_f32("points", g.points.reshape(n, 3), dev)
+        sh = _check_f32("sh", g.sh.reshape(n, k, 3), dev)
+        out = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        center = (ctypes.c_float * 3)(*[float(v) for v in self.images[image_idx].camera_center.cpu()])
+        with torch.cuda.device(dev):
+            rc = lib.gsx_sh_to_rgb(_ptr(pts), _ptr(sh), int(g.sh_degree), n, center, _ptr(out), _stream_handle(dev))
+        _ffi.check(rc)
+        return out
+
+    def _inputs(self, image_idx: Optional[int] = None):
         g = self.gaussians
         dev = g.points.device
         _require_gpu(dev)
         n = int(g.points.shape[0])
+        colors = g.colors if image_idx is None else self._colors(image_idx)
         tensors = [
             _check_f32("points", g.points.reshape(n, 3), dev),
             _check_f32("scales", g.scales.reshape(n, 3), dev),
             _check_f32("quaternions", g.quaternions.reshape(n, 4), dev),
             _check_f32("opacity", g.opacity.reshape(n, 1), dev),
-            _check_f32("colors", g.colors.reshape(n, 3), dev),
+            _check_f32("colors", colors.reshape(n, 3), dev),
         ]
         return dev, n, tensors
 
@@ -147,7 +168,7 @@ class GaussianScene:
     def preprocess(self, image_idx: int) -> PreprocessedScene:
         """Projection + depth sort on the GPU (gsx_preprocess); fields as splat/schema.py:13-25."""
         lib = _ffi.load()
-        dev, n, tensors = self._inputs()
+        dev, n, tensors = self._inputs(image_idx)
         cam = self.images[image_idx].gsx_camera()
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
         xy, col, c2, dep, inv, rad = f(n, 2), f(n, 3), f(n, 2, 2), f(n), f(n, 2, 2), f(n)
@@ -188,7 +209,7 @@ class GaussianScene:
         The first frame of a scene (no hint yet) always takes the synchronising path.
         """
         lib = _ffi.load()
-        dev, n, tensors = self._inputs()
+        dev, n, tensors = self._inputs(image_idx)
         cam = self.images[image_idx].gsx_camera()
         width, height = cam.width, cam.height
         params = _ffi.default_params()

@@ -29,6 +29,9 @@ class Gaussians:
         self.quaternions[:, 0] = 1.0
         p = 0.9999 * torch.ones((n, 1), dtype=f32)                             # gaussians.py:31-33
         self.opacity = torch.log(p / (1 - p)).to(dev)
+        # build extension: spherical-harmonic colour (N,K,3); None = use `colors` like the reference
+        self.sh: Optional[torch.Tensor] = None
+        self.sh_degree = 0
 
     def __len__(self) -> int:
         return int(self.points.shape[0])
@@ -37,6 +40,8 @@ class Gaussians:
         dev = torch.device(device)
         for name in ("points", "colors", "scales", "quaternions", "opacity"):
             setattr(self, name, getattr(self, name).to(dev).contiguous())
+        if self.sh is not None:
+            self.sh = self.sh.to(dev).contiguous()
         self.device = dev
         return self
 
@@ -48,4 +53,21 @@ class Gaussians:
         g.scales = torch.as_tensor(scales).to(g.device, f32).reshape(-1, 3).contiguous()
         g.quaternions = torch.as_tensor(quaternions).to(g.device, f32).reshape(-1, 4).contiguous()
         g.opacity = torch.as_tensor(opacity_logit).to(g.device, f32).reshape(-1, 1).contiguous()
+        return g
+
+    @classmethod
+    def from_ply(cls, path: str, device=None) -> "Gaussians":
+        """Loads a ``.ply``: a trained 3D Gaussian Splatting checkpoint (log-scales -> linear, SH
+        coefficients, logit opacity) or a plain xyz+rgb point cloud (then the reference's
+        constructor defaults apply).  Build extension -- see ``ply.py``."""
+        from .ply import load_gaussians
+
+        d = load_gaussians(path)
+        if "sh" not in d:
+            return cls(torch.from_numpy(d["points"]), torch.from_numpy(d["colors_0_255"]), device=device)
+        n = d["points"].shape[0]
+        g = cls.from_arrays(d["points"], torch.zeros((n, 3)), d["scales"], d["quaternions"], d["opacity"],
+                            device=device)
+        g.sh = torch.from_numpy(d["sh"]).to(g.device).contiguous()
+        g.sh_degree = int(d["sh_degree"])
         return g

@@ -371,3 +371,37 @@ def render_image(pre, width: int, height: int, tile: int = 16, scalar: bool = Fa
     if stats is not None:
         stats["pairs"] = pairs
     return image
+
+
+# --------------------------------------------------------------------------- SH (build extension)
+
+_SH_C0 = 0.28209479177387814
+_SH_C1 = 0.4886025119029199
+_SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+          1.445305721320277, -0.5900435899266435)
+
+
+def sh_to_rgb(points, sh, degree: int, camera_center) -> np.ndarray:
+    """Spherical harmonics -> RGB in the published 3D Gaussian Splatting convention (Kerbl et al.
+    2023, ``eval_sh``; not part of /root/reference, which has no SH at all -- PARITY UNPINNED).
+    float64 inside, so it is an independent check of the float32 kernel."""
+    p = np.asarray(points, np.float64)
+    c = np.asarray(sh, np.float64)
+    d = p - np.asarray(camera_center, np.float64)[None, :]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    res = _SH_C0 * c[:, 0]
+    if degree > 0:
+        res = res - _SH_C1 * y * c[:, 1] + _SH_C1 * z * c[:, 2] - _SH_C1 * x * c[:, 3]
+    if degree > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        res = (res + _SH_C2[0] * xy * c[:, 4] + _SH_C2[1] * yz * c[:, 5] + _SH_C2[2] * (2 * zz - xx - yy) * c[:, 6]
+               + _SH_C2[3] * xz * c[:, 7] + _SH_C2[4] * (xx - yy) * c[:, 8])
+        if degree > 2:
+            res = (res + _SH_C3[0] * y * (3 * xx - yy) * c[:, 9] + _SH_C3[1] * xy * z * c[:, 10]
+                   + _SH_C3[2] * y * (4 * zz - xx - yy) * c[:, 11]
+                   + _SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * c[:, 12]
+                   + _SH_C3[4] * x * (4 * zz - xx - yy) * c[:, 13] + _SH_C3[5] * z * (xx - yy) * c[:, 14]
+                   + _SH_C3[6] * x * (xx - 3 * yy) * c[:, 15])
+    return np.maximum(res + 0.5, 0.0).astype(np.float32)
