@@ -168,7 +168,8 @@ def main() -> None:
     tile, layout = 16, "wh3"
 
     def render_strip(window, out, origin):
-        scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=window, out=out, out_origin=origin)
+        scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=window, out=out, out_origin=origin,
+                               no_sync=not args.sync_frames)
 
     def step():
         # 1 GPU: speculative frames (GSX_FLAG_NO_SYNC) -- the pair list is sized by the previous
@@ -197,14 +198,17 @@ def main() -> None:
     for _ in range(args.warmup):
         frame = step()
     fence()
-    if world == 1:
-        scene.confirm_frames()
+    scene.confirm_frames()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame = step()
     fence()
     elapsed = time.perf_counter() - t0
-    respeculated = scene.confirm_frames() if world == 1 else 0
+    respeculated = scene.confirm_frames()
+    if world > 1:
+        flag = torch.tensor([respeculated], dtype=torch.int64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        respeculated = int(flag.item())
     if respeculated:
         raise SystemExit("speculative frames missed their instance hint %d times: timing invalid" % respeculated)
     if world > 1:
@@ -259,7 +263,7 @@ def main() -> None:
                        "semantics": "ref_cpu", "layout": layout, "n_visible": nvis, "tile_instances": d,
                        "frames_in_flight": max(1, len(streams)),
                        "ms_per_frame_one_in_flight": None if latency_ms is None else round(latency_ms, 4),
-                       "frame_sync": "host reads instance count every frame" if (args.sync_frames or world > 1)
+                       "frame_sync": "host reads instance count every frame" if args.sync_frames
                        else "speculative (GSX_FLAG_NO_SYNC), counts confirmed after the timed region",
                        "parallelism": "1 GPU" if world == 1 else "%d column strips + RCCL gather" % world},
             "fps": round(1e3 / ms_per_step, 2),

@@ -123,7 +123,8 @@ class GaussianScene:
                                              device=gaussians.device)
         self.gaussians = gaussians
         self._instances_hint = 0      # workspace sizing: largest instance count seen (+10 %)
-        self._last_instances = 0      # instance count of the latest full frame (speculative hint)
+        self._last_instances = 0      # instance count of the latest full frame
+        self._last_counts = {}        # (image, tile, window, semantics) -> instance count (speculative hints)
         self._pending = []            # speculative frames awaiting confirm_frames()
         self._pinned_pool = None
         self._pinned_next = 0
@@ -229,10 +230,12 @@ class GaussianScene:
             ow, oh = (out.shape[0], out.shape[1]) if layout == "wh3" else (out.shape[1], out.shape[0])
             params.out_x0, params.out_y0, params.out_w, params.out_h = int(out_origin[0]), int(out_origin[1]), int(ow), int(oh)
         cap = max(self._instances_hint, 8 * n + 4096)
-        speculative = bool(no_sync and not timing and self._last_instances > 0 and tile_window is None
-                           and semantics == "ref_cpu")
+        # the hint is the instance count of the previous frame with the same tile window
+        hint_key = (image_idx, tile_size, None if tile_window is None else tuple(int(v) for v in tile_window), semantics)
+        last = self._last_counts.get(hint_key, 0)
+        speculative = bool(no_sync and not timing and last > 0)
         if speculative:
-            hint = int(self._last_instances * 1.06) + 1024
+            hint = int(last * 1.06) + 1024
             cap = max(cap, hint)
             params.flags |= _ffi.GSX_FLAG_NO_SYNC
             params.instances_hint = hint
@@ -259,11 +262,14 @@ class GaussianScene:
         _ffi.check(rc)
         if speculative and st.reserved == 1:
             # counts are still in flight: remember what has to be confirmed
-            self._pending.append((pinned, hint, image_idx, tile_size, layout, out))
+            self._pending.append((pinned, hint, hint_key, dict(
+                image_idx=image_idx, tile_size=tile_size, layout=layout, tile_window=tile_window, out=out,
+                out_origin=out_origin, semantics=semantics)))
             if stats is not None:
                 stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
             return out
         self._instances_hint = max(self._instances_hint, int(st.n_instances * 1.1))
+        self._last_counts[hint_key] = int(st.n_instances)
         if tile_window is None and semantics == "ref_cpu":
             self._last_instances = int(st.n_instances)
         if stats is not None:
@@ -291,13 +297,14 @@ class GaussianScene:
         torch.cuda.synchronize(self.gaussians.points.device)
         redone = 0
         pending, self._pending = self._pending, []
-        for pinned, hint, image_idx, tile_size, layout, out in pending:
+        for pinned, hint, hint_key, call in pending:
             st = ctypes.cast(ctypes.c_void_p(pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents
-            self._last_instances = int(st.n_instances)
+            self._last_counts[hint_key] = int(st.n_instances)
+            if hint_key[2] is None and hint_key[3] == "ref_cpu":
+                self._last_instances = int(st.n_instances)
             if st.n_instances > hint:
                 redone += 1
-                full = self.render_image_hip(image_idx, tile_size=tile_size, layout=layout)
-                out.copy_(full)
+                self.render_image_hip(**call)          # synchronising path, same output tensor
         return redone
 
     def render_image(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:

@@ -362,11 +362,19 @@ def test_speculative_frames_equal_synchronised_frames(tmp_path):
     assert scene.confirm_frames() == 0
     assert torch.equal(a, ref) and torch.equal(b.permute(1, 0, 2), ref)
     # a hint that is too small drops pairs on the device; confirm_frames notices and re-renders
-    scene._last_instances = 1000
+    for key in scene._last_counts:
+        scene._last_counts[key] = 1000
     c = scene.render_image_hip(1, no_sync=True)
     assert scene.confirm_frames() == 1
     assert torch.equal(c, ref)
     assert scene._last_instances == 7379
+    # strips speculate too, each on the count of its own window
+    strip = torch.empty((64, 256, 3), device="cuda:0")
+    for _ in range(2):
+        st = {}
+        scene.render_image_hip(1, tile_window=(4, 8, 0, 15), out=strip, out_origin=(64, 0), no_sync=True, stats=st)
+    assert st.get("speculative") is True and scene.confirm_frames() == 0
+    assert torch.equal(strip, ref[64:128])
 
 
 def test_frames_in_flight_on_several_streams(tmp_path):
