@@ -10,7 +10,7 @@
  *     on the current HIP device, unless the name ends in `_host`.
  *   - All work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
  *     Calls that report a host-side count (n_visible / n_instances) synchronise that stream
- *     once; nothing else blocks.
+ *     once, after their last launch; nothing else blocks.
  *   - The library never allocates, frees or retains device memory: the caller owns inputs,
  *     outputs and the workspace (size from gsx_workspace_bytes).
  *   - Return value: GSX_OK (0) or a negative GsxStatus; gsx_last_error() gives a thread-local
@@ -82,7 +82,7 @@ typedef struct GsxParams {
     int32_t tile_x0, tile_x1, tile_y0, tile_y1;
     int32_t out_x0, out_y0, out_w, out_h;
     int32_t flags;          /* GSX_FLAG_* */
-    int32_t instances_hint; /* with GSX_FLAG_NO_SYNC: upper bound of n_instances, > 0 */
+    int32_t instances_hint; /* unused (kept for layout compatibility) */
     int32_t reserved[4];
 } GsxParams;
 
@@ -90,22 +90,21 @@ typedef struct GsxParams {
  * then waits for the frame to finish).  Off by default: timing is measurement, not product. */
 #define GSX_FLAG_TIMING 1
 
-/* Speculative frame: enqueue everything without waiting for the device.  The (Gaussian, tile) pair
- * list is sized by params->instances_hint (normally the n_instances of the previous frame of the
- * same scene) instead of the count read back from the device, so the call returns as soon as the
- * launches are queued.  stats_host must then be PINNED host memory that stays valid until the
- * stream has passed this frame: n_visible / n_instances arrive by an asynchronous copy
- * (stats_host->reserved == 1 says so); read them after synchronising the stream.  If n_instances
- * turns out larger than instances_hint, pairs were dropped and the frame must be rendered again
- * (without the flag, or with a larger hint).  Ignored (normal, synchronising path) when the hint
- * exceeds the workspace capacity or the window has more than 65535 tiles. */
+/* Enqueue the frame without waiting for the device at all.  Normally a render call synchronises
+ * the stream once, after its last launch, to fill stats_host and to detect a pair count beyond
+ * the workspace capacity.  With this flag it returns as soon as the launches are queued:
+ * stats_host must then be PINNED host memory that stays valid until the stream has passed this
+ * frame; n_visible / n_instances arrive by an asynchronous copy (stats_host->reserved holds the
+ * pair capacity the frame was enqueued with, > 0); read them after synchronising the stream.  If
+ * n_instances turns out larger than that capacity, pairs were dropped and the frame must be
+ * rendered again with a larger workspace. */
 #define GSX_FLAG_NO_SYNC 2
 
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
 enum {
     GSX_STAGE_PROJECT = 0,    /* projection, depth keys, record packing         */
     GSX_STAGE_DEPTH_SORT = 1, /* stable sort of N depth keys                    */
-    GSX_STAGE_SCAN = 2,       /* tile-count scan + the host read-back of D      */
+    GSX_STAGE_SCAN = 2,       /* tile-count scan                                 */
     GSX_STAGE_BIN = 3,        /* frame clear, key emit, tile sort, tile ranges  */
     GSX_STAGE_BLEND = 4,      /* the compositing kernel alone                   */
     GSX_STAGE_TOTAL = 5

@@ -91,7 +91,7 @@ struct Plan {
     gsx::OutDesc out;
     int semantics;
     bool timing;
-    int64_t hint;  // > 0: speculative frame, no host synchronisation (GSX_FLAG_NO_SYNC)
+    bool no_sync;  // GSX_FLAG_NO_SYNC: nothing waits for the device
 };
 
 // Optional per-stage timing with HIP events on the launch stream (GSX_FLAG_TIMING).
@@ -111,7 +111,7 @@ struct StageTimer {
         (void)hipEventRecord(ev[n], s);
         ++n;
     }
-    // marks: 0 start | 1 project (+keys) | 2 depth sort | 3 scan+readback | 4 bin | 5 blend
+    // marks: 0 start | 1 project (+keys) | 2 depth sort | 3 scan | 4 bin | 5 blend
     void finish(GsxFrameStats *st) {
         if (n > 0) (void)hipEventSynchronize(ev[n - 1]);
         if (st) {
@@ -145,9 +145,7 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     if (!out_image) return fail(GSX_ERR_INVALID_ARGUMENT, "out_image is NULL");
     p.semantics = d.semantics;
     p.timing = (d.flags & GSX_FLAG_TIMING) != 0;
-    p.hint = (d.flags & GSX_FLAG_NO_SYNC) ? (int64_t)d.instances_hint : 0;
-    if ((d.flags & GSX_FLAG_NO_SYNC) && d.instances_hint <= 0)
-        return fail(GSX_ERR_INVALID_ARGUMENT, "GSX_FLAG_NO_SYNC needs instances_hint > 0");
+    p.no_sync = (d.flags & GSX_FLAG_NO_SYNC) != 0 && !p.timing;
     gsx::TileGrid &g = p.grid;
     g.tile = tile;
     g.ntx = tiles_along(width, tile, d.semantics);
@@ -217,65 +215,59 @@ int clear_outside_window(const Plan &p, hipStream_t s) {
     return GSX_OK;
 }
 
-// Steps shared by both render entry points once records / rects / counts exist (rank order).
+// Steps shared by both render entry points once records / rects / counts exist.
 // `order` = Gaussian index of each depth rank (nullptr: rows are already in compositing order).
+// The pair count D never has to reach the host for the frame to be enqueued: the kernels read
+// it from device memory and their grids are sized by the workspace capacity.  The normal call
+// synchronises ONCE, after the last launch, to report the counts and to detect D > capacity;
+// GSX_FLAG_NO_SYNC skips even that (the counts then arrive asynchronously in pinned memory).
 int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t cap, const uint32_t *order,
                   int64_t n_visible_known, GsxFrameStats *stats, StageTimer &tm, hipStream_t s) {
     uint32_t *counts = (uint32_t *)(ws + c.counts), *offsets = (uint32_t *)(ws + c.offsets);
     uint32_t *counters = (uint32_t *)(ws + c.counters);
     void *temp = ws + c.temp;
     GSX_HIP(gsx::scan_counts(temp, c.temp_bytes, counts, order, offsets, n, s));
-    // Speculative frame: the pair list is sized by the caller's hint (normally the previous frame's
-    // count), nothing waits for the device.  Needs 16-bit tile ids (the padding key is 0xFFFF).
-    const bool speculative = p.hint > 0 && p.hint <= cap && p.grid.count() <= 65535 && !p.timing;
-    int64_t d = 0;
-    if (speculative) {
-        d = p.hint;
+    tm.mark();  // 3: scan
+    const size_t out_bytes = (size_t)p.out.w * p.out.h * 3 * sizeof(float);
+    int64_t *dev2 = (int64_t *)(counters + 8);
+    if (p.grid.count() == 0 || n == 0) {
+        GSX_HIP(hipMemsetAsync(p.out.ptr, 0, out_bytes, s));
+    } else {
+        int rc = clear_outside_window(p, s);
+        if (rc != GSX_OK) return rc;
+        uint2 *ranges = (uint2 *)(ws + c.ranges);
+        const uint32_t *sorted_vals = nullptr;
+        GSX_HIP(gsx::bin_instances(temp, c.temp_bytes, (const gsx::TileRect *)(ws + c.rect), order, offsets, n, cap,
+                                   p.grid, ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0),
+                                   (uint32_t *)(ws + c.tvals1), ranges, &sorted_vals, s));
+        tm.mark();  // 4: bin
+        GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
+                                  ranges, p.grid, p.out, p.semantics, s));
+        tm.mark();  // 5: blend
+    }
+    GSX_HIP(gsx::publish_counts(counters, offsets + n, n_visible_known, dev2, s));
+    if (p.no_sync) {
         if (stats) {
-            int64_t *dev2 = (int64_t *)(counters + 8);
-            GSX_HIP(gsx::publish_counts(counters, offsets + n, n_visible_known, dev2, s));
             // stats must be pinned host memory; the two counts land when the stream gets here
             GSX_HIP(hipMemcpyAsync(stats, dev2, 16, hipMemcpyDeviceToHost, s));
             stats->n_tiles = p.grid.count();
-            stats->reserved = 1;  // 1 = counts are delivered asynchronously
+            stats->reserved = cap;  // > 0: counts are delivered asynchronously; value = pair capacity used
         }
-        tm.mark();
-    } else {
-        uint32_t host[2] = {0, 0};
-        GSX_HIP(hipMemcpyAsync(&host[0], offsets + n, 4, hipMemcpyDeviceToHost, s));
-        if (n_visible_known < 0) GSX_HIP(hipMemcpyAsync(&host[1], counters, 4, hipMemcpyDeviceToHost, s));
-        GSX_HIP(hipStreamSynchronize(s));
-        tm.mark();  // 3: scan + read-back
-        d = host[0];
-        if (stats) {
-            stats->n_visible = n_visible_known < 0 ? (int64_t)host[1] : n_visible_known;
-            stats->n_instances = d;
-            stats->n_tiles = p.grid.count();
-            stats->reserved = 0;
-        }
-    }
-    const size_t out_bytes = (size_t)p.out.w * p.out.h * 3 * sizeof(float);
-    if (d > cap) {
-        GSX_HIP(hipMemsetAsync(p.out.ptr, 0, out_bytes, s));
-        return fail(GSX_ERR_WORKSPACE_TOO_SMALL, "frame needs %lld tile instances, workspace holds %lld", (long long)d,
-                    (long long)cap);
-    }
-    if (d == 0 || p.grid.count() == 0) {
-        GSX_HIP(hipMemsetAsync(p.out.ptr, 0, out_bytes, s));
         return GSX_OK;
     }
-    int rc = clear_outside_window(p, s);
-    if (rc != GSX_OK) return rc;
-    uint2 *ranges = (uint2 *)(ws + c.ranges);
-    const uint32_t *sorted_vals = nullptr;
-    GSX_HIP(gsx::bin_instances(temp, c.temp_bytes, (const gsx::TileRect *)(ws + c.rect), order, offsets, n, d,
-                               speculative, p.grid, ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0), (uint32_t *)(ws + c.tvals1),
-                               ranges, &sorted_vals, s));
-    tm.mark();  // 4: bin
-    GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals, ranges,
-                              p.grid, p.out, p.semantics, s));
-    tm.mark();  // 5: blend
+    int64_t host2[2] = {0, 0};
+    GSX_HIP(hipMemcpyAsync(host2, dev2, 16, hipMemcpyDeviceToHost, s));
+    GSX_HIP(hipStreamSynchronize(s));
+    if (stats) {
+        stats->n_visible = host2[0];
+        stats->n_instances = host2[1];
+        stats->n_tiles = p.grid.count();
+        stats->reserved = 0;
+    }
     tm.finish(stats);
+    if (host2[1] > cap)
+        return fail(GSX_ERR_WORKSPACE_TOO_SMALL, "frame needs %lld tile instances, workspace holds %lld",
+                    (long long)host2[1], (long long)cap);
     return GSX_OK;
 }
 
@@ -410,6 +402,33 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     GSX_HIP(gsx::launch_count_visible(k0, n, counters, s));
     tm.mark();  // 2: depth sort
     return bin_and_blend(p, c, ws, n, cap, v0, -1, stats_host, tm, s);
+}
+
+// Test hook (not part of include/gsx.h): the pipeline's radix sort on caller-provided pairs.
+// keys / vals: n 32-bit words each, sorted in place; key16 != 0 sorts uint16 keys.  scratch must
+// hold 2 * 4n bytes + gsx radix table (use gsx_workspace_bytes(n, 16, 16, 16, n)).  count_dev
+// (may be NULL) = device pointer to the element count, as the tile sort uses it.
+int gsx_debug_sort_pairs(void *keys, uint32_t *vals, int64_t n, int32_t key_bits, int32_t key16,
+                         const uint32_t *count_dev, void *scratch, size_t scratch_bytes, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 0 || !keys || !vals || !scratch) return fail(GSX_ERR_INVALID_ARGUMENT, "bad arguments");
+    size_t need = align_up((size_t)n * 4) * 2 + gsx::radix_temp_bytes(n);
+    if (scratch_bytes < need) return fail(GSX_ERR_WORKSPACE_TOO_SMALL, "scratch needs %zu bytes", need);
+    char *sc = (char *)scratch;
+    uint32_t *valt = (uint32_t *)(sc + align_up((size_t)n * 4));
+    void *temp = sc + 2 * align_up((size_t)n * 4);
+    uint32_t *vc = vals, *va = valt;
+    if (key16) {
+        uint16_t *kc = (uint16_t *)keys, *ka = (uint16_t *)sc;
+        GSX_HIP(gsx::radix_sort_pairs_u16(temp, kc, ka, vc, va, count_dev, n, key_bits, s));
+        if (kc != (uint16_t *)keys) GSX_HIP(hipMemcpyAsync(keys, kc, (size_t)n * 2, hipMemcpyDeviceToDevice, s));
+    } else {
+        uint32_t *kc = (uint32_t *)keys, *ka = (uint32_t *)sc;
+        GSX_HIP(gsx::radix_sort_pairs_u32(temp, kc, ka, vc, va, count_dev, n, key_bits, s));
+        if (kc != (uint32_t *)keys) GSX_HIP(hipMemcpyAsync(keys, kc, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (vc != vals) GSX_HIP(hipMemcpyAsync(vals, vc, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    return GSX_OK;
 }
 
 int gsx_sh_to_rgb(const float *means3d, const float *sh, int32_t degree, int64_t n, const float *camera_center_host,

@@ -8,15 +8,9 @@
 //      STABLE sort on the tile id alone (13 bits at 1080p, 2 radix passes instead of 6 for a
 //      64-bit tile|depth key) leaves every tile's entries in depth order, ties broken by
 //      original index exactly like a stable argsort.
-// rocPRIM provides the device-wide radix sort and scan primitives; the emit / range kernels
-// are ours.
-#include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
-#include <rocprim/types/double_buffer.hpp>
+// The radix sort (gsx_sort.hip) and the scan below are ours; no library primitive is left on the
+// path.  D never leaves the device: every kernel after the scan reads it from offsets[n] and is
+// launched on a grid sized by the workspace capacity.
 
 #include "gsx_internal.h"
 
@@ -76,16 +70,17 @@ __global__ void __launch_bounds__(kBlock)
 
 // ranges[t] = [first, last+1) of tile t inside the tile-sorted pair list; untouched (zeroed by
 // the caller) for tiles with no entries.
-// PADDED: the pair list was sized by the caller's hint and padded with all-ones keys.
-template <typename Key, bool PADDED>
+// The grid covers the workspace capacity; the true pair count is read from device memory.
+template <typename Key>
 __global__ void __launch_bounds__(kBlock)
-    tile_ranges_kernel(const Key *__restrict__ keys, int64_t d, uint2 *__restrict__ ranges) {
-    int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    tile_ranges_kernel(const Key *__restrict__ keys, const uint32_t *__restrict__ d_dev, uint32_t cap,
+                       uint2 *__restrict__ ranges) {
+    const uint32_t d = min(*d_dev, cap);
+    const uint32_t j = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     if (j >= d) return;
     const Key t = keys[j];
-    if (PADDED && t == (Key)~(Key)0) return;
-    if (j == 0 || keys[j - 1] != t) ranges[t].x = (uint32_t)j;
-    if (j == d - 1 || keys[j + 1] != t) ranges[t].y = (uint32_t)(j + 1);
+    if (j == 0 || keys[j - 1] != t) ranges[t].x = j;
+    if (j == d - 1 || keys[j + 1] != t) ranges[t].y = j + 1;
 }
 
 // Device-side frame counts in the layout of the first two GsxFrameStats fields.
@@ -99,113 +94,144 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBl
 
 }  // namespace
 
-// counts[order[r]] for r < n, 0 for r == n: the scan input in rank order without a gather pass.
-struct PermutedCount {
-    const uint32_t *counts, *order;
-    uint32_t n;
-    __host__ __device__ uint32_t operator()(uint32_t r) const {
-        return r < n ? counts[order ? order[r] : r] : 0u;
+// Exclusive scan of the tile counts in depth-rank order, reduce-then-scan in two launches:
+//   1. every workgroup gathers counts[order[r]] for its 2048 ranks (the only random access),
+//      parks them in offsets[r] and stores their sum in block_sums[b];
+//   2. every workgroup adds up the block sums before it (at most a few thousand values) and
+//      scans its own 2048 parked counts in place; the last one also stores the grand total D at
+//      offsets[n].
+constexpr int kScanItems = 8;
+constexpr int kScanChunk = kBlock * kScanItems;
+
+__device__ __forceinline__ uint32_t count_at(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ order,
+                                             int64_t r, int64_t n) {
+    return r < n ? counts[order ? order[r] : (uint32_t)r] : 0u;
+}
+
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *wsum) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_down((int)v, o);
+    if (lane == 0) wsum[w] = v;
+    __syncthreads();
+    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return total;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    scan_block_sums_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ order, int64_t n,
+                           uint32_t *__restrict__ block_sums, uint32_t *__restrict__ offsets) {
+    __shared__ uint32_t wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanItems;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t c = count_at(counts, order, base + k, n);
+        if (base + k <= n) offsets[base + k] = c;
+        v += c;
     }
-};
-using CountIter = rocprim::transform_iterator<rocprim::counting_iterator<uint32_t>, PermutedCount, uint32_t>;
+    const uint32_t total = block_sum(v, wsum);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
 
-// Depth keys: always the onesweep radix sort (rocPRIM's default switches to a merge sort up to
-// 1M items, which measured 160 us at N = 1M against ~70 us for four onesweep passes).
-using DepthSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                   rocprim::default_config, 65536>;
-
-template <typename Config, typename Key>
-hipError_t sort_impl(void *temp, size_t &temp_bytes, Key *&keys_cur, Key *&keys_alt, uint32_t *&vals_cur,
-                     uint32_t *&vals_alt, int64_t n, int end_bit, hipStream_t s) {
-    rocprim::double_buffer<Key> kb(keys_cur, keys_alt);
-    rocprim::double_buffer<uint32_t> vb(vals_cur, vals_alt);
-    hipError_t e = rocprim::radix_sort_pairs<Config>(temp, temp_bytes, kb, vb, (size_t)n, 0u, (unsigned)end_bit, s);
-    keys_cur = kb.current();
-    keys_alt = kb.alternate();
-    vals_cur = vb.current();
-    vals_alt = vb.alternate();
-    return e;
+__global__ void __launch_bounds__(kBlock)
+    scan_apply_kernel(int64_t n, const uint32_t *__restrict__ block_sums, uint32_t *__restrict__ offsets) {
+    __shared__ uint32_t wsum[4];
+    uint32_t before = 0;
+    for (uint32_t k = threadIdx.x; k < blockIdx.x; k += kBlock) before += block_sums[k];
+    before = block_sum(before, wsum);
+    const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanItems;
+    uint32_t c[kScanItems], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        c[k] = base + k <= n ? offsets[base + k] : 0u;
+        mine += c[k];
+    }
+    // exclusive scan of `mine` over the workgroup
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    uint32_t run = before + x - mine;
+    for (int k = 0; k < w; ++k) run += wsum[k];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k <= n) offsets[base + k] = run;   // r == n receives the grand total
+        run += c[k];
+    }
 }
 
 size_t binning_temp_bytes(int64_t n, int64_t cap) {
-    size_t a = 0, b = 0, b16 = 0, c = 0;
-    uint32_t *k = nullptr, *k2 = nullptr, *v = nullptr, *v2 = nullptr;
-    uint16_t *h = nullptr, *h2 = nullptr;
-    hipError_t e;
-    e = sort_impl<DepthSortConfig>(nullptr, a, k, k2, v, v2, n > 0 ? n : 1, 32, (hipStream_t)0);
-    if (e != hipSuccess) return 0;
-    e = sort_impl<rocprim::default_config>(nullptr, b, k, k2, v, v2, cap > 0 ? cap : 1, 32, (hipStream_t)0);
-    if (e != hipSuccess) return 0;
-    e = sort_impl<rocprim::default_config>(nullptr, b16, h, h2, v, v2, cap > 0 ? cap : 1, 16, (hipStream_t)0);
-    if (e != hipSuccess) return 0;
-    CountIter it(rocprim::counting_iterator<uint32_t>(0u), PermutedCount{k, k, 0u});
-    e = rocprim::exclusive_scan(nullptr, c, it, k, 0u, (size_t)(n + 1), rocprim::plus<uint32_t>(), (hipStream_t)0);
-    if (e != hipSuccess) return 0;
-    size_t m = a > b ? a : b;
-    m = m > b16 ? m : b16;
-    m = m > c ? m : c;
+    const size_t scan = ((size_t)(n + 1 + kScanChunk - 1) / kScanChunk + 1) * sizeof(uint32_t);
+    const size_t r = radix_temp_bytes(n > cap ? n : cap);
+    const size_t m = scan > r ? scan : r;
     return (m + 255) & ~(size_t)255;
 }
 
 hipError_t sort_by_depth(void *temp, size_t temp_bytes, uint32_t *&keys_cur, uint32_t *&keys_alt, uint32_t *&vals_cur,
                          uint32_t *&vals_alt, int64_t n, hipStream_t s) {
+    (void)temp_bytes;
     if (n == 0) return hipSuccess;
-    return sort_impl<DepthSortConfig>(temp, temp_bytes, keys_cur, keys_alt, vals_cur, vals_alt, n, 32, s);
+    return radix_sort_pairs_u32(temp, keys_cur, keys_alt, vals_cur, vals_alt, nullptr, n, 32, s);
 }
 
 hipError_t scan_counts(void *temp, size_t temp_bytes, const uint32_t *counts, const uint32_t *order,
                        uint32_t *offsets, int64_t n, hipStream_t s) {
-    CountIter it(rocprim::counting_iterator<uint32_t>(0u), PermutedCount{counts, order, (uint32_t)n});
-    return rocprim::exclusive_scan(temp, temp_bytes, it, offsets, 0u, (size_t)(n + 1), rocprim::plus<uint32_t>(), s);
+    (void)temp_bytes;
+    const unsigned nb = (unsigned)((n + 1 + kScanChunk - 1) / kScanChunk);
+    uint32_t *block_sums = (uint32_t *)temp;
+    scan_block_sums_kernel<<<nb, kBlock, 0, s>>>(counts, order, n, block_sums, offsets);
+    scan_apply_kernel<<<nb, kBlock, 0, s>>>(n, block_sums, offsets);
+    return hipGetLastError();
 }
 
 // Emit (tile id, Gaussian index) pairs in rank order, sort them stably by tile id and derive
-// every tile's [first, last) range.  Tile ids fit 16 bits for any frame up to 65535 tiles (4K has
+// every tile's [first, last) range.  Tile ids fit 16 bits for any frame up to 65536 tiles (4K has
 // 32 026), which halves the key traffic of the sort; larger frames use 32-bit ids.
-// keys0 / keys1 / vals0 / vals1 each hold `d` 32-bit words.  *sorted_vals = the sorted values.
-// padded: `d` is the caller's hint, not the true count (which only the device knows): the key
-// buffer is pre-filled with all-ones keys that sort behind every tile, and pairs past `d` are dropped.
+// keys0 / keys1 / vals0 / vals1 each hold `cap` 32-bit words; the pair count D = offsets[n] stays
+// on the device, pairs beyond `cap` are dropped (the caller compares D with cap afterwards).
 template <typename Key>
-hipError_t bin_impl(void *temp, size_t temp_bytes, const TileRect *rect, const uint32_t *order,
-                    const uint32_t *offsets, int64_t n, int64_t d, bool padded, const TileGrid &grid, void *keys0,
-                    void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges, int key_bits,
-                    const uint32_t **sorted_vals, hipStream_t s) {
+hipError_t bin_impl(void *temp, const TileRect *rect, const uint32_t *order, const uint32_t *offsets, int64_t n,
+                    int64_t cap, const TileGrid &grid, void *keys0, void *keys1, uint32_t *vals0, uint32_t *vals1,
+                    uint2 *ranges, int key_bits, const uint32_t **sorted_vals, hipStream_t s) {
     Key *kc = (Key *)keys0, *ka = (Key *)keys1;
     uint32_t *vc = vals0, *va = vals1;
-    hipError_t e;
-    if (padded) {
-        e = hipMemsetAsync(kc, 0xFF, sizeof(Key) * (size_t)d, s);
-        if (e != hipSuccess) return e;
-        key_bits = (int)sizeof(Key) * 8;
-    }
-    emit_kernel<Key><<<blocks_for(n), kBlock, 0, s>>>(rect, order, offsets, n, grid, (uint32_t)d, kc, vc);
-    e = hipGetLastError();
+    const uint32_t *d_dev = offsets + n;
+    emit_kernel<Key><<<blocks_for(n), kBlock, 0, s>>>(rect, order, offsets, n, grid, (uint32_t)cap, kc, vc);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = sort_impl<rocprim::default_config>(temp, temp_bytes, kc, ka, vc, va, d, key_bits, s);
-    if (e != hipSuccess) return e;
-    if (padded)
-        tile_ranges_kernel<Key, true><<<blocks_for(d), kBlock, 0, s>>>(kc, d, ranges);
+    if (sizeof(Key) == 2)
+        e = radix_sort_pairs_u16(temp, (uint16_t *&)kc, (uint16_t *&)ka, vc, va, d_dev, cap, key_bits, s);
     else
-        tile_ranges_kernel<Key, false><<<blocks_for(d), kBlock, 0, s>>>(kc, d, ranges);
+        e = radix_sort_pairs_u32(temp, (uint32_t *&)kc, (uint32_t *&)ka, vc, va, d_dev, cap, key_bits, s);
+    if (e != hipSuccess) return e;
+    tile_ranges_kernel<Key><<<blocks_for(cap), kBlock, 0, s>>>(kc, d_dev, (uint32_t)cap, ranges);
     *sorted_vals = vc;
     return hipGetLastError();
 }
 
 hipError_t bin_instances(void *temp, size_t temp_bytes, const TileRect *rect, const uint32_t *order,
-                         const uint32_t *offsets, int64_t n, int64_t d, bool padded, const TileGrid &grid,
-                         void *keys0, void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges,
-                         const uint32_t **sorted_vals, hipStream_t s) {
+                         const uint32_t *offsets, int64_t n, int64_t cap, const TileGrid &grid, void *keys0,
+                         void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges, const uint32_t **sorted_vals,
+                         hipStream_t s) {
+    (void)temp_bytes;
     const int64_t nt = grid.count();
     hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)nt, s);
     *sorted_vals = vals0;
-    if (e != hipSuccess || d == 0 || n == 0) return e;
+    if (e != hipSuccess || cap == 0 || n == 0) return e;
     int bits = 1;
     while (((int64_t)1 << bits) < nt) ++bits;
-    if (nt <= 65535)
-        return bin_impl<uint16_t>(temp, temp_bytes, rect, order, offsets, n, d, padded, grid, keys0, keys1, vals0,
-                                  vals1, ranges, bits, sorted_vals, s);
-    return bin_impl<uint32_t>(temp, temp_bytes, rect, order, offsets, n, d, padded, grid, keys0, keys1, vals0, vals1,
-                              ranges, bits, sorted_vals, s);
+    if (nt <= 65536)
+        return bin_impl<uint16_t>(temp, rect, order, offsets, n, cap, grid, keys0, keys1, vals0, vals1, ranges, bits,
+                                  sorted_vals, s);
+    return bin_impl<uint32_t>(temp, rect, order, offsets, n, cap, grid, keys0, keys1, vals0, vals1, ranges, bits,
+                              sorted_vals, s);
 }
 
 hipError_t publish_counts(const uint32_t *n_visible, const uint32_t *total, int64_t n_visible_known, int64_t *out2,

@@ -84,17 +84,27 @@ hipError_t scan_counts(void *temp, size_t temp_bytes, const uint32_t *counts, co
                        uint32_t *offsets, int64_t n, hipStream_t s);
 // Emits one (tile id, Gaussian index) pair per covered tile in rank order, stable-sorts them by
 // tile id and fills ranges[t] = [first, last) for every tile of the window.  keys0/keys1/vals0/
-// vals1 hold d 32-bit words each; *sorted_vals points at the sorted Gaussian indices.
-// padded = speculative mode: d is an upper bound supplied by the caller, the true count stays on
-// the device (offsets[n]); pairs beyond d are dropped.
+// vals1 hold cap 32-bit words each; *sorted_vals points at the sorted Gaussian indices.  The pair
+// count D = offsets[n] is only read on the device; pairs beyond cap are dropped.
 hipError_t bin_instances(void *temp, size_t temp_bytes, const TileRect *rect, const uint32_t *order,
-                         const uint32_t *offsets, int64_t n, int64_t d, bool padded, const TileGrid &grid,
-                         void *keys0, void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges,
-                         const uint32_t **sorted_vals, hipStream_t s);
+                         const uint32_t *offsets, int64_t n, int64_t cap, const TileGrid &grid, void *keys0,
+                         void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges, const uint32_t **sorted_vals,
+                         hipStream_t s);
 // out2[0] = n_visible, out2[1] = n_instances as int64 (device memory), for an asynchronous copy
 // into the first two fields of a GsxFrameStats.
 hipError_t publish_counts(const uint32_t *n_visible, const uint32_t *total, int64_t n_visible_known, int64_t *out2,
                           hipStream_t s);
+
+// ---- gsx_sort.hip: stable LSD radix sort, 8-bit digits, key bits [0, key_bits).  The element
+// count is min(*n_dev, bound) (n_dev == nullptr: bound); grids are sized by `bound`.  Buffers
+// ping-pong; on return keys_cur / vals_cur point at the sorted data.  temp: radix_temp_bytes(bound).
+size_t radix_temp_bytes(int64_t max_items);
+hipError_t radix_sort_pairs_u32(void *temp, uint32_t *&keys_cur, uint32_t *&keys_alt, uint32_t *&vals_cur,
+                                uint32_t *&vals_alt, const uint32_t *n_dev, int64_t bound, int key_bits,
+                                hipStream_t s);
+hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys_alt, uint32_t *&vals_cur,
+                                uint32_t *&vals_alt, const uint32_t *n_dev, int64_t bound, int key_bits,
+                                hipStream_t s);
 
 // ---- gsx_sh.hip
 hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, int64_t n, const float *center,

@@ -124,7 +124,7 @@ class GaussianScene:
         self.gaussians = gaussians
         self._instances_hint = 0      # workspace sizing: largest instance count seen (+10 %)
         self._last_instances = 0      # instance count of the latest full frame
-        self._last_counts = {}        # (image, tile, window, semantics) -> instance count (speculative hints)
+        self._cap_hints = {}          # (image, tile, window, semantics) -> pair capacity for the next frame
         self._pending = []            # speculative frames awaiting confirm_frames()
         self._pinned_pool = None
         self._pinned_next = 0
@@ -203,11 +203,10 @@ class GaussianScene:
         ``out`` may then be a strip-sized buffer whose pixel (0,0) is frame pixel ``out_origin``.
         ``timing`` asks the library for per-stage HIP-event times (``stats["stage_ms"]``); the call
         then waits for the frame.
-        ``no_sync`` (GSX_FLAG_NO_SYNC) enqueues the frame without waiting for the device: the pair
-        list is sized by the instance count of this scene's previous frame (+6 %); the counts arrive
-        later in pinned memory and ``confirm_frames()`` must be called (it synchronises) before the
-        images are trusted -- it re-renders, synchronously, any frame whose count exceeded the hint.
-        The first frame of a scene (no hint yet) always takes the synchronising path.
+        ``no_sync`` (GSX_FLAG_NO_SYNC) enqueues the frame without waiting for the device at all: the
+        counts arrive later in pinned memory and ``confirm_frames()`` must be called (it
+        synchronises) before the images are trusted -- it re-renders, on the normal path, any frame
+        whose pair count exceeded the workspace capacity it was enqueued with.
         """
         lib = _ffi.load()
         dev, n, tensors = self._inputs(image_idx)
@@ -229,16 +228,13 @@ class GaussianScene:
                 raise ValueError("out must be contiguous")
             ow, oh = (out.shape[0], out.shape[1]) if layout == "wh3" else (out.shape[1], out.shape[0])
             params.out_x0, params.out_y0, params.out_w, params.out_h = int(out_origin[0]), int(out_origin[1]), int(ow), int(oh)
-        cap = max(self._instances_hint, 8 * n + 4096)
-        # the hint is the instance count of the previous frame with the same tile window
-        hint_key = (image_idx, tile_size, None if tile_window is None else tuple(int(v) for v in tile_window), semantics)
-        last = self._last_counts.get(hint_key, 0)
-        speculative = bool(no_sync and not timing and last > 0)
+        # pair capacity: 1.1 x the count this (camera, tile size, window, semantics) produced last time
+        # -- the binning kernels' grids are sized by it -- or a generous guess for a first frame
+        cap_key = (image_idx, tile_size, None if tile_window is None else tuple(int(v) for v in tile_window), semantics)
+        cap = self._cap_hints.get(cap_key, 0) or max(self._instances_hint, 8 * n + 4096)
+        speculative = bool(no_sync and not timing)
         if speculative:
-            hint = int(last * 1.06) + 1024
-            cap = max(cap, hint)
             params.flags |= _ffi.GSX_FLAG_NO_SYNC
-            params.instances_hint = hint
             if len(self._pending) >= _PINNED_SLOTS:
                 self.confirm_frames()
             pinned = self._pinned_slot()
@@ -253,30 +249,35 @@ class GaussianScene:
                 if nbytes == 0:
                     raise _ffi.GsxError(_ffi.GSX_ERR_INVALID_ARGUMENT, "gsx_workspace_bytes rejected the sizes")
                 ws = _WORKSPACE.get(dev, nbytes)
+                # hand over exactly the bytes of `cap` pairs (the buffer may be larger): the library
+                # derives its pair capacity -- and the binning grids -- from the size it is given
                 rc = lib.gsx_render_forward(ctypes.byref(cam), *[_ptr(t) for t in tensors], n, tile_size, _ptr(out),
-                                            ctypes.byref(params), st_ref, _ptr(ws), ws.numel(),
+                                            ctypes.byref(params), st_ref, _ptr(ws), nbytes,
                                             _stream_handle(dev))
                 if rc != _ffi.GSX_ERR_WORKSPACE_TOO_SMALL:
                     break
                 cap = int(st.n_instances * 1.25) + 4096
         _ffi.check(rc)
-        if speculative and st.reserved == 1:
+        if speculative:
             # counts are still in flight: remember what has to be confirmed
-            self._pending.append((pinned, hint, hint_key, dict(
+            self._pending.append((pinned, cap_key, dict(
                 image_idx=image_idx, tile_size=tile_size, layout=layout, tile_window=tile_window, out=out,
                 out_origin=out_origin, semantics=semantics)))
             if stats is not None:
                 stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
             return out
-        self._instances_hint = max(self._instances_hint, int(st.n_instances * 1.1))
-        self._last_counts[hint_key] = int(st.n_instances)
-        if tile_window is None and semantics == "ref_cpu":
-            self._last_instances = int(st.n_instances)
+        self._note_count(cap_key, int(st.n_instances))
         if stats is not None:
             stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles)
             if timing:
                 stats["stage_ms"] = {k: float(st.stage_ms[i]) for i, k in enumerate(_ffi.STAGE_NAMES)}
         return out
+
+    def _note_count(self, cap_key, n_instances: int) -> None:
+        self._instances_hint = max(self._instances_hint, int(n_instances * 1.1))
+        self._cap_hints[cap_key] = int(n_instances * 1.1) + 4096
+        if cap_key[2] is None and cap_key[3] == "ref_cpu":
+            self._last_instances = n_instances
 
     def _pinned_slot(self) -> torch.Tensor:
         """One 64-byte slot of a pinned ring (pinning memory per frame would dominate the frame)."""
@@ -290,19 +291,18 @@ class GaussianScene:
 
     def confirm_frames(self) -> int:
         """Synchronises and validates every frame rendered with ``no_sync=True`` since the last call.
-        A frame whose true instance count exceeded its hint (pairs were dropped) is rendered again
-        on the synchronising path into the same output tensor.  Returns the number of re-renders."""
+        A frame whose pair count exceeded the capacity of the workspace it was enqueued with (pairs
+        were dropped) is rendered again on the normal path into the same output tensor.  Returns the
+        number of re-renders."""
         if not self._pending:
             return 0
         torch.cuda.synchronize(self.gaussians.points.device)
         redone = 0
         pending, self._pending = self._pending, []
-        for pinned, hint, hint_key, call in pending:
+        for pinned, cap_key, call in pending:
             st = ctypes.cast(ctypes.c_void_p(pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents
-            self._last_counts[hint_key] = int(st.n_instances)
-            if hint_key[2] is None and hint_key[3] == "ref_cpu":
-                self._last_instances = int(st.n_instances)
-            if st.n_instances > hint:
+            self._note_count(cap_key, int(st.n_instances))
+            if st.n_instances > st.reserved:           # more pairs than the workspace held: dropped
                 redone += 1
                 self.render_image_hip(**call)          # synchronising path, same output tensor
         return redone

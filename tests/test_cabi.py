@@ -46,6 +46,10 @@ def test_argument_errors_do_not_need_a_gpu():
     lib = _ffi.load()
     assert lib.gsx_workspace_bytes(-1, 64, 64, 16, 10) == 0
     assert lib.gsx_workspace_bytes(10, 0, 64, 16, 10) == 0
+    # pure host arithmetic (no library primitive with device queries is left on the path)
+    small, big = lib.gsx_workspace_bytes(1000, 256, 256, 16, 8000), lib.gsx_workspace_bytes(1_000_000, 1920, 1080, 16, 5_000_000)
+    assert 0 < small < big and big % 256 == 0
+    assert big >= 1_000_000 * (16 + 48 + 8 + 8 + 16) + 5_000_000 * 16
     rc = lib.gsx_project_points(None, None, 0, None, None, None)
     assert rc == _ffi.GSX_ERR_INVALID_ARGUMENT
     assert b"camera" in lib.gsx_last_error()

@@ -361,13 +361,19 @@ def test_speculative_frames_equal_synchronised_frames(tmp_path):
     b = scene.render_image_hip(1, no_sync=True, layout="hw3")
     assert scene.confirm_frames() == 0
     assert torch.equal(a, ref) and torch.equal(b.permute(1, 0, 2), ref)
-    # a hint that is too small drops pairs on the device; confirm_frames notices and re-renders
-    for key in scene._last_counts:
-        scene._last_counts[key] = 1000
-    c = scene.render_image_hip(1, no_sync=True)
-    assert scene.confirm_frames() == 1
-    assert torch.equal(c, ref)
-    assert scene._last_instances == 7379
+    # a workspace that is too small drops pairs on the device; confirm_frames notices and re-renders
+    from intro_to_gaussian_splatting_amd import gaussian_scene
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    sc = make_scene(500, 256, 256, seed=21)
+    sc["scales"][:] *= 40.0                      # every splat covers most tiles: D >> 8 N + 4096
+    big = _scene_from_arrays(tmp_path / "big", sc)
+    gaussian_scene._WORKSPACE.buffers.clear()
+    c = big.render_image_hip(1, no_sync=True)    # first frame of the scene, enqueued blind
+    assert big.confirm_frames() == 1
+    assert torch.equal(c, big.render_image_hip(1)) and big._last_instances > 8 * 500 + 4096
+    d = big.render_image_hip(1, no_sync=True)    # the workspace has grown: no miss any more
+    assert big.confirm_frames() == 0 and torch.equal(c, d)
     # strips speculate too, each on the count of its own window
     strip = torch.empty((64, 256, 3), device="cuda:0")
     for _ in range(2):
@@ -375,6 +381,7 @@ def test_speculative_frames_equal_synchronised_frames(tmp_path):
         scene.render_image_hip(1, tile_window=(4, 8, 0, 15), out=strip, out_origin=(64, 0), no_sync=True, stats=st)
     assert st.get("speculative") is True and scene.confirm_frames() == 0
     assert torch.equal(strip, ref[64:128])
+    assert scene._last_instances == 7379
 
 
 def test_frames_in_flight_on_several_streams(tmp_path):
@@ -476,3 +483,42 @@ def test_spherical_harmonics_kernel_and_trained_ply_pipeline(tmp_path):
                                             sc["quaternions"], sc["opacity"], device="cuda:0")
             img_plain = GaussianScene(str(tmp_path), g_plain).render_image(1)
             assert torch.max(torch.abs(img - img_plain)).item() <= 1e-5
+
+
+@pytest.mark.parametrize("n,bits,key16", [(1, 32, 0), (63, 32, 0), (8192, 32, 0), (8193, 32, 0), (100_003, 32, 0),
+                                          (1_000_000, 32, 0), (70_001, 13, 1), (3_000_017, 16, 1), (500_000, 9, 1),
+                                          (40_000, 24, 0)])
+def test_radix_sort_is_a_stable_sort(n, bits, key16):
+    """gsx_sort.hip against torch's stable sort: same keys, same permutation (stability = the tie
+    rule of the depth order and the reason the tile sort keeps depth order), incl. a device count."""
+    _need_gpu()
+    import ctypes
+
+    from intro_to_gaussian_splatting_amd import _ffi
+
+    lib = _ffi.load()
+    fn = lib.gsx_debug_sort_pairs
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    gen = torch.Generator(device="cuda:0").manual_seed(n)
+    hi = (1 << bits) - 1
+    # few distinct values in the low byte and many duplicates overall: exercises ties hard
+    keys64 = torch.randint(0, min(hi, 5000) + 1, (n,), generator=gen, device="cuda:0", dtype=torch.int64)
+    if bits > 16:
+        keys64 = keys64 * 65537 % (hi + 1)
+    vals = torch.arange(n, device="cuda:0", dtype=torch.int32)
+    scratch = torch.empty(2 * ((n * 4 + 255) // 256 * 256) + (256 * (n // 2048 + 2) + 256) * 4 + 4096,
+                          dtype=torch.uint8, device="cuda:0")
+    for live in (n, max(1, (2 * n) // 3)):
+        keys = keys64.to(torch.int16 if key16 else torch.int32).clone()
+        v = vals.clone()
+        count = torch.tensor([live], dtype=torch.int32, device="cuda:0")
+        rc = fn(keys.data_ptr(), v.data_ptr(), n, bits, key16, count.data_ptr() if live != n else None,
+                scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.gsx_last_error()
+        torch.cuda.synchronize()
+        ref_k, ref_p = torch.sort(keys64[:live], stable=True)
+        got_k = keys[:live].to(torch.int64) & (0xFFFF if key16 else 0xFFFFFFFF)
+        assert torch.equal(got_k, ref_k)
+        assert torch.equal(v[:live].to(torch.int64), ref_p)
