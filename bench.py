@@ -49,9 +49,9 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (unpacked VALU)
 # VALU lane-ops the compositing loop issues per (pixel, Gaussian) pair, counted in the gfx950 ISA of
-# blend_tile16_kernel: per record and lane (4 pixels) 23 unpacked + 10 packed
-# (2 lane-ops each) + 4 v_exp_f32 = 47, i.e. 11.75 per pair.
-VALU_OPS_PER_PAIR = 11.75
+# blend_tile16_kernel: per trip (2 records x 4 pixels of a lane) 18 unpacked +
+# 32 packed (2 lane-ops each) + 8 v_exp_f32 = 90 lane-ops in 58 issue slots, i.e. 11.25 per pair.
+VALU_OPS_PER_PAIR = 11.25
 PMC_FILE = os.path.join(ROOT, "profiles", "r1_pmc_c3.json")
 
 
@@ -128,13 +128,15 @@ def cpu_baseline(sc, scene, gpu_frame: torch.Tensor, budget_s: float = 20.0):
     }, err, int(inst)
 
 
-def pmc_traffic(workload: str, world: int):
-    """HBM-side bytes per compositing launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes (MI355X_MICROARCH.md: FETCH_SIZE doubled on gfx950); recorded for C3 on 1 GPU."""
+def pmc_record(workload: str, world: int):
+    """PMC measurements of the compositing launch, taken with rocprofv3 in separate passes (FETCH_SIZE,
+    WRITE_SIZE, SQ_*; MI355X_MICROARCH.md: FETCH_SIZE doubled on gfx950) and committed under profiles/;
+    recorded for C3 on 1 GPU.  Returns (HBM-side bytes per launch, VALU busy fraction) or (None, None)."""
     if workload != "c3" or world != 1 or not os.path.exists(PMC_FILE):
-        return None
+        return None, None
     with open(PMC_FILE) as f:
-        return json.load(f)["blend_traffic_bytes_per_launch"]["total"]
+        d = json.load(f)
+    return d["blend_traffic_bytes_per_launch"]["total"], d.get("blend_valu", {}).get("valu_busy_frac")
 
 
 def main() -> None:
@@ -269,11 +271,13 @@ def main() -> None:
             "fps": round(1e3 / ms_per_step, 2),
             "roofline": {"bound": "hbm", "kernel": "blend_tile16_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": pmc_traffic(args.workload, world), "bytes_per_launch": blend_bytes,
+                         "traffic": pmc_record(args.workload, world)[0], "bytes_per_launch": blend_bytes,
                          "avg_ms": round(blend_ms, 4), "valu_frac": round(valu, 4),
+                         "valu_busy_pmc": pmc_record(args.workload, world)[1],
                          "note": "compositing under reference CPU semantics is VALU-bound (256 evaluations per "
-                                 "36-B record); valu_frac = 256*D*%.2f lane-ops / t / unpacked FP32 VALU peak; "
-                                 "traffic = HBM-side bytes per launch from rocprofv3 PMC passes (profiles/r1_pmc_c3.json)"
+                                 "36-B record); valu_frac = 256*D*%.2f lane-ops / t / (256 CU x 4 SIMD x 32 lanes x "
+                                 "2.4 GHz); valu_busy_pmc = SQ_ACTIVE_INST_VALU share of kernel cycles; traffic = "
+                                 "HBM-side bytes per launch; both from rocprofv3 PMC passes (profiles/r1_pmc_c3.json)"
                                  % VALU_OPS_PER_PAIR},
             "frame_roofline": {"bytes": frame_bytes, "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                                "unit": "GB/s", "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
