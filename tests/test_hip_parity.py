@@ -522,3 +522,24 @@ def test_radix_sort_is_a_stable_sort(n, bits, key16):
         got_k = keys[:live].to(torch.int64) & (0xFFFF if key16 else 0xFFFFFFFF)
         assert torch.equal(got_k, ref_k)
         assert torch.equal(v[:live].to(torch.int64), ref_p)
+
+
+@pytest.mark.parametrize("width,height,tile,n", [(250, 190, 16, 3000), (333, 257, 16, 2000), (600, 500, 2, 1500),
+                                                 (130, 70, 7, 800)])
+def test_awkward_frame_sizes_and_many_tiles(tmp_path, width, height, tile, n):
+    """Frames that are not multiples of the tile (unaligned rows -> the scalar store path), and a
+    frame with more than 65536 tiles (600x500 at tile 2: 74 451 tiles -> 32-bit tile ids)."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd.strips import tiles_along
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    sc = make_scene(n, width, height, seed=width)
+    scene = _scene_from_arrays(tmp_path, sc)
+    _, ref, inst = _oracle_frame(scene, sc, tile)
+    for layout in ("wh3", "hw3"):
+        stats = {}
+        img = scene.render_image_hip(1, tile_size=tile, layout=layout, stats=stats)
+        assert stats["n_instances"] == inst and stats["n_tiles"] == tiles_along(width, tile) * tiles_along(height, tile)
+        got = img.cpu().numpy() if layout == "wh3" else img.permute(1, 0, 2).cpu().numpy()
+        assert got.shape == (width, height, 3)
+        assert np.max(np.abs(got - ref)) <= PIXEL_TOL
