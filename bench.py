@@ -184,12 +184,14 @@ def main() -> None:
                 with torch.cuda.stream(st):
                     return scene.render_image_hip(1, tile_size=tile, layout=layout, out=outs[st],
                                                   no_sync=not args.sync_frames)
-            return scene.render_image_hip(1, tile_size=tile, layout=layout, no_sync=not args.sync_frames)
+            return scene.render_image_hip(1, tile_size=tile, layout=layout, out=single_out,
+                                          no_sync=not args.sync_frames)
         return strips.render_sharded(render_strip, width, height, tile, layout, device)
 
     step.count = 0
     streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if (world == 1 and args.streams > 1) else []
     outs = {st: torch.empty((width, height, 3), dtype=torch.float32, device=device) for st in streams}
+    single_out = torch.empty((width, height, 3), dtype=torch.float32, device=device) if world == 1 else None
 
     def fence():
         if world > 1:
@@ -223,10 +225,11 @@ def main() -> None:
     # frame latency with ONE frame in flight (same process, same scene), for reference
     latency_ms = None
     if world == 1 and len(streams) > 1:
+        lat_out = outs[streams[0]]      # preallocated: pending frames keep their output tensors alive
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            scene.render_image_hip(1, tile_size=tile, layout=layout, no_sync=not args.sync_frames)
+            scene.render_image_hip(1, tile_size=tile, layout=layout, out=lat_out, no_sync=not args.sync_frames)
         torch.cuda.synchronize()
         latency_ms = (time.perf_counter() - t1) / args.steps * 1e3
         scene.confirm_frames()

@@ -222,14 +222,16 @@ int clear_outside_window(const Plan &p, hipStream_t s) {
 // synchronises ONCE, after the last launch, to report the counts and to detect D > capacity;
 // GSX_FLAG_NO_SYNC skips even that (the counts then arrive asynchronously in pinned memory).
 int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t cap, const uint32_t *order,
-                  int64_t n_visible_known, GsxFrameStats *stats, StageTimer &tm, hipStream_t s) {
+                  const uint32_t *sorted_keys, int64_t n_visible_known, GsxFrameStats *stats, StageTimer &tm,
+                  hipStream_t s) {
     uint32_t *counts = (uint32_t *)(ws + c.counts), *offsets = (uint32_t *)(ws + c.offsets);
     uint32_t *counters = (uint32_t *)(ws + c.counters);
     void *temp = ws + c.temp;
-    GSX_HIP(gsx::scan_counts(temp, c.temp_bytes, counts, order, offsets, n, s));
+    int64_t *dev2 = (int64_t *)(counters + 8);
+    GSX_HIP(gsx::scan_counts(temp, c.temp_bytes, counts, order, sorted_keys, offsets, n, counters, n_visible_known,
+                             dev2, s));
     tm.mark();  // 3: scan
     const size_t out_bytes = (size_t)p.out.w * p.out.h * 3 * sizeof(float);
-    int64_t *dev2 = (int64_t *)(counters + 8);
     if (p.grid.count() == 0 || n == 0) {
         GSX_HIP(hipMemsetAsync(p.out.ptr, 0, out_bytes, s));
     } else {
@@ -245,7 +247,6 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
                                   ranges, p.grid, p.out, p.semantics, s));
         tm.mark();  // 5: blend
     }
-    GSX_HIP(gsx::publish_counts(counters, offsets + n, n_visible_known, dev2, s));
     if (p.no_sync) {
         if (stats) {
             // stats must be pinned host memory; the two counts land when the stream gets here
@@ -368,7 +369,7 @@ int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t t
                                           (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts),
                                           p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 2: pack
-    return bin_and_blend(p, c, ws, n, cap, nullptr, n, stats_host, tm, s);
+    return bin_and_blend(p, c, ws, n, cap, nullptr, nullptr, n, stats_host, tm, s);
 }
 
 int gsx_render_forward(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
@@ -389,19 +390,16 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     char *ws = (char *)workspace;
     uint32_t *k0 = (uint32_t *)(ws + c.keys0), *k1 = (uint32_t *)(ws + c.keys1);
     uint32_t *v0 = (uint32_t *)(ws + c.vals0), *v1 = (uint32_t *)(ws + c.vals1);
-    uint32_t *counters = (uint32_t *)(ws + c.counters);
     StageTimer tm;
     tm.begin(p.timing, s);
-    GSX_HIP(hipMemsetAsync(counters, 0, 64, s));
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
     GSX_HIP(gsx::launch_project_pack(*camera, in, n, p.grid, p.semantics, k0, v0, (gsx::Record *)(ws + c.rec),
                                      (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts),
                                      p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 1: project (+ depth keys)
     GSX_HIP(gsx::sort_by_depth(ws + c.temp, c.temp_bytes, k0, k1, v0, v1, n, s));
-    GSX_HIP(gsx::launch_count_visible(k0, n, counters, s));
     tm.mark();  // 2: depth sort
-    return bin_and_blend(p, c, ws, n, cap, v0, -1, stats_host, tm, s);
+    return bin_and_blend(p, c, ws, n, cap, v0, k0, -1, stats_host, tm, s);
 }
 
 // Test hook (not part of include/gsx.h): the pipeline's radix sort on caller-provided pairs.

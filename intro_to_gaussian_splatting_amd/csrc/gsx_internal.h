@@ -79,9 +79,12 @@ size_t binning_temp_bytes(int64_t n, int64_t cap);
 hipError_t sort_by_depth(void *temp, size_t temp_bytes, uint32_t *&keys_cur, uint32_t *&keys_alt, uint32_t *&vals_cur,
                          uint32_t *&vals_alt, int64_t n, hipStream_t s);
 // offsets[r] = sum over ranks r' < r of counts[order[r']] for r in [0, n]; order == nullptr means
-// the identity (rows already in compositing order).
+// the identity (rows already in compositing order).  Also delivers the frame counts on the device:
+// counts2[0] = visible Gaussians (first culled key of sorted_keys, or n_visible_known when >= 0),
+// counts2[1] = offsets[n] = D, as int64 (the first two fields of a GsxFrameStats).
 hipError_t scan_counts(void *temp, size_t temp_bytes, const uint32_t *counts, const uint32_t *order,
-                       uint32_t *offsets, int64_t n, hipStream_t s);
+                       const uint32_t *sorted_keys, uint32_t *offsets, int64_t n, uint32_t *n_visible,
+                       int64_t n_visible_known, int64_t *counts2, hipStream_t s);
 // Emits one (tile id, Gaussian index) pair per covered tile in rank order, stable-sorts them by
 // tile id and fills ranges[t] = [first, last) for every tile of the window.  keys0/keys1/vals0/
 // vals1 hold cap 32-bit words each; *sorted_vals points at the sorted Gaussian indices.  The pair
@@ -90,11 +93,6 @@ hipError_t bin_instances(void *temp, size_t temp_bytes, const TileRect *rect, co
                          const uint32_t *offsets, int64_t n, int64_t cap, const TileGrid &grid, void *keys0,
                          void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges, const uint32_t **sorted_vals,
                          hipStream_t s);
-// out2[0] = n_visible, out2[1] = n_instances as int64 (device memory), for an asynchronous copy
-// into the first two fields of a GsxFrameStats.
-hipError_t publish_counts(const uint32_t *n_visible, const uint32_t *total, int64_t n_visible_known, int64_t *out2,
-                          hipStream_t s);
-
 // ---- gsx_sort.hip: stable LSD radix sort, 8-bit digits, key bits [0, key_bits).  The element
 // count is min(*n_dev, bound) (n_dev == nullptr: bound); grids are sized by `bound`.  Buffers
 // ping-pong; on return keys_cur / vals_cur point at the sorted data.  temp: radix_temp_bytes(bound).

@@ -508,7 +508,8 @@ def test_radix_sort_is_a_stable_sort(n, bits, key16):
     if bits > 16:
         keys64 = keys64 * 65537 % (hi + 1)
     vals = torch.arange(n, device="cuda:0", dtype=torch.int32)
-    scratch = torch.empty(2 * ((n * 4 + 255) // 256 * 256) + (256 * (n // 2048 + 2) + 256) * 4 + 4096,
+    blocks = n // 2048 + 2
+    scratch = torch.empty(2 * ((n * 4 + 255) // 256 * 256) + (256 * blocks + 256 * (blocks // 32 + 2) * 4) * 4 + 4096,
                           dtype=torch.uint8, device="cuda:0")
     for live in (n, max(1, (2 * n) // 3)):
         keys = keys64.to(torch.int16 if key16 else torch.int32).clone()
