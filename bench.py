@@ -186,9 +186,10 @@ def main() -> None:
                                                   no_sync=not args.sync_frames)
             return scene.render_image_hip(1, tile_size=tile, layout=layout, out=single_out,
                                           no_sync=not args.sync_frames)
-        return strips.render_sharded(render_strip, width, height, tile, layout, device)
+        return strips.render_sharded(render_strip, width, height, tile, layout, device, cache=strip_cache)
 
     step.count = 0
+    strip_cache = {}
     streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if (world == 1 and args.streams > 1) else []
     outs = {st: torch.empty((width, height, 3), dtype=torch.float32, device=device) for st in streams}
     single_out = torch.empty((width, height, 3), dtype=torch.float32, device=device) if world == 1 else None

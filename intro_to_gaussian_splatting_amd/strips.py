@@ -39,13 +39,16 @@ def strip_plan(n_tiles: int, world_size: int) -> Tuple[int, List[Tuple[int, int]
 
 def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor, Tuple[int, int]], None],
                    width: int, height: int, tile: int, layout: str, device: torch.device,
-                   group: Optional[dist.ProcessGroup] = None, all_ranks: bool = False) -> Optional[torch.Tensor]:
+                   group: Optional[dist.ProcessGroup] = None, all_ranks: bool = False,
+                   cache: Optional[dict] = None) -> Optional[torch.Tensor]:
     """Renders this rank's strip with ``render_fn(tile_window, out_strip, out_origin)`` and gathers
     the frame on rank 0 (or on every rank with ``all_ranks``).
 
     ``render_fn`` must fully write ``out_strip`` (zeros where nothing is rendered), exactly what
     ``GaussianScene.render_image_hip(..., tile_window=, out=, out_origin=)`` does.
     Returns the frame ((W,H,3) for "wh3", (H,W,3) for "hw3") or None on non-root ranks.
+    ``cache`` (a dict owned by the caller) lets consecutive frames reuse the frame / strip buffers
+    instead of allocating them per call; the returned frame is then overwritten by the next call.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -62,13 +65,20 @@ def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor,
     if rows == 0:
         return torch.zeros((lead, other, 3), dtype=torch.float32, device=device) if is_dst else None
 
+    def buffer(name, shape):
+        if cache is None:
+            return torch.empty(shape, dtype=torch.float32, device=device)
+        key = (name, shape, str(device))
+        if key not in cache:
+            cache[key] = torch.empty(shape, dtype=torch.float32, device=device)
+        return cache[key]
+
     frame = None
     if is_dst:
-        frame = torch.empty((max(covered, lead), other, 3), dtype=torch.float32, device=device)
+        frame = buffer("frame", (max(covered, lead), other, 3))
         if covered < lead:
             frame[covered:].zero_()                    # never-rendered last tile row(s)
-    strip = frame[rank * rows:(rank + 1) * rows] if is_dst else torch.empty(
-        (rows, other, 3), dtype=torch.float32, device=device)
+    strip = frame[rank * rows:(rank + 1) * rows] if is_dst else buffer("strip", (rows, other, 3))
     render_fn(window, strip, origin)
     if world == 1:
         return frame[:lead]

@@ -77,3 +77,7 @@ def test_single_process_path_without_process_group():
     frame = strips.render_sharded(fn, w, h, t, "wh3", torch.device("cpu"))
     full, _, _ = c_oracle.render(golden_preprocessed(g), w, h, t)
     assert np.array_equal(frame.numpy(), full)
+    cache = {}
+    a = strips.render_sharded(fn, w, h, t, "wh3", torch.device("cpu"), cache=cache)
+    b = strips.render_sharded(fn, w, h, t, "wh3", torch.device("cpu"), cache=cache)
+    assert a.data_ptr() == b.data_ptr() and np.array_equal(b.numpy(), full)   # buffers are reused
