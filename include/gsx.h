@@ -176,6 +176,14 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Replaces Gaussians.get_3d_covariance_matrix (splat/gaussians.py:54-69): covariance_out (n,3,3) =
+ * (R S)(R S)^T from linear scales (n,3) and quaternions (n,4) (w,x,y,z), the quaternion
+ * normalised twice as the reference does.  The render entry points compute this inline; the
+ * function exists for callers of the reference's method.
+ */
+int gsx_covariance_3d(const float *scales, const float *quats, int64_t n, float *covariance_out, void *stream);
+
+/*
  * Debug helper on the same projection: replaces GaussianScene.render_points_image
  * (splat/gaussian_scene.py:44-51, splat/image.py:72-89).  Writes (x_pix, y_pix, ndc_z) for every
  * Gaussian in input order into points_out (n,3) and 1/0 into in_view_out (n) (uint8).

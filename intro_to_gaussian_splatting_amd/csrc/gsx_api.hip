@@ -439,6 +439,13 @@ int gsx_sh_to_rgb(const float *means3d, const float *sh, int32_t degree, int64_t
     return GSX_OK;
 }
 
+int gsx_covariance_3d(const float *scales, const float *quats, int64_t n, float *covariance_out, void *stream) {
+    if (n < 0) return fail(GSX_ERR_INVALID_ARGUMENT, "n is negative");
+    if (n > 0 && (!scales || !quats || !covariance_out)) return fail(GSX_ERR_INVALID_ARGUMENT, "an array is NULL");
+    GSX_HIP(gsx::launch_covariance3d(scales, quats, n, covariance_out, (hipStream_t)stream));
+    return GSX_OK;
+}
+
 int gsx_project_points(const GsxCamera *camera, const float *means3d, int64_t n, float *points_out,
                        uint8_t *in_view_out, void *stream) {
     if (!camera) return fail(GSX_ERR_INVALID_ARGUMENT, "camera is NULL");

@@ -69,6 +69,7 @@ hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, cons
                                const uint32_t *sorted_idx, int64_t n, const StageOneOut &out, hipStream_t s);
 hipError_t launch_pack_preprocessed(const PreprocessedIn &in, int64_t n, const TileGrid &grid, int semantics,
                                     Record *rec, TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s);
+hipError_t launch_covariance3d(const float *scales, const float *quats, int64_t n, float *out, hipStream_t s);
 hipError_t launch_project_points(const GsxCamera &cam, const float *means3d, int64_t n, float *points_out,
                                  uint8_t *in_view, hipStream_t s);
 

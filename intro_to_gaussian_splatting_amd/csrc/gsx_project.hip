@@ -38,13 +38,10 @@ __device__ __forceinline__ float row4(float p0, float p1, float p2, const float 
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-// Everything of stage 1 for one visible Gaussian.  Rows 2 of J (all zero) and the structural
-// zeros J01, J10 are skipped: adding an exact zero does not change a float32 sum.
-__device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1, float p2, float tz,
-                                        float s0, float s1, float s2, float qw, float qx, float qy, float qz,
-                                        Projected &o) {
-    const float *V = cam.world2view, *F = cam.full_proj;
-    // Sigma3D
+// Sigma = (R S)(R S)^T with the quaternion normalised twice (F.normalize, then build_rotation's
+// own division): splat/gaussians.py:54-69, splat/utils.py:132-155.
+__device__ __forceinline__ void covariance3d(float s0, float s1, float s2, float qw, float qx, float qy, float qz,
+                                             float (&S)[3][3]) {
     float n1 = sqrtf(((qw * qw + qx * qx) + qy * qy) + qz * qz);
     n1 = fmaxf(n1, 1e-12f);
     float a0 = qw / n1, a1 = qx / n1, a2 = qy / n1, a3 = qz / n1;
@@ -60,7 +57,7 @@ __device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1
     R[2][0] = 2.0f * (x * z - w * y);
     R[2][1] = 2.0f * (y * z + w * x);
     R[2][2] = 1.0f - 2.0f * (x * x + y * y);
-    float M[3][3], S[3][3];
+    float M[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         M[i][0] = R[i][0] * s0;
@@ -71,6 +68,16 @@ __device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) S[i][j] = (M[i][0] * M[j][0] + M[i][1] * M[j][1]) + M[i][2] * M[j][2];
+}
+
+// Everything of stage 1 for one visible Gaussian.  Rows 2 of J (all zero) and the structural
+// zeros J01, J10 are skipped: adding an exact zero does not change a float32 sum.
+__device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1, float p2, float tz,
+                                        float s0, float s1, float s2, float qw, float qx, float qy, float qz,
+                                        Projected &o) {
+    const float *V = cam.world2view, *F = cam.full_proj;
+    float S[3][3];
+    covariance3d(s0, s1, s2, qw, qx, qy, qz, S);
 
     // pixel position
     float cw = row4(p0, p1, p2, F, 3);
@@ -337,9 +344,29 @@ __global__ void __launch_bounds__(kBlock)
     in_view[i] = tz >= 0.2f ? 1 : 0;
 }
 
+__global__ void __launch_bounds__(kBlock)
+    covariance3d_kernel(const float *__restrict__ scales, const float *__restrict__ quats, int64_t n,
+                        float *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float S[3][3];
+    covariance3d(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2], quats[4 * i], quats[4 * i + 1], quats[4 * i + 2],
+                 quats[4 * i + 3], S);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) out[9 * i + 3 * a + b] = S[a][b];
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
+
+hipError_t launch_covariance3d(const float *scales, const float *quats, int64_t n, float *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    covariance3d_kernel<<<blocks_for(n), kBlock, 0, s>>>(scales, quats, n, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_depth_keys(const GsxCamera &cam, const float *means3d, int64_t n, uint32_t *keys,
                              uint32_t *vals, hipStream_t s) {

@@ -45,6 +45,30 @@ class Gaussians:
         self.device = dev
         return self
 
+    def get_3d_covariance_matrix(self) -> torch.Tensor:
+        """(N,3,3) Sigma = (R S)(R S)^T, computed on the GPU (gsx_covariance_3d); same result as the
+        reference's method (splat/gaussians.py:54-69).  The render path does not call this (the
+        projection kernel computes Sigma inline); it exists for users of the reference's API."""
+        import ctypes
+
+        from . import _ffi
+
+        lib = _ffi.load()
+        dev = self.points.device
+        if dev.type != "cuda":
+            raise RuntimeError("get_3d_covariance_matrix runs as a HIP kernel: the tensors are on %s "
+                               "(no CPU fallback)" % dev)
+        n = len(self)
+        s = self.scales.reshape(n, 3).contiguous()
+        q = self.quaternions.reshape(n, 4).contiguous()
+        out = torch.empty((n, 3, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.gsx_covariance_3d(ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(q.data_ptr()), n,
+                                       ctypes.c_void_p(out.data_ptr()),
+                                       ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _ffi.check(rc)
+        return out
+
     @classmethod
     def from_arrays(cls, points, colors_0_255, scales, quaternions, opacity_logit, device=None) -> "Gaussians":
         """Builds a container and overwrites the constructor's defaults with explicit values."""

@@ -432,6 +432,20 @@ def test_cuda_kernel_semantics_against_its_cpu_restatement(tmp_path, name):
     assert not torch.equal(cpu_sem, img)                           # and the two semantics do differ
 
 
+def test_covariance_3d_method(tmp_path, golden):
+    """Gaussians.get_3d_covariance_matrix (splat/gaussians.py:54-69) on the GPU: bit-identical to the
+    oracle's operation order, within re-association distance of the reference's own matrices."""
+    _need_gpu()
+    from oracle import cpu_ref
+
+    g = golden
+    scene = _scene_from_golden(tmp_path, g)
+    cov = scene.gaussians.get_3d_covariance_matrix().cpu().numpy()
+    assert np.array_equal(cov, cpu_ref.covariance_3d(g["scales"], g["quaternions"]))
+    ref = g["covariance_3d"]
+    assert cov.shape == ref.shape and np.all(np.abs(cov - ref) <= 1e-9 + 2e-6 * np.abs(ref).max(axis=(1, 2), keepdims=True))
+
+
 def test_points_projection_helper(tmp_path):
     _need_gpu()
     g = load_golden("cull_96x80_n400")
