@@ -558,3 +558,56 @@ def test_awkward_frame_sizes_and_many_tiles(tmp_path, width, height, tile, n):
         got = img.cpu().numpy() if layout == "wh3" else img.permute(1, 0, 2).cpu().numpy()
         assert got.shape == (width, height, 3)
         assert np.max(np.abs(got - ref)) <= PIXEL_TOL
+
+
+def test_captured_frame_replays_in_a_hip_graph(tmp_path):
+    """A no-sync frame has no host dependency, so the whole frame records into a hipGraph; a replay
+    renders from the current Gaussian tensors."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    sc = make_scene(50_000, 640, 480, seed=8)
+    scene = _scene_from_arrays(tmp_path, sc)
+    ref = scene.render_image_hip(1)
+    frame = scene.capture_frame(1)
+    frame.out.zero_()
+    frame.replay()
+    assert torch.equal(frame.confirm(), ref)
+    # parameters changed in place (same tensors): the replay sees them
+    scene.gaussians.colors.mul_(0.5)
+    frame.replay()
+    half = scene.render_image_hip(1)
+    assert torch.equal(frame.confirm(), half) and not torch.equal(half, ref)
+    assert scene.confirm_frames() == 0
+
+
+def test_c_abi_rejects_bad_arguments(tmp_path):
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import _ffi
+
+    g = load_golden("small_64x48_n300")
+    scene = _scene_from_golden(tmp_path, g)
+    small = torch.empty((16, 48, 3), device="cuda:0")
+    with pytest.raises(_ffi.GsxError, match="does not fit"):       # window larger than the strip buffer
+        scene.render_image_hip(1, tile_window=(0, 3, 0, 2), out=small, out_origin=(0, 0))
+    with pytest.raises(_ffi.GsxError, match="rejected the sizes"):
+        scene.render_image_hip(1, tile_size=0)
+    with pytest.raises(KeyError):
+        scene.render_image_hip(1, semantics="std_3dgs")
+    lib = _ffi.load()
+    p = _ffi.default_params()
+    p.layout = 7
+    out = torch.empty((64, 48, 3), device="cuda:0")
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda:0")
+    cam = scene.images[1].gsx_camera()
+    import ctypes
+    rc = lib.gsx_render_forward(ctypes.byref(cam), None, None, None, None, None, 0, 16, out.data_ptr(), ctypes.byref(p),
+                                None, ws.data_ptr(), ws.numel(), None)
+    assert rc == _ffi.GSX_ERR_INVALID_ARGUMENT and b"layout" in lib.gsx_last_error()
+    rc = lib.gsx_render_forward(ctypes.byref(cam), None, None, None, None, None, 5, 16, out.data_ptr(), None, None,
+                                ws.data_ptr(), ws.numel(), None)
+    assert rc == _ffi.GSX_ERR_INVALID_ARGUMENT and b"NULL" in lib.gsx_last_error()
+    tiny = torch.empty(256, dtype=torch.uint8, device="cuda:0")
+    rc = lib.gsx_render_forward(ctypes.byref(cam), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(),
+                                out.data_ptr(), 100, 16, out.data_ptr(), None, None, tiny.data_ptr(), tiny.numel(), None)
+    assert rc == _ffi.GSX_ERR_WORKSPACE_TOO_SMALL
