@@ -8,7 +8,7 @@ library or without a GPU the render methods raise.
 Surface kept from the reference:
   ``GaussianScene(colmap_path, gaussians)``, ``.images[idx]``, ``.gaussians``,
   ``.preprocess(idx) -> PreprocessedScene``            (gaussian_scene.py:70-144)
-  ``.render_image(idx, tile_size=16) -> (W,H,3)``      (gaussian_scene.py:200-238, CPU semantics)
+  ``.render_image(idx, tile_size=16) -> (W,H,3)``      (gaussian_scene.py:200-238, CPU semantics; host tensor)
   ``.render_points_image(idx)``                        (gaussian_scene.py:44-51)
 Added: ``.render_image_hip`` (explicit layout / tile window / stats), ``.render_preprocessed``
 (the argument list of the reference's native ``render_image``, splat/c/render.cu:90-101).
@@ -356,8 +356,11 @@ class GaussianScene:
 
     def render_image(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:
         """(W,H,3) float32 indexed [x,y]; same result as the reference's pure-Python
-        ``render_image`` (gaussian_scene.py:200-238), computed on the GPU."""
-        return self.render_image_hip(image_idx, tile_size=tile_size, layout="wh3")
+        ``render_image`` (gaussian_scene.py:200-238), computed on the GPU and -- like the reference,
+        whose image is a CPU tensor (gaussian_scene.py:206) -- returned in host memory, so that
+        ``plt.imshow(scene.render_image(i))`` keeps working.  ``render_image_hip`` is the same frame
+        left on the device."""
+        return self.render_image_hip(image_idx, tile_size=tile_size, layout="wh3").cpu()
 
     render = render_image  # the name BASELINE.json's north star uses
 
