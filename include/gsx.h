@@ -81,9 +81,8 @@ typedef struct GsxParams {
     int32_t layout;    /* GsxLayout, default GSX_LAYOUT_WH3     */
     int32_t tile_x0, tile_x1, tile_y0, tile_y1;
     int32_t out_x0, out_y0, out_w, out_h;
-    int32_t flags;          /* GSX_FLAG_* */
-    int32_t instances_hint; /* unused (kept for layout compatibility) */
-    int32_t reserved[4];
+    int32_t flags; /* GSX_FLAG_* */
+    int32_t reserved[5];
 } GsxParams;
 
 /* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call

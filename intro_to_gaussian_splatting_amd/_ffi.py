@@ -38,7 +38,7 @@ class GsxParams(ctypes.Structure):
     _fields_ = [("semantics", c_int32), ("layout", c_int32),
                 ("tile_x0", c_int32), ("tile_x1", c_int32), ("tile_y0", c_int32), ("tile_y1", c_int32),
                 ("out_x0", c_int32), ("out_y0", c_int32), ("out_w", c_int32), ("out_h", c_int32),
-                ("flags", c_int32), ("instances_hint", c_int32), ("reserved", c_int32 * 4)]
+                ("flags", c_int32), ("reserved", c_int32 * 5)]
 
 
 class GsxFrameStats(ctypes.Structure):

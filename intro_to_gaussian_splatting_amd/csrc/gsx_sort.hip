@@ -40,6 +40,8 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t b
     return n < bound ? n : bound;
 }
 
+// Each thread owns kRounds CONSECUTIVE items (one or two 16-byte loads) -- the histogram does not
+// care about order, so the count kernel reads wide; the scatter kernel needs the wave-striped order.
 template <typename Key, int kRounds>
 __global__ void __launch_bounds__(kThreads)
     count_kernel(const Key *__restrict__ keys, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
@@ -47,15 +49,30 @@ __global__ void __launch_bounds__(kThreads)
     __shared__ uint32_t h[kBins];
     const uint32_t n = load_count(n_dev, bound);
     constexpr int kItems = kThreads * kRounds;
+    constexpr int kPerVec = 16 / sizeof(Key), kVecs = kRounds / kPerVec;   // 8 x u16 or 4 x u32 per 16 B
+    static_assert(kRounds % kPerVec == 0, "a thread's items must fill whole 16-byte vectors");
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * (uint32_t)kItems;
-    if (base < n) {
-#pragma unroll 4
-        for (int r = 0; r < kRounds; ++r) {
-            const uint32_t i = base + (uint32_t)r * kThreads + threadIdx.x;
-            if (i < n) atomicAdd(&h[((uint32_t)keys[i] >> shift) & (kBins - 1)], 1u);
+    const uint32_t first = blockIdx.x * (uint32_t)kItems + threadIdx.x * (uint32_t)kRounds;
+    if (first + kRounds <= n) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(keys + first);   // first is a multiple of kRounds
+#pragma unroll
+        for (int v = 0; v < kVecs; ++v) {
+            const uint4 q = src[v];
+            const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (sizeof(Key) == 4) {
+                    atomicAdd(&h[(w4[c] >> shift) & (kBins - 1)], 1u);
+                } else {
+                    atomicAdd(&h[((w4[c] & 0xFFFFu) >> shift) & (kBins - 1)], 1u);
+                    atomicAdd(&h[((w4[c] >> 16) >> shift) & (kBins - 1)], 1u);
+                }
+            }
         }
+    } else {
+        for (int r = 0; r < kRounds; ++r)
+            if (first + r < n) atomicAdd(&h[((uint32_t)keys[first + r] >> shift) & (kBins - 1)], 1u);
     }
     __syncthreads();
     table[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
