@@ -611,3 +611,29 @@ def test_c_abi_rejects_bad_arguments(tmp_path):
     rc = lib.gsx_render_forward(ctypes.byref(cam), out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(),
                                 out.data_ptr(), 100, 16, out.data_ptr(), None, None, tiny.data_ptr(), tiny.numel(), None)
     assert rc == _ffi.GSX_ERR_WORKSPACE_TOO_SMALL
+
+
+def test_scene_built_like_the_notebooks(tmp_path):
+    """cpu_render.ipynb builds Gaussians(points, rgb) with the constructor defaults (scale 0.001,
+    identity rotation, opacity logit(0.9999)): tiny splats, so the eigenvalue floor (0.1) and the
+    determinant floor (1e-3) set every radius and conic.  52 363 points like Treehill's sparse cloud."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene, write_colmap_text
+    from oracle import c_oracle
+
+    sc = make_scene(52_363, 256, 256, seed=100)
+    write_colmap_text(str(tmp_path), sc)
+    g = Gaussians(torch.from_numpy(sc["points"]), torch.from_numpy(np.floor(sc["colors_0_255"])), device="cuda:0")
+    scene = GaussianScene(str(tmp_path), g)
+    cam = _oracle_cam(scene)
+    pre = c_oracle.preprocess(sc["points"], g.colors.cpu().numpy(), g.scales.cpu().numpy(), g.quaternions.cpu().numpy(),
+                              g.opacity.cpu().numpy(), cam)
+    ref, _, inst = c_oracle.render(pre, 256, 256, 16)
+    stats = {}
+    img = scene.render_image_hip(1, stats=stats)
+    assert stats["n_instances"] == inst and stats["n_visible"] == 52_363
+    assert np.max(np.abs(img.cpu().numpy() - ref)) <= PIXEL_TOL
+    gp = scene.preprocess(1)
+    assert torch.all(gp.radius == 2.0)                          # ceil(3 sqrt(mid + sqrt(0.1))) with a ~1e-6 px covariance
+    assert ref.max() > 0.7 and ref.max() < 0.7311 * 255 / 256 + 0.3   # double sigmoid: sigma(sigma(9.21)) = 0.7311 per splat
