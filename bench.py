@@ -105,27 +105,48 @@ def cpu_baseline(sc, scene, gpu_frame: torch.Tensor, budget_s: float = 20.0):
     # the projection is whole-frame work; charge the sample its share
     mpix = sample_px / (t_render + t_pre * frac) / 1e6
     x0, x1, y0, y1 = window[0] * tile, window[1] * tile, window[2] * tile, window[3] * tile
-    err = float(np.abs(gpu_frame[x0:x1, y0:y1].cpu().numpy() - ref[x0:x1, y0:y1]).max()) if n_tiles else 0.0
+    err, psnr = 0.0, float("inf")
+    if n_tiles:
+        diff = gpu_frame[x0:x1, y0:y1].cpu().numpy().astype(np.float64) - ref[x0:x1, y0:y1]
+        err = float(np.abs(diff).max())
+        mse = float((diff * diff).mean())
+        psnr = float("inf") if mse == 0.0 else 10.0 * np.log10(1.0 / mse)
 
     # the reference's own loop is single-threaded pure Python: time the scalar restatement on one tile
+    # first, then on as much of a 4x4-tile window as fits ~8 s
     tx, ty = ntx // 2, nty // 2
     st = {}
     t0 = time.perf_counter()
     cpu_ref.render_image(pre, w, h, tile, scalar=True, window=(tx, tx + 1, ty, ty + 1), stats=st)
     t_py = time.perf_counter() - t0
+    side = int(max(1, min(4, np.floor(np.sqrt(8.0 / max(t_py, 1e-3))))))
+    if side > 1:
+        ax, ay = max(0, min(tx, ntx - side)), max(0, min(ty, nty - side))
+        st = {}
+        t0 = time.perf_counter()
+        cpu_ref.render_image(pre, w, h, tile, scalar=True, window=(ax, ax + side, ay, ay + side), stats=st)
+        t_py = time.perf_counter() - t0
+        tx, ty = ax, ay
     py_pairs = max(st.get("pairs", 0), 1)
     us_per_pair = t_py / py_pairs * 1e6
     total_pairs = inst * tile * tile
     py_mpix = (ntx * nty * tile * tile) / (us_per_pair * 1e-6 * max(total_pairs, 1)) / 1e6
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        cpu_model = "unknown"
     return {
         "value": round(mpix, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+        "cpu_model": cpu_model, "os_cpu_count": os.cpu_count(), "torch_num_threads": torch.get_num_threads(),
         "sample": "oracle/raster_cpu.c (C restatement, %d threads) on %s: %.2f s render + %.2f s projection share; "
                   "%d (pixel,Gaussian) pairs" % (cores, label, t_render, t_pre * frac, pairs),
         "seconds": round(t_render + t_pre * frac, 3),
         "python_port": {"us_per_pair": round(us_per_pair, 3), "pairs": int(py_pairs), "cores": 1,
                         "extrapolated_mpixels_per_s": float("%.3g" % py_mpix),
-                        "sample": "oracle/cpu_ref.py scalar loop on tile (%d,%d)" % (tx, ty)},
-    }, err, int(inst)
+                        "sample": "oracle/cpu_ref.py scalar loop on the %dx%d-tile window at tile (%d,%d)"
+                                  % (side, side, tx, ty)},
+    }, err, int(inst), psnr
 
 
 def pmc_record(workload: str, world: int):
@@ -288,9 +309,10 @@ def main() -> None:
             "stage_ms": {k: round(v, 4) for k, v in stage.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            base, err, inst = cpu_baseline(sc, scene, frame)
+            base, err, inst, psnr = cpu_baseline(sc, scene, frame)
             out["cpu_baseline"] = base
             out["max_abs_dpixel"] = err
+            out["psnr_db"] = None if psnr == float("inf") else round(psnr, 2)
             out["parity_ok"] = bool(err <= 1e-4 and inst == d)
         print(json.dumps(out), flush=True)
     if world > 1:

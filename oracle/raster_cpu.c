@@ -190,32 +190,39 @@ typedef struct {
     const int32_t *tile_items;
     float *image;                /* (W,H,3) indexed [x,y] */
     int wx0, wx1, wy0, wy1;      /* tile-index window */
-    int next;                    /* work counter (tile id) */
     int64_t pairs;
     pthread_mutex_t mu;
+    /* the work counter is written by every thread: keep it off the cache lines of the read-only
+       fields above, or each fetch-add evicts the pointers the inner loops dereference */
+    char pad0[128];
+    int next;                    /* work counter (tile id) */
+    char pad1[128];
 } RenderJob;
 
 static void render_one_tile(RenderJob *jb, int tix, int tiy) {
     int T = jb->tile, x0 = tix * T, y0 = tiy * T, H = jb->H;
     int64_t b = jb->tile_start[tix * jb->nty + tiy], e = jb->tile_start[tix * jb->nty + tiy + 1];
     if (b == e) return;                                    /* gaussian_scene.py:219-220 */
+    const int32_t *restrict items = jb->tile_items;
+    const float *restrict means = jb->means, *restrict inv = jb->inv, *restrict op2 = jb->op2,
+                *restrict colors = jb->colors;
     for (int px = x0; px < x0 + T; ++px)
         for (int py = y0; py < y0 + T; ++py) {
             float Tw = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
             float fx_ = (float)px, fy_ = (float)py;
             for (int64_t k = b; k < e; ++k) {              /* render_pixel, :146-171 */
-                int32_t g = jb->tile_items[k];
-                const float *Q = jb->inv + 4 * (int64_t)g;
-                float e0 = jb->means[2 * (int64_t)g] - fx_, e1 = jb->means[2 * (int64_t)g + 1] - fy_;
+                int32_t g = items[k];
+                const float *Q = inv + 4 * (int64_t)g;
+                float e0 = means[2 * (int64_t)g] - fx_, e1 = means[2 * (int64_t)g + 1] - fy_;
                 float d0 = -0.5f * e0, d1 = -0.5f * e1;     /* utils.py:363-364 */
                 float t0 = d0 * Q[0] + d1 * Q[2];
                 float t1 = d0 * Q[1] + d1 * Q[3];
                 float w = expf(t0 * e0 + t1 * e1);
-                float alpha = w * jb->op2[g];               /* second sigmoid, :164 */
+                float alpha = w * op2[g];                   /* second sigmoid, :164 */
                 float test = Tw * (1.0f - alpha);
                 if (test < 0.000001f) break;                /* return before accumulating, :166 */
                 float ta = Tw * alpha;
-                const float *c = jb->colors + 3 * (int64_t)g;
+                const float *c = colors + 3 * (int64_t)g;
                 C0 += ta * c[0]; C1 += ta * c[1]; C2 += ta * c[2];
                 Tw = test;
             }
