@@ -637,3 +637,53 @@ def test_scene_built_like_the_notebooks(tmp_path):
     gp = scene.preprocess(1)
     assert torch.all(gp.radius == 2.0)                          # ceil(3 sqrt(mid + sqrt(0.1))) with a ~1e-6 px covariance
     assert ref.max() > 0.7 and ref.max() < 0.7311 * 255 / 256 + 0.3   # double sigmoid: sigma(sigma(9.21)) = 0.7311 per splat
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_small_scenes(tmp_path, seed):
+    """Seeded sweep over frame sizes, tile sizes, layouts, semantics, tile windows, culled and
+    degenerate splats; every frame against the C restatement."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd.strips import tiles_along
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+    from oracle import c_oracle
+
+    rs = np.random.RandomState(1000 + seed)
+    width, height = int(rs.randint(20, 400)), int(rs.randint(20, 300))
+    tile = int(rs.choice([1, 2, 3, 8, 16, 16, 16, 17, 32, 64]))
+    n = int(rs.choice([1, 2, 17, 100, 1000, 5000]))
+    sc = make_scene(n, width, height, seed=seed, behind_fraction=float(rs.choice([0.0, 0.3])))
+    sc["scales"] *= np.float32(rs.choice([0.05, 1.0, 1.0, 6.0]))
+    if n >= 17:
+        sc["scales"][3] = 0.0                       # degenerate: zero covariance -> the floors decide
+        sc["quaternions"][5] = 0.0                  # zero quaternion -> NaN rotation, like the reference
+        sc["opacity"][7] = 80.0
+        sc["opacity"][9] = -80.0
+    layout = str(rs.choice(["wh3", "hw3"]))
+    scene = _scene_from_arrays(tmp_path, sc)
+    cam = _oracle_cam(scene)
+    pre = c_oracle.preprocess(sc["points"], scene.gaussians.colors.cpu().numpy(), sc["scales"], sc["quaternions"],
+                              sc["opacity"], cam)
+    ntx, nty = tiles_along(width, tile), tiles_along(height, tile)
+    window = None
+    if ntx > 1 and nty > 1 and rs.rand() < 0.5:
+        a, b = sorted(rs.randint(0, ntx + 1, 2))
+        c, d = sorted(rs.randint(0, nty + 1, 2))
+        if a < b and c < d:
+            window = (int(a), int(b), int(c), int(d))
+    ref, _, inst = c_oracle.render(pre, width, height, tile, window=window)
+    stats = {}
+    img = scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=window, stats=stats)
+    got = img.cpu().numpy() if layout == "wh3" else img.permute(1, 0, 2).cpu().numpy()
+    finite = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), finite)
+    assert np.max(np.abs(got[finite] - ref[finite]), initial=0.0) <= PIXEL_TOL
+    assert stats["n_visible"] == pre.points.shape[0]
+    if window is None:
+        assert stats["n_instances"] == inst
+    # the CUDA-kernel semantics on the same scene (whole frame) against its restatement
+    img2 = scene.render_image_hip(1, tile_size=tile, layout="hw3", semantics="ref_cuda").cpu().numpy()
+    ref2 = c_oracle.render_cuda_semantics(pre, width, height)
+    ok = np.isfinite(ref2) & np.isfinite(img2)
+    diff = np.abs(img2 - ref2)[ok]
+    assert (diff > PIXEL_TOL).mean() < 2e-3 if diff.size else True
