@@ -44,7 +44,18 @@ typedef enum GsxSemantics {
     GSX_SEM_REF_CPU = 0,
     /* splat/c/render.cu:21-87: single sigmoid, alpha clamped to 0.99, stop at 0.001, per-pixel
      * inclusive bbox cull, int-truncated means, all tiles rendered. */
-    GSX_SEM_REF_CUDA = 1
+    GSX_SEM_REF_CUDA = 1,
+    /* Build extension (not in the reference -- parity unpinned): the forward
+     * pass of the published 3D Gaussian Splatting rasteriser (Kerbl et al. 2023).  Stage 1: cull
+     * z_view <= 0.2, quaternion normalised once, focal = extent / (2 tan(fov/2)), pixel =
+     * ((ndc + 1) extent - 1) / 2, 0.3 added to the diagonal of the 2D covariance, symmetric conic,
+     * Gaussians with det == 0 or an empty tile rectangle dropped, single sigmoid.  Tiles: every tile
+     * whose index lies in [(int)((p - r) / T), (int)((p + r + T - 1) / T)) clamped to the grid, all
+     * tiles of the frame (partial edge tiles included).  Per pixel: skip when the exponent is > 0,
+     * alpha = min(0.99, opacity * exp(exponent)), skip when alpha < 1/255, stop (before
+     * accumulating) when T (1 - alpha) < 1e-4, out = C + T_final * background.  Whole-path entry
+     * point only (gsx_render_forward). */
+    GSX_SEM_STD_3DGS = 2
 } GsxSemantics;
 
 /* Memory layout of the output frame. */
@@ -82,7 +93,8 @@ typedef struct GsxParams {
     int32_t tile_x0, tile_x1, tile_y0, tile_y1;
     int32_t out_x0, out_y0, out_w, out_h;
     int32_t flags; /* GSX_FLAG_* */
-    int32_t reserved[5];
+    float background[3]; /* GSX_SEM_STD_3DGS only: colour behind the last Gaussian (default 0) */
+    int32_t reserved[2];
 } GsxParams;
 
 /* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call

@@ -21,6 +21,7 @@ GSX_ERR_UNSUPPORTED = -4
 
 GSX_SEM_REF_CPU = 0
 GSX_SEM_REF_CUDA = 1
+GSX_SEM_STD_3DGS = 2
 GSX_LAYOUT_WH3 = 0
 GSX_LAYOUT_HW3 = 1
 GSX_FLAG_TIMING = 1
@@ -38,7 +39,7 @@ class GsxParams(ctypes.Structure):
     _fields_ = [("semantics", c_int32), ("layout", c_int32),
                 ("tile_x0", c_int32), ("tile_x1", c_int32), ("tile_y0", c_int32), ("tile_y1", c_int32),
                 ("out_x0", c_int32), ("out_y0", c_int32), ("out_w", c_int32), ("out_h", c_int32),
-                ("flags", c_int32), ("reserved", c_int32 * 5)]
+                ("flags", c_int32), ("background", c_float * 3), ("reserved", c_int32 * 2)]
 
 
 class GsxFrameStats(ctypes.Structure):

@@ -92,6 +92,7 @@ struct Plan {
     int semantics;
     bool timing;
     bool no_sync;  // GSX_FLAG_NO_SYNC: nothing waits for the device
+    float background[3];
 };
 
 // Optional per-stage timing with HIP events on the launch stream (GSX_FLAG_TIMING).
@@ -139,8 +140,9 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     if (params) d = *params;
     if (width <= 0 || height <= 0) return fail(GSX_ERR_INVALID_ARGUMENT, "image size %dx%d is not positive", width, height);
     if (tile <= 0 || tile > 1024) return fail(GSX_ERR_INVALID_ARGUMENT, "tile size %d out of range [1,1024]", tile);
-    if (d.semantics != GSX_SEM_REF_CPU && d.semantics != GSX_SEM_REF_CUDA)
+    if (d.semantics != GSX_SEM_REF_CPU && d.semantics != GSX_SEM_REF_CUDA && d.semantics != GSX_SEM_STD_3DGS)
         return fail(GSX_ERR_UNSUPPORTED, "unknown semantics %d", d.semantics);
+    for (int i = 0; i < 3; ++i) p.background[i] = d.background[i];
     if (d.layout != GSX_LAYOUT_WH3 && d.layout != GSX_LAYOUT_HW3) return fail(GSX_ERR_INVALID_ARGUMENT, "unknown layout %d", d.layout);
     if (!out_image) return fail(GSX_ERR_INVALID_ARGUMENT, "out_image is NULL");
     p.semantics = d.semantics;
@@ -232,7 +234,15 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
                              dev2, s));
     tm.mark();  // 3: scan
     const size_t out_bytes = (size_t)p.out.w * p.out.h * 3 * sizeof(float);
-    if (p.grid.count() == 0 || n == 0) {
+    if (p.grid.count() > 0 && n == 0 && p.semantics == GSX_SEM_STD_3DGS) {
+        // no Gaussians: every pixel of the window is the background colour
+        int rc = clear_outside_window(p, s);
+        if (rc != GSX_OK) return rc;
+        uint2 *ranges = (uint2 *)(ws + c.ranges);
+        GSX_HIP(hipMemsetAsync(ranges, 0, (size_t)p.grid.count() * sizeof(uint2), s));
+        GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), nullptr, (const uint32_t *)(ws + c.tvals0), ranges,
+                                  p.grid, p.out, p.semantics, p.background, s));
+    } else if (p.grid.count() == 0 || n == 0) {
         GSX_HIP(hipMemsetAsync(p.out.ptr, 0, out_bytes, s));
     } else {
         int rc = clear_outside_window(p, s);
@@ -244,7 +254,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
                                    (uint32_t *)(ws + c.tvals1), ranges, &sorted_vals, s));
         tm.mark();  // 4: bin
         GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
-                                  ranges, p.grid, p.out, p.semantics, s));
+                                  ranges, p.grid, p.out, p.semantics, p.background, s));
         tm.mark();  // 5: blend
     }
     if (p.no_sync) {
@@ -353,6 +363,8 @@ int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t t
     Plan p;
     int rc = make_plan(image_width, image_height, tile_size, out_image, params, p);
     if (rc != GSX_OK) return rc;
+    if (p.semantics == GSX_SEM_STD_3DGS)
+        return fail(GSX_ERR_UNSUPPORTED, "GSX_SEM_STD_3DGS has its own stage 1: use gsx_render_forward");
     if (n < 0 || n >= (int64_t)1 << 31) return fail(GSX_ERR_INVALID_ARGUMENT, "n = %lld out of range", (long long)n);
     if (n > 0 && (!point_means || !point_colors || !inverse_covariance_2d || !min_x || !max_x || !min_y || !max_y || !opacity))
         return fail(GSX_ERR_INVALID_ARGUMENT, "an input array is NULL");

@@ -316,15 +316,20 @@ __global__ void __launch_bounds__(64)
     }
 }
 
-// The reference's CUDA-kernel semantics (splat/c/render.cu:21-87), any tile size, one pixel per
-// lane: per-pixel inclusive bounding-box cull, alpha = min(0.99, opacity * strength), stop
-// (before accumulating) when T(1 - alpha) < 0.001, every tile of the frame including partial edge
-// tiles.  The truncated means and the a, 2b, c conic are baked into the records by the packing
-// kernels.  Not the hot path of this build (the parity target is the CPU semantics); kept simple.
+// Per-pixel rule sets, any tile size, one pixel per lane, every tile of the frame including partial
+// edge tiles.  Not the hot path of this build (the parity target is the CPU semantics); kept simple.
+//   GSX_SEM_REF_CUDA (splat/c/render.cu:21-87): per-pixel inclusive bounding-box cull,
+//     alpha = min(0.99, opacity * strength), stop (before accumulating) when T(1 - alpha) < 0.001.
+//     The truncated means and the a, 2b, c conic are baked into the records by the packing kernels,
+//     log2(opacity) rides in the exponent.
+//   GSX_SEM_STD_3DGS (published 3DGS forward pass, include/gsx.h): skip when the exponent is > 0,
+//     alpha = min(0.99, opacity * exp(exponent)), skip when alpha < 1/255, stop when
+//     T(1 - alpha) < 1e-4, out = C + T * background.  The record holds the opacity itself.
+template <int SEM>
 __global__ void __launch_bounds__(64)
-    blend_refcuda_kernel(const Record *__restrict__ rec, const float4 *__restrict__ bbox,
-                         const uint32_t *__restrict__ vals, const uint2 *__restrict__ ranges, TileGrid g,
-                         OutDesc out) {
+    blend_rules_kernel(const Record *__restrict__ rec, const float4 *__restrict__ bbox,
+                       const uint32_t *__restrict__ vals, const uint2 *__restrict__ ranges, TileGrid g,
+                       OutDesc out, float bg0, float bg1, float bg2) {
     __shared__ float4 sh[4][64];
     const int lane = threadIdx.x;
     const uint32_t t = xcd_remap(blockIdx.x, (uint32_t)g.count());
@@ -348,20 +353,29 @@ __global__ void __launch_bounds__(64)
                 sh[0][lane] = q->a;
                 sh[1][lane] = q->b;
                 sh[2][lane] = q->c;
-                sh[3][lane] = bbox[gi];
+                if (SEM == GSX_SEM_REF_CUDA) sh[3][lane] = bbox[gi];
             }
             __syncthreads();
             for (uint32_t k = 0; k < nb; ++k) {
-                const float4 A = sh[0][k], B = sh[1][k], bb = sh[3][k];
+                const float4 A = sh[0][k], B = sh[1][k];
                 const float cb = sh[2][k].x;
-                const bool inside = fx >= bb.x && fx <= bb.y && fy >= bb.z && fy <= bb.w;
                 const float e_x = A.x - fx, e_y = A.y - fy;
-                const float a0 = __builtin_fmaf(e_x * e_x, A.z, B.y);
-                const float pw = __builtin_fmaf(e_y, __builtin_fmaf(e_y, B.x, e_x * A.w), a0);
-                const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(pw));
+                bool use;
+                float alpha;
+                if (SEM == GSX_SEM_REF_CUDA) {
+                    const float4 bb = sh[3][k];
+                    use = fx >= bb.x && fx <= bb.y && fy >= bb.z && fy <= bb.w;
+                    const float a0 = __builtin_fmaf(e_x * e_x, A.z, B.y);
+                    const float pw = __builtin_fmaf(e_y, __builtin_fmaf(e_y, B.x, e_x * A.w), a0);
+                    alpha = fminf(0.99f, __builtin_amdgcn_exp2f(pw));
+                } else {
+                    const float pw = __builtin_fmaf(e_y, __builtin_fmaf(e_y, B.x, e_x * A.w), (e_x * e_x) * A.z);
+                    alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(pw));
+                    use = !(pw > 0.0f) && !(alpha < 1.0f / 255.0f);
+                }
                 const float ta = T * alpha, test = T - ta;
-                if (inside && !done) {
-                    if (test < 0.001f) {
+                if (use && !done) {
+                    if (test < (SEM == GSX_SEM_REF_CUDA ? 0.001f : 0.0001f)) {
                         done = true;
                     } else {
                         c0 = __builtin_fmaf(ta, B.z, c0);
@@ -376,6 +390,11 @@ __global__ void __launch_bounds__(64)
         }
         if (valid) {
             float *o = out.ptr + (int64_t)(px - out.x0) * out.stride_x + (int64_t)(py - out.y0) * out.stride_y;
+            if (SEM == GSX_SEM_STD_3DGS) {
+                c0 = __builtin_fmaf(T, bg0, c0);
+                c1 = __builtin_fmaf(T, bg1, c1);
+                c2 = __builtin_fmaf(T, bg2, c2);
+            }
             o[0] = c0;
             o[1] = c1;
             o[2] = c2;
@@ -386,11 +405,18 @@ __global__ void __launch_bounds__(64)
 }  // namespace
 
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
-                        const TileGrid &grid, const OutDesc &out, int semantics, hipStream_t s) {
+                        const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
+                        hipStream_t s) {
     const int64_t nt = grid.count();
     if (nt <= 0) return hipSuccess;
     if (semantics == GSX_SEM_REF_CUDA) {
-        blend_refcuda_kernel<<<(unsigned)nt, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out);
+        blend_rules_kernel<GSX_SEM_REF_CUDA><<<(unsigned)nt, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out,
+                                                                        0.0f, 0.0f, 0.0f);
+        return hipGetLastError();
+    }
+    if (semantics == GSX_SEM_STD_3DGS) {
+        blend_rules_kernel<GSX_SEM_STD_3DGS><<<(unsigned)nt, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out,
+                                                                        background[0], background[1], background[2]);
         return hipGetLastError();
     }
     if (semantics != GSX_SEM_REF_CPU) return hipErrorNotSupported;

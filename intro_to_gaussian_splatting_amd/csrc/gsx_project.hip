@@ -40,13 +40,17 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(
 
 // Sigma = (R S)(R S)^T with the quaternion normalised twice (F.normalize, then build_rotation's
 // own division): splat/gaussians.py:54-69, splat/utils.py:132-155.
+// `twice` = false (GSX_SEM_STD_3DGS): normalised once, as the 3DGS model's rotation activation does.
 __device__ __forceinline__ void covariance3d(float s0, float s1, float s2, float qw, float qx, float qy, float qz,
-                                             float (&S)[3][3]) {
+                                             float (&S)[3][3], bool twice = true) {
     float n1 = sqrtf(((qw * qw + qx * qx) + qy * qy) + qz * qz);
     n1 = fmaxf(n1, 1e-12f);
     float a0 = qw / n1, a1 = qx / n1, a2 = qy / n1, a3 = qz / n1;
-    float n2 = sqrtf(((a0 * a0 + a1 * a1) + a2 * a2) + a3 * a3);
-    float w = a0 / n2, x = a1 / n2, y = a2 / n2, z = a3 / n2;
+    float w = a0, x = a1, y = a2, z = a3;
+    if (twice) {
+        float n2 = sqrtf(((a0 * a0 + a1 * a1) + a2 * a2) + a3 * a3);
+        w = a0 / n2; x = a1 / n2; y = a2 / n2; z = a3 / n2;
+    }
     float R[3][3];
     R[0][0] = 1.0f - 2.0f * (y * y + z * z);
     R[0][1] = 2.0f * (x * y - w * z);
@@ -70,31 +74,20 @@ __device__ __forceinline__ void covariance3d(float s0, float s1, float s2, float
         for (int j = 0; j < 3; ++j) S[i][j] = (M[i][0] * M[j][0] + M[i][1] * M[j][1]) + M[i][2] * M[j][2];
 }
 
-// Everything of stage 1 for one visible Gaussian.  Rows 2 of J (all zero) and the structural
+// EWA 2D covariance ((((J W) Sigma) W^T) J^T)[:2,:2], left to right (splat/utils.py:320-354), with
+// the view-space point clamped to 1.3 tan(fov/2).  Rows 2 of J (all zero) and the structural
 // zeros J01, J10 are skipped: adding an exact zero does not change a float32 sum.
-__device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1, float p2, float tz,
-                                        float s0, float s1, float s2, float qw, float qx, float qy, float qz,
-                                        Projected &o) {
-    const float *V = cam.world2view, *F = cam.full_proj;
-    float S[3][3];
-    covariance3d(s0, s1, s2, qw, qx, qy, qz, S);
-
-    // pixel position
-    float cw = row4(p0, p1, p2, F, 3);
-    float ndcx = row4(p0, p1, p2, F, 0) / cw;
-    float ndcy = row4(p0, p1, p2, F, 1) / cw;
-    o.x = (ndcx + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
-    o.y = (ndcy + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
-
-    // EWA
+__device__ __forceinline__ void ewa_covariance(const GsxCamera &cam, float fx, float fy, float p0, float p1, float p2,
+                                               float tz, const float (&S)[3][3], Projected &o) {
+    const float *V = cam.world2view;
     float tx = row4(p0, p1, p2, V, 0), ty = row4(p0, p1, p2, V, 1);
     float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
     float cx = fminf(fmaxf(tx / tz, -limx), limx) * tz;
     float cy = fminf(fmaxf(ty / tz, -limy), limy) * tz;
-    float j00 = cam.fx / tz;
-    float j02 = -(cam.fx * cx) / (tz * tz);
-    float j11 = cam.fy / tz;
-    float j12 = -(cam.fy * cy) / (tz * tz);
+    float j00 = fx / tz;
+    float j02 = -(fx * cx) / (tz * tz);
+    float j11 = fy / tz;
+    float j12 = -(fy * cy) / (tz * tz);
     // A = J @ Wm, Wm[i][j] = V[j*4+i]
     float A[2][3], B[2][3], C[2][3];
 #pragma unroll
@@ -114,6 +107,24 @@ __device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1
     o.cb = C[0][1] * j11 + C[0][2] * j12;
     o.cc = C[1][0] * j00 + C[1][2] * j02;
     o.cd = C[1][1] * j11 + C[1][2] * j12;
+}
+
+// Everything of stage 1 for one visible Gaussian.
+__device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1, float p2, float tz,
+                                        float s0, float s1, float s2, float qw, float qx, float qy, float qz,
+                                        Projected &o) {
+    const float *F = cam.full_proj;
+    float S[3][3];
+    covariance3d(s0, s1, s2, qw, qx, qy, qz, S);
+
+    // pixel position
+    float cw = row4(p0, p1, p2, F, 3);
+    float ndcx = row4(p0, p1, p2, F, 0) / cw;
+    float ndcy = row4(p0, p1, p2, F, 1) / cw;
+    o.x = (ndcx + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
+    o.y = (ndcy + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
+
+    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o);
 
     float det = o.ca * o.cd - o.cb * o.cc;
     det = fmaxf(det, 1e-3f);
@@ -133,6 +144,58 @@ __device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1
     o.max_x = ceilf(o.x + o.radius);
     o.min_y = floorf(o.y - o.radius);
     o.max_y = ceilf(o.y + o.radius);
+}
+
+// GSX_SEM_STD_3DGS stage 1 (published 3DGS forward pass; see include/gsx.h).  Returns false when
+// the Gaussian is dropped (det == 0).  o.q00, o.q01 = o.q10, o.q11 = the symmetric conic.
+__device__ __forceinline__ bool project_std(const GsxCamera &cam, float p0, float p1, float p2, float tz,
+                                            float s0, float s1, float s2, float qw, float qx, float qy, float qz,
+                                            Projected &o) {
+    const float *F = cam.full_proj;
+    float S[3][3];
+    covariance3d(s0, s1, s2, qw, qx, qy, qz, S, false);
+    float pw = 1.0f / (row4(p0, p1, p2, F, 3) + 0.0000001f);
+    float ndcx = row4(p0, p1, p2, F, 0) * pw, ndcy = row4(p0, p1, p2, F, 1) * pw;
+    o.x = ((ndcx + 1.0f) * (float)cam.width - 1.0f) * 0.5f;
+    o.y = ((ndcy + 1.0f) * (float)cam.height - 1.0f) * 0.5f;
+    float fx = (float)cam.width / (2.0f * cam.tan_fovx), fy = (float)cam.height / (2.0f * cam.tan_fovy);
+    ewa_covariance(cam, fx, fy, p0, p1, p2, tz, S, o);
+    o.ca = o.ca + 0.3f;
+    o.cd = o.cd + 0.3f;
+    o.cc = o.cb;
+    float det = o.ca * o.cd - o.cb * o.cb;
+    if (det == 0.0f) return false;
+    float det_inv = 1.0f / det;
+    o.q00 = o.cd * det_inv;
+    o.q01 = -o.cb * det_inv;
+    o.q10 = o.q01;
+    o.q11 = o.ca * det_inv;
+    float mid = 0.5f * (o.ca + o.cd);
+    float root = sqrtf(fmaxf(0.1f, mid * mid - det));
+    float lam = fmaxf(mid + root, mid - root);
+    o.radius = ceilf(3.0f * sqrtf(lam));
+    o.depth = tz;
+    o.min_x = o.x - o.radius; o.max_x = o.x + o.radius;
+    o.min_y = o.y - o.radius; o.max_y = o.y + o.radius;
+    return true;
+}
+
+// GSX_SEM_STD_3DGS tile range along one axis: [(int)((p - r)/T), (int)((p + r + T - 1)/T)) clamped
+// to [0, nt], then to the window.  (int) truncates toward zero; NaN -> no tile.
+__device__ __forceinline__ void axis_range_std(float p, float r, int T, int nt, int w0, int w1, int &lo, int &hi) {
+    const float big = 1073741824.0f;
+    float a = (p - r) / (float)T;
+    float b = ((p + r + (float)T) - 1.0f) / (float)T;
+    if (!(a == a) || !(b == b)) {
+        lo = 1;
+        hi = 0;
+        return;
+    }
+    int ia = (int)fminf(fmaxf(a, -big), big), ib = (int)fminf(fmaxf(b, -big), big);
+    ia = ia < 0 ? 0 : (ia > nt ? nt : ia);
+    ib = ib < 0 ? 0 : (ib > nt ? nt : ib);
+    lo = ia < w0 ? w0 : ia;
+    hi = (ib > w1 ? w1 : ib) - 1;
 }
 
 // Tile index range along one axis for the reference's test `mn <= t*T + T and mx >= t*T`
@@ -183,7 +246,10 @@ __device__ __forceinline__ void axis_range_pixels(float mn, float mx, int T, int
 __device__ __forceinline__ uint32_t tile_rect(float mnx, float mxx, float mny, float mxy, const TileGrid &g,
                                               int semantics, TileRect &r) {
     int lx, hx, ly, hy;
-    if (semantics == GSX_SEM_REF_CUDA) {
+    if (semantics == GSX_SEM_STD_3DGS) {  // arguments are (x, radius, y, radius)
+        axis_range_std(mnx, mxx, g.tile, g.ntx, g.wx0, g.wx1, lx, hx);
+        axis_range_std(mny, mxy, g.tile, g.nty, g.wy0, g.wy1, ly, hy);
+    } else if (semantics == GSX_SEM_REF_CUDA) {
         axis_range_pixels(mnx, mxx, g.tile, g.width, g.wx0, g.wx1, lx, hx);
         axis_range_pixels(mny, mxy, g.tile, g.height, g.wy0, g.wy1, ly, hy);
     } else {
@@ -243,7 +309,8 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
         q10 = q01;
     }
     out.a = make_float4(x, y, q00 * k, (q01 + q10) * k);
-    out.b = make_float4(q11 * k, log2f(op), cr, cg);
+    // STD_3DGS multiplies by the opacity after the exponential (its exponent is tested on its own)
+    out.b = make_float4(q11 * k, semantics == GSX_SEM_STD_3DGS ? op : log2f(op), cr, cg);
     out.c = make_float4(cb, depth, 0.0f, 0.0f);
 }
 
@@ -259,7 +326,8 @@ __global__ void __launch_bounds__(kBlock)
     float p0 = p[0], p1 = p[1], p2 = p[2];
     float tz = row4(p0, p1, p2, cam.world2view, 2);
     vals[g] = (uint32_t)g;
-    if (!(tz >= 0.2f)) {                                        // utils.py:293-310
+    const bool std3dgs = semantics == GSX_SEM_STD_3DGS;
+    if (std3dgs ? !(tz > 0.2f) : !(tz >= 0.2f)) {               // utils.py:293-310
         TileRect e;
         e.x0 = 1; e.x1 = 0; e.y0 = 1; e.y1 = 0;
         keys[g] = kCulledKey;
@@ -270,7 +338,11 @@ __global__ void __launch_bounds__(kBlock)
     keys[g] = __float_as_uint(tz);
     const float *s = in.scales + 3 * g, *q = in.quats + 4 * g, *c = in.colors + 3 * g;
     Projected o;
-    project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
+    bool keep = true;
+    if (std3dgs)
+        keep = project_std(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
+    else
+        project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
     float op = sigmoidf(in.opacity_logit[g]);
     if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);
     Record out;
@@ -278,7 +350,13 @@ __global__ void __launch_bounds__(kBlock)
     rec[g] = out;
     if (bbox) bbox[g] = make_float4(o.min_x, o.max_x, o.min_y, o.max_y);
     TileRect tr;
-    counts[g] = tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, semantics, tr);
+    uint32_t cnt = std3dgs ? tile_rect(o.x, o.radius, o.y, o.radius, grid, semantics, tr)
+                           : tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, semantics, tr);
+    if (!keep) {
+        tr.x0 = 1; tr.x1 = 0; tr.y0 = 1; tr.y1 = 0;
+        cnt = 0u;
+    }
+    counts[g] = cnt;
     rect[g] = tr;
 }
 

@@ -56,7 +56,8 @@ class _Workspace:
 
 _WORKSPACE = _Workspace()
 _PINNED_SLOTS = 256
-_SEMANTICS = {"ref_cpu": _ffi.GSX_SEM_REF_CPU, "ref_cuda": _ffi.GSX_SEM_REF_CUDA}
+_SEMANTICS = {"ref_cpu": _ffi.GSX_SEM_REF_CPU, "ref_cuda": _ffi.GSX_SEM_REF_CUDA,
+              "std_3dgs": _ffi.GSX_SEM_STD_3DGS}
 
 
 def _stream_handle(device: torch.device) -> ctypes.c_void_p:
@@ -217,8 +218,14 @@ class GaussianScene:
                          tile_window: Optional[Tuple[int, int, int, int]] = None,
                          out: Optional[torch.Tensor] = None, out_origin: Tuple[int, int] = (0, 0),
                          stats: Optional[dict] = None, timing: bool = False,
-                         no_sync: bool = False, semantics: str = "ref_cpu") -> torch.Tensor:
+                         no_sync: bool = False, semantics: str = "ref_cpu",
+                         background: Tuple[float, float, float] = (0.0, 0.0, 0.0)) -> torch.Tensor:
         """Full forward render in libgsx (gsx_render_forward).
+
+        semantics: "ref_cpu" (the reference's ``render_image``), "ref_cuda" (its CUDA kernel's rules
+        on the same stage 1) or "std_3dgs" (build extension: the published 3DGS forward pass --
+        0.3 dilation, alpha clamp 0.99, 1/255 skip, T < 1e-4 stop, ``background`` behind the last
+        Gaussian, every tile of the frame; see include/gsx.h).
 
         layout "wh3" -> (W,H,3) indexed [x,y] like ``render_image``; "hw3" -> (H,W,3).
         tile_window (tx0,tx1,ty0,ty1) renders only those tiles (row/column strips for multi-GPU);
@@ -237,6 +244,7 @@ class GaussianScene:
         params = _ffi.default_params()
         params.layout = _ffi.GSX_LAYOUT_WH3 if layout == "wh3" else _ffi.GSX_LAYOUT_HW3
         params.semantics = _SEMANTICS[semantics]
+        params.background[0], params.background[1], params.background[2] = [float(v) for v in background]
         if timing:
             params.flags |= _ffi.GSX_FLAG_TIMING
         if tile_window is not None:
@@ -284,7 +292,7 @@ class GaussianScene:
             # counts are still in flight: remember what has to be confirmed
             self._pending.append((pinned, cap_key, dict(
                 image_idx=image_idx, tile_size=tile_size, layout=layout, tile_window=tile_window, out=out,
-                out_origin=out_origin, semantics=semantics)))
+                out_origin=out_origin, semantics=semantics, background=background)))
             if stats is not None:
                 stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
             return out

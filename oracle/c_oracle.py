@@ -114,3 +114,30 @@ def render_cuda_semantics(pre, width: int, height: int, nthreads: Optional[int] 
             _fp(sop), ctypes.c_int64(means.shape[0]), _fp(image), int(nthreads))
     assert rc == 0
     return image
+
+
+def render_std3dgs(points, colors, scales, quats, opacity_logit, cam: Camera, tile: int = 16,
+                   background=(0.0, 0.0, 0.0), nthreads: Optional[int] = None,
+                   window: Optional[Tuple[int, int, int, int]] = None):
+    """GSX_SEM_STD_3DGS on the CPU (orc_render_std3dgs; parity unpinned, see raster_cpu.c).
+    Returns (image (H,W,3) indexed [y,x], n_visible, instances, stage1 (n,8))."""
+    f = lambda a, w: np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1, w))  # noqa: E731
+    points, colors, scales, quats = f(points, 3), f(colors, 3), f(scales, 3), f(quats, 4)
+    op = f(opacity_logit, 1)
+    n = points.shape[0]
+    image = np.zeros((int(cam.height), int(cam.width), 3), np.float32)
+    stage1 = np.zeros((max(n, 1), 8), np.float32)
+    bg = (ctypes.c_float * 3)(*[float(v) for v in background])
+    win = None
+    if window is not None:
+        win = (ctypes.c_int32 * 4)(*[int(v) for v in window])
+    if nthreads is None:
+        nthreads = os.cpu_count() or 1
+    nvis, inst = ctypes.c_int64(0), ctypes.c_int64(0)
+    c = _cam(cam)
+    fn = lib().orc_render_std3dgs
+    fn.restype = ctypes.c_int
+    rc = fn(ctypes.byref(c), _fp(points), _fp(colors), _fp(scales), _fp(quats), _fp(op), ctypes.c_int64(n),
+            int(tile), bg, _fp(image), int(nthreads), win, ctypes.byref(nvis), ctypes.byref(inst), _fp(stage1))
+    assert rc == 0
+    return image, nvis.value, inst.value, stage1[:n]

@@ -43,6 +43,27 @@ static void mm3(const float *A, const float *B, float *C) {
 
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+/* (((J W) Sigma) W^T) J^T with the view-space point clamped to 1.3 tan(fov/2) (utils.py:320-354) */
+static void ewa2d(const OrcCamera *cam, float fx, float fy, const float *p, float tz, const float *S, float *D) {
+    const float *V = cam->V;
+    float tx = row4(p, V, 0), ty = row4(p, V, 1);
+    float limx = 1.3f * cam->tan_fovx, limy = 1.3f * cam->tan_fovy;
+    float cx = fminf(fmaxf(tx / tz, -limx), limx) * tz;
+    float cy = fminf(fmaxf(ty / tz, -limy), limy) * tz;
+    float J[9] = {0}, Wm[9], Wt[9], Jt[9], A[9], B[9], C[9];
+    J[0] = fx / tz;
+    J[2] = -(fx * cx) / (tz * tz);
+    J[4] = fy / tz;
+    J[5] = -(fy * cy) / (tz * tz);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Wm[i * 3 + j] = V[j * 4 + i];            /* V[:3,:3]^T */
+            Wt[i * 3 + j] = V[i * 4 + j];
+            Jt[i * 3 + j] = J[j * 3 + i];
+        }
+    mm3(J, Wm, A); mm3(A, S, B); mm3(B, Wt, C); mm3(C, Jt, D);
+}
+
 /* One Gaussian of stage 1.  Returns 0 when culled (z_view < 0.2). */
 static int project_one(const OrcCamera *cam, const float *p, const float *s, const float *q,
                        float *xy, float *c2, float *depth, float *inv, float *radius, float *bbox) {
@@ -79,22 +100,8 @@ static int project_one(const OrcCamera *cam, const float *p, const float *s, con
     float yp = (ndcy + 1.0f) * ((float)cam->height - 1.0f) * 0.5f;
 
     /* EWA 2D covariance (utils.py:320-354) */
-    float tx = row4(p, V, 0), ty = row4(p, V, 1);
-    float limx = 1.3f * cam->tan_fovx, limy = 1.3f * cam->tan_fovy;
-    float cx = fminf(fmaxf(tx / tz, -limx), limx) * tz;
-    float cy = fminf(fmaxf(ty / tz, -limy), limy) * tz;
-    float J[9] = {0}, Wm[9], Wt[9], Jt[9], A[9], B[9], C[9], D[9];
-    J[0] = cam->fx / tz;
-    J[2] = -(cam->fx * cx) / (tz * tz);
-    J[4] = cam->fy / tz;
-    J[5] = -(cam->fy * cy) / (tz * tz);
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            Wm[i * 3 + j] = V[j * 4 + i];            /* V[:3,:3]^T */
-            Wt[i * 3 + j] = V[i * 4 + j];
-            Jt[i * 3 + j] = J[j * 3 + i];
-        }
-    mm3(J, Wm, A); mm3(A, S, B); mm3(B, Wt, C); mm3(C, Jt, D);
+    float D[9];
+    ewa2d(cam, cam->fx, cam->fy, p, tz, S, D);
     float ca = D[0], cb = D[1], cc = D[3], cd = D[4];
 
     /* inverse (utils.py:368-393) */
@@ -391,4 +398,184 @@ int orc_render_cuda_semantics(int H, int W, const float *means, const float *col
     return 0;
 }
 
-int orc_version(void) { return 2; }
+/* ---------------------------------------------------------------- GSX_SEM_STD_3DGS (extension)
+ *
+ * CPU restatement of the forward pass of the published 3D Gaussian Splatting rasteriser (Kerbl,
+ * Kopanas, Leimkuehler, Drettakis, SIGGRAPH 2023; its CUDA rasteriser "diff-gaussian-rasterization",
+ * forward pass: preprocess -> duplicate with keys -> radix sort -> per-tile ranges -> render).
+ * PARITY UNPINNED: that rasteriser is NOT part of /root/reference (SURVEY.md 8(f) rank 3 lists the
+ * mode as a build extension) and cannot be built here (CUDA); this follows the published
+ * algorithm step by step:
+ *   stage 1  z_view <= 0.2 culled; quaternion normalised once; Sigma = (R S)(R S)^T; p_w = 1/(w+1e-7);
+ *            pixel = ((ndc + 1) extent - 1)/2; focal = extent/(2 tan(fov/2)); EWA with the 1.3 clamp;
+ *            cov00 += 0.3, cov11 += 0.3; det == 0 dropped; conic = (c, -b, a)/det;
+ *            lambda = mid +- sqrt(max(0.1, mid^2 - det)); r = ceil(3 sqrt(max lambda));
+ *            tiles [(int)((p - r)/T), (int)((p + r + T - 1)/T)) clamped to the grid; empty dropped;
+ *            opacity = sigmoid(logit).
+ *   order    per tile by view depth, ties by Gaussian index (stable radix sort of tile|depth keys).
+ *   stage 2  pixel (px,py) at integer coordinates; d = mean - pixel; power = -0.5 (A dx^2 + C dy^2)
+ *            - B dx dy; power > 0 skipped; alpha = min(0.99, opacity exp(power)); alpha < 1/255
+ *            skipped; T(1 - alpha) < 1e-4 stops the pixel; C += c alpha T; out = C + T bg.
+ * image: (H,W,3) float32 indexed [y][x].  window = {tx0,tx1,ty0,ty1} (tile indices) or NULL.
+ * stage1 (optional, n x 8): x, y, conic A, B, C, radius, depth, opacity per Gaussian in INPUT order
+ * (NaN row when culled) -- for bit-level comparison of stage 1.
+ */
+typedef struct {
+    int W, H, tile, ntx, nty;
+    const float *g;              /* n x 8 packed stage-1 rows */
+    const float *colors;
+    const int64_t *tile_start;
+    const int32_t *tile_items;
+    float bg[3];
+    float *image;
+    int wx0, wx1, wy0, wy1;
+    char pad0[128];
+    int next;
+    char pad1[128];
+} StdJob;
+
+static void *std_worker(void *arg) {
+    StdJob *jb = (StdJob *)arg;
+    int nwx = jb->wx1 - jb->wx0, nwy = jb->wy1 - jb->wy0, T_ = jb->tile;
+    const float *restrict G = jb->g, *restrict colors = jb->colors;
+    const int32_t *restrict items = jb->tile_items;
+    for (;;) {
+        int id = __atomic_fetch_add(&jb->next, 1, __ATOMIC_RELAXED);
+        if (id >= nwx * nwy) break;
+        int tix = jb->wx0 + id / nwy, tiy = jb->wy0 + id % nwy;
+        int64_t b = jb->tile_start[(int64_t)tix * jb->nty + tiy], e = jb->tile_start[(int64_t)tix * jb->nty + tiy + 1];
+        for (int py = tiy * T_; py < tiy * T_ + T_ && py < jb->H; ++py)
+            for (int px = tix * T_; px < tix * T_ + T_ && px < jb->W; ++px) {
+                float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+                float fx_ = (float)px, fy_ = (float)py;
+                for (int64_t k = b; k < e; ++k) {
+                    const float *r = G + 8 * (int64_t)items[k];
+                    float dx = r[0] - fx_, dy = r[1] - fy_;
+                    float power = -0.5f * (r[2] * dx * dx + r[4] * dy * dy) - r[3] * dx * dy;
+                    if (power > 0.0f) continue;
+                    float alpha = fminf(0.99f, r[7] * expf(power));
+                    if (alpha < 1.0f / 255.0f) continue;
+                    float test_T = T * (1.0f - alpha);
+                    if (test_T < 0.0001f) break;
+                    const float *c = colors + 3 * (int64_t)items[k];
+                    C0 += c[0] * alpha * T; C1 += c[1] * alpha * T; C2 += c[2] * alpha * T;
+                    T = test_T;
+                }
+                float *o = jb->image + ((int64_t)py * jb->W + px) * 3;
+                o[0] = C0 + T * jb->bg[0]; o[1] = C1 + T * jb->bg[1]; o[2] = C2 + T * jb->bg[2];
+            }
+    }
+    return NULL;
+}
+
+static inline int std_tile_index(float v, int nt) {
+    if (!(v == v)) return -1;
+    const float big = 1073741824.0f;
+    int i = (int)fminf(fmaxf(v, -big), big);
+    return i < 0 ? 0 : (i > nt ? nt : i);
+}
+
+int orc_render_std3dgs(const OrcCamera *cam, const float *points, const float *colors, const float *scales,
+                       const float *quats, const float *opacity_logit, int64_t n, int tile, const float *bg,
+                       float *image, int nthreads, const int32_t *window, int64_t *n_vis_out,
+                       int64_t *instances_out, float *stage1) {
+    int W = cam->width, H = cam->height;
+    if (tile <= 0 || W <= 0 || H <= 0) return -1;
+    memset(image, 0, (size_t)W * H * 3 * sizeof(float));
+    int ntx = (W + tile - 1) / tile, nty = (H + tile - 1) / tile;
+    size_t cap = (size_t)(n > 0 ? n : 1);
+    float *G = malloc(cap * 8 * 4);
+    int32_t *rect = malloc(cap * 4 * 4);
+    uint32_t *key = malloc(cap * 4);
+    int64_t *val = malloc(cap * 8);
+    int64_t m = 0;
+    const float *V = cam->V, *F = cam->F;
+    float fx = (float)W / (2.0f * cam->tan_fovx), fy = (float)H / (2.0f * cam->tan_fovy);
+    for (int64_t i = 0; i < n; ++i) {
+        const float *p = points + 3 * i, *s = scales + 3 * i, *q = quats + 4 * i;
+        float *g = G + 8 * i;
+        for (int c = 0; c < 8; ++c) g[c] = NAN;
+        rect[4 * i] = 1; rect[4 * i + 1] = 0; rect[4 * i + 2] = 1; rect[4 * i + 3] = 0;
+        float tz = row4(p, V, 2);
+        if (!(tz > 0.2f)) continue;
+        memcpy(&key[m], &tz, 4);
+        val[m++] = i;
+        float n1 = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+        n1 = fmaxf(n1, 1e-12f);
+        float w = q[0] / n1, x = q[1] / n1, y = q[2] / n1, z = q[3] / n1;
+        float R[9], M[9], S[9], D[9];
+        R[0] = 1.0f - 2.0f * (y * y + z * z); R[1] = 2.0f * (x * y - w * z); R[2] = 2.0f * (x * z + w * y);
+        R[3] = 2.0f * (x * y + w * z); R[4] = 1.0f - 2.0f * (x * x + z * z); R[5] = 2.0f * (y * z - w * x);
+        R[6] = 2.0f * (x * z - w * y); R[7] = 2.0f * (y * z + w * x); R[8] = 1.0f - 2.0f * (x * x + y * y);
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) M[a * 3 + b] = R[a * 3 + b] * s[b];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+                S[a * 3 + b] = (M[a * 3 + 0] * M[b * 3 + 0] + M[a * 3 + 1] * M[b * 3 + 1]) + M[a * 3 + 2] * M[b * 3 + 2];
+        float pw = 1.0f / (row4(p, F, 3) + 0.0000001f);
+        float ndcx = row4(p, F, 0) * pw, ndcy = row4(p, F, 1) * pw;
+        float xp = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f, yp = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
+        ewa2d(cam, fx, fy, p, tz, S, D);
+        float ca = D[0] + 0.3f, cb = D[1], cd = D[4] + 0.3f;
+        float det = ca * cd - cb * cb;
+        if (det == 0.0f) continue;
+        float det_inv = 1.0f / det;
+        float mid = 0.5f * (ca + cd);
+        float root = sqrtf(fmaxf(0.1f, mid * mid - det));
+        float lam = fmaxf(mid + root, mid - root);
+        float r = ceilf(3.0f * sqrtf(lam));
+        g[0] = xp; g[1] = yp; g[2] = cd * det_inv; g[3] = -cb * det_inv; g[4] = ca * det_inv;
+        g[5] = r; g[6] = tz; g[7] = sigmoidf_(opacity_logit[i]);
+        float T = (float)tile;
+        int lx = std_tile_index((xp - r) / T, ntx), hx = std_tile_index(((xp + r + T) - 1.0f) / T, ntx);
+        int ly = std_tile_index((yp - r) / T, nty), hy = std_tile_index(((yp + r + T) - 1.0f) / T, nty);
+        if (lx < 0 || hx < 0 || ly < 0 || hy < 0 || (hx - lx) * (hy - ly) <= 0) continue;
+        rect[4 * i] = lx; rect[4 * i + 1] = hx - 1; rect[4 * i + 2] = ly; rect[4 * i + 3] = hy - 1;
+    }
+    if (stage1) memcpy(stage1, G, (size_t)n * 8 * 4);
+    radix_sort_pairs(key, val, m);                 /* stable: ties keep ascending Gaussian index */
+    int64_t ntiles = (int64_t)ntx * nty;
+    int64_t *start = calloc((size_t)ntiles + 1, 8);
+    for (int64_t k = 0; k < m; ++k) {
+        int64_t i = val[k];
+        for (int a = rect[4 * i]; a <= rect[4 * i + 1]; ++a)
+            for (int b = rect[4 * i + 2]; b <= rect[4 * i + 3]; ++b) start[(int64_t)a * nty + b + 1]++;
+    }
+    for (int64_t t = 0; t < ntiles; ++t) start[t + 1] += start[t];
+    int64_t Dn = start[ntiles];
+    int32_t *items = malloc((size_t)(Dn > 0 ? Dn : 1) * 4);
+    int64_t *fill = malloc((size_t)(ntiles > 0 ? ntiles : 1) * 8);
+    memcpy(fill, start, (size_t)ntiles * 8);
+    for (int64_t k = 0; k < m; ++k) {
+        int64_t i = val[k];
+        for (int a = rect[4 * i]; a <= rect[4 * i + 1]; ++a)
+            for (int b = rect[4 * i + 2]; b <= rect[4 * i + 3]; ++b) items[fill[(int64_t)a * nty + b]++] = (int32_t)i;
+    }
+    StdJob jb;
+    memset(&jb, 0, sizeof jb);
+    jb.W = W; jb.H = H; jb.tile = tile; jb.ntx = ntx; jb.nty = nty;
+    jb.g = G; jb.colors = colors; jb.tile_start = start; jb.tile_items = items; jb.image = image;
+    jb.bg[0] = bg ? bg[0] : 0.0f; jb.bg[1] = bg ? bg[1] : 0.0f; jb.bg[2] = bg ? bg[2] : 0.0f;
+    jb.wx0 = 0; jb.wx1 = ntx; jb.wy0 = 0; jb.wy1 = nty;
+    if (window) {
+        jb.wx0 = window[0] < 0 ? 0 : window[0]; jb.wx1 = window[1] > ntx || window[1] <= 0 ? ntx : window[1];
+        jb.wy0 = window[2] < 0 ? 0 : window[2]; jb.wy1 = window[3] > nty || window[3] <= 0 ? nty : window[3];
+    }
+    int64_t inst = 0;
+    for (int a = jb.wx0; a < jb.wx1; ++a)
+        for (int b = jb.wy0; b < jb.wy1; ++b) inst += start[(int64_t)a * nty + b + 1] - start[(int64_t)a * nty + b];
+    if (jb.wx1 > jb.wx0 && jb.wy1 > jb.wy0) {
+        if (nthreads < 1) nthreads = 1;
+        if (nthreads > 256) nthreads = 256;
+        pthread_t th[256];
+        for (int t = 1; t < nthreads; ++t) pthread_create(&th[t], NULL, std_worker, &jb);
+        std_worker(&jb);
+        for (int t = 1; t < nthreads; ++t) pthread_join(th[t], NULL);
+    }
+    if (n_vis_out) *n_vis_out = m;
+    if (instances_out) *instances_out = inst;
+    free(G); free(rect); free(key); free(val); free(start); free(items); free(fill);
+    return 0;
+}
+
+int orc_version(void) { return 3; }

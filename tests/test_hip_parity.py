@@ -593,7 +593,7 @@ def test_c_abi_rejects_bad_arguments(tmp_path):
     with pytest.raises(_ffi.GsxError, match="rejected the sizes"):
         scene.render_image_hip(1, tile_size=0)
     with pytest.raises(KeyError):
-        scene.render_image_hip(1, semantics="std_3dgs")
+        scene.render_image_hip(1, semantics="no_such_rules")
     lib = _ffi.load()
     p = _ffi.default_params()
     p.layout = 7
