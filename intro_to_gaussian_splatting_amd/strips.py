@@ -20,9 +20,12 @@ import torch
 import torch.distributed as dist
 
 
-def tiles_along(extent: int, tile: int) -> int:
-    """Tiles the CPU-semantics renderer produces along an axis: ``len(range(0, extent - tile, tile))``
-    (splat/gaussian_scene.py:208,214)."""
+def tiles_along(extent: int, tile: int, semantics: str = "ref_cpu") -> int:
+    """Tiles along an axis.  "ref_cpu": what the CPU-semantics renderer produces,
+    ``len(range(0, extent - tile, tile))`` (splat/gaussian_scene.py:208,214: the last row / column is
+    never rendered); "ref_cuda" / "std_3dgs": the whole frame, ``ceil(extent / tile)``."""
+    if semantics != "ref_cpu":
+        return -(-extent // tile)
     return max(0, -(-(extent - tile) // tile)) if extent > tile else 0
 
 
@@ -40,7 +43,7 @@ def strip_plan(n_tiles: int, world_size: int) -> Tuple[int, List[Tuple[int, int]
 def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor, Tuple[int, int]], None],
                    width: int, height: int, tile: int, layout: str, device: torch.device,
                    group: Optional[dist.ProcessGroup] = None, all_ranks: bool = False,
-                   cache: Optional[dict] = None) -> Optional[torch.Tensor]:
+                   cache: Optional[dict] = None, semantics: str = "ref_cpu") -> Optional[torch.Tensor]:
     """Renders this rank's strip with ``render_fn(tile_window, out_strip, out_origin)`` and gathers
     the frame on rank 0 (or on every rank with ``all_ranks``).
 
@@ -49,12 +52,14 @@ def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor,
     Returns the frame ((W,H,3) for "wh3", (H,W,3) for "hw3") or None on non-root ranks.
     ``cache`` (a dict owned by the caller) lets consecutive frames reuse the frame / strip buffers
     instead of allocating them per call; the returned frame is then overwritten by the next call.
+    ``semantics`` only decides how many tile rows exist (see ``tiles_along``); with partial edge tiles
+    the last strip's buffer extends past the frame and the surplus rows are cut off after the gather.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lead, other = (width, height) if layout == "wh3" else (height, width)
-    n_lead = tiles_along(lead, tile)
-    n_other = tiles_along(other, tile)
+    n_lead = tiles_along(lead, tile, semantics)
+    n_other = tiles_along(other, tile, semantics)
     per, plan = strip_plan(n_lead, world)
     rows = per * tile                                  # strip extent in pixels, tile aligned
     t0, t1 = plan[rank]
