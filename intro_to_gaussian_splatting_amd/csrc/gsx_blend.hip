@@ -187,65 +187,12 @@ __global__ void __launch_bounds__(64)
         const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
         if ((uint32_t)lane < nb) {
             const Record *q = rec + vals[base + lane];
-            if (VARIANT == 3) {
-                // geometry (x, y, Q00, qs | q11, lop) and colour apart: the loop fetches the NEXT trip's
-                // geometry while it still works on this trip, the colour only where it is used
-                const float4 b = q->b, c = q->c;
-                sh[0][lane] = q->a;
-                reinterpret_cast<float2 *>(&sh[1][0])[lane] = make_float2(b.x, b.y);
-                sh[2][lane] = make_float4(b.z, b.w, c.x, 0.0f);
-            } else {
-                sh[0][lane] = q->a;
-                sh[1][lane] = q->b;
-                sh[2][lane] = q->c;
-            }
+            sh[0][lane] = q->a;
+            sh[1][lane] = q->b;
+            sh[2][lane] = q->c;
         }
         __syncthreads();
-        if (VARIANT == 3) {
-            const float4 *gA = &sh[0][0];
-            const float2 *gB = reinterpret_cast<const float2 *>(&sh[1][0]);
-            const float4 *gC = &sh[2][0];
-            uint32_t k = 0;
-            if (!checked) {
-                float4 A0 = gA[0], A1 = gA[1];
-                float2 G0 = gB[0], G1 = gB[1];
-                for (; k + 1 < nb; k += 2) {
-                    v2f aa0, ab0, aa1, ab1;
-                    alphas(A0, G0.x, G0.y, cx, cya, cyb, aa0, ab0);
-                    alphas(A1, G1.x, G1.y, cx, cya, cyb, aa1, ab1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // next trip's geometry into the registers that just died (entries past nb are
-                    // stale but inside the buffer, and never used)
-                    A0 = gA[k + 2];
-                    G0 = gB[k + 2];
-                    A1 = gA[k + 3];
-                    G1 = gB[k + 3];
-                    const float4 C0 = gC[k], C1 = gC[k + 1];
-                    __builtin_amdgcn_sched_barrier(0);
-                    const v2f ta0a = Ta * aa0, ta0b = Tb * ab0;
-                    const v2f t1a = Ta - ta0a, t1b = Tb - ta0b;
-                    const v2f ta1a = t1a * aa1, ta1b = t1b * ab1;
-                    const v2f t2a = t1a - ta1a, t2b = t1b - ta1b;
-                    if (__builtin_expect(__any(fminf(min4(t1a, t1b), min4(t2a, t2b)) < kStopRefCpu), 0)) {
-                        checked = true;
-                        break;
-                    }
-                    GSX_ACCUMULATE(ta0a, ta0b, C0.x, C0.y, C0.z);
-                    GSX_ACCUMULATE(ta1a, ta1b, C1.x, C1.y, C1.z);
-                    Ta = t2a;
-                    Tb = t2b;
-                }
-            }
-            for (; k < nb; ++k) {  // tail record of the batch, or the checked path
-                const float4 A0 = gA[k], C0 = gC[k];
-                const float2 G0 = gB[k];
-                v2f aa0, ab0, ta0a, ta0b;
-                alphas(A0, G0.x, G0.y, cx, cya, cyb, aa0, ab0);
-                checked_pair(aa0, Ta, ta0a);
-                checked_pair(ab0, Tb, ta0b);
-                GSX_ACCUMULATE(ta0a, ta0b, C0.x, C0.y, C0.z);
-            }
-        } else if (VARIANT == 0) {
+        if (VARIANT == 0) {
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
                 // e = mean - pixel, the pixel coordinate formed first, as the reference does
@@ -485,9 +432,7 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             const char *e = getenv("GSX_BLEND_LDS_PAD");
             return e ? (unsigned)atoi(e) : 0u;
         }();
-        if (variant == 3)
-            blend_tile16_kernel<3><<<(unsigned)nt, 64, pad, s>>>(rec, sorted_vals, ranges, grid, out);
-        else if (variant == 0)
+        if (variant == 0)
             blend_tile16_kernel<0><<<(unsigned)nt, 64, pad, s>>>(rec, sorted_vals, ranges, grid, out);
         else
             blend_tile16_kernel<1><<<(unsigned)nt, 64, pad, s>>>(rec, sorted_vals, ranges, grid, out);
