@@ -21,7 +21,12 @@ from .colmap import Camera, Image
 def _rotation_from_qvec(qvec) -> torch.Tensor:
     """(w,x,y,z) -> 3x3, normalising first (splat/utils.py:132-155, float32)."""
     q = torch.tensor([float(v) for v in qvec], dtype=torch.float32)
-    q = q / torch.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+    # Correctly rounded float32 square root (double sqrt of a float32, rounded once more, is exact).
+    # torch.sqrt on the CPU is NOT correctly rounded on every host -- it is 1 ulp off on the EPYC 9575F
+    # of the MI355X box while exact on the build host -- and the camera constants must not depend on
+    # the host they were computed on (the golden vectors were captured where torch.sqrt is exact).
+    norm = torch.tensor(math.sqrt(float(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])), dtype=torch.float32)
+    q = q / norm
     w, x, y, z = q[0], q[1], q[2], q[3]
     rows = [
         [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],

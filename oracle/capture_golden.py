@@ -32,6 +32,12 @@ FIXTURES = {
     "small_80x64_n120_tile8": dict(n=120, width=80, height=64, seed=5, tile=8),
     "cull_96x80_n400": dict(n=400, width=96, height=80, seed=7, tile=16, behind_fraction=0.25),
     "c1_256x256_n2000": dict(n=2000, width=256, height=256, seed=0, tile=16),
+    # tile_size=2 as in the reference's notebooks; odd frame sizes; another camera pose
+    "tile2_40x32_n80": dict(n=80, width=40, height=32, seed=11, tile=2),
+    "pose_70x50_n250": dict(n=250, width=70, height=50, seed=13, tile=16,
+                            qvec=(0.8, 0.3, -0.45, 0.25), tvec=(-0.7, 0.2, 2.1)),
+    # many Gaussians per pixel: the T(1-alpha) < 1e-6 stop rule fires (checked by the tests)
+    "dense_48x48_n1500": dict(n=1500, width=48, height=48, seed=17, tile=16),
 }
 
 

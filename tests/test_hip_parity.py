@@ -687,3 +687,16 @@ def test_randomised_small_scenes(tmp_path, seed):
     ok = np.isfinite(ref2) & np.isfinite(img2)
     diff = np.abs(img2 - ref2)[ok]
     assert (diff > PIXEL_TOL).mean() < 2e-3 if diff.size else True
+
+
+def test_camera_constants_equal_the_references_on_this_host(tmp_path, golden):
+    """The camera constants are computed on the host; they must come out bit-equal to the ones the
+    reference computed where the golden vectors were captured, also on the GPU box's CPU (whose
+    torch.sqrt is not correctly rounded -- image.py takes the square root in double)."""
+    _need_gpu()
+    g = golden
+    cam = _scene_from_golden(tmp_path, g).images[1].gsx_camera()
+    assert np.array_equal(np.array(list(cam.world2view), np.float32).reshape(4, 4), g["world2view"])
+    assert np.array_equal(np.array(list(cam.full_proj), np.float32).reshape(4, 4), g["full_proj_transform"])
+    assert np.float32(cam.tan_fovx) == g["tan_fovX"][0] and np.float32(cam.tan_fovy) == g["tan_fovY"][0]
+    assert np.float32(cam.fx) == g["f_x"][0] and np.float32(cam.fy) == g["f_y"][0]

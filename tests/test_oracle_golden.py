@@ -156,3 +156,28 @@ def test_cuda_semantics_restatement_against_numpy():
     # differs from the CPU path by construction (single sigmoid, clamp, per-pixel cull, edge tiles)
     cpu_sem, _, _ = c_oracle.render(pre, w, h, 16)
     assert np.max(np.abs(img.transpose(1, 0, 2) - cpu_sem)) > 0.05
+
+
+def test_dense_fixture_exercises_the_stop_rule():
+    """dense_48x48_n1500 exists so that `T(1-alpha) < 1e-6 -> return before accumulating`
+    (splat/gaussian_scene.py:166) is covered by a vector of the reference itself: in its first tile
+    the rule must fire for a good share of the pixels (and the image parity tests then pin it)."""
+    from oracle import cpu_ref
+
+    g = load_golden("dense_48x48_n1500")
+    pre = golden_preprocessed(g)
+    lst = cpu_ref.tile_list(pre, 0, 0, 16)
+    op2 = cpu_ref.sigmoid(pre.sigmoid_opacity[lst, 0]).astype(np.float64)
+    pts, Q = pre.points[lst].astype(np.float64), pre.inverse_covariance_2d[lst].astype(np.float64)
+    fired = 0
+    for px in range(0, 16, 3):
+        for py in range(0, 16, 3):
+            d = pts - np.array([px, py], np.float64)
+            w = np.exp(-0.5 * np.einsum("ni,nij,nj->n", d, Q, d)) * op2
+            T = 1.0
+            for a in w:
+                if T * (1 - a) < 1e-6:
+                    fired += 1
+                    break
+                T *= 1 - a
+    assert fired >= 5
