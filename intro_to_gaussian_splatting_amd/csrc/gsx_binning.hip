@@ -145,8 +145,25 @@ __global__ void __launch_bounds__(kBlock)
                       const uint32_t *__restrict__ n_visible, int64_t n_visible_known,
                       int64_t *__restrict__ counts2) {
     __shared__ uint32_t wsum[4];
+    __shared__ uint64_t wide[kBlock];
     uint32_t before = 0;
-    for (uint32_t k = threadIdx.x; k < blockIdx.x; k += kBlock) before += block_sums[k];
+    uint64_t before64 = 0;  // the 32-bit offsets wrap beyond 2^32 pairs; the reported total must not
+    for (uint32_t k = threadIdx.x; k < blockIdx.x; k += kBlock) {
+        before += block_sums[k];
+        before64 += block_sums[k];
+    }
+    const bool last = blockIdx.x == gridDim.x - 1;  // holds r == n
+    if (last) {
+        wide[threadIdx.x] = before64;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t t = 0;
+            for (int k = 0; k < kBlock; ++k) t += wide[k];
+            wide[0] = t;
+        }
+        __syncthreads();
+        before64 = wide[0];
+    }
     before = block_sum(before, wsum);
     const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanItems;
     uint32_t c[kScanItems], mine = 0;
@@ -172,7 +189,7 @@ __global__ void __launch_bounds__(kBlock)
         if (base + k <= n) offsets[base + k] = run;   // r == n receives the grand total
         if (base + k == n) {
             counts2[0] = n_visible_known >= 0 ? n_visible_known : (int64_t)*n_visible;
-            counts2[1] = (int64_t)run;
+            counts2[1] = (int64_t)(before64 + (uint64_t)(run - before));   // = run while D < 2^32
         }
         run += c[k];
     }

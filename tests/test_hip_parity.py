@@ -700,3 +700,35 @@ def test_camera_constants_equal_the_references_on_this_host(tmp_path, golden):
     assert np.array_equal(np.array(list(cam.full_proj), np.float32).reshape(4, 4), g["full_proj_transform"])
     assert np.float32(cam.tan_fovx) == g["tan_fovX"][0] and np.float32(cam.tan_fovy) == g["tan_fovY"][0]
     assert np.float32(cam.fx) == g["f_x"][0] and np.float32(cam.fy) == g["f_y"][0]
+
+
+def test_pair_count_beyond_32_bits_is_reported_not_wrapped(tmp_path):
+    """17 000 frame-filling Gaussians x 262 144 tiles of 2x2 pixels = 4.46e9 pairs: more than the
+    32-bit offsets hold.  The frame cannot be rendered, but the count that comes back must be the
+    true one (a wrapped count could pass for a small frame)."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import _ffi
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    w = h = 1026
+    sc = make_scene(17000, w, h, seed=2)
+    sc["scales"] = np.full_like(sc["scales"], 50.0)            # every bounding box covers the frame
+    scene = _scene_from_arrays(tmp_path, sc)
+    lib = _ffi.load()
+    dev, n, tensors = scene._inputs(1)
+    cam = scene.images[1].gsx_camera()
+    cap = 1 << 20
+    nbytes = lib.gsx_workspace_bytes(n, w, h, 2, cap)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = torch.empty((w, h, 3), dtype=torch.float32, device=dev)
+    st = _ffi.GsxFrameStats()
+    import ctypes
+
+    rc = lib.gsx_render_forward(ctypes.byref(cam), *[ctypes.c_void_p(t.data_ptr()) for t in tensors], n, 2,
+                                ctypes.c_void_p(out.data_ptr()), None, ctypes.byref(st),
+                                ctypes.c_void_p(ws.data_ptr()), nbytes,
+                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == _ffi.GSX_ERR_WORKSPACE_TOO_SMALL
+    assert st.n_visible == 17000 and st.n_instances == 17000 * 512 * 512
+    with pytest.raises(_ffi.GsxError):                          # the Python surface gives up cleanly
+        scene.render_image_hip(1, tile_size=2)
