@@ -111,6 +111,11 @@ typedef struct GsxParams {
  * rendered again with a larger workspace. */
 #define GSX_FLAG_NO_SYNC 2
 
+/* Composite with the any-tile-size kernels (one pixel per lane) even when tile == 16, where the
+ * specialised 4-pixels-per-lane kernels would run.  Same arithmetic, same pixels bit for bit; exists
+ * so that tests can hold the two kernel families against each other. */
+#define GSX_FLAG_GENERIC_KERNELS 4
+
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
 enum {
     GSX_STAGE_PROJECT = 0,    /* projection, depth keys, record packing         */

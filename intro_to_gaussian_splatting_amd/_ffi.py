@@ -26,6 +26,7 @@ GSX_LAYOUT_WH3 = 0
 GSX_LAYOUT_HW3 = 1
 GSX_FLAG_TIMING = 1
 GSX_FLAG_NO_SYNC = 2
+GSX_FLAG_GENERIC_KERNELS = 4
 STAGE_NAMES = ("project", "depth_sort", "scan", "bin", "blend", "total")
 
 

@@ -92,6 +92,7 @@ struct Plan {
     int semantics;
     bool timing;
     bool no_sync;  // GSX_FLAG_NO_SYNC: nothing waits for the device
+    bool generic;  // GSX_FLAG_GENERIC_KERNELS
     float background[3];
 };
 
@@ -148,6 +149,7 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     p.semantics = d.semantics;
     p.timing = (d.flags & GSX_FLAG_TIMING) != 0;
     p.no_sync = (d.flags & GSX_FLAG_NO_SYNC) != 0 && !p.timing;
+    p.generic = (d.flags & GSX_FLAG_GENERIC_KERNELS) != 0;
     gsx::TileGrid &g = p.grid;
     g.tile = tile;
     g.ntx = tiles_along(width, tile, d.semantics);
@@ -241,7 +243,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
         uint2 *ranges = (uint2 *)(ws + c.ranges);
         GSX_HIP(hipMemsetAsync(ranges, 0, (size_t)p.grid.count() * sizeof(uint2), s));
         GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), nullptr, (const uint32_t *)(ws + c.tvals0), ranges,
-                                  p.grid, p.out, p.semantics, p.background, s));
+                                  p.grid, p.out, p.semantics, p.background, p.generic, s));
     } else if (p.grid.count() == 0 || n == 0) {
         GSX_HIP(hipMemsetAsync(p.out.ptr, 0, out_bytes, s));
     } else {
@@ -254,7 +256,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
                                    (uint32_t *)(ws + c.tvals1), ranges, &sorted_vals, s));
         tm.mark();  // 4: bin
         GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
-                                  ranges, p.grid, p.out, p.semantics, p.background, s));
+                                  ranges, p.grid, p.out, p.semantics, p.background, p.generic, s));
         tm.mark();  // 5: blend
     }
     if (p.no_sync) {

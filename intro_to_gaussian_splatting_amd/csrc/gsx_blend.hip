@@ -316,6 +316,25 @@ __global__ void __launch_bounds__(64)
     }
 }
 
+// GSX_SEM_STD_3DGS, one (pixel, Gaussian) pair.  `thr` is the pixel's alpha threshold: 1/255 while
+// the pixel is live, +inf once it has stopped (or lies outside the frame), so "alpha < thr" skips
+// everything for a dead pixel without a separate flag.  A skipped or stopping pair composites with
+// weight 0 -- fma(0, c, C) = C and T - 0 = T exactly -- which keeps the loop free of control flow.
+constexpr float kStdAlphaMin = 1.0f / 255.0f, kStdStop = 0.0001f;
+
+__device__ __forceinline__ void std_composite(float pw, float alpha, float cr, float cg, float cb, float &thr, float &T,
+                                              float &c0, float &c1, float &c2) {
+    const bool use = !(pw > 0.0f) && !(alpha < thr);
+    const float ta = T * alpha;
+    const bool stop = use && (T - ta < kStdStop);
+    const float w = (use && !stop) ? ta : 0.0f;
+    thr = stop ? __builtin_inff() : thr;
+    c0 = __builtin_fmaf(w, cr, c0);
+    c1 = __builtin_fmaf(w, cg, c1);
+    c2 = __builtin_fmaf(w, cb, c2);
+    T = T - w;
+}
+
 // Per-pixel rule sets, any tile size, one pixel per lane, every tile of the frame including partial
 // edge tiles.  Not the hot path of this build (the parity target is the CPU semantics); kept simple.
 //   GSX_SEM_REF_CUDA (splat/c/render.cu:21-87): per-pixel inclusive bounding-box cull,
@@ -345,6 +364,7 @@ __global__ void __launch_bounds__(64)
         const float fx = (float)px, fy = (float)py;
         float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
         bool done = !valid;
+        float thr = valid ? kStdAlphaMin : __builtin_inff();  // GSX_SEM_STD_3DGS: see std_composite
         for (uint32_t base = rg.x; base < rg.y; base += 64) {
             const uint32_t nb = min(64u, rg.y - base);
             if ((uint32_t)lane < nb) {
@@ -371,11 +391,12 @@ __global__ void __launch_bounds__(64)
                 } else {
                     const float pw = __builtin_fmaf(e_y, __builtin_fmaf(e_y, B.x, e_x * A.w), (e_x * e_x) * A.z);
                     alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(pw));
-                    use = !(pw > 0.0f) && !(alpha < 1.0f / 255.0f);
+                    std_composite(pw, alpha, B.z, B.w, cb, thr, T, c0, c1, c2);
+                    continue;
                 }
                 const float ta = T * alpha, test = T - ta;
                 if (use && !done) {
-                    if (test < (SEM == GSX_SEM_REF_CUDA ? 0.001f : 0.0001f)) {
+                    if (test < 0.001f) {
                         done = true;
                     } else {
                         c0 = __builtin_fmaf(ta, B.z, c0);
@@ -386,7 +407,7 @@ __global__ void __launch_bounds__(64)
                 }
             }
             __syncthreads();
-            if (__ballot(!done) == 0ull) break;
+            if (__ballot(SEM == GSX_SEM_STD_3DGS ? thr < 1.0f : !done) == 0ull) break;
         }
         if (valid) {
             float *o = out.ptr + (int64_t)(px - out.x0) * out.stride_x + (int64_t)(py - out.y0) * out.stride_y;
@@ -402,11 +423,86 @@ __global__ void __launch_bounds__(64)
     }
 }
 
+// GSX_SEM_STD_3DGS, tile = 16: one wave per tile, 4 pixels per lane sharing x (the lane / pixel
+// assignment of blend_tile16_kernel), so a record read from LDS and the x-only terms of the exponent
+// serve 4 evaluations.  Same per-pixel arithmetic as blend_rules_kernel<GSX_SEM_STD_3DGS> -- the two
+// give bit-identical frames (tested).  Pixels outside the frame (partial edge tiles) start dead.
+__global__ void __launch_bounds__(64)
+    blend_std16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
+                       const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, float bg0, float bg1, float bg2) {
+    __shared__ float4 sh[3][64];
+    const int lane = threadIdx.x;
+    const uint32_t t = xcd_remap(blockIdx.x, (uint32_t)g.count());
+    const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
+    const bool y_contig = out.stride_y < out.stride_x;
+    const int px = tx * 16 + (y_contig ? (lane >> 2) : (lane & 15));
+    const int py0 = ty * 16 + 4 * (y_contig ? (lane & 3) : (lane >> 4));
+    const float cx = (float)px;
+    float cy[4], T[4], c0[4], c1[4], c2[4], thr[4];
+    bool valid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cy[j] = (float)(py0 + j);
+        T[j] = 1.0f;
+        c0[j] = c1[j] = c2[j] = 0.0f;
+        valid[j] = px < g.width && py0 + j < g.height;
+        thr[j] = valid[j] ? kStdAlphaMin : __builtin_inff();
+    }
+    const uint2 rg = ranges[t];
+    for (uint32_t base = rg.x; base < rg.y; base += 64) {
+        const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
+        if ((uint32_t)lane < nb) {
+            const Record *q = rec + vals[base + lane];
+            sh[0][lane] = q->a;
+            sh[1][lane] = q->b;
+            sh[2][lane] = q->c;
+        }
+        __syncthreads();
+        for (uint32_t k = 0; k < nb; ++k) {
+            const float4 A = sh[0][k], B = sh[1][k];
+            const float cb = sh[2][k].x;
+            const float e_x = A.x - cx;
+            const float a0 = (e_x * e_x) * A.z, b0 = e_x * A.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e_y = A.y - cy[j];
+                const float pw = __builtin_fmaf(e_y, __builtin_fmaf(e_y, B.x, b0), a0);
+                const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(pw));
+                std_composite(pw, alpha, B.z, B.w, cb, thr[j], T[j], c0[j], c1[j], c2[j]);
+            }
+        }
+        __syncthreads();
+        if (__ballot(fminf(fminf(thr[0], thr[1]), fminf(thr[2], thr[3])) < 1.0f) == 0ull) break;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c0[j] = __builtin_fmaf(T[j], bg0, c0[j]);
+        c1[j] = __builtin_fmaf(T[j], bg1, c1[j]);
+        c2[j] = __builtin_fmaf(T[j], bg2, c2[j]);
+    }
+    float *o = out.ptr + (int64_t)(px - out.x0) * out.stride_x + (int64_t)(py0 - out.y0) * out.stride_y;
+    if (y_contig && valid[3] && (reinterpret_cast<uintptr_t>(o) & 15u) == 0) {
+        float4 *o4 = reinterpret_cast<float4 *>(o);
+        o4[0] = make_float4(c0[0], c1[0], c2[0], c0[1]);
+        o4[1] = make_float4(c1[1], c2[1], c0[2], c1[2]);
+        o4[2] = make_float4(c2[2], c0[3], c1[3], c2[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!valid[j]) continue;
+            float *oj = o + (int64_t)j * out.stride_y;
+            oj[0] = c0[j];
+            oj[1] = c1[j];
+            oj[2] = c2[j];
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
-                        hipStream_t s) {
+                        bool generic, hipStream_t s) {
     const int64_t nt = grid.count();
     if (nt <= 0) return hipSuccess;
     if (semantics == GSX_SEM_REF_CUDA) {
@@ -415,12 +511,17 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
         return hipGetLastError();
     }
     if (semantics == GSX_SEM_STD_3DGS) {
+        if (grid.tile == 16 && !generic) {
+            blend_std16_kernel<<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, background[0],
+                                                           background[1], background[2]);
+            return hipGetLastError();
+        }
         blend_rules_kernel<GSX_SEM_STD_3DGS><<<(unsigned)nt, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out,
                                                                         background[0], background[1], background[2]);
         return hipGetLastError();
     }
     if (semantics != GSX_SEM_REF_CPU) return hipErrorNotSupported;
-    if (grid.tile == 16) {
+    if (grid.tile == 16 && !generic) {
         // GSX_BLEND_VARIANT: measurement knob for A/B runs of the compositing loop (default 1)
         static const int variant = [] {
             const char *e = getenv("GSX_BLEND_VARIANT");

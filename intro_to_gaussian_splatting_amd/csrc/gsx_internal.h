@@ -110,9 +110,9 @@ hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, i
                             float *colors, hipStream_t s);
 
 // ---- gsx_blend.hip
-// background: 3 floats, read on the host (GSX_SEM_STD_3DGS only).
+// background: 3 floats, read on the host (GSX_SEM_STD_3DGS only); generic: GSX_FLAG_GENERIC_KERNELS.
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
-                        hipStream_t s);
+                        bool generic, hipStream_t s);
 
 }  // namespace gsx

@@ -219,7 +219,8 @@ class GaussianScene:
                          out: Optional[torch.Tensor] = None, out_origin: Tuple[int, int] = (0, 0),
                          stats: Optional[dict] = None, timing: bool = False,
                          no_sync: bool = False, semantics: str = "ref_cpu",
-                         background: Tuple[float, float, float] = (0.0, 0.0, 0.0)) -> torch.Tensor:
+                         background: Tuple[float, float, float] = (0.0, 0.0, 0.0),
+                         generic_kernels: bool = False) -> torch.Tensor:
         """Full forward render in libgsx (gsx_render_forward).
 
         semantics: "ref_cpu" (the reference's ``render_image``), "ref_cuda" (its CUDA kernel's rules
@@ -247,6 +248,8 @@ class GaussianScene:
         params.background[0], params.background[1], params.background[2] = [float(v) for v in background]
         if timing:
             params.flags |= _ffi.GSX_FLAG_TIMING
+        if generic_kernels:     # tests: the any-tile-size kernels also at tile 16 (same pixels)
+            params.flags |= _ffi.GSX_FLAG_GENERIC_KERNELS
         if tile_window is not None:
             params.tile_x0, params.tile_x1, params.tile_y0, params.tile_y1 = [int(v) for v in tile_window]
         if out is None:

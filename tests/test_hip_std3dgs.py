@@ -121,3 +121,20 @@ def test_std3dgs_rejected_on_the_stage2_entry():
     with pytest.raises(_ffi.GsxError, match="gsx_render_forward"):
         render_preprocessed(32, 32, 16, z(4, 2), z(4, 3), z(4, 2, 2), z(4), z(4), z(4), z(4), z(4, 1),
                             semantics="std_3dgs")
+
+
+@pytest.mark.parametrize("semantics", ["std_3dgs", "ref_cpu"])
+def test_tile16_kernels_equal_the_generic_kernels_bit_for_bit(tmp_path, semantics):
+    """tile == 16 runs the 4-pixels-per-lane kernels; GSX_FLAG_GENERIC_KERNELS forces the
+    one-pixel-per-lane family: same arithmetic per pixel, so the frames must be identical."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    w, h = 300, 200                                       # std_3dgs: partial edge tiles on both axes
+    sc = make_scene(20000, w, h, seed=9, behind_fraction=0.1)
+    scene = _scene_from_arrays(tmp_path, sc)
+    kw = dict(semantics=semantics, background=(0.3, 0.2, 0.1)) if semantics == "std_3dgs" else dict(semantics=semantics)
+    for layout in ("wh3", "hw3"):
+        fast = scene.render_image_hip(1, layout=layout, **kw)
+        slow = scene.render_image_hip(1, layout=layout, generic_kernels=True, **kw)
+        assert torch.equal(fast, slow), (semantics, layout)
