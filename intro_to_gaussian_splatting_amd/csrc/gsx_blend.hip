@@ -527,16 +527,10 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             const char *e = getenv("GSX_BLEND_VARIANT");
             return e ? atoi(e) : 1;
         }();
-        // GSX_BLEND_LDS_PAD: extra dynamic LDS per workgroup = an occupancy cap (160 KiB / CU), so that
-        // kernels of other frames in flight find free wave slots next to the compositing waves
-        static const unsigned pad = [] {
-            const char *e = getenv("GSX_BLEND_LDS_PAD");
-            return e ? (unsigned)atoi(e) : 0u;
-        }();
         if (variant == 0)
-            blend_tile16_kernel<0><<<(unsigned)nt, 64, pad, s>>>(rec, sorted_vals, ranges, grid, out);
+            blend_tile16_kernel<0><<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out);
         else
-            blend_tile16_kernel<1><<<(unsigned)nt, 64, pad, s>>>(rec, sorted_vals, ranges, grid, out);
+            blend_tile16_kernel<1><<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out);
     } else {
         blend_generic_kernel<<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out);
     }
