@@ -1,7 +1,7 @@
 """Turns the rocprofv3 outputs a gpurun call left under gpurun_out/ into the summaries committed
 under profiles/ (kernel stats per frame, PMC traffic / VALU busy of the compositing kernel).
 
-    python tools/summarize_profiles.py r1f          # reads gpurun_out/prof_<tag>*, pmc3_*, bench_c*.json
+    python tools/summarize_profiles.py r1g          # reads gpurun_out/prof_<tag>*, pmc3_*, bench_c*.json
 """
 import collections
 import csv
@@ -10,7 +10,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1f"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1g"
 pmc = sys.argv[2] if len(sys.argv) > 2 else "pmc3"
 
 
@@ -90,6 +90,14 @@ for w in ("c1", "c2", "c3", "c4"):
     lines.append("| %s | %.4f | %.0f | %.4f | %.4f | %.2g | %.2f |" % (
         w, d["ms_per_step"], d["value"], d["config"]["ms_per_frame_one_in_flight"], d["roofline"]["avg_ms"],
         d.get("max_abs_dpixel", float("nan")), d["cpu_baseline"]["value"]))
+import os
+if os.path.exists("gpurun_out/bench_c3_std3dgs.json"):
+    shutil.copy("gpurun_out/bench_c3_std3dgs.json", "profiles/%s_bench_c3_std3dgs.json" % tag)
+    d = json.load(open("gpurun_out/bench_c3_std3dgs.json"))
+    lines.append("| c3, std_3dgs rules | %.4f | %.0f | %.4f | %.4f | %.2g (+ %d threshold flips <= %.2g) | %.2f |" % (
+        d["ms_per_step"], d["value"], d["config"]["ms_per_frame_one_in_flight"], d["roofline"]["avg_ms"],
+        d.get("max_abs_dpixel", float("nan")), d["cpu_baseline"]["threshold_flip_pixels"],
+        d["cpu_baseline"]["max_abs_dpixel_incl_flips"], d["cpu_baseline"]["value"]))
 lines.append("\n## PMC, compositing kernel (profiles/r1_pmc_c3.json)\n")
 lines.append("```\n%s\n%s\n%s\n```" % (json.dumps(out["calibration"]), json.dumps(out["blend_traffic_bytes_per_launch"]),
                                         json.dumps(out["blend_valu"])))
