@@ -381,7 +381,8 @@ def main() -> None:
             if ref_rules:
                 out["parity_ok"] = bool(err <= 1e-4 and inst == d)
             else:   # 1/255-threshold flips are counted apart (tests/test_hip_std3dgs.py states the bar)
-                out["parity_ok"] = bool(err <= 1e-4 and (inst is None or inst == d) and
+                # the default binning drops (Gaussian, tile) pairs that cannot reach alpha = 1/255: D <= published D
+                out["parity_ok"] = bool(err <= 1e-4 and (inst is None or d <= inst) and
                                         base["threshold_flip_pixels"] <= 2 + 1e-5 * base["window_pixels"] and
                                         base["max_abs_dpixel_incl_flips"] < 0.006)
         print(json.dumps(out), flush=True)

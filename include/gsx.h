@@ -116,6 +116,15 @@ typedef struct GsxParams {
  * so that tests can hold the two kernel families against each other. */
 #define GSX_FLAG_GENERIC_KERNELS 4
 
+/* GSX_SEM_STD_3DGS only.  By default a Gaussian is binned into the tiles met by the bounding box of
+ * the ellipse on which its alpha reaches 1/255 (with a 1 % safety margin on alpha), intersected with
+ * the published rectangle (the square of the 3-sigma radius): a pixel outside that ellipse is skipped
+ * by the alpha < 1/255 rule anyway, so the frame is the same bit for bit while the tile lists get
+ * shorter (24 % fewer pairs on the benchmark scene; a Gaussian whose opacity is below 1/255 is in
+ * no tile at all).  This flag bins with the published rectangles instead, e.g. to compare
+ * GsxFrameStats.n_instances with another implementation of the published algorithm. */
+#define GSX_FLAG_PUBLISHED_RECTS 8
+
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
 enum {
     GSX_STAGE_PROJECT = 0,    /* projection, depth keys, record packing         */

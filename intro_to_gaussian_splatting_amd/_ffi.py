@@ -27,6 +27,7 @@ GSX_LAYOUT_HW3 = 1
 GSX_FLAG_TIMING = 1
 GSX_FLAG_NO_SYNC = 2
 GSX_FLAG_GENERIC_KERNELS = 4
+GSX_FLAG_PUBLISHED_RECTS = 8
 STAGE_NAMES = ("project", "depth_sort", "scan", "bin", "blend", "total")
 
 

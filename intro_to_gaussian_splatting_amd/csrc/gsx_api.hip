@@ -93,6 +93,7 @@ struct Plan {
     bool timing;
     bool no_sync;  // GSX_FLAG_NO_SYNC: nothing waits for the device
     bool generic;  // GSX_FLAG_GENERIC_KERNELS
+    bool tight;    // GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS
     float background[3];
 };
 
@@ -150,6 +151,7 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     p.timing = (d.flags & GSX_FLAG_TIMING) != 0;
     p.no_sync = (d.flags & GSX_FLAG_NO_SYNC) != 0 && !p.timing;
     p.generic = (d.flags & GSX_FLAG_GENERIC_KERNELS) != 0;
+    p.tight = d.semantics == GSX_SEM_STD_3DGS && (d.flags & GSX_FLAG_PUBLISHED_RECTS) == 0;
     gsx::TileGrid &g = p.grid;
     g.tile = tile;
     g.ntx = tiles_along(width, tile, d.semantics);
@@ -407,7 +409,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     StageTimer tm;
     tm.begin(p.timing, s);
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
-    GSX_HIP(gsx::launch_project_pack(*camera, in, n, p.grid, p.semantics, k0, v0, (gsx::Record *)(ws + c.rec),
+    GSX_HIP(gsx::launch_project_pack(*camera, in, n, p.grid, p.semantics, p.tight, k0, v0, (gsx::Record *)(ws + c.rec),
                                      (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts),
                                      p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 1: project (+ depth keys)

@@ -198,6 +198,21 @@ __device__ __forceinline__ void axis_range_std(float p, float r, int T, int nt, 
     hi = (ib > w1 ? w1 : ib) - 1;
 }
 
+// Tight variant (default under GSX_SEM_STD_3DGS, see GSX_FLAG_PUBLISHED_RECTS in include/gsx.h):
+// tiles holding a pixel with |pixel - p| <= e, intersected with the published range.
+__device__ __forceinline__ void axis_range_std_tight(float p, float e, int T, int &lo, int &hi) {
+    const float big = 1073741824.0f;
+    float a = floorf((p - e) / (float)T), b = floorf((p + e) / (float)T);
+    if (!(a == a) || !(b == b)) {
+        lo = 1;
+        hi = 0;
+        return;
+    }
+    int ia = (int)fminf(fmaxf(a, -big), big), ib = (int)fminf(fmaxf(b, -big), big);
+    lo = ia > lo ? ia : lo;
+    hi = ib < hi ? ib : hi;
+}
+
 // Tile index range along one axis for the reference's test `mn <= t*T + T and mx >= t*T`
 // (gaussian_scene.py:209-217), clamped to the window [w0, w1).  Exact for every finite input;
 // NaN compares false in the reference, i.e. the Gaussian is in no tile.
@@ -317,7 +332,7 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
 // One thread per Gaussian, ORIGINAL order (coalesced reads of the parameter arrays, coalesced
 // writes): depth key for the sort, compositing record, tile rectangle and tile count.
 __global__ void __launch_bounds__(kBlock)
-    project_pack_kernel(GsxCamera cam, GaussiansIn in, int64_t n, TileGrid grid, int semantics,
+    project_pack_kernel(GsxCamera cam, GaussiansIn in, int64_t n, TileGrid grid, int semantics, bool tight,
                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, Record *__restrict__ rec,
                         TileRect *__restrict__ rect, uint32_t *__restrict__ counts, float4 *__restrict__ bbox) {
     int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -352,6 +367,25 @@ __global__ void __launch_bounds__(kBlock)
     TileRect tr;
     uint32_t cnt = std3dgs ? tile_rect(o.x, o.radius, o.y, o.radius, grid, semantics, tr)
                            : tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, semantics, tr);
+    if (std3dgs && tight && keep && cnt) {
+        // alpha = op exp(power) >= 1/255  <=>  -power <= log(255 op); on the level set of a Gaussian with
+        // covariance (ca, cb; cb, cd) the coordinates reach sqrt(2 log(255 op) ca) and sqrt(... cd).
+        // The margin of 0.01 on the logarithm (1 % on alpha) is far above any rounding of alpha itself.
+        const float lim = logf(255.0f * op) + 0.01f;
+        if (!(lim > 0.0f)) {
+            keep = false;  // alpha < 1/255 everywhere
+        } else {
+            int lx = tr.x0, hx = tr.x1, ly = tr.y0, hy = tr.y1;
+            axis_range_std_tight(o.x, sqrtf(2.0f * lim * o.ca) * 1.0001f, grid.tile, lx, hx);
+            axis_range_std_tight(o.y, sqrtf(2.0f * lim * o.cd) * 1.0001f, grid.tile, ly, hy);
+            if (lx > hx || ly > hy) {
+                keep = false;
+            } else {
+                tr.x0 = (uint16_t)lx; tr.x1 = (uint16_t)hx; tr.y0 = (uint16_t)ly; tr.y1 = (uint16_t)hy;
+                cnt = (uint32_t)(hx - lx + 1) * (uint32_t)(hy - ly + 1);
+            }
+        }
+    }
     if (!keep) {
         tr.x0 = 1; tr.x1 = 0; tr.y0 = 1; tr.y1 = 0;
         cnt = 0u;
@@ -460,11 +494,11 @@ hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t
 }
 
 hipError_t launch_project_pack(const GsxCamera &cam, const GaussiansIn &in, int64_t n, const TileGrid &grid,
-                               int semantics, uint32_t *keys, uint32_t *vals, Record *rec, TileRect *rect,
-                               uint32_t *counts, float4 *bbox, hipStream_t s) {
+                               int semantics, bool tight_rects, uint32_t *keys, uint32_t *vals, Record *rec,
+                               TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    project_pack_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, n, grid, semantics, keys, vals, rec, rect, counts,
-                                                         bbox);
+    project_pack_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, n, grid, semantics, tight_rects, keys, vals, rec,
+                                                         rect, counts, bbox);
     return hipGetLastError();
 }
 

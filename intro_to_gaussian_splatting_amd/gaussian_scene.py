@@ -220,7 +220,7 @@ class GaussianScene:
                          stats: Optional[dict] = None, timing: bool = False,
                          no_sync: bool = False, semantics: str = "ref_cpu",
                          background: Tuple[float, float, float] = (0.0, 0.0, 0.0),
-                         generic_kernels: bool = False) -> torch.Tensor:
+                         generic_kernels: bool = False, published_rects: bool = False) -> torch.Tensor:
         """Full forward render in libgsx (gsx_render_forward).
 
         semantics: "ref_cpu" (the reference's ``render_image``), "ref_cuda" (its CUDA kernel's rules
@@ -250,6 +250,8 @@ class GaussianScene:
             params.flags |= _ffi.GSX_FLAG_TIMING
         if generic_kernels:     # tests: the any-tile-size kernels also at tile 16 (same pixels)
             params.flags |= _ffi.GSX_FLAG_GENERIC_KERNELS
+        if published_rects:     # std_3dgs: bin with the published 3-sigma squares (same pixels, longer lists)
+            params.flags |= _ffi.GSX_FLAG_PUBLISHED_RECTS
         if tile_window is not None:
             params.tile_x0, params.tile_x1, params.tile_y0, params.tile_y1 = [int(v) for v in tile_window]
         if out is None:
@@ -263,7 +265,8 @@ class GaussianScene:
             params.out_x0, params.out_y0, params.out_w, params.out_h = int(out_origin[0]), int(out_origin[1]), int(ow), int(oh)
         # pair capacity: 1.1 x the count this (camera, tile size, window, semantics) produced last time
         # -- the binning kernels' grids are sized by it -- or a generous guess for a first frame
-        cap_key = (image_idx, tile_size, None if tile_window is None else tuple(int(v) for v in tile_window), semantics)
+        cap_key = (image_idx, tile_size, None if tile_window is None else tuple(int(v) for v in tile_window),
+                   semantics + ("/published" if published_rects else ""))
         cap = self._cap_hints.get(cap_key, 0) or max(self._instances_hint, 8 * n + 4096)
         speculative = bool(no_sync and not timing)
         if speculative:
@@ -295,7 +298,8 @@ class GaussianScene:
             # counts are still in flight: remember what has to be confirmed
             self._pending.append((pinned, cap_key, dict(
                 image_idx=image_idx, tile_size=tile_size, layout=layout, tile_window=tile_window, out=out,
-                out_origin=out_origin, semantics=semantics, background=background)))
+                out_origin=out_origin, semantics=semantics, background=background,
+                generic_kernels=generic_kernels, published_rects=published_rects)))
             if stats is not None:
                 stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
             return out

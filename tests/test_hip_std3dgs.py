@@ -45,10 +45,18 @@ def test_std3dgs_matches_oracle(tmp_path, n, w, h, tile, seed, behind):
     bg = (0.25, 0.5, 0.75)
     ref, nvis, inst, _ = _std_oracle(scene, sc, tile=tile, background=bg)
     stats = {}
-    img = scene.render_image_hip(1, tile_size=tile, layout="hw3", semantics="std_3dgs", background=bg, stats=stats)
+    img = scene.render_image_hip(1, tile_size=tile, layout="hw3", semantics="std_3dgs", background=bg, stats=stats,
+                                 published_rects=True)
     assert tuple(img.shape) == (h, w, 3)
     assert stats["n_visible"] == nvis and stats["n_instances"] == inst
     _check(img.cpu().numpy(), ref, "hw3")
+    # default binning (bounding box of the alpha >= 1/255 ellipse): shorter lists, the same frame bit for bit
+    tight = {}
+    img_t = scene.render_image_hip(1, tile_size=tile, layout="hw3", semantics="std_3dgs", background=bg, stats=tight)
+    assert torch.equal(img_t, img)
+    assert tight["n_visible"] == nvis and tight["n_instances"] <= inst
+    if n >= 1000:
+        assert tight["n_instances"] < inst
     img_wh3 = scene.render_image_hip(1, tile_size=tile, layout="wh3", semantics="std_3dgs", background=bg)
     assert torch.equal(img_wh3.permute(1, 0, 2), img)          # same kernel arithmetic, other store addressing
 
@@ -106,7 +114,8 @@ def test_std3dgs_known_answer_single_gaussian(tmp_path):
     scene = _scene_from_arrays(tmp_path, sc)
     bg = (0.0, 0.0, 1.0)
     st = {}
-    img = scene.render_image_hip(1, layout="hw3", semantics="std_3dgs", background=bg, stats=st).cpu().numpy()
+    img = scene.render_image_hip(1, layout="hw3", semantics="std_3dgs", background=bg, stats=st,
+                                 published_rects=True).cpu().numpy()
     assert st["n_visible"] == 1 and st["n_instances"] == 4
     alpha = 0.5 * np.exp(-0.5 * (0.25 + 0.25) / 4.3)
     np.testing.assert_allclose(img[15, 15], np.array([1.0, 0.5, 0.25]) * alpha + (1 - alpha) * np.array(bg), atol=2e-6)
@@ -157,6 +166,10 @@ def test_std3dgs_randomized_sweep(tmp_path, seed):
     bg = tuple(float(v) for v in rs.uniform(0, 1, 3))
     ref, nvis, inst, _ = _std_oracle(scene, sc, tile=tile, background=bg)
     st = {}
-    img = scene.render_image_hip(1, tile_size=tile, layout="hw3", semantics="std_3dgs", background=bg, stats=st)
+    img = scene.render_image_hip(1, tile_size=tile, layout="hw3", semantics="std_3dgs", background=bg, stats=st,
+                                 published_rects=True)
     assert st["n_visible"] == nvis and st["n_instances"] == inst, (w, h, tile, n)
     _check(img.cpu().numpy(), ref, (w, h, tile, n))
+    st2 = {}
+    img2 = scene.render_image_hip(1, tile_size=tile, layout="hw3", semantics="std_3dgs", background=bg, stats=st2)
+    assert torch.equal(img2, img) and st2["n_instances"] <= inst, (w, h, tile, n)
