@@ -12,6 +12,10 @@ is sharded as strips of tile rows across the ranks (every rank holds the full Ga
 runs the projection; binning, sorting and compositing cover only its strip) and the frame is
 gathered on rank 0 over RCCL: total work is fixed, so "scaling" is "strong".
 
+On one GPU every frame is enqueued as ONE hipGraph launch (GaussianScene.capture_frame: all ~30
+kernel launches, the clears and the asynchronous count copy of a frame are recorded once and replayed;
+--no-graphs enqueues them one by one) and 3 frames are in flight on 3 HIP streams (--streams).
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant kernel (tile compositing): algorithmic bytes per launch over its
                 average duration, measured live with HIP events on the launch stream;
@@ -229,6 +233,11 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=3,
                     help="frames in flight: consecutive frames alternate over this many HIP streams, so one "
                          "frame's latency-bound sorts overlap another's VALU-bound compositing (1 GPU only)")
+    ap.add_argument("--settle-ms", type=float, default=150.0,
+                    help="untimed frames rendered during setup, before the --warmup steps, for this many ms")
+    ap.add_argument("--no-graphs", action="store_true",
+                    help="enqueue every frame as ~30 separate launches instead of replaying it as one hipGraph "
+                         "(GaussianScene.capture_frame); 1 GPU only")
     ap.add_argument("--sync-frames", action="store_true",
                     help="read the instance count back inside every frame instead of speculating on it")
     args = ap.parse_args()
@@ -258,6 +267,11 @@ def main() -> None:
         # frame's instance count, so nothing waits for the device inside a frame; the counts are
         # confirmed after the timed region (confirm_frames) and a miss invalidates the run.
         if world == 1:
+            if graphs:          # the whole frame (every launch, clear and count copy) is ONE graph launch
+                st = gstreams[step.count % len(gstreams)]
+                step.count += 1
+                with torch.cuda.stream(st):
+                    return graphs[st].replay()
             if len(streams) > 1:
                 st = streams[step.count % len(streams)]
                 step.count += 1
@@ -274,12 +288,22 @@ def main() -> None:
     streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if (world == 1 and args.streams > 1) else []
     outs = {st: torch.empty((width, height, 3), dtype=torch.float32, device=device) for st in streams}
     single_out = torch.empty((width, height, 3), dtype=torch.float32, device=device) if world == 1 else None
+    use_graphs = world == 1 and not args.no_graphs and not args.sync_frames
+    gstreams = (streams or [torch.cuda.Stream(device)]) if use_graphs else []
+    graphs = {st: scene.capture_frame(1, tile_size=tile, layout=layout, semantics=sem) for st in gstreams}
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # setup, untimed: let clocks and caches settle (the first ~100 frames after start-up run 5-10 % slow)
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+    scene.confirm_frames()
     frame = None
     for _ in range(args.warmup):
         frame = step()
@@ -291,6 +315,8 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
     respeculated = scene.confirm_frames()
+    for gf in graphs.values():
+        gf.confirm()            # raises if a replay needed more pairs than the graph was captured with
     if world > 1:
         flag = torch.tensor([respeculated], dtype=torch.int64, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
@@ -306,15 +332,31 @@ def main() -> None:
 
     # frame latency with ONE frame in flight (same process, same scene), for reference
     latency_ms = None
-    if world == 1 and len(streams) > 1:
-        lat_out = outs[streams[0]]      # preallocated: pending frames keep their output tensors alive
+    launches_ms = None
+    if world == 1 and (len(streams) > 1 or graphs):
+        lat_out = single_out            # preallocated: pending frames keep their output tensors alive
+        one = graphs[gstreams[0]] if graphs else None
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            scene.render_image_hip(1, tile_size=tile, layout=layout, out=lat_out, no_sync=not args.sync_frames,
-                                   semantics=sem)
+            if one is not None:
+                one.replay()
+            else:
+                scene.render_image_hip(1, tile_size=tile, layout=layout, out=lat_out, no_sync=not args.sync_frames,
+                                       semantics=sem)
         torch.cuda.synchronize()
         latency_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        scene.confirm_frames()
+    if graphs and len(streams) > 1:
+        # for reference: the same frames in flight, every frame enqueued as separate launches
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            st = streams[i % len(streams)]
+            with torch.cuda.stream(st):
+                scene.render_image_hip(1, tile_size=tile, layout=layout, out=outs[st], no_sync=True, semantics=sem)
+        torch.cuda.synchronize()
+        launches_ms = (time.perf_counter() - t1) / args.steps * 1e3
         scene.confirm_frames()
 
     # per-stage HIP-event times of this rank's share (live, same process, separate loop)
@@ -352,7 +394,9 @@ def main() -> None:
             "config": {"workload": desc, "n_gaussians": n, "width": width, "height": height, "tile": tile,
                        "semantics": sem, "layout": layout, "n_visible": nvis, "tile_instances": d,
                        "frames_in_flight": max(1, len(streams)),
+                       "launch": "one hipGraph replay per frame" if graphs else "separate kernel launches",
                        "ms_per_frame_one_in_flight": None if latency_ms is None else round(latency_ms, 4),
+                       "ms_per_frame_separate_launches": None if launches_ms is None else round(launches_ms, 4),
                        "frame_sync": "host reads instance count every frame" if args.sync_frames
                        else "speculative (GSX_FLAG_NO_SYNC), counts confirmed after the timed region",
                        "parallelism": "1 GPU" if world == 1 else "%d column strips + RCCL gather" % world},

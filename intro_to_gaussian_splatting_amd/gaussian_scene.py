@@ -316,11 +316,14 @@ class GaussianScene:
         if cap_key[2] is None and cap_key[3] == "ref_cpu":
             self._last_instances = n_instances
 
-    def _pinned_slot(self) -> torch.Tensor:
-        """One 64-byte slot of a pinned ring (pinning memory per frame would dominate the frame)."""
+    def _ensure_pinned_pool(self) -> None:
         if self._pinned_pool is None:
             self._pinned_pool = torch.zeros((_PINNED_SLOTS, ctypes.sizeof(_ffi.GsxFrameStats)),
                                             dtype=torch.uint8).pin_memory()
+
+    def _pinned_slot(self) -> torch.Tensor:
+        """One 64-byte slot of a pinned ring (pinning memory per frame would dominate the frame)."""
+        self._ensure_pinned_pool()
         slot = self._pinned_pool[self._pinned_next % _PINNED_SLOTS]
         self._pinned_next += 1
         slot.zero_()
@@ -360,6 +363,7 @@ class GaussianScene:
         stream = torch.cuda.Stream(dev)
         with torch.cuda.stream(stream):   # same call once on the capture stream: sizes its scratch buffer
             self.render_image_hip(image_idx, tile_size=tile_size, layout=layout, out=out, semantics=semantics)
+        self._ensure_pinned_pool()                      # pinning memory is not allowed while capturing
         torch.cuda.synchronize(dev)
         before = len(self._pending)
         graph = torch.cuda.CUDAGraph()
