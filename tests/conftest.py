@@ -13,6 +13,16 @@ GOLDEN_NAMES = ["small_64x48_n300", "small_80x64_n120_tile8", "cull_96x80_n400",
                 "tile2_40x32_n80", "pose_70x50_n250", "dense_48x48_n1500"]
 
 
+def pytest_addoption(parser):
+    parser.addoption("--reverse", action="store_true", help="run the collected tests in reverse order "
+                     "(shakes out tests that only pass because an earlier one initialised something)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--reverse"):
+        items.reverse()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real AMD GPU (MI355X); run with -m gpu")
 
