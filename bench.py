@@ -49,6 +49,8 @@ WORKLOADS = {
     "c2": (100_000, 1920, 1080, "C2: synthetic 100k Gaussians, 1920x1080"),
     "c3": (1_000_000, 1920, 1080, "C3: synthetic 1M Gaussians, 1920x1080 (metric config)"),
     "c4": (5_000_000, 3840, 2160, "C4: synthetic 5M Gaussians, 3840x2160"),
+    # not a BASELINE config: index-width / capacity stress (2.0e7 Gaussians, ~8.5e7 pairs, ~3 GB of workspace)
+    "stress20m": (20_000_000, 3840, 2160, "stress: synthetic 20M Gaussians, 3840x2160"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (unpacked VALU)
@@ -349,7 +351,11 @@ def main() -> None:
         scene.confirm_frames()
     if graphs and len(streams) > 1:
         # for reference: the same frames in flight, every frame enqueued as separate launches
+        for st in streams:              # untimed: this path's per-stream workspaces are allocated on first use
+            with torch.cuda.stream(st):
+                scene.render_image_hip(1, tile_size=tile, layout=layout, out=outs[st], no_sync=True, semantics=sem)
         torch.cuda.synchronize()
+        scene.confirm_frames()
         t1 = time.perf_counter()
         for i in range(args.steps):
             st = streams[i % len(streams)]
