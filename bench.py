@@ -234,7 +234,8 @@ def main() -> None:
                          "published 3DGS forward-pass rules (reported under config.semantics)")
     ap.add_argument("--streams", type=int, default=3,
                     help="frames in flight: consecutive frames alternate over this many HIP streams, so one "
-                         "frame's latency-bound sorts overlap another's VALU-bound compositing (1 GPU only)")
+                         "frame's latency-bound sorts overlap another's VALU-bound compositing (N > 1: the strips of "
+                         "consecutive frames, strips.StripPipeline)")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed frames rendered during setup, before the --warmup steps, for this many ms")
     ap.add_argument("--no-graphs", action="store_true",
@@ -282,6 +283,8 @@ def main() -> None:
                                                   no_sync=not args.sync_frames, semantics=sem)
             return scene.render_image_hip(1, tile_size=tile, layout=layout, out=single_out,
                                           no_sync=not args.sync_frames, semantics=sem)
+        if pipeline is not None:
+            return pipeline.submit()
         return strips.render_sharded(render_strip, width, height, tile, layout, device, cache=strip_cache,
                                      semantics=sem)
 
@@ -290,6 +293,11 @@ def main() -> None:
     streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if (world == 1 and args.streams > 1) else []
     outs = {st: torch.empty((width, height, 3), dtype=torch.float32, device=device) for st in streams}
     single_out = torch.empty((width, height, 3), dtype=torch.float32, device=device) if world == 1 else None
+    # N > 1: strips of consecutive frames in flight on side streams, gathers in frame order on this stream
+    pipeline = None
+    if world > 1 and args.streams > 1 and not args.sync_frames:
+        pipeline = strips.StripPipeline(render_strip, width, height, tile, layout, device, depth=args.streams,
+                                        semantics=sem)
     use_graphs = world == 1 and not args.no_graphs and not args.sync_frames
     gstreams = (streams or [torch.cuda.Stream(device)]) if use_graphs else []
     graphs = {st: scene.capture_frame(1, tile_size=tile, layout=layout, semantics=sem) for st in gstreams}
@@ -380,6 +388,16 @@ def main() -> None:
         for k, v in stats.get("stage_ms", {}).items():
             stage[k] = stage.get(k, 0.0) + v / reps
 
+    strips_ok = None
+    if world > 1:
+        # the gathered frame must equal the single-GPU frame bit for bit
+        last = step()
+        torch.cuda.synchronize()
+        scene.confirm_frames()
+        if rank == 0:
+            alone = scene.render_image_hip(1, tile_size=tile, layout=layout, semantics=sem)
+            strips_ok = bool(torch.equal(last, alone))
+        dist.barrier()
     if rank == 0:
         d, nvis = int(stats["n_instances"]), int(stats["n_visible"])
         my_tiles = int(stats["n_tiles"])
@@ -399,7 +417,7 @@ def main() -> None:
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "n_gaussians": n, "width": width, "height": height, "tile": tile,
                        "semantics": sem, "layout": layout, "n_visible": nvis, "tile_instances": d,
-                       "frames_in_flight": max(1, len(streams)),
+                       "frames_in_flight": max(1, len(streams)) if world == 1 else (pipeline.depth if pipeline else 1),
                        "launch": "one hipGraph replay per frame" if graphs else "separate kernel launches",
                        "ms_per_frame_one_in_flight": None if latency_ms is None else round(latency_ms, 4),
                        "ms_per_frame_separate_launches": None if launches_ms is None else round(launches_ms, 4),
@@ -423,6 +441,8 @@ def main() -> None:
                                "unit": "GB/s", "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in stage.items()},
         }
+        if strips_ok is not None:
+            out["strips_equal_single_gpu"] = strips_ok
         if world == 1 and not args.no_cpu_baseline:
             base, err, inst, psnr = cpu_baseline(sc, scene, frame, semantics=sem)
             out["cpu_baseline"] = base

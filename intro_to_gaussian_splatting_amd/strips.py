@@ -95,3 +95,69 @@ def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor,
         return frame[:lead]
     dist.gather(strip, None, dst=0, group=group)
     return None
+
+
+class StripPipeline:
+    """Consecutive frames of one camera, sharded as strips, with up to ``depth`` frames in flight.
+
+    Frame i is rendered on side stream ``i % depth`` into its own strip buffer, so the latency-bound
+    binning kernels of one frame overlap the compositing and the gather of the previous ones (the
+    same trick the single-GPU benchmark plays with whole frames).  The gathers are all issued from
+    the caller's stream, in frame order -- one collective stream, the same order on every rank --
+    after waiting for the event that marks the strip as rendered; a strip buffer is handed back to
+    its side stream only after the gather that read it.  On a CPU device (gloo tests) the pipeline
+    degenerates to ``render_sharded`` one frame at a time.
+
+    ``submit()`` enqueues one frame and returns the frame tensor on rank 0 (None elsewhere); the
+    tensor is the pipeline's own buffer and is overwritten by the next gather.
+    """
+
+    def __init__(self, render_fn, width: int, height: int, tile: int, layout: str, device: torch.device,
+                 depth: int = 3, group: Optional[dist.ProcessGroup] = None, semantics: str = "ref_cpu") -> None:
+        self.render_fn, self.group, self.device = render_fn, group, torch.device(device)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        lead, other = (width, height) if layout == "wh3" else (height, width)
+        n_lead, n_other = tiles_along(lead, tile, semantics), tiles_along(other, tile, semantics)
+        per, plan = strip_plan(n_lead, self.world)
+        self.rows, self.lead = per * tile, lead
+        t0, t1 = plan[self.rank]
+        self.window = (t0, t1, 0, n_other) if layout == "wh3" else (0, n_other, t0, t1)
+        self.origin = (self.rank * self.rows, 0) if layout == "wh3" else (0, self.rank * self.rows)
+        covered = self.world * self.rows
+        self.on_gpu = self.device.type == "cuda"
+        self.depth = max(1, depth) if self.on_gpu else 1
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.strips = [torch.zeros((max(self.rows, 1), other, 3), **f32) for _ in range(self.depth)]
+        self.frame = torch.zeros((max(covered, lead, 1), other, 3), **f32) if self.rank == 0 else None
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.depth)] if self.on_gpu else []
+        self.released = [None] * self.depth      # event on the caller's stream: the gather has read strip k
+        self.count = 0
+
+    def submit(self) -> Optional[torch.Tensor]:
+        k = self.count % self.depth
+        self.count += 1
+        strip = self.strips[k]
+        if self.rows > 0:
+            if self.on_gpu:
+                main = torch.cuda.current_stream(self.device)
+                side = self.streams[k]
+                if self.released[k] is not None:
+                    side.wait_event(self.released[k])
+                else:
+                    side.wait_stream(main)            # first use: buffers were created on the caller's stream
+                with torch.cuda.stream(side):
+                    self.render_fn(self.window, strip, self.origin)
+                main.wait_event(side.record_event())
+            else:
+                self.render_fn(self.window, strip, self.origin)
+            if self.world == 1:
+                self.frame[:self.rows].copy_(strip)
+            elif self.rank == 0:
+                dist.gather(strip, [self.frame[r * self.rows:(r + 1) * self.rows] for r in range(self.world)], dst=0,
+                            group=self.group)
+            else:
+                dist.gather(strip, None, dst=0, group=self.group)
+            if self.on_gpu:
+                self.released[k] = torch.cuda.current_stream(self.device).record_event()
+        return self.frame[:self.lead] if self.rank == 0 else None

@@ -732,3 +732,31 @@ def test_pair_count_beyond_32_bits_is_reported_not_wrapped(tmp_path):
     assert st.n_visible == 17000 and st.n_instances == 17000 * 512 * 512
     with pytest.raises(_ffi.GsxError):                          # the Python surface gives up cleanly
         scene.render_image_hip(1, tile_size=2)
+
+
+@pytest.mark.parametrize("layout", ["wh3", "hw3"])
+def test_strip_pipeline_frames_in_flight_on_one_gpu(tmp_path, layout):
+    """strips.StripPipeline with 3 frames in flight on side streams (world size 1: the collective is a
+    copy, the stream / event choreography is the real one): every submitted frame equals the plain
+    render."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import strips
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    w, h = 320, 200
+    sc = make_scene(30000, w, h, seed=21)
+    scene = _scene_from_arrays(tmp_path, sc)
+    ref = scene.render_image_hip(1, layout=layout)
+
+    def render(window, out, origin):
+        scene.render_image_hip(1, layout=layout, tile_window=window, out=out, out_origin=origin, no_sync=True)
+
+    pipe = strips.StripPipeline(render, w, h, 16, layout, torch.device("cuda:0"), depth=3)
+    for i in range(8):
+        frame = pipe.submit()
+        if i in (0, 3, 7):
+            torch.cuda.synchronize()
+            assert torch.equal(frame, ref), i
+    torch.cuda.synchronize()
+    assert scene.confirm_frames() == 0
+    assert torch.equal(frame, ref)

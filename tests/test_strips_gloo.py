@@ -131,3 +131,32 @@ def test_std3dgs_strips_with_partial_edge_tiles(tmp_path, layout, world):
     full = full if layout == "hw3" else full.transpose(1, 0, 2)
     frame = np.load(tmp_path / "frame_0.npy")
     assert frame.shape == full.shape and np.array_equal(frame, full)
+
+
+# ---- StripPipeline (frames in flight on a GPU; one frame at a time on the CPU devices of this test)
+
+def _pipeline_worker(rank, world, port, name, layout, result_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden(name)
+        w, h, t = int(g["width"]), int(g["height"]), int(g["tile"])
+        pipe = strips.StripPipeline(_oracle_strip_renderer(golden_preprocessed(g), w, h, t, layout), w, h, t, layout,
+                                    torch.device("cpu"), depth=3)
+        frames = [pipe.submit() for _ in range(4)]             # more frames than buffers
+        if rank == 0:
+            assert all(f is not None for f in frames)
+            np.save(os.path.join(result_dir, "pipe_%d.npy" % rank), frames[-1].numpy())
+        else:
+            assert all(f is None for f in frames)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,layout,world", [("pose_70x50_n250", "wh3", 2), ("small_64x48_n300", "hw3", 3)])
+def test_strip_pipeline_equals_single_frame(tmp_path, name, layout, world):
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), name, layout, str(tmp_path)), nprocs=world, join=True)
+    g = load_golden(name)
+    full, _, _ = c_oracle.render(golden_preprocessed(g), int(g["width"]), int(g["height"]), int(g["tile"]))
+    full = full if layout == "wh3" else full.transpose(1, 0, 2)
+    assert np.array_equal(np.load(tmp_path / "pipe_0.npy"), full)
