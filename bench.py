@@ -61,6 +61,28 @@ VALU_OPS_PER_PAIR = 11.25
 PMC_FILE = os.path.join(ROOT, "profiles", "r1_pmc_c3.json")
 
 
+def build_scene_from_ply(ply_path: str, colmap_dir, image_id: int, width: int, height: int, device: str):
+    """BASELINE config 3 as written ("Treehill pretrained .ply (~1M Gaussians), 1920x1080"): a trained 3DGS
+    checkpoint supplied by the user (there is none offline), rendered from a COLMAP camera if a model
+    directory is given, else from the synthetic Treehill-pose camera at width x height.  Returns the same
+    (arrays, scene) pair as build_scene; colours are the view-dependent SH colours of that camera."""
+    g = Gaussians.from_ply(ply_path, device=device)
+    if colmap_dir:
+        scene = GaussianScene(colmap_dir, g)
+    else:
+        cam_only = make_scene(1, width, height, seed=0)
+        with tempfile.TemporaryDirectory() as tmp:
+            write_colmap_text(tmp, cam_only, image_id=image_id)
+            scene = GaussianScene(tmp, g)
+    if image_id not in scene.images:
+        raise SystemExit("image id %d not in the COLMAP model (have %s...)" % (image_id, sorted(scene.images)[:5]))
+    if image_id != 1:                       # the bench renders camera 1
+        scene.images = {1: scene.images[image_id]}
+    sc = dict(points=g.points.cpu().numpy(), scales=g.scales.cpu().numpy(), quaternions=g.quaternions.cpu().numpy(),
+              opacity=g.opacity.cpu().numpy())
+    return sc, scene
+
+
 def build_scene(workload: str, device: str):
     n, w, h, _ = WORKLOADS[workload]
     sc = make_scene(n, w, h, seed=0)
@@ -88,7 +110,7 @@ def cpu_baseline_std3dgs(sc, scene, cam, gpu_frame: torch.Tensor, budget_s: floa
     cores = os.cpu_count() or 1
     w, h, tile = cam.width, cam.height, 16
     ntx, nty = strips.tiles_along(w, tile, "std_3dgs"), strips.tiles_along(h, tile, "std_3dgs")
-    colors = scene.gaussians.colors.cpu().numpy()
+    colors = scene._colors(1).cpu().numpy()         # SH scenes: the colours of this camera
     run = lambda win: c_oracle.render_std3dgs(sc["points"], colors, sc["scales"], sc["quaternions"],  # noqa: E731
                                               sc["opacity"], cam, tile=tile, nthreads=cores, window=win)
     px = max(0, ntx // 2 - 4)
@@ -142,7 +164,7 @@ def cpu_baseline(sc, scene, gpu_frame: torch.Tensor, budget_s: float = 20.0, sem
         return cpu_baseline_std3dgs(sc, scene, cam, gpu_frame, budget_s)
     cores = os.cpu_count() or 1
     t0 = time.perf_counter()
-    pre = c_oracle.preprocess(sc["points"], scene.gaussians.colors.cpu().numpy(), sc["scales"], sc["quaternions"],
+    pre = c_oracle.preprocess(sc["points"], scene._colors(1).cpu().numpy(), sc["scales"], sc["quaternions"],
                               sc["opacity"], cam)
     t_pre = time.perf_counter() - t0
     w, h, tile = c.width, c.height, 16
@@ -229,6 +251,10 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ply", default=None, help="render this trained 3DGS .ply instead of the synthetic workload "
+                    "(BASELINE config 3 as written; frame size from --workload unless --colmap is given)")
+    ap.add_argument("--colmap", default=None, help="COLMAP model directory (cameras + images) for --ply")
+    ap.add_argument("--image-id", type=int, default=1, help="COLMAP image id to render with --colmap")
     ap.add_argument("--semantics", default="ref_cpu", choices=["ref_cpu", "std_3dgs"],
                     help="ref_cpu = the reference's render_image (the metric); std_3dgs = build extension, the "
                          "published 3DGS forward-pass rules (reported under config.semantics)")
@@ -258,7 +284,14 @@ def main() -> None:
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
     n, width, height, desc = WORKLOADS[args.workload]
-    sc, scene = build_scene(args.workload, str(device))
+    if args.ply:
+        sc, scene = build_scene_from_ply(args.ply, args.colmap, args.image_id, width, height, str(device))
+        cam1 = scene.images[1].gsx_camera()
+        n, width, height = int(sc["points"].shape[0]), cam1.width, cam1.height
+        desc = "trained .ply %s (%d Gaussians, SH degree %d), %dx%d" % (
+            os.path.basename(args.ply), n, scene.gaussians.sh_degree, width, height)
+    else:
+        sc, scene = build_scene(args.workload, str(device))
     tile, layout, sem = 16, "wh3", args.semantics
 
     def render_strip(window, out, origin):
@@ -414,7 +447,7 @@ def main() -> None:
             "metric": "Mpixels/sec forward raster (1M Gaussians, 1080p) + max |dpixel| vs CPU ref",
             "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "user-supplied .ply" if args.ply else "synthetic",
             "config": {"workload": desc, "n_gaussians": n, "width": width, "height": height, "tile": tile,
                        "semantics": sem, "layout": layout, "n_visible": nvis, "tile_instances": d,
                        "frames_in_flight": max(1, len(streams)) if world == 1 else (pipeline.depth if pipeline else 1),

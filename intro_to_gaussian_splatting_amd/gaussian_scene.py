@@ -167,7 +167,7 @@ class GaussianScene:
         pts = _check_f32("points", g.points.reshape(n, 3), dev)
         sh = _check_f32("sh", g.sh.reshape(n, k, 3), dev)
         out = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        center = (ctypes.c_float * 3)(*[float(v) for v in self.images[image_idx].camera_center.cpu()])
+        center = (ctypes.c_float * 3)(*self.images[image_idx].camera_center_host)   # no device read per frame
         with torch.cuda.device(dev):
             rc = lib.gsx_sh_to_rgb(_ptr(pts), _ptr(sh), int(g.sh_degree), n, center, _ptr(out), _stream_handle(dev))
         _ffi.check(rc)

@@ -90,7 +90,9 @@ class GaussianImage:
         self.world2view = world2view.to(dev)
         self.projection_matrix = projection.to(dev)
         self.full_proj_transform = full_proj.to(dev)
-        self.camera_center = world2view.inverse()[3, :3].to(dev)
+        center = world2view.inverse()[3, :3]
+        self.camera_center = center.to(dev)
+        self.camera_center_host = tuple(float(v) for v in center)   # read per frame by the SH kernel's caller
 
         cam = _ffi.GsxCamera()
         cam.world2view[:] = world2view.reshape(-1).tolist()

@@ -760,3 +760,34 @@ def test_strip_pipeline_frames_in_flight_on_one_gpu(tmp_path, layout):
     torch.cuda.synchronize()
     assert scene.confirm_frames() == 0
     assert torch.equal(frame, ref)
+
+
+@pytest.mark.parametrize("n,deg,skip", [(1, 3, 0), (255, 1, 0), (256, 2, 0), (257, 3, 0), (1000, 2, 1), (70001, 3, 0),
+                                        (513, 0, 0)])
+def test_sh_kernel_block_edges_and_unaligned_input(n, deg, skip):
+    """gsx_sh_to_rgb stages 256 Gaussians' coefficients through LDS with 16-byte loads: block tails,
+    every degree's row length (3, 12, 27, 48 floats) and a coefficient pointer that is not 16-byte
+    aligned (a view that skips one Gaussian at degree 2)."""
+    _need_gpu()
+    import ctypes
+
+    from intro_to_gaussian_splatting_amd import _ffi
+    from oracle import cpu_ref
+
+    lib = _ffi.load()
+    rs = np.random.RandomState(n + deg)
+    k = (deg + 1) ** 2
+    pts = rs.normal(size=(n + skip, 3)).astype(np.float32)
+    sh = rs.normal(0, 0.3, size=(n + skip, k, 3)).astype(np.float32)
+    center = np.array([0.3, -0.2, 4.0], np.float32)
+    d_pts = torch.from_numpy(pts).cuda()[skip:].contiguous()
+    d_sh_all = torch.from_numpy(sh).cuda()
+    d_sh = d_sh_all[skip:]                                   # a view: base pointer + skip * 12 k bytes
+    assert d_sh.is_contiguous() and (skip == 0 or d_sh.data_ptr() % 16 != 0)
+    out = torch.empty((n, 3), dtype=torch.float32, device="cuda:0")
+    c = (ctypes.c_float * 3)(*center.tolist())
+    rc = lib.gsx_sh_to_rgb(ctypes.c_void_p(d_pts.data_ptr()), ctypes.c_void_p(d_sh.data_ptr()), deg, n, c,
+                           ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _ffi.check(rc)
+    ref = cpu_ref.sh_to_rgb(pts[skip:], sh[skip:], deg, center)
+    assert np.max(np.abs(out.cpu().numpy() - ref)) <= 3e-6
