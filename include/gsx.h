@@ -192,8 +192,11 @@ int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t t
 /*
  * Whole hot path: projection -> depth order -> tile binning -> compositing.  Replaces
  * GaussianScene.render_image (splat/gaussian_scene.py:200-238) and, with GSX_SEM_REF_CUDA /
- * GSX_LAYOUT_HW3, GaussianScene.render_image_cuda (splat/gaussian_scene.py:263-285).
- * stats_host may be NULL.  Synchronises `stream` once (to learn n_instances).
+ * GSX_LAYOUT_HW3, GaussianScene.render_image_cuda (splat/gaussian_scene.py:263-285); with
+ * GSX_SEM_STD_3DGS (build extension) it is the forward pass of the published 3DGS rasteriser.
+ * stats_host may be NULL.  Synchronises `stream` once, after the last launch, to report the counts
+ * and to detect n_instances > capacity (GSX_ERR_WORKSPACE_TOO_SMALL; stats_host->n_instances then
+ * holds the count to size the workspace for); with GSX_FLAG_NO_SYNC it does not synchronise at all.
  */
 int gsx_render_forward(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
                        const float *opacity_logit, const float *colors, int64_t n, int32_t tile_size,
