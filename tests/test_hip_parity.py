@@ -127,7 +127,7 @@ def test_tile_size_two_like_the_notebook(tmp_path):
     g = load_golden("small_80x64_n120_tile8")
     scene = _scene_from_golden(tmp_path, g)
     sc = {k: g[k] for k in ("points", "scales", "quaternions", "opacity")}
-    for tile in (2, 5, 32):
+    for tile in (1, 2, 5, 32, 63, 64):                  # 63 / 64: one tile (or none) covers the frame
         _, ref, inst = _oracle_frame(scene, sc, tile)
         stats = {}
         img = scene.render_image_hip(1, tile_size=tile, stats=stats)
