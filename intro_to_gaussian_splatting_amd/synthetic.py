@@ -26,14 +26,17 @@ def _rotation(qvec) -> np.ndarray:
 
 
 def make_scene(n: int, width: int, height: int, seed: int = 0, behind_fraction: float = 0.0,
-               qvec=TREEHILL_QVEC, tvec=TREEHILL_TVEC) -> Dict[str, np.ndarray]:
+               qvec=TREEHILL_QVEC, tvec=TREEHILL_TVEC, spread: float = 1.0,
+               sigma_scale: float = 1.0) -> Dict[str, np.ndarray]:
     """Returns float32 arrays ``points (n,3)``, ``colors_0_255 (n,3)``, ``scales (n,3)`` (linear),
     ``quaternions (n,4)`` (w,x,y,z, unnormalised), ``opacity (n,1)`` (logit) plus the camera
     ``qvec, tvec, fx, fy, cx, cy, width, height``.
 
     Draw order: z, u, v, sigma(n,3), q(n,4), opacity(n,1), rgb(n,3).  ``behind_fraction`` > 0
     additionally moves that share of the points behind the z >= 0.2 cull plane (drawn last, so
-    the default stream is unchanged).
+    the default stream is unchanged).  ``spread`` > 1 places points up to that multiple of the
+    frustum's half-width off axis (beyond 1.3 the EWA clamp of splat/utils.py:336-337 is active),
+    ``sigma_scale`` scales the footprints; both leave the random stream untouched.
     """
     rs = np.random.RandomState(seed)
     fx = fy = 0.75 * width
@@ -48,6 +51,7 @@ def make_scene(n: int, width: int, height: int, seed: int = 0, behind_fraction: 
     if behind_fraction > 0.0:
         behind = rs.uniform(0.0, 1.0, n) < behind_fraction
         z = np.where(behind, -z * 0.5 + 0.15, z)
+    u, v, sigma_px = u * spread, v * spread, sigma_px * sigma_scale
     p_cam = np.stack([u * tanx * np.abs(z), v * tany * np.abs(z), z], axis=1)
     R, t = _rotation(qvec), np.asarray(tvec, dtype=np.float64)
     # camera = R @ world + t  =>  world = R^T (camera - t)

@@ -38,6 +38,9 @@ FIXTURES = {
                             qvec=(0.8, 0.3, -0.45, 0.25), tvec=(-0.7, 0.2, 2.1)),
     # many Gaussians per pixel: the T(1-alpha) < 1e-6 stop rule fires (checked by the tests)
     "dense_48x48_n1500": dict(n=1500, width=48, height=48, seed=17, tile=16),
+    # points up to 2x the frustum half-width off axis with large footprints: the 1.3 tan(fov/2) clamp
+    # of the EWA projection is active and off-screen Gaussians reach into the frame
+    "wide_64x64_n400": dict(n=400, width=64, height=64, seed=19, tile=16, spread=2.0, sigma_scale=4.0),
 }
 
 
