@@ -41,6 +41,9 @@ FIXTURES = {
     # points up to 2x the frustum half-width off axis with large footprints: the 1.3 tan(fov/2) clamp
     # of the EWA projection is active and off-screen Gaussians reach into the frame
     "wide_64x64_n400": dict(n=400, width=64, height=64, seed=19, tile=16, spread=2.0, sigma_scale=4.0),
+    # footprints of ~0.1 px: the determinant floor 1e-3 (utils.py:387) and the discriminant floor 0.1
+    # (utils.py:414) decide the conic and the radius
+    "tiny_48x48_n600": dict(n=600, width=48, height=48, seed=23, tile=16, sigma_scale=0.07),
 }
 
 
