@@ -44,6 +44,9 @@ FIXTURES = {
     # footprints of ~0.1 px: the determinant floor 1e-3 (utils.py:387) and the discriminant floor 0.1
     # (utils.py:414) decide the conic and the radius
     "tiny_48x48_n600": dict(n=600, width=48, height=48, seed=23, tile=16, sigma_scale=0.07),
+    # the notebook flow: Gaussians(points, colors) with the constructor's own scales / quaternions /
+    # opacity (gaussians.py:23-33), nothing overwritten
+    "defaults_64x64_n800": dict(n=800, width=64, height=64, seed=29, tile=16, defaults=True),
 }
 
 
@@ -84,15 +87,21 @@ def capture(name: str, spec: dict, GaussianScene, Gaussians) -> None:
 
     spec = dict(spec)
     tile = spec.pop("tile")
+    defaults = spec.pop("defaults", False)
     sc = make_scene(**spec)
     with tempfile.TemporaryDirectory() as tmp:
         write_colmap_text(os.path.join(tmp, "colmap"), sc)
         with torch.no_grad():
             g = Gaussians(torch.from_numpy(sc["points"]), torch.from_numpy(sc["colors_0_255"]), model_path=tmp)
             g.points = torch.from_numpy(sc["points"]).float()
-            g.scales = torch.from_numpy(sc["scales"]).float()
-            g.quaternions = torch.from_numpy(sc["quaternions"]).float()
-            g.opacity = torch.from_numpy(sc["opacity"]).float()
+            if defaults:        # keep what the reference's constructor set; store it as the fixture's inputs
+                sc["scales"] = g.scales.detach().numpy().astype(np.float32)
+                sc["quaternions"] = g.quaternions.detach().numpy().astype(np.float32)
+                sc["opacity"] = g.opacity.detach().numpy().astype(np.float32)
+            else:
+                g.scales = torch.from_numpy(sc["scales"]).float()
+                g.quaternions = torch.from_numpy(sc["quaternions"]).float()
+                g.opacity = torch.from_numpy(sc["opacity"]).float()
             scene = GaussianScene(os.path.join(tmp, "colmap"), g)
             cam = scene.images[1]
             from splat.utils import in_view_frustum

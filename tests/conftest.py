@@ -10,7 +10,8 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 GOLDEN_NAMES = ["small_64x48_n300", "small_80x64_n120_tile8", "cull_96x80_n400", "c1_256x256_n2000",
-                "tile2_40x32_n80", "pose_70x50_n250", "dense_48x48_n1500", "wide_64x64_n400", "tiny_48x48_n600"]
+                "tile2_40x32_n80", "pose_70x50_n250", "dense_48x48_n1500", "wide_64x64_n400", "tiny_48x48_n600",
+                "defaults_64x64_n800"]
 
 
 def pytest_addoption(parser):

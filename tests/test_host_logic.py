@@ -175,3 +175,16 @@ def test_sh_oracle_degree0_reproduces_rgb():
     dirs = rs.normal(size=(20000, 3))
     cols = cpu_ref.sh_to_rgb(dirs * 5.0, sh * np.array([1.0] + [0.05] * 15)[None, :, None], 3, [0, 0, 0])
     assert np.allclose(cols.mean(0), rgb[0], atol=5e-3)
+
+
+def test_constructor_defaults_equal_the_references_bit_for_bit():
+    """defaults_64x64_n800 was captured without overwriting anything the reference's Gaussians
+    constructor sets (gaussians.py:19-33): our constructor must produce the same tensors."""
+    from conftest import load_golden
+
+    g = load_golden("defaults_64x64_n800")
+    ours = Gaussians(torch.from_numpy(g["points"]), torch.from_numpy(g["colors_0_255"]), device="cpu")
+    assert np.array_equal(ours.scales.numpy(), g["scales"])
+    assert np.array_equal(ours.quaternions.numpy(), g["quaternions"])
+    assert np.array_equal(ours.opacity.numpy(), g["opacity"])
+    assert np.array_equal(ours.colors.numpy(), g["colors"])
