@@ -8,7 +8,8 @@
 // __amd_rocclr_fillBufferAligned per frame, rocprofv3 profiles/r1c).  It also needs the element
 // count on the HOST, which forced a device->host read-back in the middle of every frame.
 //
-// This implementation is the classic three-kernel LSD pass, sized for these inputs:
+// This implementation is the classic three-kernel LSD pass (two kernels for small inputs, see
+// SELF_SCAN below), sized for these inputs:
 //   count    each workgroup histograms its 2048 (4096 beyond 8M items) consecutive items by the pass's 8-bit digit in LDS
 //            and stores table[digit][workgroup];
 //   scan     one workgroup per digit row turns its row into an exclusive prefix and records the
@@ -33,6 +34,10 @@ constexpr int kBins = 256;                         // 8-bit digits
 // enough workgroups in flight at 1M items; 16 halves the digit table for inputs beyond 8M.
 constexpr int kSmallRounds = 8, kLargeRounds = 16;
 constexpr int64_t kLargeInput = 8 << 20;
+// Up to this many workgroups (131 072 items) a pass has no row-scan launch: measured one frame in flight,
+// 2 000 Gaussians 96 -> 85 us, 100 000 Gaussians 166 -> 161 us; beyond ~100 workgroups the
+// per-workgroup table walk costs more than the launch it saves (207 workgroups: +7 us per sort).
+constexpr int kSelfScanBlocks = 64;
 
 __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t bound) {
     if (!n_dev) return bound;
@@ -42,7 +47,9 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t b
 
 // Each thread owns kRounds CONSECUTIVE items (one or two 16-byte loads) -- the histogram does not
 // care about order, so the count kernel reads wide; the scatter kernel needs the wave-striped order.
-template <typename Key, int kRounds>
+// BLOCK_MAJOR: table[workgroup][digit] (what the self-scanning scatter reads, coalesced over the
+// digits) instead of table[digit][workgroup] (contiguous rows for the row-scan kernel).
+template <typename Key, int kRounds, bool BLOCK_MAJOR>
 __global__ void __launch_bounds__(kThreads)
     count_kernel(const Key *__restrict__ keys, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
                  uint32_t *__restrict__ table, int nblocks) {
@@ -75,7 +82,10 @@ __global__ void __launch_bounds__(kThreads)
             if (first + r < n) atomicAdd(&h[((uint32_t)keys[first + r] >> shift) & (kBins - 1)], 1u);
     }
     __syncthreads();
-    table[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    if (BLOCK_MAJOR)
+        table[(size_t)blockIdx.x * kBins + threadIdx.x] = h[threadIdx.x];
+    else
+        table[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // One workgroup per digit row: in-place exclusive scan of table[d][0..nblocks), total -> totals[d].
@@ -108,7 +118,11 @@ __global__ void __launch_bounds__(kThreads) row_scan_kernel(uint32_t *__restrict
     if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
-template <typename Key, int kRounds>
+// SELF_SCAN: there is no row-scan launch; `table` holds the raw per-workgroup counts and every
+// workgroup adds up, for each digit, the counts of the workgroups before it and the row total itself
+// (nblocks loads per thread).  Pays for small inputs, where a pass is three launch latencies and
+// the table is a few KiB.
+template <typename Key, int kRounds, bool SELF_SCAN>
 __global__ void __launch_bounds__(kThreads)
     scatter_kernel(const Key *__restrict__ kin, const uint32_t *__restrict__ vin, Key *__restrict__ kout,
                    uint32_t *__restrict__ vout, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
@@ -165,7 +179,31 @@ __global__ void __launch_bounds__(kThreads)
     {
         const int d = threadIdx.x;
         const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
-        const uint32_t t = totals[d], l = c0 + c1 + c2 + c3;
+        uint32_t t, before;
+        if (SELF_SCAN) {
+            t = 0;
+            before = 0;
+            int b = 0;
+            for (; b + 8 <= nblocks; b += 8) {      // 8 independent loads in flight (block-major: coalesced over d)
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = table[(size_t)(b + u) * kBins + d];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    before += b + u < (int)blockIdx.x ? v[u] : 0u;
+                    t += v[u];
+                }
+            }
+            for (; b < nblocks; ++b) {
+                const uint32_t v = table[(size_t)b * kBins + d];
+                before += b < (int)blockIdx.x ? v : 0u;
+                t += v;
+            }
+        } else {
+            t = totals[d];
+            before = table[(size_t)d * nblocks + blockIdx.x];
+        }
+        const uint32_t l = c0 + c1 + c2 + c3;
         uint32_t x = t, y = l;  // inclusive wave scans of the global totals and of the local counts
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -186,7 +224,7 @@ __global__ void __launch_bounds__(kThreads)
             lb += lsum[k];
         }
         const uint32_t lstart = lb + y - l;                       // first parked slot of digit d
-        const uint32_t gstart = gb + x - t + table[(size_t)d * nblocks + blockIdx.x];
+        const uint32_t gstart = gb + x - t + before;
         gbase[d] = gstart - lstart;
         cnt[0][d] = lstart;
         cnt[1][d] = lstart + c0;
@@ -224,11 +262,22 @@ hipError_t sort_rounds(void *temp, Key *&kc, Key *&ka, uint32_t *&vc, uint32_t *
     const int nblocks = (int)((bound + kItems - 1) / kItems);
     uint32_t *table = (uint32_t *)temp;
     uint32_t *totals = table + (size_t)kBins * nblocks;
+    const bool self_scan = nblocks <= kSelfScanBlocks;
     for (int shift = 0; shift < key_bits; shift += 8) {
-        count_kernel<Key, kRounds><<<nblocks, kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, table, nblocks);
-        row_scan_kernel<<<kBins, kThreads, 0, s>>>(table, nblocks, totals);
-        scatter_kernel<Key, kRounds><<<nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound, shift, table,
-                                                                  totals, nblocks);
+        if (self_scan)
+            count_kernel<Key, kRounds, true><<<nblocks, kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, table,
+                                                                          nblocks);
+        else
+            count_kernel<Key, kRounds, false><<<nblocks, kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, table,
+                                                                           nblocks);
+        if (self_scan) {
+            scatter_kernel<Key, kRounds, true><<<nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
+                                                                            shift, table, totals, nblocks);
+        } else {
+            row_scan_kernel<<<kBins, kThreads, 0, s>>>(table, nblocks, totals);
+            scatter_kernel<Key, kRounds, false><<<nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
+                                                                             shift, table, totals, nblocks);
+        }
         Key *tk = kc; kc = ka; ka = tk;
         uint32_t *tv = vc; vc = va; va = tv;
     }
