@@ -379,7 +379,13 @@ class GaussianScene:
         whose image is a CPU tensor (gaussian_scene.py:206) -- returned in host memory, so that
         ``plt.imshow(scene.render_image(i))`` keeps working.  ``render_image_hip`` is the same frame
         left on the device."""
-        return self.render_image_hip(image_idx, tile_size=tile_size, layout="wh3").cpu()
+        frame = self.render_image_hip(image_idx, tile_size=tile_size, layout="wh3")
+        # page-locked destination (torch's caching host allocator keeps the pages registered between
+        # calls): the copy runs at PCIe rate instead of through a pageable staging loop
+        host = torch.empty(frame.shape, dtype=frame.dtype, pin_memory=True)
+        host.copy_(frame, non_blocking=True)
+        torch.cuda.current_stream(frame.device).synchronize()
+        return host
 
     render = render_image  # the name BASELINE.json's north star uses
 
