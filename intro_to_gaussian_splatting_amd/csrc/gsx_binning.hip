@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(kBlock)
                            uint32_t *__restrict__ offsets, uint32_t *__restrict__ n_visible) {
     __shared__ uint32_t wsum[4];
     const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanItems;
+    if (sorted_keys && n == 0 && base == 0) *n_visible = 0u;   // no key to find the boundary at
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
