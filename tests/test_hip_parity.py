@@ -157,6 +157,11 @@ def test_empty_all_culled_and_tiny_frames(tmp_path):
     sc_t = make_scene(64, 16, 16, seed=4)
     scene = _scene_from_arrays(tmp_path / "t", sc_t)
     assert not scene.render_image(1).any()
+    # an empty scene right after a real frame: its counts are zeros, not what the shared workspace held
+    _scene_from_arrays(tmp_path / "w", sc).render_image_hip(1)
+    stats = {}
+    _scene_from_arrays(tmp_path / "e2", empty).render_image_hip(1, stats=stats)
+    assert stats["n_visible"] == 0 and stats["n_instances"] == 0
 
 
 def test_last_tile_row_and_column_stay_zero_and_single_splat_value(tmp_path):
