@@ -53,6 +53,29 @@ for seed in range(first, first + count):
     d = float(np.abs(img - ref).max()) if img.size else 0.0
     assert d <= 1e-4, ("ref pixels", tag, d)
     worst_ref = max(worst_ref, d)
+    # ---- a random tile window of the same frame (multi-GPU strips use these)
+    from intro_to_gaussian_splatting_amd import strips
+    ntx, nty = strips.tiles_along(w, tile), strips.tiles_along(h, tile)
+    if ntx > 0 and nty > 0:
+        x0, y0 = int(rs.randint(0, ntx)), int(rs.randint(0, nty))
+        win = (x0, int(rs.randint(x0, ntx)) + 1, y0, int(rs.randint(y0, nty)) + 1)
+        wref, _, winst = c_oracle.render(pre, w, h, tile, window=win)
+        st = {}
+        wimg = scene.render_image_hip(1, tile_size=tile, layout="wh3", tile_window=win, stats=st).cpu().numpy()
+        inside = np.zeros((w, h), bool)
+        inside[win[0] * tile:win[1] * tile, win[2] * tile:win[3] * tile] = True
+        assert not wimg[~inside].any(), ("window outside", tag, win)
+        assert float(np.abs(wimg - wref).max()) <= 1e-4, ("window pixels", tag, win)
+        # the oracle counts instances over all tiles; inside the window the GPU count is the sum of its lists
+        assert st["n_instances"] <= inst, ("window count", tag, win)
+    # ---- the reference's CUDA-kernel rules (every pixel tests every Gaussian on the CPU side: keep it small)
+    if w * h * max(n, 1) <= 3e8:
+        cref = c_oracle.render_cuda_semantics(pre, w, h)
+        cimg = scene.render_image_hip(1, tile_size=tile, layout="hw3", semantics="ref_cuda").cpu().numpy()
+        dc = np.abs(cimg.astype(np.float64) - cref).max(axis=-1) if cimg.size else np.zeros(1)
+        # stop rule at T(1-alpha) < 1e-3: a pixel whose test sits within an ulp of the threshold may stop one
+        # Gaussian earlier or later on one side (<= 1e-3 of colour); everything else agrees to 1e-4
+        assert int((dc > 1e-4).sum()) <= 2 + 1e-5 * dc.size and dc.max() < 2e-3, ("ref_cuda pixels", tag, float(dc.max()))
     # ---- published 3DGS rules
     bg = tuple(float(v) for v in rs.uniform(0, 1, 3))
     sref, nvis, sinst, _ = c_oracle.render_std3dgs(sc["points"], colors, sc["scales"], sc["quaternions"], sc["opacity"],
