@@ -76,6 +76,32 @@ for seed in range(first, first + count):
         # stop rule at T(1-alpha) < 1e-3: a pixel whose test sits within an ulp of the threshold may stop one
         # Gaussian earlier or later on one side (<= 1e-3 of colour); everything else agrees to 1e-4
         assert int((dc > 1e-4).sum()) <= 2 + 1e-5 * dc.size and dc.max() < 2e-3, ("ref_cuda pixels", tag, float(dc.max()))
+    # ---- the stage-2 entry point on stage-1 arrays that no projection would produce: NaN / infinite /
+    #      inverted bounding boxes, asymmetric inverse covariances (render.cu:90-101 takes them as given)
+    if len(pre.depths) > 0:
+        import copy
+        from intro_to_gaussian_splatting_amd import render_preprocessed
+        m = len(pre.depths)
+        bad = {k: np.array(getattr(pre, k), copy=True) for k in ("min_x", "max_x", "min_y", "max_y", "inverse_covariance_2d")}
+        pick = lambda frac: rs.uniform(size=m) < frac  # noqa: E731
+        bad["min_x"][pick(0.05)] = np.nan
+        bad["max_y"][pick(0.05)] = np.nan
+        bad["max_x"][pick(0.05)] = np.inf
+        bad["min_y"][pick(0.05)] = -np.inf
+        sw = pick(0.05)
+        bad["min_x"][sw], bad["max_x"][sw] = bad["max_x"][sw].copy(), bad["min_x"][sw].copy()
+        bad["min_x"][pick(0.03)] = 3.0e9
+        bad["max_x"][pick(0.03)] = -3.0e9
+        bad["inverse_covariance_2d"][:, 0, 1] *= rs.uniform(0.9, 1.1, m).astype(np.float32)
+        pre_bad = pre._replace(**bad)
+        bref, _, binst = c_oracle.render(pre_bad, w, h, tile)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+        st = {}
+        bimg = render_preprocessed(h, w, tile, t(pre_bad.points), t(pre_bad.colors), t(pre_bad.inverse_covariance_2d),
+                                   t(pre_bad.min_x), t(pre_bad.max_x), t(pre_bad.min_y), t(pre_bad.max_y),
+                                   t(pre_bad.sigmoid_opacity), stats=st).cpu().numpy()
+        assert st["n_instances"] == binst, ("stage-2 counts", tag, st, binst)
+        assert float(np.abs(bimg - bref).max()) <= 1e-4, ("stage-2 pixels", tag)
     # ---- published 3DGS rules
     bg = tuple(float(v) for v in rs.uniform(0, 1, 3))
     sref, nvis, sinst, _ = c_oracle.render_std3dgs(sc["points"], colors, sc["scales"], sc["quaternions"], sc["opacity"],
