@@ -1,10 +1,10 @@
 #!/bin/bash
-# Evidence for one round, run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r1h'):
+# Evidence for one round, run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r1i'):
 #   rocprofv3 kernel-trace stats of bench.py at C3 with one and with three frames in flight,
 #   three separate PMC passes (FETCH_SIZE; WRITE_SIZE; SQ_* + GRBM_GUI_ACTIVE; never combined with
 #   other trace domains), the bench line of every workload and of the std_3dgs rule set, the smoke.
 # Then, back in the build container:  python tools/summarize_profiles.py <tag>
-TAG=${1:-r1h}
+TAG=${1:-r1i}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O

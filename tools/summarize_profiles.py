@@ -1,7 +1,7 @@
 """Turns the rocprofv3 outputs a gpurun call left under gpurun_out/ into the summaries committed
 under profiles/ (kernel stats per frame, PMC traffic / VALU busy of the compositing kernel).
 
-    python tools/summarize_profiles.py r1h          # reads gpurun_out/prof_<tag>*, pmc3_*, bench_c*.json
+    python tools/summarize_profiles.py r1i          # reads gpurun_out/prof_<tag>*, pmc3_*, bench_c*.json
 """
 import collections
 import csv
@@ -10,7 +10,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1h"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1i"
 pmc = sys.argv[2] if len(sys.argv) > 2 else "pmc3"
 
 
