@@ -92,7 +92,12 @@ for seed in range(first, first + count):
         bad["min_x"][sw], bad["max_x"][sw] = bad["max_x"][sw].copy(), bad["min_x"][sw].copy()
         bad["min_x"][pick(0.03)] = 3.0e9
         bad["max_x"][pick(0.03)] = -3.0e9
-        bad["inverse_covariance_2d"][:, 0, 1] *= rs.uniform(0.9, 1.1, m).astype(np.float32)
+        # asymmetric off-diagonals with (nearly) the same sum: the quadratic form stays positive definite.  (An
+        # indefinite form can push alpha towards 1, where the reference's "return before accumulating" drops a
+        # contribution of size T alpha c and rounding decides which side of the 1e-6 test a pixel falls on.)
+        eps = rs.uniform(-0.1, 0.1, m).astype(np.float32)
+        bad["inverse_covariance_2d"][:, 0, 1] *= (1 + eps)
+        bad["inverse_covariance_2d"][:, 1, 0] *= (1 - eps)
         pre_bad = pre._replace(**bad)
         bref, _, binst = c_oracle.render(pre_bad, w, h, tile)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
@@ -101,7 +106,12 @@ for seed in range(first, first + count):
                                    t(pre_bad.min_x), t(pre_bad.max_x), t(pre_bad.min_y), t(pre_bad.max_y),
                                    t(pre_bad.sigmoid_opacity), stats=st).cpu().numpy()
         assert st["n_instances"] == binst, ("stage-2 counts", tag, st, binst)
-        assert float(np.abs(bimg - bref).max()) <= 1e-4, ("stage-2 pixels", tag)
+        db = np.abs(bimg - bref)
+        if not db.max() <= 1e-4:
+            ix = np.unravel_index(np.nanargmax(db), db.shape)
+            print("stage-2 mismatch", tag, "max", db.max(), "at", ix, "gpu", bimg[ix[0], ix[1]], "cpu", bref[ix[0], ix[1]],
+                  "pixels off", int((db.max(axis=-1) > 1e-4).sum()), "nan gpu/cpu", int(np.isnan(bimg).sum()), int(np.isnan(bref).sum()))
+        assert float(db.max()) <= 1e-4, ("stage-2 pixels", tag)
     # ---- published 3DGS rules
     bg = tuple(float(v) for v in rs.uniform(0, 1, 3))
     sref, nvis, sinst, _ = c_oracle.render_std3dgs(sc["points"], colors, sc["scales"], sc["quaternions"], sc["opacity"],
