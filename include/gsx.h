@@ -94,7 +94,12 @@ typedef struct GsxParams {
     int32_t out_x0, out_y0, out_w, out_h;
     int32_t flags; /* GSX_FLAG_* */
     float background[3]; /* GSX_SEM_STD_3DGS only: colour behind the last Gaussian (default 0) */
-    int32_t reserved[2];
+    /* gsx_render_forward only.  NULL (default): the camera constants are the `camera` argument, read at
+     * call time.  Otherwise a GsxCamera in DEVICE memory that the projection kernel reads when it RUNS
+     * -- the call (and a hipGraph that recorded it) then follows whatever the buffer holds at that
+     * moment, e.g. a camera that moves between replays of a captured frame.  `camera` must still be
+     * given: its width / height size the frame on the host and must equal the buffer's. */
+    const GsxCamera *camera_device;
 } GsxParams;
 
 /* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call

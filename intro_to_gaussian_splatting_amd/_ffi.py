@@ -41,7 +41,7 @@ class GsxParams(ctypes.Structure):
     _fields_ = [("semantics", c_int32), ("layout", c_int32),
                 ("tile_x0", c_int32), ("tile_x1", c_int32), ("tile_y0", c_int32), ("tile_y1", c_int32),
                 ("out_x0", c_int32), ("out_y0", c_int32), ("out_w", c_int32), ("out_h", c_int32),
-                ("flags", c_int32), ("background", c_float * 3), ("reserved", c_int32 * 2)]
+                ("flags", c_int32), ("background", c_float * 3), ("camera_device", c_void_p)]
 
 
 class GsxFrameStats(ctypes.Structure):

@@ -94,6 +94,7 @@ struct Plan {
     bool no_sync;  // GSX_FLAG_NO_SYNC: nothing waits for the device
     bool generic;  // GSX_FLAG_GENERIC_KERNELS
     bool tight;    // GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS
+    const GsxCamera *camera_device;
     float background[3];
 };
 
@@ -145,6 +146,7 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     if (d.semantics != GSX_SEM_REF_CPU && d.semantics != GSX_SEM_REF_CUDA && d.semantics != GSX_SEM_STD_3DGS)
         return fail(GSX_ERR_UNSUPPORTED, "unknown semantics %d", d.semantics);
     for (int i = 0; i < 3; ++i) p.background[i] = d.background[i];
+    p.camera_device = d.camera_device;
     if (d.layout != GSX_LAYOUT_WH3 && d.layout != GSX_LAYOUT_HW3) return fail(GSX_ERR_INVALID_ARGUMENT, "unknown layout %d", d.layout);
     if (!out_image) return fail(GSX_ERR_INVALID_ARGUMENT, "out_image is NULL");
     p.semantics = d.semantics;
@@ -409,7 +411,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     StageTimer tm;
     tm.begin(p.timing, s);
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
-    GSX_HIP(gsx::launch_project_pack(*camera, in, n, p.grid, p.semantics, p.tight, k0, v0, (gsx::Record *)(ws + c.rec),
+    GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, k0, v0, (gsx::Record *)(ws + c.rec),
                                      (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts),
                                      p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 1: project (+ depth keys)

@@ -63,9 +63,10 @@ hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t
 // bbox (REF_CUDA only, else may be null): (min_x, max_x, min_y, max_y) per Gaussian for the
 // per-pixel cull of splat/c/render.cu:55-60.
 // tight_rects: GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS (see include/gsx.h).
-hipError_t launch_project_pack(const GsxCamera &cam, const GaussiansIn &in, int64_t n, const TileGrid &grid,
-                               int semantics, bool tight_rects, uint32_t *keys, uint32_t *vals, Record *rec,
-                               TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s);
+// cam_device (may be null): GsxParams.camera_device, read by the kernel instead of `cam`.
+hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
+                               const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys, uint32_t *vals,
+                               Record *rec, TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s);
 hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
                                const uint32_t *sorted_idx, int64_t n, const StageOneOut &out, hipStream_t s);
 hipError_t launch_pack_preprocessed(const PreprocessedIn &in, int64_t n, const TileGrid &grid, int semantics,

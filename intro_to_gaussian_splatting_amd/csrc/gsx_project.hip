@@ -331,12 +331,16 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
 
 // One thread per Gaussian, ORIGINAL order (coalesced reads of the parameter arrays, coalesced
 // writes): depth key for the sort, compositing record, tile rectangle and tile count.
+template <bool DEVICE_CAMERA>
 __global__ void __launch_bounds__(kBlock)
-    project_pack_kernel(GsxCamera cam, GaussiansIn in, int64_t n, TileGrid grid, int semantics, bool tight,
+    project_pack_kernel(GsxCamera cam_arg, const GsxCamera *__restrict__ cam_dev, GaussiansIn in, int64_t n,
+                        TileGrid grid, int semantics, bool tight,
                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, Record *__restrict__ rec,
                         TileRect *__restrict__ rect, uint32_t *__restrict__ counts, float4 *__restrict__ bbox) {
     int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= n) return;
+    // GsxParams.camera_device: the constants as they are in device memory now (uniform scalar loads)
+    const GsxCamera &cam = DEVICE_CAMERA ? *cam_dev : cam_arg;
     const float *p = in.means3d + 3 * g;
     float p0 = p[0], p1 = p[1], p2 = p[2];
     float tz = row4(p0, p1, p2, cam.world2view, 2);
@@ -493,12 +497,16 @@ hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_project_pack(const GsxCamera &cam, const GaussiansIn &in, int64_t n, const TileGrid &grid,
-                               int semantics, bool tight_rects, uint32_t *keys, uint32_t *vals, Record *rec,
-                               TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s) {
+hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
+                               const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys, uint32_t *vals,
+                               Record *rec, TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    project_pack_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, n, grid, semantics, tight_rects, keys, vals, rec,
-                                                         rect, counts, bbox);
+    if (cam_device)
+        project_pack_kernel<true><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics, tight_rects,
+                                                                   keys, vals, rec, rect, counts, bbox);
+    else
+        project_pack_kernel<false><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics,
+                                                                    tight_rects, keys, vals, rec, rect, counts, bbox);
     return hipGetLastError();
 }
 

@@ -119,8 +119,24 @@ class CapturedFrame:
     ``out`` is the frame buffer it writes, ``confirm()`` (synchronises) checks that the last replay
     did not exceed the pair capacity recorded in the graph and returns the frame."""
 
-    def __init__(self, scene: "GaussianScene", graph, out: torch.Tensor, pinned: torch.Tensor, call: dict) -> None:
+    def __init__(self, scene: "GaussianScene", graph, out: torch.Tensor, pinned: torch.Tensor, call: dict,
+                 camera_buffer: Optional[torch.Tensor] = None) -> None:
         self.scene, self.graph, self.out, self._pinned, self._call = scene, graph, out, pinned, call
+        self._camera_buffer = camera_buffer      # device copy of the GsxCamera the recorded kernels read
+
+    def set_camera(self, image_idx: int) -> None:
+        """Points the captured frame at another camera of the scene (same frame size): the next
+        ``replay()`` enqueued on this stream renders that view.  Only for frames captured with
+        ``movable_camera=True``.  The constants are copied on the current stream; do not call this
+        while a replay of this frame is still in flight on another stream."""
+        if self._camera_buffer is None:
+            raise RuntimeError("this frame was captured with its camera baked in: capture it with movable_camera=True")
+        cam = self.scene.images[image_idx].gsx_camera()
+        first = self.scene.images[self._call["image_idx"]].gsx_camera()
+        if (cam.width, cam.height) != (first.width, first.height):
+            raise ValueError("a captured frame keeps its size: %dx%d, the new camera is %dx%d"
+                             % (first.width, first.height, cam.width, cam.height))
+        self._camera_buffer.copy_(torch.frombuffer(bytearray(bytes(cam)), dtype=torch.uint8))
 
     def replay(self) -> torch.Tensor:
         self.graph.replay()
@@ -220,7 +236,8 @@ class GaussianScene:
                          stats: Optional[dict] = None, timing: bool = False,
                          no_sync: bool = False, semantics: str = "ref_cpu",
                          background: Tuple[float, float, float] = (0.0, 0.0, 0.0),
-                         generic_kernels: bool = False, published_rects: bool = False) -> torch.Tensor:
+                         generic_kernels: bool = False, published_rects: bool = False,
+                         camera_buffer: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Full forward render in libgsx (gsx_render_forward).
 
         semantics: "ref_cpu" (the reference's ``render_image``), "ref_cuda" (its CUDA kernel's rules
@@ -252,6 +269,11 @@ class GaussianScene:
             params.flags |= _ffi.GSX_FLAG_GENERIC_KERNELS
         if published_rects:     # std_3dgs: bin with the published 3-sigma squares (same pixels, longer lists)
             params.flags |= _ffi.GSX_FLAG_PUBLISHED_RECTS
+        if camera_buffer is not None:   # GsxParams.camera_device: the kernels read the camera from this buffer
+            if camera_buffer.device != dev or camera_buffer.dtype != torch.uint8 or \
+                    camera_buffer.numel() != ctypes.sizeof(_ffi.GsxCamera):
+                raise ValueError("camera_buffer must be %d bytes (uint8) on %s" % (ctypes.sizeof(_ffi.GsxCamera), dev))
+            params.camera_device = camera_buffer.data_ptr()
         if tile_window is not None:
             params.tile_x0, params.tile_x1, params.tile_y0, params.tile_y1 = [int(v) for v in tile_window]
         if out is None:
@@ -299,7 +321,7 @@ class GaussianScene:
             self._pending.append((pinned, cap_key, dict(
                 image_idx=image_idx, tile_size=tile_size, layout=layout, tile_window=tile_window, out=out,
                 out_origin=out_origin, semantics=semantics, background=background,
-                generic_kernels=generic_kernels, published_rects=published_rects)))
+                generic_kernels=generic_kernels, published_rects=published_rects, camera_buffer=camera_buffer)))
             if stats is not None:
                 stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
             return out
@@ -348,30 +370,44 @@ class GaussianScene:
         return redone
 
     def capture_frame(self, image_idx: int, tile_size: int = 16, layout: str = "wh3",
-                      semantics: str = "ref_cpu") -> "CapturedFrame":
+                      semantics: str = "ref_cpu", movable_camera: bool = False,
+                      headroom: float = 1.1) -> "CapturedFrame":
         """Records one whole frame of this camera (every launch, clear and the asynchronous count
         copy) into a hipGraph.  ``frame.replay()`` then re-renders it with ONE graph launch (~20 us
         of host time instead of ~120 us for ~30 separate launches) from the CURRENT contents of the
-        Gaussian tensors -- the camera constants and all buffer addresses are baked in.  Possible
-        because the no-sync frame has no host dependency at all."""
+        Gaussian tensors -- all buffer addresses are baked in, and so are the camera constants unless
+        ``movable_camera`` is set: then the projection kernel reads them from a device buffer
+        (GsxParams.camera_device) that ``frame.set_camera(other_image_idx)`` rewrites between replays
+        (same frame size; stored-RGB scenes only, the SH colour kernel takes the camera centre by
+        value).  The graph holds room for ``headroom`` x the pair count of the captured view; a replay
+        that needs more (another camera may) is reported by ``confirm()``.  Possible because the
+        no-sync frame has no host dependency at all."""
         dev = self.gaussians.points.device
         _require_gpu(dev)
         cam = self.images[image_idx].gsx_camera()
         shape = (cam.width, cam.height, 3) if layout == "wh3" else (cam.height, cam.width, 3)
         out = torch.empty(shape, dtype=torch.float32, device=dev)
-        self.render_image_hip(image_idx, tile_size=tile_size, layout=layout, out=out, semantics=semantics)
+        cam_buf = None
+        if movable_camera:
+            if getattr(self.gaussians, "sh", None) is not None:
+                raise RuntimeError("movable_camera needs stored RGB colours (the SH kernel takes the camera centre by value)")
+            cam_buf = torch.frombuffer(bytearray(bytes(cam)), dtype=torch.uint8).to(dev)
+        kw = dict(tile_size=tile_size, layout=layout, out=out, semantics=semantics, camera_buffer=cam_buf)
+        st = {}
+        self.render_image_hip(image_idx, stats=st, **kw)
+        # pair capacity the recorded launches are sized for
+        self._cap_hints[(image_idx, tile_size, None, semantics)] = int(st["n_instances"] * max(headroom, 1.0)) + 4096
         stream = torch.cuda.Stream(dev)
         with torch.cuda.stream(stream):   # same call once on the capture stream: sizes its scratch buffer
-            self.render_image_hip(image_idx, tile_size=tile_size, layout=layout, out=out, semantics=semantics)
+            self.render_image_hip(image_idx, **kw)
         self._ensure_pinned_pool()                      # pinning memory is not allowed while capturing
         torch.cuda.synchronize(dev)
         before = len(self._pending)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
-            self.render_image_hip(image_idx, tile_size=tile_size, layout=layout, out=out, semantics=semantics,
-                                  no_sync=True)
+            self.render_image_hip(image_idx, no_sync=True, **kw)
         pinned, _, call = self._pending.pop(before)     # the graph owns this frame's count slot from now on
-        return CapturedFrame(self, graph, out, pinned, call)
+        return CapturedFrame(self, graph, out, pinned, call, camera_buffer=cam_buf)
 
     def render_image(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:
         """(W,H,3) float32 indexed [x,y]; same result as the reference's pure-Python

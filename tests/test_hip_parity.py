@@ -796,3 +796,35 @@ def test_sh_kernel_block_edges_and_unaligned_input(n, deg, skip):
     _ffi.check(rc)
     ref = cpu_ref.sh_to_rgb(pts[skip:], sh[skip:], deg, center)
     assert np.max(np.abs(out.cpu().numpy() - ref)) <= 3e-6
+
+
+def test_captured_frame_follows_a_moving_camera(tmp_path):
+    """capture_frame(movable_camera=True): the recorded projection kernel reads the camera from a device
+    buffer (GsxParams.camera_device); set_camera() + replay() renders another view with the same graph."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd.image import GaussianImage
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    sc = make_scene(20000, 320, 240, seed=31)
+    scene = _scene_from_arrays(tmp_path, sc)
+    first = scene.images[1]
+    # two more poses of the same camera model
+    from intro_to_gaussian_splatting_amd.colmap import read_camera_file, read_image_file
+    cam_model = read_camera_file(str(tmp_path))[1]
+    base = read_image_file(str(tmp_path))[1]
+    for idx, (dq, dt) in {2: ((0.02, -0.03, 0.01), (0.3, -0.1, 0.2)), 3: ((-0.05, 0.02, 0.04), (-0.4, 0.2, -0.3))}.items():
+        q = np.array(base.qvec, np.float64) + np.array((0.0,) + dq)
+        t = np.array(base.tvec, np.float64) + np.array(dt)
+        scene.images[idx] = GaussianImage(camera=cam_model, image=base._replace(qvec=q / np.linalg.norm(q), tvec=t),
+                                          device="cuda:0")
+    refs = {i: scene.render_image_hip(i).clone() for i in (1, 2, 3)}
+    assert not torch.equal(refs[1], refs[2]) and not torch.equal(refs[2], refs[3])
+    frame = scene.capture_frame(1, movable_camera=True, headroom=1.5)
+    for i in (1, 2, 3, 1, 3):
+        frame.set_camera(i)
+        frame.replay()
+        assert torch.equal(frame.confirm(), refs[i]), i
+    baked = scene.capture_frame(1)
+    with pytest.raises(RuntimeError, match="movable_camera"):
+        baked.set_camera(2)
+    assert first is scene.images[1]
