@@ -474,6 +474,14 @@ def main() -> None:
                                "unit": "GB/s", "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in stage.items()},
         }
+        if stage.get("project", 0.0) > 0.0 and world == 1:
+            # the HBM-bound stage: 56 B read + 68 B written per Gaussian (record 48, keys/values 8, rectangle 8,
+            # count 4); the HIP-event bracket includes the launch, the kernel alone is ~5 us shorter (profiles/)
+            pb = 124.0 * n
+            out["project_roofline"] = {"bound": "hbm", "kernel": "project_pack_kernel", "bytes_per_launch": pb,
+                                       "avg_ms": round(stage["project"], 4),
+                                       "achieved": round(pb / (stage["project"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": round(pb / (stage["project"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if strips_ok is not None:
             out["strips_equal_single_gpu"] = strips_ok
         if world == 1 and not args.no_cpu_baseline:
