@@ -18,12 +18,17 @@ from oracle import c_oracle, cpu_ref  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+big = len(sys.argv) > 3 and sys.argv[3] == "big"     # larger frames (up to > 65 536 tiles) and populations
 worst_ref, worst_std, flips_total = 0.0, 0.0, 0
 for seed in range(first, first + count):
     rs = np.random.RandomState(77000 + seed)
     w, h = int(rs.randint(3, 400)), int(rs.randint(3, 300))
     tile = int(rs.choice([1, 2, 3, 4, 7, 8, 16, 16, 16, 16, 17, 32, 40]))
     n = int(rs.choice([0, 1, 2, 17, 300, 2500, 20000]))
+    if big:
+        w, h = int(rs.randint(300, 2200)), int(rs.randint(200, 1300))
+        tile = int(rs.choice([3, 4, 8, 16, 16, 16]))
+        n = int(rs.choice([5000, 50000, 200000]))
     q = rs.normal(size=4)
     sc = make_scene(max(n, 1), w, h, seed=seed, behind_fraction=float(rs.choice([0.0, 0.0, 0.3, 1.0])),
                     qvec=tuple(q / np.linalg.norm(q)), tvec=tuple(rs.normal(size=3)),
