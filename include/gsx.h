@@ -83,7 +83,8 @@ typedef struct GsxCamera {
 /*
  * Options.  gsx_default_params() fills the reference's behaviour; a NULL params pointer means
  * the defaults.  The tile window selects which tiles this call renders (multi-GPU strips):
- * tiles [tile_x0, tile_x1) x [tile_y0, tile_y1); tile_x1 / tile_y1 <= 0 means "to the end".
+ * tiles [tile_x0, tile_x1) x [tile_y0, tile_y1); tile_x1 / tile_y1 < 0 (the default, -1) means "to the
+ * end", tile_x1 == tile_x0 (or y) is an empty window: nothing is rendered, `out` is zeroed.
  * `out` always addresses a buffer of out_w x out_h pixels whose pixel (0,0) is frame pixel
  * (out_x0, out_y0); out_w / out_h <= 0 means the whole frame.
  */
@@ -133,9 +134,9 @@ typedef struct GsxParams {
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
 enum {
     GSX_STAGE_PROJECT = 0,    /* projection, depth keys, record packing         */
-    GSX_STAGE_DEPTH_SORT = 1, /* stable sort of N depth keys                    */
-    GSX_STAGE_SCAN = 2,       /* tile-count scan                                 */
-    GSX_STAGE_BIN = 3,        /* frame clear, key emit, tile sort, tile ranges  */
+    GSX_STAGE_DEPTH_SORT = 1, /* stable sort of the depth keys (drops Gaussians that reach no tile) */
+    GSX_STAGE_SCAN = 2,       /* tile-count sums + (tile, Gaussian) pair emission */
+    GSX_STAGE_BIN = 3,        /* frame clear, tile sort, tile ranges            */
     GSX_STAGE_BLEND = 4,      /* the compositing kernel alone                   */
     GSX_STAGE_TOTAL = 5
 };
@@ -215,6 +216,15 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
  * function exists for callers of the reference's method.
  */
 int gsx_covariance_3d(const float *scales, const float *quats, int64_t n, float *covariance_out, void *stream);
+
+/*
+ * Replaces GaussianScene.get_2d_covariance (splat/gaussian_scene.py:53-68 -> compute_2d_covariance,
+ * splat/utils.py:320-354): the EWA 2D covariance (n,2,2) of caller-given points (n,3) with 3D covariances
+ * (n,3,3) under `camera` -- view-space point clamped at 1.3 tan(fov/2), J from the COLMAP focal lengths,
+ * (((J W) Sigma) W^T) J^T left to right, top-left 2x2.  No cull: every row is projected.
+ */
+int gsx_covariance_2d(const GsxCamera *camera, const float *points, const float *covariance_3d, int64_t n,
+                      float *covariance_2d_out, void *stream);
 
 /*
  * Debug helper on the same projection: replaces GaussianScene.render_points_image

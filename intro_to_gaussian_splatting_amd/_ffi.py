@@ -63,6 +63,7 @@ SIGNATURES = {
     "gsx_render_forward": (ctypes.c_int, [POINTER(GsxCamera)] + [_FP] * 5 + [c_int64, c_int32, _FP,
                            POINTER(GsxParams), POINTER(GsxFrameStats), c_void_p, c_size_t, c_void_p]),
     "gsx_covariance_3d": (ctypes.c_int, [_FP, _FP, c_int64, _FP, c_void_p]),
+    "gsx_covariance_2d": (ctypes.c_int, [POINTER(GsxCamera), _FP, _FP, c_int64, _FP, c_void_p]),
     "gsx_project_points": (ctypes.c_int, [POINTER(GsxCamera), _FP, c_int64, _FP, c_void_p, c_void_p]),
     "gsx_sh_to_rgb": (ctypes.c_int, [_FP, _FP, c_int32, c_int64, POINTER(c_float), _FP, c_void_p]),
 }

@@ -2,8 +2,10 @@
 
 Counterpart of what ``GaussianScene.__init__`` needs from the reference's
 ``splat/read_colmap.py:87-239`` and ``splat/utils.py:269-290`` (``.bin`` preferred over ``.txt``).
-Only the fields the render path reads are kept: camera model / size / params and image pose /
-camera id / name; 2D keypoints and 3D point ids are skipped.
+Same record fields as the reference's namedtuples (``Camera``: id, model, width, height, params;
+``Image``: id, qvec, tvec, camera_id, name, xys, point3D_ids); the render path reads camera model /
+size / params and image pose / camera id / name.  Both readers are held against the reference's own
+parse of a committed model (tests/golden/colmap_model*, captured by oracle/capture_golden.py).
 """
 from __future__ import annotations
 
@@ -28,6 +30,8 @@ class Image(NamedTuple):
     tvec: np.ndarray
     camera_id: int
     name: str
+    xys: np.ndarray = np.zeros((0, 2))            # 2D keypoints (n, 2)
+    point3D_ids: np.ndarray = np.zeros(0, dtype=np.int64)
 
 
 # COLMAP camera model id -> (name, number of params)
@@ -65,9 +69,11 @@ def read_images_text(path: str) -> Dict[int, Image]:
                 continue
             tok = line.split()
             img_id = int(tok[0])
+            pts = fid.readline().split()           # the keypoint line: x y point3D_id triples
+            xys = np.array([float(v) for v in pts[0::3] + pts[1::3]]).reshape(2, -1).T
+            ids = np.array([int(v) for v in pts[2::3]], dtype=np.int64)
             out[img_id] = Image(img_id, np.array([float(v) for v in tok[1:5]]),
-                                np.array([float(v) for v in tok[5:8]]), int(tok[8]), tok[9])
-            fid.readline()  # the keypoint line of this image (x y point3D_id triples): not needed
+                                np.array([float(v) for v in tok[5:8]]), int(tok[8]), tok[9], xys, ids)
     return out
 
 
@@ -104,8 +110,13 @@ def read_images_binary(path: str) -> Dict[int, Image]:
                     break
                 name += ch
             (npts,) = _unpack(fid, "Q")
-            fid.seek(24 * npts, os.SEEK_CUR)  # (x, y, point3D_id) triples: not needed
-            out[rec[0]] = Image(rec[0], np.array(rec[1:5]), np.array(rec[5:8]), rec[8], name.decode("utf-8"))
+            raw = fid.read(24 * npts)              # (x, y, point3D_id) triples: double, double, int64
+            if len(raw) != 24 * npts:
+                raise ValueError("truncated COLMAP binary file")
+            trip = np.frombuffer(raw, dtype=np.dtype([("x", "<f8"), ("y", "<f8"), ("id", "<i8")]))
+            xys = np.stack([trip["x"], trip["y"]], axis=1) if npts else np.zeros((0, 2))
+            out[rec[0]] = Image(rec[0], np.array(rec[1:5]), np.array(rec[5:8]), rec[8], name.decode("utf-8"),
+                                xys, trip["id"].astype(np.int64))
     return out
 
 

@@ -27,6 +27,7 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 constexpr size_t kAlign = 256;
+constexpr int64_t kMaxPairs = ((int64_t)1 << 31) - 1;
 inline size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 
 // Number of tiles along an axis.  REF_CPU iterates range(0, extent - tile, tile)
@@ -39,10 +40,16 @@ inline int32_t tiles_along(int32_t extent, int32_t tile, int semantics) {
 
 struct Carve {
     size_t keys0, keys1, vals0, vals1;      // n x u32: depth keys / original indices (ping-pong)
-    size_t rec, rect, counts, offsets, bbox;  // per Gaussian
-    size_t tkeys0, tkeys1, tvals0, tvals1;  // cap x u32: tile ids / depth ranks (ping-pong)
+    size_t rec, rect, rrect, bbox;          // per Gaussian: record, tile rectangle by index / by depth rank
+    size_t tkeys0, tkeys1, tvals0, tvals1;  // cap x u32: tile ids / Gaussian indices (ping-pong)
     size_t ranges, counters, temp, temp_bytes, total;
 };
+
+// The 64-byte `counters` block: what the kernels of one frame hand to each other on the device.
+//   u32 [0] Gaussians behind the cull plane   [1] Gaussians kept by the depth sort (M)
+//       [2] min(D, 2^32 - 1)                   [3] spare
+//   i64 at byte 16: n_visible, D (the first two fields of a GsxFrameStats)
+enum { kCtrCulled = 0, kCtrKept = 1, kCtrPairs = 2 };
 
 Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes) {
     Carve c;
@@ -56,8 +63,7 @@ Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes) {
     c.keys0 = take(nn * 4); c.keys1 = take(nn * 4); c.vals0 = take(nn * 4); c.vals1 = take(nn * 4);
     c.rec = take(nn * sizeof(gsx::Record));
     c.rect = take(nn * sizeof(gsx::TileRect));
-    c.counts = take((nn + 1) * 4);
-    c.offsets = take((nn + 1) * 4);
+    c.rrect = take(nn * sizeof(gsx::TileRect));
     c.bbox = take(nn * sizeof(float4));
     c.tkeys0 = take(cc * 4); c.tkeys1 = take(cc * 4); c.tvals0 = take(cc * 4); c.tvals1 = take(cc * 4);
     c.ranges = take((size_t)(max_tiles > 0 ? max_tiles : 1) * sizeof(uint2));
@@ -163,8 +169,9 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     if (g.ntx > 65535 || g.nty > 65535) return fail(GSX_ERR_UNSUPPORTED, "more than 65535 tiles along an axis");
     g.wx0 = d.tile_x0 < 0 ? 0 : d.tile_x0;
     g.wy0 = d.tile_y0 < 0 ? 0 : d.tile_y0;
-    g.wx1 = (d.tile_x1 <= 0 || d.tile_x1 > g.ntx) ? g.ntx : d.tile_x1;
-    g.wy1 = (d.tile_y1 <= 0 || d.tile_y1 > g.nty) ? g.nty : d.tile_y1;
+    // tile_x1 / tile_y1 < 0: "to the end" (the default); x1 == x0 is an EMPTY window, also at tile 0
+    g.wx1 = (d.tile_x1 < 0 || d.tile_x1 > g.ntx) ? g.ntx : d.tile_x1;
+    g.wy1 = (d.tile_y1 < 0 || d.tile_y1 > g.nty) ? g.nty : d.tile_y1;
     if (g.wx0 > g.wx1) g.wx0 = g.wx1;
     if (g.wy0 > g.wy1) g.wy0 = g.wy1;
     gsx::OutDesc &o = p.out;
@@ -192,88 +199,116 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     return GSX_OK;
 }
 
-// Zero the pixels of the output buffer that no tile of the window covers (the compositing kernel
-// writes every pixel of every tile it owns, empty tiles included): up to four rectangles instead
-// of a whole-frame memset (25 MB at 1080p).
-int clear_outside_window(const Plan &p, hipStream_t s) {
+// The pixels of the output buffer that no tile of the window covers (the compositing kernel writes every
+// pixel of every tile it owns, empty tiles included): up to four rectangles, zeroed by extra workgroups
+// of the compositing launch instead of a whole-frame memset (25 MB at 1080p).  whole = true: the entire
+// buffer (nothing is rendered).
+gsx::ClearPlan make_clear_plan(const Plan &p, bool whole) {
     const gsx::OutDesc &o = p.out;
     const int T = p.grid.tile;
+    gsx::ClearPlan cp;
+    memset(&cp, 0, sizeof cp);
     // window in buffer-local pixel coordinates along (slow, fast) memory axes
     const bool wh3 = o.stride_y < o.stride_x;  // x is the slow axis
     const int64_t slow_n = wh3 ? o.w : o.h, fast_n = wh3 ? o.h : o.w;
+    cp.pitch = fast_n * 3;
+    auto rect = [&](int64_t s0, int64_t s1, int64_t f0, int64_t f1) {
+        if (s1 <= s0 || f1 <= f0) return;
+        const int i = cp.n++;
+        cp.s0[i] = (int32_t)s0; cp.rows[i] = (int32_t)(s1 - s0);
+        cp.f0[i] = (int32_t)f0; cp.fw[i] = (int32_t)(f1 - f0);
+        cp.first[i + 1] = cp.first[i] + gsx::clear_blocks_for(s1 - s0, f1 - f0);
+    };
+    if (whole || p.grid.count() == 0) {
+        // row by row blocks of at most 2^31 floats each: one rectangle per quarter keeps 32-bit indices safe
+        const int64_t q = (slow_n + 3) / 4;
+        for (int k = 0; k < 4; ++k) rect(k * q, (k + 1) * q < slow_n ? (k + 1) * q : slow_n, 0, fast_n);
+        return cp;
+    }
     int64_t ws0 = (int64_t)(wh3 ? p.grid.wx0 : p.grid.wy0) * T - (wh3 ? o.x0 : o.y0);
     int64_t ws1 = (int64_t)(wh3 ? p.grid.wx1 : p.grid.wy1) * T;
     int64_t wf1 = (int64_t)(wh3 ? p.grid.wy1 : p.grid.wx1) * T;
     ws1 = (ws1 > (wh3 ? p.grid.width : p.grid.height) ? (wh3 ? p.grid.width : p.grid.height) : ws1) - (wh3 ? o.x0 : o.y0);
     wf1 = (wf1 > (wh3 ? p.grid.height : p.grid.width) ? (wh3 ? p.grid.height : p.grid.width) : wf1) - (wh3 ? o.y0 : o.x0);
     int64_t wf0 = (int64_t)(wh3 ? p.grid.wy0 : p.grid.wx0) * T - (wh3 ? o.y0 : o.x0);
-    const size_t px = 3 * sizeof(float), pitch = (size_t)fast_n * px;
-    char *base = (char *)o.ptr;
-    auto rect = [&](int64_t s0, int64_t s1, int64_t f0, int64_t f1) -> hipError_t {
-        if (s1 <= s0 || f1 <= f0) return hipSuccess;
-        if (f0 == 0 && f1 == fast_n)  // whole rows: one contiguous block
-            return hipMemsetAsync(base + (size_t)s0 * pitch, 0, (size_t)(s1 - s0) * pitch, s);
-        return hipMemset2DAsync(base + (size_t)s0 * pitch + (size_t)f0 * px, pitch, 0, (size_t)(f1 - f0) * px,
-                                (size_t)(s1 - s0), s);
-    };
-    GSX_HIP(rect(0, ws0, 0, fast_n));
-    GSX_HIP(rect(ws1, slow_n, 0, fast_n));
-    GSX_HIP(rect(ws0, ws1, 0, wf0));
-    GSX_HIP(rect(ws0, ws1, wf1, fast_n));
-    return GSX_OK;
+    rect(0, ws0, 0, fast_n);
+    rect(ws1, slow_n, 0, fast_n);
+    rect(ws0, ws1, 0, wf0);
+    rect(ws0, ws1, wf1, fast_n);
+    return cp;
 }
 
-// Steps shared by both render entry points once records / rects / counts exist.
-// `order` = Gaussian index of each depth rank (nullptr: rows are already in compositing order).
+// Steps shared by both render entry points once records and rank-ordered tile rectangles exist.
+// `order` = Gaussian index of each depth rank (nullptr: rows are already in compositing order);
+// `m_dev` = number of ranks on the device (nullptr: n); `culled_dev` = Gaussians behind the cull plane.
 // The pair count D never has to reach the host for the frame to be enqueued: the kernels read
 // it from device memory and their grids are sized by the workspace capacity.  The normal call
 // synchronises ONCE, after the last launch, to report the counts and to detect D > capacity;
-// GSX_FLAG_NO_SYNC skips even that (the counts then arrive asynchronously in pinned memory).
-int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t cap, const uint32_t *order,
-                  const uint32_t *sorted_keys, int64_t n_visible_known, GsxFrameStats *stats, StageTimer &tm,
-                  hipStream_t s) {
-    uint32_t *counts = (uint32_t *)(ws + c.counts), *offsets = (uint32_t *)(ws + c.offsets);
+// GSX_FLAG_NO_SYNC skips even that (the counts then arrive in pinned memory on their own).
+int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t cap, const gsx::TileRect *rrect,
+                  const uint32_t *order, const uint32_t *m_dev, const uint32_t *culled_dev, GsxFrameStats *stats,
+                  StageTimer &tm, hipStream_t s) {
     uint32_t *counters = (uint32_t *)(ws + c.counters);
     void *temp = ws + c.temp;
-    int64_t *dev2 = (int64_t *)(counters + 8);
-    GSX_HIP(gsx::scan_counts(temp, c.temp_bytes, counts, order, sorted_keys, offsets, n, counters, n_visible_known,
-                             dev2, s));
-    tm.mark();  // 3: scan
-    const size_t out_bytes = (size_t)p.out.w * p.out.h * 3 * sizeof(float);
+    int64_t *dev2 = (int64_t *)(counters + 4);
+    uint2 *ranges = (uint2 *)(ws + c.ranges);
+    bool counts_on_device = false, counts_in_host = false;
     if (p.grid.count() > 0 && n == 0 && p.semantics == GSX_SEM_STD_3DGS) {
         // no Gaussians: every pixel of the window is the background colour
-        int rc = clear_outside_window(p, s);
-        if (rc != GSX_OK) return rc;
-        uint2 *ranges = (uint2 *)(ws + c.ranges);
-        GSX_HIP(hipMemsetAsync(ranges, 0, (size_t)p.grid.count() * sizeof(uint2), s));
+        tm.mark();  // 3: scan + emit
+        GSX_HIP(gsx::launch_zero_words((uint32_t *)ranges, (size_t)p.grid.count() * 2, s));
         GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), nullptr, (const uint32_t *)(ws + c.tvals0), ranges,
-                                  p.grid, p.out, p.semantics, p.background, p.generic, s));
-    } else if (p.grid.count() == 0 || n == 0) {
-        GSX_HIP(hipMemsetAsync(p.out.ptr, 0, out_bytes, s));
+                                  p.grid, p.out, p.semantics, p.background, p.generic, make_clear_plan(p, false), s));
+    } else if (n == 0) {
+        tm.mark();
+        GSX_HIP(gsx::launch_clear(make_clear_plan(p, true), p.out.ptr, s));
     } else {
-        int rc = clear_outside_window(p, s);
-        if (rc != GSX_OK) return rc;
-        uint2 *ranges = (uint2 *)(ws + c.ranges);
-        const uint32_t *sorted_vals = nullptr;
-        GSX_HIP(gsx::bin_instances(temp, c.temp_bytes, (const gsx::TileRect *)(ws + c.rect), order, offsets, n, cap,
-                                   p.grid, ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0),
-                                   (uint32_t *)(ws + c.tvals1), ranges, &sorted_vals, s));
-        tm.mark();  // 4: bin
-        GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
-                                  ranges, p.grid, p.out, p.semantics, p.background, p.generic, s));
-        tm.mark();  // 5: blend
+        // the counts are produced by the emit kernel even when no tile is rendered (an empty window
+        // still reports n_visible; its pair count is 0 because every rectangle was clamped away)
+        gsx::BinCounts bc{dev2, nullptr, counters + kCtrPairs, culled_dev, n};
+        if (p.no_sync && stats) {
+            // pinned host memory is device-visible: the emit kernel stores the two counts there itself
+            void *alias = nullptr;
+            if (hipHostGetDevicePointer(&alias, stats, 0) == hipSuccess && alias) {
+                bc.stats2_host = (int64_t *)alias;
+                counts_in_host = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        GSX_HIP(gsx::emit_instances(temp, rrect, order, m_dev, n, cap, p.grid, ws + c.tkeys0, (uint32_t *)(ws + c.tvals0),
+                                    ranges, bc, s));
+        counts_on_device = true;
+        tm.mark();  // 3: scan + emit
+        if (p.grid.count() == 0) {
+            GSX_HIP(gsx::launch_clear(make_clear_plan(p, true), p.out.ptr, s));
+        } else {
+            const uint32_t *sorted_vals = nullptr;
+            GSX_HIP(gsx::sort_instances(temp, cap, p.grid, ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0),
+                                        (uint32_t *)(ws + c.tvals1), ranges, counters + kCtrPairs, &sorted_vals, s));
+            tm.mark();  // 4: tile sort
+            GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
+                                      ranges, p.grid, p.out, p.semantics, p.background, p.generic,
+                                      make_clear_plan(p, false), s));
+            tm.mark();  // 5: blend
+        }
     }
     if (p.no_sync) {
         if (stats) {
             // stats must be pinned host memory; the two counts land when the stream gets here
-            GSX_HIP(hipMemcpyAsync(stats, dev2, 16, hipMemcpyDeviceToHost, s));
+            if (!counts_on_device) {
+                stats->n_visible = 0;
+                stats->n_instances = 0;
+            } else if (!counts_in_host) {
+                GSX_HIP(hipMemcpyAsync(stats, dev2, 16, hipMemcpyDeviceToHost, s));
+            }
             stats->n_tiles = p.grid.count();
             stats->reserved = cap;  // > 0: counts are delivered asynchronously; value = pair capacity used
         }
         return GSX_OK;
     }
     int64_t host2[2] = {0, 0};
-    GSX_HIP(hipMemcpyAsync(host2, dev2, 16, hipMemcpyDeviceToHost, s));
+    if (counts_on_device) GSX_HIP(hipMemcpyAsync(host2, dev2, 16, hipMemcpyDeviceToHost, s));
     GSX_HIP(hipStreamSynchronize(s));
     if (stats) {
         stats->n_visible = host2[0];
@@ -292,6 +327,9 @@ int check_workspace(void *workspace, size_t bytes, int64_t n, int64_t max_tiles,
     if (!workspace) return fail(GSX_ERR_INVALID_ARGUMENT, "workspace is NULL");
     if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0) return fail(GSX_ERR_INVALID_ARGUMENT, "workspace must be 256-byte aligned");
     cap = capacity_for(bytes, n, max_tiles);
+    // the kernels index pairs with 32 bits and gsx_workspace_bytes sizes for < 2^31 pairs: a larger
+    // buffer (a 288 GB part can hand over 68 GB and more) must not raise the capacity beyond that
+    if (cap > kMaxPairs) cap = kMaxPairs;
     if (cap < 0)
         return fail(GSX_ERR_WORKSPACE_TOO_SMALL, "workspace of %zu bytes cannot hold %lld Gaussians", bytes, (long long)n);
     c = carve(n, cap, max_tiles, gsx::binning_temp_bytes(n, cap));
@@ -311,6 +349,8 @@ void gsx_default_params(GsxParams *params) {
     memset(params, 0, sizeof *params);
     params->semantics = GSX_SEM_REF_CPU;
     params->layout = GSX_LAYOUT_WH3;
+    params->tile_x1 = -1;
+    params->tile_y1 = -1;
 }
 
 size_t gsx_workspace_bytes(int64_t n, int32_t width, int32_t height, int32_t tile, int64_t max_instances) {
@@ -347,7 +387,7 @@ int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *s
     uint32_t *counters = (uint32_t *)(ws + c.counters);
     GSX_HIP(hipMemsetAsync(counters, 0, 64, s));
     GSX_HIP(gsx::launch_depth_keys(*camera, means3d, n, k0, v0, s));
-    GSX_HIP(gsx::sort_by_depth(ws + c.temp, c.temp_bytes, k0, k1, v0, v1, n, s));
+    GSX_HIP(gsx::radix_sort_pairs_u32(ws + c.temp, k0, k1, v0, v1, nullptr, n, 32, s));
     GSX_HIP(gsx::launch_count_visible(k0, n, counters, s));
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
     gsx::StageOneOut out{points_xy, colors_out, covariance_2d, depths, inverse_covariance_2d, radius,
@@ -384,10 +424,12 @@ int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t t
     tm.mark();  // 1: (no depth sort on this entry point)
     gsx::PreprocessedIn in{point_means, point_colors, inverse_covariance_2d, min_x, max_x, min_y, max_y, opacity};
     GSX_HIP(gsx::launch_pack_preprocessed(in, n, p.grid, p.semantics, (gsx::Record *)(ws + c.rec),
-                                          (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts),
+                                          (gsx::TileRect *)(ws + c.rect),
                                           p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 2: pack
-    return bin_and_blend(p, c, ws, n, cap, nullptr, nullptr, n, stats_host, tm, s);
+    // rows are already in compositing order: the rectangles by row ARE the rectangles by rank
+    return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rect), nullptr, nullptr, nullptr, stats_host,
+                         tm, s);
 }
 
 int gsx_render_forward(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
@@ -411,13 +453,16 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     StageTimer tm;
     tm.begin(p.timing, s);
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
+    uint32_t *counters = (uint32_t *)(ws + c.counters);
     GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, k0, v0, (gsx::Record *)(ws + c.rec),
-                                     (gsx::TileRect *)(ws + c.rect), (uint32_t *)(ws + c.counts),
+                                     (gsx::TileRect *)(ws + c.rect), counters,
                                      p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 1: project (+ depth keys)
-    GSX_HIP(gsx::sort_by_depth(ws + c.temp, c.temp_bytes, k0, k1, v0, v1, n, s));
-    tm.mark();  // 2: depth sort
-    return bin_and_blend(p, c, ws, n, cap, v0, k0, -1, stats_host, tm, s);
+    GSX_HIP(gsx::sort_depth_compact(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
+                                    (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s));
+    tm.mark();  // 2: depth sort (drops what reaches no tile, leaves the rectangles in rank order)
+    return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rrect), v0, counters + kCtrKept,
+                         counters + kCtrCulled, stats_host, tm, s);
 }
 
 // Test hook (not part of include/gsx.h): the pipeline's radix sort on caller-provided pairs.
@@ -461,6 +506,15 @@ int gsx_covariance_3d(const float *scales, const float *quats, int64_t n, float 
     if (n < 0) return fail(GSX_ERR_INVALID_ARGUMENT, "n is negative");
     if (n > 0 && (!scales || !quats || !covariance_out)) return fail(GSX_ERR_INVALID_ARGUMENT, "an array is NULL");
     GSX_HIP(gsx::launch_covariance3d(scales, quats, n, covariance_out, (hipStream_t)stream));
+    return GSX_OK;
+}
+
+int gsx_covariance_2d(const GsxCamera *camera, const float *points, const float *covariance_3d, int64_t n,
+                      float *covariance_2d_out, void *stream) {
+    if (!camera) return fail(GSX_ERR_INVALID_ARGUMENT, "camera is NULL");
+    if (n < 0) return fail(GSX_ERR_INVALID_ARGUMENT, "n is negative");
+    if (n > 0 && (!points || !covariance_3d || !covariance_2d_out)) return fail(GSX_ERR_INVALID_ARGUMENT, "an array is NULL");
+    GSX_HIP(gsx::launch_covariance2d(*camera, points, covariance_3d, n, covariance_2d_out, (hipStream_t)stream));
     return GSX_OK;
 }
 

@@ -3,14 +3,25 @@
 // The reference sorts all visible Gaussians once by view depth (splat/gaussian_scene.py:117) and
 // then, for every tile, boolean-masks that sorted list (:209-218), so each tile's list is in
 // global depth order.  Here the same lists are produced with two stable radix sorts:
-//   1. N keys  (depth bits, value = original index)  -> depth rank of every Gaussian;
+//   1. N keys  (depth bits, value = original index)  -> depth rank of every Gaussian that reaches a
+//      tile of the window (gsx_sort.hip: the first pass drops the others, the last pass leaves the
+//      tile rectangles in rank order);
 //   2. D keys  (window-local tile id, value = Gaussian index), emitted in rank order, so a
 //      STABLE sort on the tile id alone (13 bits at 1080p, 2 radix passes instead of 6 for a
 //      64-bit tile|depth key) leaves every tile's entries in depth order, ties broken by
 //      original index exactly like a stable argsort.
 // The radix sort (gsx_sort.hip) and the scan below are ours; no library primitive is left on the
-// path.  D never leaves the device: every kernel after the scan reads it from offsets[n] and is
+// path.  D never leaves the device: every kernel after the scan reads it from device memory and is
 // launched on a grid sized by the workspace capacity.
+//
+// Between the two sorts (round 2: two kernels, all reads coalesced, no per-rank offset array):
+//   chunk_sums   every workgroup adds up the tile counts of its 1024 consecutive depth ranks (from the
+//                rank-ordered rectangles) -> sums[chunk], 64 bit;
+//   emit         every workgroup (same chunking) adds up the sums before its chunk, scans its own 1024
+//                counts in LDS and writes its (tile id, Gaussian index) pairs PAIR by pair: thread p of
+//                the chunk's pair range finds its Gaussian by binary search in the LDS offsets, so
+//                consecutive lanes write consecutive addresses whatever the mix of footprints is (one
+//                frame-filling splat is spread over the whole workgroup by construction).
 
 #include "gsx_internal.h"
 
@@ -18,251 +29,343 @@ namespace gsx {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kPerThread = 4;
+constexpr int kChunk = kBlock * kPerThread;   // depth ranks per workgroup in chunk_sums / emit
+// Up to this many chunks (2M Gaussians) the emit kernel adds up the raw chunk sums itself; beyond,
+// scan_sums_kernel turns them into prefixes first (one more launch where frames take milliseconds).
+constexpr int kSelfScanChunks = 2048;
 
-// One thread per depth rank writes that Gaussian's (tile id, rank) pairs at its scan offset.
-// A Gaussian covering more than kSerialMax tiles is spread over the whole wave instead, so one
-// huge splat does not serialise 63 idle lanes behind it.
-constexpr uint32_t kSerialMax = 16;
-
-template <typename Key>
-__device__ __forceinline__ void emit_one(const TileRect &r, uint32_t k, const TileGrid &g, uint32_t value,
-                                         uint32_t base, uint32_t limit, Key *__restrict__ keys,
-                                         uint32_t *__restrict__ vals) {
-    if (base + k >= limit) return;  // speculative mode: the instance count exceeded the caller's hint
-    uint32_t h = (uint32_t)(r.y1 - r.y0 + 1);
-    uint32_t tx = r.x0 + k / h, ty = r.y0 + k % h;
-    keys[base + k] = (Key)((tx - (uint32_t)g.wx0) * (uint32_t)g.nwy() + (ty - (uint32_t)g.wy0));
-    vals[base + k] = value;
+__device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t bound) {
+    if (!n_dev) return bound;
+    const uint32_t n = *n_dev;
+    return n < bound ? n : bound;
 }
 
-template <typename Key>
-__global__ void __launch_bounds__(kBlock)
-    emit_kernel(const TileRect *__restrict__ rect, const uint32_t *__restrict__ order,
-                const uint32_t *__restrict__ offsets, int64_t n, TileGrid g, uint32_t limit,
-                Key *__restrict__ keys, uint32_t *__restrict__ vals, uint2 *__restrict__ ranges) {
-    int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r < g.count()) ranges[r] = make_uint2(0u, 0u);  // tiles without pairs keep an empty range
-    TileRect tr;
-    tr.x0 = 1; tr.x1 = 0; tr.y0 = 1; tr.y1 = 0;
-    uint32_t base = 0, cnt = 0, gi = 0;
-    if (r < n) {
-        base = offsets[r];
-        cnt = offsets[r + 1] - base;
-        gi = order ? order[r] : (uint32_t)r;
-        if (cnt) tr = rect[gi];
+__device__ __forceinline__ uint32_t tiles_of(const TileRect &r) {
+    return r.x0 > r.x1 ? 0u : (uint32_t)(r.x1 - r.x0 + 1) * (uint32_t)(r.y1 - r.y0 + 1);
+}
+
+// A thread's four consecutive rectangles: two 16-byte loads.
+__device__ __forceinline__ void load_rects(const TileRect *__restrict__ rrect, uint32_t first, uint32_t m,
+                                           TileRect (&r)[kPerThread]) {
+    if (first + kPerThread <= m) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(rrect + first);   // first is a multiple of 4: 32-B aligned
+        const uint4 a = src[0], b = src[1];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            r[k].x0 = (uint16_t)(w[2 * k] & 0xFFFFu);
+            r[k].x1 = (uint16_t)(w[2 * k] >> 16);
+            r[k].y0 = (uint16_t)(w[2 * k + 1] & 0xFFFFu);
+            r[k].y1 = (uint16_t)(w[2 * k + 1] >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            if (first + k < m) {
+                r[k] = rrect[first + k];
+            } else {
+                r[k].x0 = 1; r[k].x1 = 0; r[k].y0 = 1; r[k].y1 = 0;
+            }
+        }
     }
-    if (cnt <= kSerialMax)
-        for (uint32_t k = 0; k < cnt; ++k) emit_one(tr, k, g, gi, base, limit, keys, vals);
-    unsigned long long big = __ballot(cnt > kSerialMax);
-    const int lane = threadIdx.x & 63;
-    while (big) {
-        int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        TileRect br;
-        br.x0 = (uint16_t)__shfl((int)tr.x0, src);
-        br.x1 = (uint16_t)__shfl((int)tr.x1, src);
-        br.y0 = (uint16_t)__shfl((int)tr.y0, src);
-        br.y1 = (uint16_t)__shfl((int)tr.y1, src);
-        uint32_t bbase = (uint32_t)__shfl((int)base, src), bcnt = (uint32_t)__shfl((int)cnt, src);
-        uint32_t bgi = (uint32_t)__shfl((int)gi, src);
-        for (uint32_t k = lane; k < bcnt; k += 64) emit_one(br, k, g, bgi, bbase, limit, keys, vals);
+}
+
+__device__ __forceinline__ uint64_t block_sum64(uint64_t v, uint64_t *wsum) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint64_t)__shfl_down((long long)v, o);
+    if (lane == 0) wsum[w] = v;
+    __syncthreads();
+    const uint64_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return total;
+}
+
+// sums[c] = tile instances of depth ranks [1024 c, 1024 (c+1)).
+__global__ void __launch_bounds__(kBlock)
+    chunk_sums_kernel(const TileRect *__restrict__ rrect, const uint32_t *__restrict__ m_dev, uint32_t bound,
+                      uint64_t *__restrict__ sums) {
+    __shared__ uint64_t wsum[4];
+    const uint32_t m = load_count(m_dev, bound);
+    const uint32_t first = blockIdx.x * (uint32_t)kChunk + threadIdx.x * (uint32_t)kPerThread;
+    uint64_t mine = 0;
+    if (first < m) {
+        TileRect r[kPerThread];
+        load_rects(rrect, first, m, r);
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) mine += tiles_of(r[k]);
+    }
+    const uint64_t total = block_sum64(mine, wsum);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// Large inputs only: sums[0 .. nchunks] <- exclusive prefix (entry nchunks = grand total), one workgroup.
+__global__ void __launch_bounds__(kBlock) scan_sums_kernel(uint64_t *__restrict__ sums, int nchunks) {
+    __shared__ uint64_t part[kBlock];
+    const int per = (nchunks + kBlock - 1) / kBlock;
+    const int i0 = threadIdx.x * per, i1 = min(nchunks, i0 + per);
+    uint64_t mine = 0;
+    for (int i = i0; i < i1; ++i) mine += sums[i];
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int k = 0; k < kBlock; ++k) {
+            const uint64_t v = part[k];
+            part[k] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (int i = i0; i < i1; ++i) {
+        const uint64_t v = sums[i];
+        sums[i] = run;
+        run += v;
+    }
+    if (i0 < nchunks && i1 == nchunks) sums[nchunks] = run;   // exactly one thread owns the last entry
+}
+
+// counts: what the frame reports and what the tile sort reads on the device.
+//   stats2[0] = visible Gaussians, stats2[1] = D as int64 (the first two fields of a GsxFrameStats);
+//   *d32 = min(D, 2^32 - 1): element count of the tile sort.
+struct EmitCounts {
+    int64_t *stats2;
+    int64_t *stats2_host;        // device-visible alias of pinned host memory, or null
+    uint32_t *d32;
+    const uint32_t *culled_dev;  // Gaussians behind the cull plane (whole-path entry), or null
+    int64_t n_total;             // n_visible = n_total - *culled_dev
+};
+
+template <typename Key, bool PREFIXED>
+__global__ void __launch_bounds__(kBlock)
+    emit_kernel(const TileRect *__restrict__ rrect, const uint32_t *__restrict__ order,
+                const uint32_t *__restrict__ m_dev, uint32_t bound, const uint64_t *__restrict__ sums, int nchunks,
+                TileGrid g, uint32_t limit, Key *__restrict__ keys, uint32_t *__restrict__ vals,
+                uint2 *__restrict__ ranges, EmitCounts ec) {
+    __shared__ uint64_t wsum[4];
+    __shared__ uint32_t offs[kChunk + 1];
+    __shared__ TileRect srect[kChunk];
+    __shared__ uint32_t sgi[kChunk];
+    {   // tiles without pairs keep an empty range
+        const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (t < g.count()) ranges[t] = make_uint2(0u, 0u);
+    }
+    if ((int)blockIdx.x >= nchunks) return;
+    const uint32_t m = load_count(m_dev, bound);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t first = blockIdx.x * (uint32_t)kChunk + threadIdx.x * (uint32_t)kPerThread;
+
+    // ---- pairs before this chunk (and, in the last workgroup, the frame's counts)
+    uint64_t base;
+    const bool last = (int)blockIdx.x == nchunks - 1;
+    if (PREFIXED) {
+        base = sums[blockIdx.x];
+    } else {
+        uint64_t before = 0;
+        for (int k = threadIdx.x; k < (int)blockIdx.x; k += kBlock) before += sums[k];
+        base = block_sum64(before, wsum);
+    }
+
+    // ---- this chunk's rectangles, counts and local offsets
+    TileRect r[kPerThread];
+    uint32_t c[kPerThread];
+    uint64_t mine = 0;
+    load_rects(rrect, first, m, r);
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        c[k] = first + k < m ? tiles_of(r[k]) : 0u;
+        mine += c[k];
+        srect[threadIdx.x * kPerThread + k] = r[k];
+        sgi[threadIdx.x * kPerThread + k] = first + k < m ? (order ? order[first + k] : first + k) : 0u;
+    }
+    uint64_t x = mine;  // inclusive scan over the wave, then over the workgroup
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t y = (uint64_t)__shfl_up((long long)x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    uint64_t run = x - mine;
+    for (int k = 0; k < w; ++k) run += wsum[k];
+    const uint64_t chunk_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // local offsets saturate at 2^32 - 1: whatever lies beyond is beyond the pair capacity anyway
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        offs[threadIdx.x * kPerThread + k] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
+        run += c[k];
+    }
+    if (threadIdx.x == kBlock - 1) offs[kChunk] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
+    __syncthreads();
+
+    if (last && threadIdx.x == 0) {
+        const uint64_t d = PREFIXED ? sums[nchunks] : base + chunk_total;
+        const int64_t nvis = ec.n_total - (ec.culled_dev ? (int64_t)*ec.culled_dev : 0);
+        ec.stats2[0] = nvis;
+        ec.stats2[1] = (int64_t)d;
+        if (ec.stats2_host) {
+            ec.stats2_host[0] = nvis;
+            ec.stats2_host[1] = (int64_t)d;
+        }
+        *ec.d32 = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d;
+    }
+
+    // ---- pair by pair: p-th pair of the chunk -> its Gaussian (largest rank with offs <= p) -> its tile
+    if (base >= (uint64_t)limit) return;   // speculative mode: the pair count exceeded the caller's hint
+    const uint64_t room = (uint64_t)limit - base;
+    const uint32_t npairs = (uint32_t)(chunk_total < room ? chunk_total : room);
+    const uint32_t out0 = (uint32_t)base;
+    const uint32_t nwy = (uint32_t)g.nwy();
+    constexpr int kIlp = 4;                    // four searches in flight per thread: LDS latency overlaps
+    for (uint32_t p0 = threadIdx.x; p0 < npairs; p0 += kBlock * kIlp) {
+        uint32_t lo[kIlp], hi[kIlp];
+#pragma unroll
+        for (int u = 0; u < kIlp; ++u) {
+            lo[u] = 0;                         // invariant: offs[lo] <= p < offs[hi]
+            hi[u] = kChunk;
+        }
+#pragma unroll
+        for (int s = 0; s < 10; ++s) {
+#pragma unroll
+            for (int u = 0; u < kIlp; ++u) {
+                const uint32_t p = min(p0 + (uint32_t)u * kBlock, npairs - 1u);
+                const uint32_t mid = (lo[u] + hi[u]) >> 1;
+                const bool right = offs[mid] <= p;
+                lo[u] = right ? mid : lo[u];
+                hi[u] = right ? hi[u] : mid;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kIlp; ++u) {
+            const uint32_t p = p0 + (uint32_t)u * kBlock;
+            if (p >= npairs) break;
+            const TileRect tr = srect[lo[u]];
+            const uint32_t k = p - offs[lo[u]];
+            const uint32_t h = (uint32_t)(tr.y1 - tr.y0 + 1);
+            const uint32_t tx = tr.x0 + k / h, ty = tr.y0 + k % h;
+            keys[out0 + p] = (Key)((tx - (uint32_t)g.wx0) * nwy + (ty - (uint32_t)g.wy0));
+            vals[out0 + p] = sgi[lo[u]];
+        }
     }
 }
 
 // ranges[t] = [first, last+1) of tile t inside the tile-sorted pair list; untouched (zeroed by
-// the caller) for tiles with no entries.
+// the emit kernel) for tiles with no entries.  8 consecutive keys per thread.
 // The grid covers the workspace capacity; the true pair count is read from device memory.
 template <typename Key>
 __global__ void __launch_bounds__(kBlock)
     tile_ranges_kernel(const Key *__restrict__ keys, const uint32_t *__restrict__ d_dev, uint32_t cap,
                        uint2 *__restrict__ ranges) {
+    constexpr int kPer = 8;
     const uint32_t d = min(*d_dev, cap);
-    const uint32_t j = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
-    if (j >= d) return;
-    const Key t = keys[j];
-    if (j == 0 || keys[j - 1] != t) ranges[t].x = j;
-    if (j == d - 1 || keys[j + 1] != t) ranges[t].y = j + 1;
+    const uint32_t j0 = (blockIdx.x * (uint32_t)kBlock + threadIdx.x) * kPer;
+    if (j0 >= d) return;
+    Key k[kPer + 1];                 // k[0] = the key before this thread's run
+    k[0] = j0 > 0 ? keys[j0 - 1] : (Key)0;
+    const uint32_t cnt = min((uint32_t)kPer, d - j0);
+    if (cnt == kPer && sizeof(Key) == 2) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(keys + j0);
+        const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            k[1 + 2 * e] = (Key)(w4[e] & 0xFFFFu);
+            k[2 + 2 * e] = (Key)(w4[e] >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) k[1 + e] = (uint32_t)e < cnt ? keys[j0 + e] : (Key)0;
+    }
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) {
+        if ((uint32_t)e >= cnt) break;
+        const uint32_t j = j0 + e;
+        if (j == 0 || k[e] != k[e + 1]) {
+            ranges[k[e + 1]].x = j;
+            if (j > 0) ranges[k[e]].y = j;
+        }
+        if (j == d - 1) ranges[k[e + 1]].y = d;
+    }
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
 
-// Exclusive scan of the tile counts in depth-rank order, reduce-then-scan in two launches:
-//   1. every workgroup gathers counts[order[r]] for its 2048 ranks (the only random access),
-//      parks them in offsets[r] and stores their sum in block_sums[b];
-//   2. every workgroup adds up the block sums before it (at most a few thousand values) and
-//      scans its own 2048 parked counts in place; the last one also stores the grand total D at
-//      offsets[n].
-constexpr int kScanItems = 8;
-constexpr int kScanChunk = kBlock * kScanItems;
-
-__device__ __forceinline__ uint32_t count_at(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ order,
-                                             int64_t r, int64_t n) {
-    return r < n ? counts[order ? order[r] : (uint32_t)r] : 0u;
-}
-
-__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *wsum) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_down((int)v, o);
-    if (lane == 0) wsum[w] = v;
-    __syncthreads();
-    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-    return total;
-}
-
-// sorted_keys (may be null): the depth keys in rank order; the number of visible Gaussians is
-// where the culled keys start -- one writer, no atomics (a shared counter costs ~12 ns per
-// wave-level atomic, 180 us at N = 1M).
-__global__ void __launch_bounds__(kBlock)
-    scan_block_sums_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ order,
-                           const uint32_t *__restrict__ sorted_keys, int64_t n, uint32_t *__restrict__ block_sums,
-                           uint32_t *__restrict__ offsets, uint32_t *__restrict__ n_visible) {
-    __shared__ uint32_t wsum[4];
-    const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanItems;
-    if (sorted_keys && n == 0 && base == 0) *n_visible = 0u;   // no key to find the boundary at
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        const int64_t r = base + k;
-        const uint32_t c = count_at(counts, order, r, n);
-        if (r <= n) offsets[r] = c;
-        v += c;
-        if (sorted_keys && r < n) {
-            const bool vis = sorted_keys[r] != kCulledKey;
-            if (r == 0 && !vis) *n_visible = 0u;
-            if (vis && (r == n - 1 || sorted_keys[r + 1] == kCulledKey)) *n_visible = (uint32_t)(r + 1);
-        }
-    }
-    const uint32_t total = block_sum(v, wsum);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-// counts2[0] = n_visible, counts2[1] = D as int64: the first two fields of a GsxFrameStats.
-__global__ void __launch_bounds__(kBlock)
-    scan_apply_kernel(int64_t n, const uint32_t *__restrict__ block_sums, uint32_t *__restrict__ offsets,
-                      const uint32_t *__restrict__ n_visible, int64_t n_visible_known,
-                      int64_t *__restrict__ counts2) {
-    __shared__ uint32_t wsum[4];
-    __shared__ uint64_t wide[kBlock];
-    uint32_t before = 0;
-    uint64_t before64 = 0;  // the 32-bit offsets wrap beyond 2^32 pairs; the reported total must not
-    for (uint32_t k = threadIdx.x; k < blockIdx.x; k += kBlock) {
-        before += block_sums[k];
-        before64 += block_sums[k];
-    }
-    const bool last = blockIdx.x == gridDim.x - 1;  // holds r == n
-    if (last) {
-        wide[threadIdx.x] = before64;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t t = 0;
-            for (int k = 0; k < kBlock; ++k) t += wide[k];
-            wide[0] = t;
-        }
-        __syncthreads();
-        before64 = wide[0];
-    }
-    before = block_sum(before, wsum);
-    const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanItems;
-    uint32_t c[kScanItems], mine = 0;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        c[k] = base + k <= n ? offsets[base + k] : 0u;
-        mine += c[k];
-    }
-    // exclusive scan of `mine` over the workgroup
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t x = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)x, o);
-        if (lane >= o) x += y;
-    }
-    if (lane == 63) wsum[w] = x;
-    __syncthreads();
-    uint32_t run = before + x - mine;
-    for (int k = 0; k < w; ++k) run += wsum[k];
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        if (base + k <= n) offsets[base + k] = run;   // r == n receives the grand total
-        if (base + k == n) {
-            counts2[0] = n_visible_known >= 0 ? n_visible_known : (int64_t)*n_visible;
-            counts2[1] = (int64_t)(before64 + (uint64_t)(run - before));   // = run while D < 2^32
-        }
-        run += c[k];
-    }
-}
-
 size_t binning_temp_bytes(int64_t n, int64_t cap) {
-    const size_t scan = ((size_t)(n + 1 + kScanChunk - 1) / kScanChunk + 1) * sizeof(uint32_t);
-    const size_t r = radix_temp_bytes(n > cap ? n : cap);
-    const size_t m = scan > r ? scan : r;
-    return (m + 255) & ~(size_t)255;
+    const size_t nchunks = (size_t)((n + kChunk - 1) / kChunk) + 2;
+    // two regions: [radix digit table for max(n, cap) items] [chunk sums]
+    const size_t r = (radix_temp_bytes(n > cap ? n : cap) + 255) & ~(size_t)255;
+    return r + ((nchunks * sizeof(uint64_t) + 255) & ~(size_t)255);
 }
 
-hipError_t sort_by_depth(void *temp, size_t temp_bytes, uint32_t *&keys_cur, uint32_t *&keys_alt, uint32_t *&vals_cur,
-                         uint32_t *&vals_alt, int64_t n, hipStream_t s) {
-    (void)temp_bytes;
-    if (n == 0) return hipSuccess;
-    return radix_sort_pairs_u32(temp, keys_cur, keys_alt, vals_cur, vals_alt, nullptr, n, 32, s);
+static uint64_t *sums_of(void *temp, int64_t n, int64_t cap) {
+    const size_t r = (radix_temp_bytes(n > cap ? n : cap) + 255) & ~(size_t)255;
+    return (uint64_t *)((char *)temp + r);
 }
 
-hipError_t scan_counts(void *temp, size_t temp_bytes, const uint32_t *counts, const uint32_t *order,
-                       const uint32_t *sorted_keys, uint32_t *offsets, int64_t n, uint32_t *n_visible,
-                       int64_t n_visible_known, int64_t *counts2, hipStream_t s) {
-    (void)temp_bytes;
-    const unsigned nb = (unsigned)((n + 1 + kScanChunk - 1) / kScanChunk);
-    uint32_t *block_sums = (uint32_t *)temp;
-    scan_block_sums_kernel<<<nb, kBlock, 0, s>>>(counts, order, sorted_keys, n, block_sums, offsets, n_visible);
-    scan_apply_kernel<<<nb, kBlock, 0, s>>>(n, block_sums, offsets, n_visible, n_visible_known, counts2);
+// (tile id, Gaussian index) pairs in rank order.  Tile ids fit 16 bits for any frame up to 65536 tiles
+// (4K has 32 026), which halves the key traffic of the sort; larger frames use 32-bit ids.
+// keys0 / vals0 hold `cap` 32-bit words each; the pair count D stays on the device (*bc.d32), pairs
+// beyond `cap` are dropped (the caller compares D with cap afterwards).
+template <typename Key>
+hipError_t emit_impl(void *temp, const TileRect *rrect, const uint32_t *order, const uint32_t *m_dev, int64_t n,
+                     int64_t cap, const TileGrid &grid, void *keys0, uint32_t *vals0, uint2 *ranges, const BinCounts &bc,
+                     hipStream_t s) {
+    const int64_t nt = grid.count();
+    const int nchunks = (int)((n + kChunk - 1) / kChunk);
+    uint64_t *sums = sums_of(temp, n, cap);
+    chunk_sums_kernel<<<nchunks, kBlock, 0, s>>>(rrect, m_dev, (uint32_t)n, sums);
+    const EmitCounts ec{bc.stats2, bc.stats2_host, bc.d32, bc.culled_dev, bc.n_total};
+    const unsigned tiles_grid = blocks_for(nt);
+    const unsigned egrid = (unsigned)nchunks > tiles_grid ? (unsigned)nchunks : tiles_grid;
+    if (nchunks <= kSelfScanChunks) {
+        emit_kernel<Key, false><<<egrid, kBlock, 0, s>>>(rrect, order, m_dev, (uint32_t)n, sums, nchunks, grid,
+                                                         (uint32_t)cap, (Key *)keys0, vals0, ranges, ec);
+    } else {
+        scan_sums_kernel<<<1, kBlock, 0, s>>>(sums, nchunks);
+        emit_kernel<Key, true><<<egrid, kBlock, 0, s>>>(rrect, order, m_dev, (uint32_t)n, sums, nchunks, grid,
+                                                        (uint32_t)cap, (Key *)keys0, vals0, ranges, ec);
+    }
     return hipGetLastError();
 }
 
-// Emit (tile id, Gaussian index) pairs in rank order, sort them stably by tile id and derive
-// every tile's [first, last) range.  Tile ids fit 16 bits for any frame up to 65536 tiles (4K has
-// 32 026), which halves the key traffic of the sort; larger frames use 32-bit ids.
-// keys0 / keys1 / vals0 / vals1 each hold `cap` 32-bit words; the pair count D = offsets[n] stays
-// on the device, pairs beyond `cap` are dropped (the caller compares D with cap afterwards).
+// Stable sort of the pairs by tile id + every tile's [first, last) range.
 template <typename Key>
-hipError_t bin_impl(void *temp, const TileRect *rect, const uint32_t *order, const uint32_t *offsets, int64_t n,
-                    int64_t cap, const TileGrid &grid, void *keys0, void *keys1, uint32_t *vals0, uint32_t *vals1,
-                    uint2 *ranges, int key_bits, const uint32_t **sorted_vals, hipStream_t s) {
+hipError_t sort_impl(void *temp, int64_t cap, void *keys0, void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges,
+                     int key_bits, const uint32_t *d32, const uint32_t **sorted_vals, hipStream_t s) {
     Key *kc = (Key *)keys0, *ka = (Key *)keys1;
     uint32_t *vc = vals0, *va = vals1;
-    const uint32_t *d_dev = offsets + n;
-    const int64_t nt = grid.count();
-    emit_kernel<Key><<<blocks_for(n > nt ? n : nt), kBlock, 0, s>>>(rect, order, offsets, n, grid, (uint32_t)cap, kc,
-                                                                     vc, ranges);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    hipError_t e;
     if (sizeof(Key) == 2)
-        e = radix_sort_pairs_u16(temp, (uint16_t *&)kc, (uint16_t *&)ka, vc, va, d_dev, cap, key_bits, s);
+        e = radix_sort_pairs_u16(temp, (uint16_t *&)kc, (uint16_t *&)ka, vc, va, d32, cap, key_bits, s);
     else
-        e = radix_sort_pairs_u32(temp, (uint32_t *&)kc, (uint32_t *&)ka, vc, va, d_dev, cap, key_bits, s);
+        e = radix_sort_pairs_u32(temp, (uint32_t *&)kc, (uint32_t *&)ka, vc, va, d32, cap, key_bits, s);
     if (e != hipSuccess) return e;
-    tile_ranges_kernel<Key><<<blocks_for(cap), kBlock, 0, s>>>(kc, d_dev, (uint32_t)cap, ranges);
+    tile_ranges_kernel<Key><<<blocks_for((cap + 7) / 8), kBlock, 0, s>>>(kc, d32, (uint32_t)cap, ranges);
     *sorted_vals = vc;
     return hipGetLastError();
 }
 
-hipError_t bin_instances(void *temp, size_t temp_bytes, const TileRect *rect, const uint32_t *order,
-                         const uint32_t *offsets, int64_t n, int64_t cap, const TileGrid &grid, void *keys0,
-                         void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges, const uint32_t **sorted_vals,
-                         hipStream_t s) {
-    (void)temp_bytes;
-    const int64_t nt = grid.count();
+hipError_t emit_instances(void *temp, const TileRect *rrect, const uint32_t *order, const uint32_t *m_dev, int64_t n,
+                          int64_t cap, const TileGrid &grid, void *keys0, uint32_t *vals0, uint2 *ranges,
+                          const BinCounts &bc, hipStream_t s) {
+    if (n <= 0) return hipErrorInvalidValue;   // callers handle the empty scene themselves
+    if (grid.count() <= 65536) return emit_impl<uint16_t>(temp, rrect, order, m_dev, n, cap, grid, keys0, vals0, ranges, bc, s);
+    return emit_impl<uint32_t>(temp, rrect, order, m_dev, n, cap, grid, keys0, vals0, ranges, bc, s);
+}
+
+hipError_t sort_instances(void *temp, int64_t cap, const TileGrid &grid, void *keys0, void *keys1, uint32_t *vals0,
+                          uint32_t *vals1, uint2 *ranges, const uint32_t *d32, const uint32_t **sorted_vals,
+                          hipStream_t s) {
     *sorted_vals = vals0;
-    if (cap == 0 || n == 0) return hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)nt, s);
+    if (cap <= 0) return hipSuccess;           // nothing fits: every range stays empty
+    const int64_t nt = grid.count();
     int bits = 1;
     while (((int64_t)1 << bits) < nt) ++bits;
-    if (nt <= 65536)
-        return bin_impl<uint16_t>(temp, rect, order, offsets, n, cap, grid, keys0, keys1, vals0, vals1, ranges, bits,
-                                  sorted_vals, s);
-    return bin_impl<uint32_t>(temp, rect, order, offsets, n, cap, grid, keys0, keys1, vals0, vals1, ranges, bits,
-                              sorted_vals, s);
+    if (nt <= 65536) return sort_impl<uint16_t>(temp, cap, keys0, keys1, vals0, vals1, ranges, bits, d32, sorted_vals, s);
+    return sort_impl<uint32_t>(temp, cap, keys0, keys1, vals0, vals1, ranges, bits, d32, sorted_vals, s);
 }
 
 }  // namespace gsx

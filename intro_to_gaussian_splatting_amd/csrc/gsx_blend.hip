@@ -52,6 +52,31 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
     return start + i;
 }
 
+// Pixels of the output buffer that no tile of the window covers are zeroed by extra workgroups of the
+// compositing launch itself (blockIdx >= number of tiles): no memset nodes on the frame path -- they cost
+// a 5 us dispatch each, and a hipGraph memset node replayed on another stream than the one it was
+// captured on left the border untouched on ROCm 7.2 (tools/debug_border.py).
+constexpr int kClearFloats = 6144;   // floats zeroed per extra workgroup
+
+__device__ __forceinline__ void clear_block(uint32_t cb, const ClearPlan &cp, float *__restrict__ base) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) i = (k < cp.n && cb >= (uint32_t)cp.first[k]) ? k : i;
+    const uint32_t per_row = (uint32_t)cp.fw[i] * 3u;
+    const uint32_t total = (uint32_t)cp.rows[i] * per_row;
+    const uint32_t e0 = (cb - (uint32_t)cp.first[i]) * (uint32_t)kClearFloats;
+    const uint32_t e1 = min(total, e0 + (uint32_t)kClearFloats);
+    float *origin = base + (int64_t)cp.s0[i] * cp.pitch + (int64_t)cp.f0[i] * 3;
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += 64) {
+        const uint32_t row = e / per_row, col = e - row * per_row;
+        origin[(int64_t)row * cp.pitch + col] = 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(64) clear_kernel(ClearPlan cp, float *__restrict__ base) {
+    clear_block(blockIdx.x, cp, base);
+}
+
 struct Splat {  // one record, unpacked (wave-uniform values); lop = log2(opacity factor)
     float mx, my, q00, qs, q11, lop, cr, cg, cb;
 };
@@ -79,15 +104,21 @@ __device__ __forceinline__ void composite(float e_s, const float (&e_p)[NPX], fl
         ta[j] = T[j] * alpha;
         test[j] = T[j] - ta[j];
     }
-    float m = test[0];
+    float m = test[0], tmin = T[0];
 #pragma unroll
-    for (int j = 1; j < NPX; ++j) m = fminf(m, test[j]);
-    if (__builtin_expect(__any(m < kStopRefCpu), 0)) {
+    for (int j = 1; j < NPX; ++j) {
+        m = fminf(m, test[j]);
+        tmin = fminf(tmin, T[j]);   // fminf drops a NaN test: a stopped pixel is found through its T
+    }
+    if (__builtin_expect(__any((m < kStopRefCpu) | (tmin == 0.0f)), 0)) {
         // some pixel of the wave saturates here (or already has, T = 0): it must not receive
-        // this Gaussian and stays at T = 0, like the reference's early return.
+        // this Gaussian and stays at T = 0, like the reference's early return.  T == 0 is tested on
+        // its own: a stopped pixel meeting a non-finite alpha would otherwise compute 0 * inf = NaN,
+        // fail `NaN < threshold` and turn NaN, where the reference has already returned
+        // (gaussian_scene.py:166-167; a live pixel never has T == 0, its T stays >= 1e-6).
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
-            const bool stop = test[j] < kStopRefCpu;
+            const bool stop = (T[j] == 0.0f) | (test[j] < kStopRefCpu);
             ta[j] = stop ? 0.0f : ta[j];
             test[j] = stop ? 0.0f : test[j];
         }
@@ -136,11 +167,12 @@ __device__ __forceinline__ void alphas(float4 A, float q11, float lop, float cx,
     } while (0)
 
 // Exact saturation rule for one pixel pair (the rare path): a pixel whose T(1-alpha) drops below
-// the threshold does not receive this Gaussian and stays at T = 0.
+// the threshold does not receive this Gaussian and stays at T = 0; a pixel that has stopped (T == 0)
+// stays stopped whatever alpha is (0 * inf = NaN must not revive it, see composite<>).
 __device__ __forceinline__ void checked_pair(v2f alpha, v2f &T, v2f &ta) {
     ta = T * alpha;
     v2f t = T - ta;
-    const bool s0 = t.x < kStopRefCpu, s1 = t.y < kStopRefCpu;
+    const bool s0 = (T.x == 0.0f) | (t.x < kStopRefCpu), s1 = (T.y == 0.0f) | (t.y < kStopRefCpu);
     ta.x = s0 ? 0.0f : ta.x;
     ta.y = s1 ? 0.0f : ta.y;
     t.x = s0 ? 0.0f : t.x;
@@ -161,8 +193,12 @@ __device__ __forceinline__ float min4(v2f a, v2f b) { return fminf(fminf(a.x, a.
 template <int VARIANT>
 __global__ void __launch_bounds__(64)
     blend_tile16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
-                        const uint2 *__restrict__ ranges, TileGrid g, OutDesc out) {
+                        const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp) {
     __shared__ float4 sh[3][64];
+    if (blockIdx.x >= (uint32_t)g.count()) {
+        clear_block(blockIdx.x - (uint32_t)g.count(), cp, out.ptr);
+        return;
+    }
     const int lane = threadIdx.x;
     const uint32_t t = xcd_remap(blockIdx.x, (uint32_t)g.count());
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
@@ -275,8 +311,12 @@ __global__ void __launch_bounds__(64)
 // reference (its notebooks use 16 and 2).
 __global__ void __launch_bounds__(64)
     blend_generic_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
-                         const uint2 *__restrict__ ranges, TileGrid g, OutDesc out) {
+                         const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp) {
     __shared__ float4 sh[3][64];
+    if (blockIdx.x >= (uint32_t)g.count()) {
+        clear_block(blockIdx.x - (uint32_t)g.count(), cp, out.ptr);
+        return;
+    }
     const int lane = threadIdx.x;
     const uint32_t t = xcd_remap(blockIdx.x, (uint32_t)g.count());
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
@@ -348,8 +388,12 @@ template <int SEM>
 __global__ void __launch_bounds__(64)
     blend_rules_kernel(const Record *__restrict__ rec, const float4 *__restrict__ bbox,
                        const uint32_t *__restrict__ vals, const uint2 *__restrict__ ranges, TileGrid g,
-                       OutDesc out, float bg0, float bg1, float bg2) {
+                       OutDesc out, float bg0, float bg1, float bg2, ClearPlan cp) {
     __shared__ float4 sh[4][64];
+    if (blockIdx.x >= (uint32_t)g.count()) {
+        clear_block(blockIdx.x - (uint32_t)g.count(), cp, out.ptr);
+        return;
+    }
     const int lane = threadIdx.x;
     const uint32_t t = xcd_remap(blockIdx.x, (uint32_t)g.count());
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
@@ -429,8 +473,12 @@ __global__ void __launch_bounds__(64)
 // give bit-identical frames (tested).  Pixels outside the frame (partial edge tiles) start dead.
 __global__ void __launch_bounds__(64)
     blend_std16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
-                       const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, float bg0, float bg1, float bg2) {
+                       const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, float bg0, float bg1, float bg2, ClearPlan cp) {
     __shared__ float4 sh[3][64];
+    if (blockIdx.x >= (uint32_t)g.count()) {
+        clear_block(blockIdx.x - (uint32_t)g.count(), cp, out.ptr);
+        return;
+    }
     const int lane = threadIdx.x;
     const uint32_t t = xcd_remap(blockIdx.x, (uint32_t)g.count());
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
@@ -500,24 +548,46 @@ __global__ void __launch_bounds__(64)
 
 }  // namespace
 
+__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t *__restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+hipError_t launch_zero_words(uint32_t *p, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    zero_words_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s) {
+    if (cp.n <= 0 || cp.first[cp.n] <= 0) return hipSuccess;
+    clear_kernel<<<(unsigned)cp.first[cp.n], 64, 0, s>>>(cp, base);
+    return hipGetLastError();
+}
+
+int clear_blocks_for(int64_t rows, int64_t fw) {
+    const int64_t floats = rows * fw * 3;
+    return (int)((floats + kClearFloats - 1) / kClearFloats);
+}
+
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
-                        bool generic, hipStream_t s) {
+                        bool generic, const ClearPlan &cp, hipStream_t s) {
     const int64_t nt = grid.count();
-    if (nt <= 0) return hipSuccess;
+    if (nt <= 0) return launch_clear(cp, out.ptr, s);
+    const unsigned nb = (unsigned)nt + (unsigned)(cp.n > 0 ? cp.first[cp.n] : 0);
     if (semantics == GSX_SEM_REF_CUDA) {
-        blend_rules_kernel<GSX_SEM_REF_CUDA><<<(unsigned)nt, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out,
-                                                                        0.0f, 0.0f, 0.0f);
+        blend_rules_kernel<GSX_SEM_REF_CUDA><<<nb, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, 0.0f, 0.0f, 0.0f, cp);
         return hipGetLastError();
     }
     if (semantics == GSX_SEM_STD_3DGS) {
         if (grid.tile == 16 && !generic) {
-            blend_std16_kernel<<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, background[0],
-                                                           background[1], background[2]);
+            blend_std16_kernel<<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, background[0], background[1],
+                                                 background[2], cp);
             return hipGetLastError();
         }
-        blend_rules_kernel<GSX_SEM_STD_3DGS><<<(unsigned)nt, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out,
-                                                                        background[0], background[1], background[2]);
+        blend_rules_kernel<GSX_SEM_STD_3DGS><<<nb, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, background[0],
+                                                              background[1], background[2], cp);
         return hipGetLastError();
     }
     if (semantics != GSX_SEM_REF_CPU) return hipErrorNotSupported;
@@ -528,11 +598,11 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             return e ? atoi(e) : 1;
         }();
         if (variant == 0)
-            blend_tile16_kernel<0><<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out);
+            blend_tile16_kernel<0><<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp);
         else
-            blend_tile16_kernel<1><<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out);
+            blend_tile16_kernel<1><<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp);
     } else {
-        blend_generic_kernel<<<(unsigned)nt, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out);
+        blend_generic_kernel<<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp);
     }
     return hipGetLastError();
 }

@@ -9,6 +9,8 @@
 namespace gsx {
 
 constexpr uint32_t kCulledKey = 0xFFFFFFFFu;  // depth key of a Gaussian behind the z >= 0.2 plane
+constexpr uint32_t kEmptyKey = 0xFFFFFFFEu;   // visible, but it reaches no tile of the window; keys >= this are
+                                              // dropped by the first pass of the depth sort
 
 // Stage-1 -> stage-2 record, 48 B, three 16-B loads, indexed by the Gaussian's index (original
 // index on the whole-path entry, row index on the stage-2 entry).  With Q'' = Q * (-1/2 log2 e):
@@ -41,6 +43,16 @@ struct OutDesc {
     int32_t x0, y0, w, h;        // frame pixel of out(0,0) and the buffer extent in pixels
 };
 
+// Up to four rectangles of the output buffer that a frame zeroes (everything no rendered tile covers), in
+// buffer-local pixels along the (slow, fast) memory axes; first[i] = first clear workgroup of rectangle i,
+// first[n] = their total.  pitch: floats per slow-axis step.
+struct ClearPlan {
+    int32_t n;
+    int32_t first[5];
+    int32_t s0[4], f0[4], rows[4], fw[4];
+    int64_t pitch;
+};
+
 struct StageOneOut {  // PreprocessedScene arrays (splat/schema.py:13-25), depth-sorted
     float *points_xy, *colors, *cov2d, *depths, *inv_cov, *radius, *min_x, *max_x, *min_y, *max_y, *sig_op;
     int32_t *order;
@@ -58,45 +70,49 @@ struct PreprocessedIn {  // argument list of splat/c/render.cu:90-101
 hipError_t launch_depth_keys(const GsxCamera &cam, const float *means3d, int64_t n, uint32_t *keys,
                              uint32_t *vals, hipStream_t s);
 hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t *n_visible, hipStream_t s);
-// Original order: depth keys + identity values for the sort, records / rects / counts indexed by
-// the ORIGINAL Gaussian index.
+// Original order: depth keys (kCulledKey behind the cull plane, kEmptyKey when no tile of the window is
+// reached) + identity values for the sort, records / rects indexed by the ORIGINAL Gaussian index.
 // bbox (REF_CUDA only, else may be null): (min_x, max_x, min_y, max_y) per Gaussian for the
 // per-pixel cull of splat/c/render.cu:55-60.
 // tight_rects: GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS (see include/gsx.h).
 // cam_device (may be null): GsxParams.camera_device, read by the kernel instead of `cam`.
+// counters: 4 words this kernel zeroes for the depth sort (culled count, kept count, ...).
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys, uint32_t *vals,
-                               Record *rec, TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s);
+                               Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s);
 hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
                                const uint32_t *sorted_idx, int64_t n, const StageOneOut &out, hipStream_t s);
 hipError_t launch_pack_preprocessed(const PreprocessedIn &in, int64_t n, const TileGrid &grid, int semantics,
-                                    Record *rec, TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s);
+                                    Record *rec, TileRect *rect, float4 *bbox, hipStream_t s);
 hipError_t launch_covariance3d(const float *scales, const float *quats, int64_t n, float *out, hipStream_t s);
+hipError_t launch_covariance2d(const GsxCamera &cam, const float *points, const float *cov3d, int64_t n, float *out,
+                               hipStream_t s);
 hipError_t launch_project_points(const GsxCamera &cam, const float *means3d, int64_t n, float *points_out,
                                  uint8_t *in_view, hipStream_t s);
 
 // ---- gsx_binning.hip
 size_t binning_temp_bytes(int64_t n, int64_t cap);
-// Stable radix sort of (depth key, index) pairs, all 32 key bits.  The two buffers of each pair
-// are ping-ponged; on return keys_cur / vals_cur point at the sorted data.
-hipError_t sort_by_depth(void *temp, size_t temp_bytes, uint32_t *&keys_cur, uint32_t *&keys_alt, uint32_t *&vals_cur,
-                         uint32_t *&vals_alt, int64_t n, hipStream_t s);
-// offsets[r] = sum over ranks r' < r of counts[order[r']] for r in [0, n]; order == nullptr means
-// the identity (rows already in compositing order).  Also delivers the frame counts on the device:
-// counts2[0] = visible Gaussians (first culled key of sorted_keys, or n_visible_known when >= 0),
-// counts2[1] = offsets[n] = D, as int64 (the first two fields of a GsxFrameStats).
-hipError_t scan_counts(void *temp, size_t temp_bytes, const uint32_t *counts, const uint32_t *order,
-                       const uint32_t *sorted_keys, uint32_t *offsets, int64_t n, uint32_t *n_visible,
-                       int64_t n_visible_known, int64_t *counts2, hipStream_t s);
-// Emits one (tile id, Gaussian index) pair per covered tile in rank order, stable-sorts them by
-// tile id and fills ranges[t] = [first, last) for every tile of the window.  keys0/keys1/vals0/
-// vals1 hold cap 32-bit words each; *sorted_vals points at the sorted Gaussian indices.  The pair
-// count D = offsets[n] is only read on the device; pairs beyond cap are dropped.
-hipError_t bin_instances(void *temp, size_t temp_bytes, const TileRect *rect, const uint32_t *order,
-                         const uint32_t *offsets, int64_t n, int64_t cap, const TileGrid &grid, void *keys0,
-                         void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges, const uint32_t **sorted_vals,
-                         hipStream_t s);
-// ---- gsx_sort.hip: stable LSD radix sort, 8-bit digits, key bits [0, key_bits).  The element
+// Where a frame's counts go on the device (and, optionally, straight into pinned host memory).
+struct BinCounts {
+    int64_t *stats2;             // [0] = visible Gaussians, [1] = D: the first two fields of a GsxFrameStats
+    int64_t *stats2_host;        // device-visible alias of a pinned GsxFrameStats, or null
+    uint32_t *d32;               // min(D, 2^32 - 1): element count of the tile sort
+    const uint32_t *culled_dev;  // Gaussians behind the cull plane (counted by the depth sort), or null
+    int64_t n_total;             // n_visible = n_total - *culled_dev
+};
+// One (tile id, Gaussian index) pair per covered tile, in rank order, from the rank-ordered tile
+// rectangles rrect[0 .. m) (m = min(*m_dev, n); m_dev == nullptr: n).  order[r] = Gaussian index of rank
+// r (nullptr: the identity).  Also zeroes ranges[] and delivers the frame's counts (bc).  keys0 / vals0
+// hold cap 32-bit words each; pairs beyond cap are dropped.
+hipError_t emit_instances(void *temp, const TileRect *rrect, const uint32_t *order, const uint32_t *m_dev, int64_t n,
+                          int64_t cap, const TileGrid &grid, void *keys0, uint32_t *vals0, uint2 *ranges,
+                          const BinCounts &bc, hipStream_t s);
+// Stable sort of the emitted pairs by tile id and ranges[t] = [first, last) for every tile of the
+// window; *sorted_vals points at the sorted Gaussian indices.  The pair count is read from *d32.
+hipError_t sort_instances(void *temp, int64_t cap, const TileGrid &grid, void *keys0, void *keys1, uint32_t *vals0,
+                          uint32_t *vals1, uint2 *ranges, const uint32_t *d32, const uint32_t **sorted_vals,
+                          hipStream_t s);
+// ---- gsx_sort.hip: stable LSD radix sort, up to 8 bits per pass, key bits [0, key_bits).  The element
 // count is min(*n_dev, bound) (n_dev == nullptr: bound); grids are sized by `bound`.  Buffers
 // ping-pong; on return keys_cur / vals_cur point at the sorted data.  temp: radix_temp_bytes(bound).
 size_t radix_temp_bytes(int64_t max_items);
@@ -106,6 +122,13 @@ hipError_t radix_sort_pairs_u32(void *temp, uint32_t *&keys_cur, uint32_t *&keys
 hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys_alt, uint32_t *&vals_cur,
                                 uint32_t *&vals_alt, const uint32_t *n_dev, int64_t bound, int key_bits,
                                 hipStream_t s);
+// Depth sort of the whole-path entry point: all 32 key bits, dropping keys >= kEmptyKey in the first
+// pass (*m_dev = Gaussians kept, *culled_dev += keys == kCulledKey; culled_dev must hold 0 when the
+// first kernel runs) and gathering rect[index] into rrect[rank] in the last one.  On return
+// vals_cur[0 .. *m_dev) = Gaussian index of each depth rank (ties: original index).
+hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
+                              int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
+                              hipStream_t s);
 
 // ---- gsx_sh.hip
 hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, int64_t n, const float *center,
@@ -113,8 +136,12 @@ hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, i
 
 // ---- gsx_blend.hip
 // background: 3 floats, read on the host (GSX_SEM_STD_3DGS only); generic: GSX_FLAG_GENERIC_KERNELS.
+// cp: what the launch zeroes besides compositing its tiles (extra workgroups of the same kernel).
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
-                        bool generic, hipStream_t s);
+                        bool generic, const ClearPlan &cp, hipStream_t s);
+hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s);   // the zero fill alone
+hipError_t launch_zero_words(uint32_t *p, size_t n, hipStream_t s);
+int clear_blocks_for(int64_t rows, int64_t fw);                              // workgroups for rows x fw pixels
 
 }  // namespace gsx

@@ -336,8 +336,9 @@ __global__ void __launch_bounds__(kBlock)
     project_pack_kernel(GsxCamera cam_arg, const GsxCamera *__restrict__ cam_dev, GaussiansIn in, int64_t n,
                         TileGrid grid, int semantics, bool tight,
                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, Record *__restrict__ rec,
-                        TileRect *__restrict__ rect, uint32_t *__restrict__ counts, float4 *__restrict__ bbox) {
+                        TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox) {
     int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g < 4) counters[g] = 0u;   // the depth sort's culled / kept counts start from zero (no memset node)
     if (g >= n) return;
     // GsxParams.camera_device: the constants as they are in device memory now (uniform scalar loads)
     const GsxCamera &cam = DEVICE_CAMERA ? *cam_dev : cam_arg;
@@ -351,10 +352,8 @@ __global__ void __launch_bounds__(kBlock)
         e.x0 = 1; e.x1 = 0; e.y0 = 1; e.y1 = 0;
         keys[g] = kCulledKey;
         rect[g] = e;
-        counts[g] = 0u;
         return;
     }
-    keys[g] = __float_as_uint(tz);
     const float *s = in.scales + 3 * g, *q = in.quats + 4 * g, *c = in.colors + 3 * g;
     Projected o;
     bool keep = true;
@@ -394,7 +393,8 @@ __global__ void __launch_bounds__(kBlock)
         tr.x0 = 1; tr.x1 = 0; tr.y0 = 1; tr.y1 = 0;
         cnt = 0u;
     }
-    counts[g] = cnt;
+    // a Gaussian that reaches no tile of the window needs no depth rank: the sort drops it in its first pass
+    keys[g] = cnt ? __float_as_uint(tz) : kEmptyKey;
     rect[g] = tr;
 }
 
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(kBlock)
 // Stage-1 arrays handed in by the caller (the reference's native argument list) -> records.
 __global__ void __launch_bounds__(kBlock)
     pack_preprocessed_kernel(PreprocessedIn in, int64_t n, TileGrid grid, int semantics, Record *__restrict__ rec,
-                             TileRect *__restrict__ rect, uint32_t *__restrict__ counts, float4 *__restrict__ bbox) {
+                             TileRect *__restrict__ rect, float4 *__restrict__ bbox) {
     int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
     float op = in.opacity[r];
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(kBlock)
     rec[r] = out;
     if (bbox) bbox[r] = make_float4(mnx, mxx, mny, mxy);
     TileRect tr;
-    counts[r] = tile_rect(mnx, mxx, mny, mxy, grid, semantics, tr);
+    tile_rect(mnx, mxx, mny, mxy, grid, semantics, tr);
     rect[r] = tr;
 }
 
@@ -474,9 +474,35 @@ __global__ void __launch_bounds__(kBlock)
         for (int b = 0; b < 3; ++b) out[9 * i + 3 * a + b] = S[a][b];
 }
 
+// GaussianScene.get_2d_covariance (splat/gaussian_scene.py:53-68 -> splat/utils.py:320-354) on caller-given
+// points and 3D covariances: no cull, every row is projected.
+__global__ void __launch_bounds__(kBlock)
+    covariance2d_kernel(GsxCamera cam, const float *__restrict__ points, const float *__restrict__ cov3d, int64_t n,
+                        float *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float p0 = points[3 * i], p1 = points[3 * i + 1], p2 = points[3 * i + 2];
+    const float tz = row4(p0, p1, p2, cam.world2view, 2);
+    float S[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) S[a][b] = cov3d[9 * i + 3 * a + b];
+    Projected o;
+    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o);
+    out[4 * i] = o.ca; out[4 * i + 1] = o.cb; out[4 * i + 2] = o.cc; out[4 * i + 3] = o.cd;
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
+
+hipError_t launch_covariance2d(const GsxCamera &cam, const float *points, const float *cov3d, int64_t n, float *out,
+                               hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    covariance2d_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, points, cov3d, n, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_covariance3d(const float *scales, const float *quats, int64_t n, float *out, hipStream_t s) {
     if (n == 0) return hipSuccess;
@@ -499,14 +525,14 @@ hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t
 
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys, uint32_t *vals,
-                               Record *rec, TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s) {
+                               Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (cam_device)
         project_pack_kernel<true><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics, tight_rects,
-                                                                   keys, vals, rec, rect, counts, bbox);
+                                                                   keys, vals, rec, rect, counters, bbox);
     else
         project_pack_kernel<false><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics,
-                                                                    tight_rects, keys, vals, rec, rect, counts, bbox);
+                                                                    tight_rects, keys, vals, rec, rect, counters, bbox);
     return hipGetLastError();
 }
 
@@ -518,9 +544,9 @@ hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, cons
 }
 
 hipError_t launch_pack_preprocessed(const PreprocessedIn &in, int64_t n, const TileGrid &grid, int semantics,
-                                    Record *rec, TileRect *rect, uint32_t *counts, float4 *bbox, hipStream_t s) {
+                                    Record *rec, TileRect *rect, float4 *bbox, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    pack_preprocessed_kernel<<<blocks_for(n), kBlock, 0, s>>>(in, n, grid, semantics, rec, rect, counts, bbox);
+    pack_preprocessed_kernel<<<blocks_for(n), kBlock, 0, s>>>(in, n, grid, semantics, rec, rect, bbox);
     return hipGetLastError();
 }
 

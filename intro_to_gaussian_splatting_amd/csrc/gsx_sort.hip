@@ -10,10 +10,11 @@
 //
 // This implementation is the classic three-kernel LSD pass (two kernels for small inputs, see
 // SELF_SCAN below), sized for these inputs:
-//   count    each workgroup histograms its 2048 (4096 beyond 8M items) consecutive items by the pass's 8-bit digit in LDS
-//            and stores table[digit][workgroup];
+//   count    each workgroup (1024 threads) histograms FOUR consecutive 2048-item chunks side by side by the
+//            pass's digit in LDS and stores table[digit][chunk .. chunk+3] as one 16-byte word per digit
+//            (round 1 stored 256 scattered 4-byte words per chunk: 9x write amplification at the memory side);
 //   scan     one workgroup per digit row turns its row into an exclusive prefix and records the
-//            row total;
+//            row total; every thread loads its 16 consecutive counts up front (one memory round trip);
 //   scatter  each workgroup re-reads its items, ranks them STABLY inside the workgroup (wave-level
 //            match by ballots, per-wave running digit counters in LDS, waves and rounds in item
 //            order), parks them in LDS in digit-major order, and streams them out: item j of the
@@ -23,21 +24,32 @@
 // No inter-workgroup communication inside a kernel (the hazards of MI355X's non-coherent per-XCD
 // L2s never arise), no fills, no host-side count: `n_dev` points at the element count in device
 // memory and the grid is sized by a host-known upper bound; workgroups past the count exit.
+//
+// Two pass modes exist for the depth sort of the whole-path entry point (sort_depth_compact):
+//   FIRST  pass 0 drops the Gaussians that reach no tile of the window (keys >= kEmptyKey): the
+//          sort compacts while it sorts, later passes and every rank-ordered stage after it only
+//          see the M Gaussians that matter (1/8 of them on a rank that owns 1/8 of the frame);
+//   FINAL  the last pass knows each Gaussian's final depth rank when it streams it out, and
+//          gathers its 8-byte tile rectangle into rank order on the way (the scan and the pair
+//          emission then read coalesced arrays; round 1 gathered counts and rectangles by index
+//          in two later kernels, 5-8x the algorithmic traffic); the sorted keys are not written.
 #include "gsx_internal.h"
 
 namespace gsx {
 namespace {
 
 constexpr int kThreads = 256;                      // 4 wavefronts
-constexpr int kBins = 256;                         // 8-bit digits
-// ROUNDS = items per lane; a workgroup owns ROUNDS * 256 consecutive items.  8 (2048 items) keeps
-// enough workgroups in flight at 1M items; 16 halves the digit table for inputs beyond 8M.
-constexpr int kSmallRounds = 8, kLargeRounds = 16;
-constexpr int64_t kLargeInput = 8 << 20;
-// Up to this many workgroups (131 072 items) a pass has no row-scan launch: measured one frame in flight,
-// 2 000 Gaussians 96 -> 85 us, 100 000 Gaussians 166 -> 161 us; beyond ~100 workgroups the
-// per-workgroup table walk costs more than the launch it saves (207 workgroups: +7 us per sort).
+constexpr int kBins = 256;                         // table rows; a pass uses the first 1 << bits of them
+constexpr int kRounds = 8;                         // items per lane
+constexpr int kItems = kThreads * kRounds;         // a chunk: 2048 consecutive items, one scatter workgroup
+constexpr int kQuad = 4;                           // chunks per count workgroup
+// Up to this many chunks (131 072 items) a pass has no row-scan launch: the count kernel writes the
+// table chunk-major and every scatter workgroup adds up the counts before its own chunk (measured
+// round 1, one frame in flight: 2 000 Gaussians 96 -> 85 us, 100 000 Gaussians 166 -> 161 us; beyond
+// ~100 chunks the per-workgroup table walk costs more than the launch it saves).
 constexpr int kSelfScanBlocks = 64;
+
+constexpr int kModePlain = 0, kModeFirst = 1, kModeFinal = 2;
 
 __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t bound) {
     if (!n_dev) return bound;
@@ -45,62 +57,99 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t b
     return n < bound ? n : bound;
 }
 
-// Each thread owns kRounds CONSECUTIVE items (one or two 16-byte loads) -- the histogram does not
-// care about order, so the count kernel reads wide; the scatter kernel needs the wave-striped order.
-// BLOCK_MAJOR: table[workgroup][digit] (what the self-scanning scatter reads, coalesced over the
-// digits) instead of table[digit][workgroup] (contiguous rows for the row-scan kernel).
-template <typename Key, int kRounds, bool BLOCK_MAJOR>
-__global__ void __launch_bounds__(kThreads)
+// Each thread owns kRounds CONSECUTIVE items of one chunk (one or two 16-byte loads) -- the histogram does
+// not care about order, so the count kernel reads wide; the scatter kernel needs the wave-striped order.
+// CHUNK_MAJOR (small inputs): 256 threads, one chunk, table[chunk][digit] (what the self-scanning scatter
+// reads, coalesced over the digits).  Otherwise: 1024 threads, four chunks side by side (one per group of
+// four waves), table[digit][chunk .. chunk+3] stored as ONE 16-byte word per digit (nbp = row pitch, a
+// multiple of 4).  FIRST: keys >= kEmptyKey are not counted (they are dropped by this pass) and the
+// culled ones among them (== kCulledKey) are added to *culled (zeroed by an earlier kernel).
+template <typename Key, bool CHUNK_MAJOR, bool FIRST>
+__global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     count_kernel(const Key *__restrict__ keys, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
-                 uint32_t *__restrict__ table, int nblocks) {
-    __shared__ uint32_t h[kBins];
+                 uint32_t mask, uint32_t *__restrict__ table, int nbp, uint32_t *__restrict__ culled) {
+    constexpr int kLanes = CHUNK_MAJOR ? 1 : kQuad;   // chunks per workgroup
+    __shared__ uint32_t h[kLanes][kBins];
+    __shared__ uint32_t s_culled;
     const uint32_t n = load_count(n_dev, bound);
-    constexpr int kItems = kThreads * kRounds;
+    const int c = CHUNK_MAJOR ? 0 : (int)(threadIdx.x >> 8);
+    const uint32_t t = threadIdx.x & 255u;
+    const uint32_t chunk = blockIdx.x * (uint32_t)kLanes + (uint32_t)c;
     constexpr int kPerVec = 16 / sizeof(Key), kVecs = kRounds / kPerVec;   // 8 x u16 or 4 x u32 per 16 B
     static_assert(kRounds % kPerVec == 0, "a thread's items must fill whole 16-byte vectors");
-    h[threadIdx.x] = 0;
+    h[c][t] = 0;
+    if (FIRST && threadIdx.x == 0) s_culled = 0;
     __syncthreads();
-    const uint32_t first = blockIdx.x * (uint32_t)kItems + threadIdx.x * (uint32_t)kRounds;
+    const uint32_t first = chunk * (uint32_t)kItems + t * (uint32_t)kRounds;
+    uint32_t my_culled = 0;
     if (first + kRounds <= n) {
         const uint4 *src = reinterpret_cast<const uint4 *>(keys + first);   // first is a multiple of kRounds
+        uint4 q[kVecs];
+#pragma unroll
+        for (int v = 0; v < kVecs; ++v) q[v] = src[v];
 #pragma unroll
         for (int v = 0; v < kVecs; ++v) {
-            const uint4 q = src[v];
-            const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+            const uint32_t w4[4] = {q[v].x, q[v].y, q[v].z, q[v].w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int e = 0; e < 4; ++e) {
                 if (sizeof(Key) == 4) {
-                    atomicAdd(&h[(w4[c] >> shift) & (kBins - 1)], 1u);
+                    if (FIRST && w4[e] >= kEmptyKey)
+                        my_culled += w4[e] == kCulledKey;
+                    else
+                        atomicAdd(&h[c][(w4[e] >> shift) & mask], 1u);
                 } else {
-                    atomicAdd(&h[((w4[c] & 0xFFFFu) >> shift) & (kBins - 1)], 1u);
-                    atomicAdd(&h[((w4[c] >> 16) >> shift) & (kBins - 1)], 1u);
+                    atomicAdd(&h[c][((w4[e] & 0xFFFFu) >> shift) & mask], 1u);
+                    atomicAdd(&h[c][((w4[e] >> 16) >> shift) & mask], 1u);
                 }
             }
         }
     } else {
         for (int r = 0; r < kRounds; ++r)
-            if (first + r < n) atomicAdd(&h[((uint32_t)keys[first + r] >> shift) & (kBins - 1)], 1u);
+            if (first + r < n) {
+                const uint32_t k = (uint32_t)keys[first + r];
+                if (FIRST && k >= kEmptyKey)
+                    my_culled += k == kCulledKey;
+                else
+                    atomicAdd(&h[c][(k >> shift) & mask], 1u);
+            }
     }
+    if (FIRST && my_culled) atomicAdd(&s_culled, my_culled);
     __syncthreads();
-    if (BLOCK_MAJOR)
-        table[(size_t)blockIdx.x * kBins + threadIdx.x] = h[threadIdx.x];
-    else
-        table[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    if (CHUNK_MAJOR) {
+        table[(size_t)blockIdx.x * kBins + t] = h[0][t];
+    } else if (threadIdx.x < kBins) {
+        reinterpret_cast<uint4 *>(table + (size_t)t * nbp)[blockIdx.x] =
+            make_uint4(h[0][t], h[kLanes > 1 ? 1 : 0][t], h[kLanes > 2 ? 2 : 0][t], h[kLanes > 3 ? 3 : 0][t]);
+    }
+    if (FIRST && threadIdx.x == 0 && s_culled) atomicAdd(culled, s_culled);
 }
 
-// One workgroup per digit row: in-place exclusive scan of table[d][0..nblocks), total -> totals[d].
-__global__ void __launch_bounds__(kThreads) row_scan_kernel(uint32_t *__restrict__ table, int nblocks,
+// One workgroup per digit row: in-place exclusive scan of table[d][0..nbp), total -> totals[d].
+// A thread owns 16 consecutive counts (4 x 16-byte loads, all in flight at once); rows longer than
+// 4096 chunks (> 8M items) take further trips with a carry.
+__global__ void __launch_bounds__(kThreads) row_scan_kernel(uint32_t *__restrict__ table, int nbp,
                                                             uint32_t *__restrict__ totals) {
+    constexpr int kPer = 16;
     __shared__ uint32_t wave_sum[4];
-    __shared__ uint32_t carry_s;
-    uint32_t *row = table + (size_t)blockIdx.x * nblocks;
+    uint32_t *row = table + (size_t)blockIdx.x * nbp;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nblocks; base += kThreads) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nblocks ? row[i] : 0u;
-        uint32_t x = v;  // inclusive scan inside the wave
+    uint32_t carry = 0;
+    for (int seg = 0; seg < nbp; seg += kThreads * kPer) {
+        const int i0 = seg + threadIdx.x * kPer;
+        uint4 q[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            q[v] = i0 + 4 * v < nbp ? reinterpret_cast<const uint4 *>(row + i0)[v] : make_uint4(0u, 0u, 0u, 0u);
+        uint32_t e[kPer] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
+                            q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {   // exclusive scan inside the thread
+            const uint32_t v = e[k];
+            e[k] = mine;
+            mine += v;
+        }
+        uint32_t x = mine;  // inclusive scan inside the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t y = __shfl_up((int)x, o);
@@ -108,26 +157,35 @@ __global__ void __launch_bounds__(kThreads) row_scan_kernel(uint32_t *__restrict
         }
         if (lane == 63) wave_sum[w] = x;
         __syncthreads();
-        uint32_t before = carry_s;
+        uint32_t before = carry;
         for (int k = 0; k < w; ++k) before += wave_sum[k];
-        if (i < nblocks) row[i] = before + x - v;
-        __syncthreads();
-        if (threadIdx.x == kThreads - 1) carry_s = before + x;
+        const uint32_t seg_total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        before += x - mine;
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (i0 + 4 * v < nbp)
+                reinterpret_cast<uint4 *>(row + i0)[v] = make_uint4(before + e[4 * v], before + e[4 * v + 1],
+                                                                    before + e[4 * v + 2], before + e[4 * v + 3]);
+        carry += seg_total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-// SELF_SCAN: there is no row-scan launch; `table` holds the raw per-workgroup counts and every
-// workgroup adds up, for each digit, the counts of the workgroups before it and the row total itself
+// SELF_SCAN: there is no row-scan launch; `table` holds the raw per-chunk counts (chunk-major) and
+// every workgroup adds up, for each digit, the counts of the chunks before it and the row total itself
 // (nblocks loads per thread).  Pays for small inputs, where a pass is three launch latencies and
 // the table is a few KiB.
-template <typename Key, int kRounds, bool SELF_SCAN>
+// MODE: kModeFirst / kModeFinal, see the head of this file.  m_out (FIRST): number of items this pass
+// keeps, i.e. the element count of every later pass.  rect / rrect (FINAL): per-Gaussian tile
+// rectangles by index / by depth rank.
+template <typename Key, bool SELF_SCAN, int MODE, int BITS>
 __global__ void __launch_bounds__(kThreads)
     scatter_kernel(const Key *__restrict__ kin, const uint32_t *__restrict__ vin, Key *__restrict__ kout,
                    uint32_t *__restrict__ vout, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
-                   const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nblocks) {
-    constexpr int kItems = kThreads * kRounds, kWaveItems = kItems / 4;
+                   const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nbp,
+                   uint32_t *__restrict__ m_out, const TileRect *__restrict__ rect, TileRect *__restrict__ rrect) {
+    constexpr int kWaveItems = kItems / 4;
     __shared__ uint32_t cnt[4][kBins];   // per-wave running digit counts, then per-wave LDS bases
     __shared__ uint32_t gbase[kBins];    // global address of parked item j of digit d = gbase[d] + j
     __shared__ uint32_t wsum[4], lsum[4];
@@ -136,8 +194,14 @@ __global__ void __launch_bounds__(kThreads)
     const uint32_t n = load_count(n_dev, bound);
     const uint32_t block_base = blockIdx.x * (uint32_t)kItems;
     if (block_base >= n) return;
-    const uint32_t live = min((uint32_t)kItems, n - block_base);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr uint32_t nbins = 1u << BITS, mask = nbins - 1u;
+    // this digit's row total and row prefix: issued now, needed after the ranking
+    uint32_t t_pre = 0, before_pre = 0;
+    if (!SELF_SCAN && (uint32_t)threadIdx.x < nbins) {
+        t_pre = totals[threadIdx.x];
+        before_pre = table[(size_t)threadIdx.x * nbp + blockIdx.x];
+    }
     for (int k = threadIdx.x; k < 4 * kBins; k += kThreads) (&cnt[0][0])[k] = 0;
     __syncthreads();
 
@@ -146,17 +210,23 @@ __global__ void __launch_bounds__(kThreads)
     const unsigned long long lt = (1ull << lane) - 1ull;
     Key key[kRounds];
     uint32_t val[kRounds];
-    uint16_t rank[kRounds];
+    bool ok[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
         const uint32_t i = wave_base + (uint32_t)r * 64 + lane;
-        const bool valid = i < n;
-        key[r] = valid ? kin[i] : (Key)0;
-        val[r] = valid ? vin[i] : 0u;
-        const uint32_t d = ((uint32_t)key[r] >> shift) & (kBins - 1);
+        ok[r] = i < n;
+        key[r] = ok[r] ? kin[i] : (Key)0;
+        val[r] = ok[r] ? vin[i] : 0u;
+        if (MODE & kModeFirst) ok[r] = ok[r] && (uint32_t)key[r] < kEmptyKey;
+    }
+    uint16_t rank[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const bool valid = ok[r];
+        const uint32_t d = ((uint32_t)key[r] >> shift) & mask;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const bool bit = (d >> b) & 1u;
             const unsigned long long m = __ballot(bit);
             peers &= bit ? m : ~m;
@@ -175,7 +245,7 @@ __global__ void __launch_bounds__(kThreads)
     __syncthreads();
 
     // ---- per digit d (thread d): where its run starts in the parked (digit-major) order and in
-    //      the global output: smaller digits (row totals) + this digit in earlier workgroups (table)
+    //      the global output: smaller digits (row totals) + this digit in earlier chunks (table)
     {
         const int d = threadIdx.x;
         const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
@@ -184,7 +254,7 @@ __global__ void __launch_bounds__(kThreads)
             t = 0;
             before = 0;
             int b = 0;
-            for (; b + 8 <= nblocks; b += 8) {      // 8 independent loads in flight (block-major: coalesced over d)
+            for (; b + 8 <= nbp; b += 8) {      // 8 independent loads in flight (chunk-major: coalesced over d)
                 uint32_t v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = table[(size_t)(b + u) * kBins + d];
@@ -194,14 +264,14 @@ __global__ void __launch_bounds__(kThreads)
                     t += v[u];
                 }
             }
-            for (; b < nblocks; ++b) {
+            for (; b < nbp; ++b) {
                 const uint32_t v = table[(size_t)b * kBins + d];
                 before += b < (int)blockIdx.x ? v : 0u;
                 t += v;
             }
         } else {
-            t = totals[d];
-            before = table[(size_t)d * nblocks + blockIdx.x];
+            t = t_pre;
+            before = before_pre;
         }
         const uint32_t l = c0 + c1 + c2 + c3;
         uint32_t x = t, y = l;  // inclusive wave scans of the global totals and of the local counts
@@ -230,15 +300,16 @@ __global__ void __launch_bounds__(kThreads)
         cnt[1][d] = lstart + c0;
         cnt[2][d] = lstart + c0 + c1;
         cnt[3][d] = lstart + c0 + c1 + c2;
+        if ((MODE & kModeFirst) && blockIdx.x == 0 && threadIdx.x == 0) *m_out = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
     __syncthreads();
+    const uint32_t live = lsum[0] + lsum[1] + lsum[2] + lsum[3];   // items of this chunk that the pass keeps
 
     // ---- park in LDS, digit-major, stable
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
-        const uint32_t i = wave_base + (uint32_t)r * 64 + lane;
-        if (i < n) {
-            const uint32_t d = ((uint32_t)key[r] >> shift) & (kBins - 1);
+        if (ok[r]) {
+            const uint32_t d = ((uint32_t)key[r] >> shift) & mask;
             const uint32_t pos = cnt[w][d] + rank[r];
             skey[pos] = key[r];
             sval[pos] = val[r];
@@ -249,55 +320,84 @@ __global__ void __launch_bounds__(kThreads)
     // ---- stream out: consecutive j of one digit -> consecutive addresses
     for (uint32_t j = threadIdx.x; j < live; j += kThreads) {
         const Key k = skey[j];
-        const uint32_t dst = gbase[((uint32_t)k >> shift) & (kBins - 1)] + j;
-        kout[dst] = k;
-        vout[dst] = sval[j];
+        const uint32_t v = sval[j];
+        const uint32_t dst = gbase[((uint32_t)k >> shift) & mask] + j;
+        if (!(MODE & kModeFinal)) kout[dst] = k;
+        vout[dst] = v;
+        if (MODE & kModeFinal) rrect[dst] = rect[v];   // the one gather by Gaussian index on the binning path
     }
 }
 
-template <typename Key, int kRounds>
-hipError_t sort_rounds(void *temp, Key *&kc, Key *&ka, uint32_t *&vc, uint32_t *&va, const uint32_t *n_dev,
-                       int64_t bound, int key_bits, hipStream_t s) {
-    constexpr int kItems = kThreads * kRounds;
-    const int nblocks = (int)((bound + kItems - 1) / kItems);
-    uint32_t *table = (uint32_t *)temp;
-    uint32_t *totals = table + (size_t)kBins * nblocks;
-    const bool self_scan = nblocks <= kSelfScanBlocks;
-    for (int shift = 0; shift < key_bits; shift += 8) {
-        if (self_scan)
-            count_kernel<Key, kRounds, true><<<nblocks, kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, table,
-                                                                          nblocks);
-        else
-            count_kernel<Key, kRounds, false><<<nblocks, kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, table,
-                                                                           nblocks);
-        if (self_scan) {
-            scatter_kernel<Key, kRounds, true><<<nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
-                                                                            shift, table, totals, nblocks);
-        } else {
-            row_scan_kernel<<<kBins, kThreads, 0, s>>>(table, nblocks, totals);
-            scatter_kernel<Key, kRounds, false><<<nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
-                                                                             shift, table, totals, nblocks);
-        }
-        Key *tk = kc; kc = ka; ka = tk;
-        uint32_t *tv = vc; vc = va; va = tv;
+struct PassPlan {
+    int nblocks, nbp, nquads;
+    bool self_scan;
+    uint32_t *table, *totals;
+};
+
+PassPlan plan_for(void *temp, int64_t bound) {
+    PassPlan p;
+    p.nblocks = (int)((bound + kItems - 1) / kItems);
+    p.nquads = (p.nblocks + kQuad - 1) / kQuad;
+    p.self_scan = p.nblocks <= kSelfScanBlocks;
+    p.nbp = p.self_scan ? p.nblocks : p.nquads * kQuad;
+    p.table = (uint32_t *)temp;
+    p.totals = p.table + (size_t)kBins * p.nquads * kQuad;
+    return p;
+}
+
+// Bits per pass: the key bits spread evenly over ceil(key_bits / 8) passes (13 tile-id bits -> 7 + 6:
+// fewer ballots per item and half the digit rows of 8 + 5), at least 6.
+inline int pass_bits(int key_bits) {
+    const int passes = (key_bits + 7) / 8;
+    const int w = (key_bits + passes - 1) / passes;
+    return w < 6 ? 6 : w;
+}
+
+template <typename Key, int MODE, int BITS>
+void launch_pass(const PassPlan &p, const Key *kc, const uint32_t *vc, Key *ka, uint32_t *va, const uint32_t *n_dev,
+                 int64_t bound, int shift, uint32_t *m_out, uint32_t *culled, const TileRect *rect, TileRect *rrect,
+                 hipStream_t s) {
+    constexpr uint32_t mask = (1u << BITS) - 1u;
+    constexpr bool first = (MODE & kModeFirst) != 0;
+    if (p.self_scan) {
+        count_kernel<Key, true, first><<<p.nblocks, kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, mask, p.table,
+                                                                       p.nbp, culled);
+        scatter_kernel<Key, true, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound, shift,
+                                                                              p.table, p.totals, p.nbp, m_out, rect, rrect);
+    } else {
+        count_kernel<Key, false, first><<<p.nquads, kQuad * kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, mask,
+                                                                               p.table, p.nbp, culled);
+        row_scan_kernel<<<1u << BITS, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
+        scatter_kernel<Key, false, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
+                                                                               shift, p.table, p.totals, p.nbp, m_out, rect,
+                                                                               rrect);
     }
-    return hipGetLastError();
 }
 
 template <typename Key>
 hipError_t sort_impl(void *temp, Key *&kc, Key *&ka, uint32_t *&vc, uint32_t *&va, const uint32_t *n_dev,
                      int64_t bound, int key_bits, hipStream_t s) {
     if (bound <= 0) return hipSuccess;
-    if (bound > kLargeInput) return sort_rounds<Key, kLargeRounds>(temp, kc, ka, vc, va, n_dev, bound, key_bits, s);
-    return sort_rounds<Key, kSmallRounds>(temp, kc, ka, vc, va, n_dev, bound, key_bits, s);
+    const PassPlan p = plan_for(temp, bound);
+    const int bits = pass_bits(key_bits);
+    for (int shift = 0; shift < key_bits; shift += bits) {
+        if (bits == 6)
+            launch_pass<Key, kModePlain, 6>(p, kc, vc, ka, va, n_dev, bound, shift, nullptr, nullptr, nullptr, nullptr, s);
+        else if (bits == 7)
+            launch_pass<Key, kModePlain, 7>(p, kc, vc, ka, va, n_dev, bound, shift, nullptr, nullptr, nullptr, nullptr, s);
+        else
+            launch_pass<Key, kModePlain, 8>(p, kc, vc, ka, va, n_dev, bound, shift, nullptr, nullptr, nullptr, nullptr, s);
+        Key *tk = kc; kc = ka; ka = tk;
+        uint32_t *tv = vc; vc = va; va = tv;
+    }
+    return hipGetLastError();
 }
 
 }  // namespace
 
 size_t radix_temp_bytes(int64_t max_items) {
-    constexpr int kItems = kThreads * kSmallRounds;
-    const size_t nblocks = (size_t)((max_items + kItems - 1) / kItems) + 1;
-    return (kBins * nblocks + kBins) * sizeof(uint32_t);
+    const size_t nblocks = (size_t)((max_items + kItems - 1) / kItems) + kQuad;
+    return (kBins * (nblocks + kQuad) + kBins) * sizeof(uint32_t);
 }
 
 hipError_t radix_sort_pairs_u32(void *temp, uint32_t *&keys_cur, uint32_t *&keys_alt, uint32_t *&vals_cur,
@@ -310,6 +410,31 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
                                 uint32_t *&vals_alt, const uint32_t *n_dev, int64_t bound, int key_bits,
                                 hipStream_t s) {
     return sort_impl<uint16_t>(temp, keys_cur, keys_alt, vals_cur, vals_alt, n_dev, bound, key_bits, s);
+}
+
+// The depth sort of the whole-path entry point: 4 passes over the IEEE bits of z_view.  Pass 0 keeps only
+// the keys < kEmptyKey (*m_dev = how many, *culled_dev += how many were == kCulledKey; culled_dev must be
+// zero when the first kernel runs), the last pass writes rrect[rank] = rect[index] instead of the keys.
+// On return vals_cur[0 .. *m_dev) = Gaussian index of each depth rank.
+hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
+                              int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
+                              hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const PassPlan p = plan_for(temp, n);
+    uint32_t *kc = keys0, *ka = keys1;
+    auto flip = [&]() {
+        uint32_t *tk = kc; kc = ka; ka = tk;
+        uint32_t *tv = vals_cur; vals_cur = vals_alt; vals_alt = tv;
+    };
+    launch_pass<uint32_t, kModeFirst, 8>(p, kc, vals_cur, ka, vals_alt, nullptr, n, 0, m_dev, culled_dev, nullptr, nullptr, s);
+    flip();
+    for (int shift = 8; shift < 24; shift += 8) {
+        launch_pass<uint32_t, kModePlain, 8>(p, kc, vals_cur, ka, vals_alt, m_dev, n, shift, nullptr, nullptr, nullptr, nullptr, s);
+        flip();
+    }
+    launch_pass<uint32_t, kModeFinal, 8>(p, kc, vals_cur, ka, vals_alt, m_dev, n, 24, nullptr, nullptr, rect, rrect, s);
+    flip();
+    return hipGetLastError();
 }
 
 }  // namespace gsx

@@ -120,9 +120,12 @@ class CapturedFrame:
     did not exceed the pair capacity recorded in the graph and returns the frame."""
 
     def __init__(self, scene: "GaussianScene", graph, out: torch.Tensor, pinned: torch.Tensor, call: dict,
-                 camera_buffer: Optional[torch.Tensor] = None) -> None:
+                 camera_buffer: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+                 capacity: int = 0) -> None:
         self.scene, self.graph, self.out, self._pinned, self._call = scene, graph, out, pinned, call
         self._camera_buffer = camera_buffer      # device copy of the GsxCamera the recorded kernels read
+        self._workspace = workspace              # scratch whose address the graph holds: lives as long as the frame
+        self.capacity = int(capacity)            # (Gaussian, tile) pairs the recorded launches have room for
 
     def set_camera(self, image_idx: int) -> None:
         """Points the captured frame at another camera of the scene (same frame size): the next
@@ -237,7 +240,8 @@ class GaussianScene:
                          no_sync: bool = False, semantics: str = "ref_cpu",
                          background: Tuple[float, float, float] = (0.0, 0.0, 0.0),
                          generic_kernels: bool = False, published_rects: bool = False,
-                         camera_buffer: Optional[torch.Tensor] = None) -> torch.Tensor:
+                         camera_buffer: Optional[torch.Tensor] = None,
+                         _private: Optional[dict] = None) -> torch.Tensor:
         """Full forward render in libgsx (gsx_render_forward).
 
         semantics: "ref_cpu" (the reference's ``render_image``), "ref_cuda" (its CUDA kernel's rules
@@ -290,12 +294,21 @@ class GaussianScene:
         cap_key = (image_idx, tile_size, None if tile_window is None else tuple(int(v) for v in tile_window),
                    semantics + ("/published" if published_rects else ""))
         cap = self._cap_hints.get(cap_key, 0) or max(self._instances_hint, 8 * n + 4096)
+        # _private (capture_frame): a pair capacity, scratch buffer and count slot owned by ONE captured
+        # frame -- its graph bakes their addresses in, so they must not be shared with or recycled by
+        # any other frame; such a call neither reads nor updates the scene's hints and pending list
+        own = _private or {}
+        if "cap" in own:
+            cap = int(own["cap"])
         speculative = bool(no_sync and not timing)
         if speculative:
             params.flags |= _ffi.GSX_FLAG_NO_SYNC
-            if len(self._pending) >= _PINNED_SLOTS:
-                self.confirm_frames()
-            pinned = self._pinned_slot()
+            if "pinned" in own:
+                pinned = own["pinned"]
+            else:
+                if len(self._pending) >= _PINNED_SLOTS:
+                    self.confirm_frames()
+                pinned = self._pinned_slot()
             st_ref = ctypes.cast(ctypes.c_void_p(pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats))
             st = st_ref.contents
         else:
@@ -306,16 +319,24 @@ class GaussianScene:
                 nbytes = lib.gsx_workspace_bytes(n, width, height, tile_size, cap)
                 if nbytes == 0:
                     raise _ffi.GsxError(_ffi.GSX_ERR_INVALID_ARGUMENT, "gsx_workspace_bytes rejected the sizes")
-                ws = _WORKSPACE.get(dev, nbytes)
+                ws = own.get("workspace")
+                if ws is None:
+                    ws = _WORKSPACE.get(dev, nbytes)
+                elif ws.numel() < nbytes:
+                    raise ValueError("private workspace holds %d bytes, the frame needs %d" % (ws.numel(), nbytes))
                 # hand over exactly the bytes of `cap` pairs (the buffer may be larger): the library
                 # derives its pair capacity -- and the binning grids -- from the size it is given
                 rc = lib.gsx_render_forward(ctypes.byref(cam), *[_ptr(t) for t in tensors], n, tile_size, _ptr(out),
                                             ctypes.byref(params), st_ref, _ptr(ws), nbytes,
                                             _stream_handle(dev))
-                if rc != _ffi.GSX_ERR_WORKSPACE_TOO_SMALL:
+                if rc != _ffi.GSX_ERR_WORKSPACE_TOO_SMALL or "cap" in own:
                     break
                 cap = int(st.n_instances * 1.25) + 4096
         _ffi.check(rc)
+        if own:
+            if stats is not None and not speculative:
+                stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles)
+            return out
         if speculative:
             # counts are still in flight: remember what has to be confirmed
             self._pending.append((pinned, cap_key, dict(
@@ -394,20 +415,28 @@ class GaussianScene:
             cam_buf = torch.frombuffer(bytearray(bytes(cam)), dtype=torch.uint8).to(dev)
         kw = dict(tile_size=tile_size, layout=layout, out=out, semantics=semantics, camera_buffer=cam_buf)
         st = {}
-        self.render_image_hip(image_idx, stats=st, **kw)
-        # pair capacity the recorded launches are sized for
-        self._cap_hints[(image_idx, tile_size, None, semantics)] = int(st["n_instances"] * max(headroom, 1.0)) + 4096
+        self.render_image_hip(image_idx, stats=st, **kw)    # normal path: the pair count of this view
+        # What the graph bakes in belongs to this frame alone: the pair capacity the recorded launches are
+        # sized for (headroom x this view's count), a scratch buffer of exactly that size and a pinned
+        # slot for the counts.  None of them comes from (or goes back to) the scene's shared pools.
+        lib = _ffi.load()
+        n = int(self.gaussians.points.shape[0])
+        cap = int(st["n_instances"] * max(float(headroom), 1.0)) + 4096
+        nbytes = lib.gsx_workspace_bytes(n, cam.width, cam.height, tile_size, cap)
+        if nbytes == 0:
+            raise _ffi.GsxError(_ffi.GSX_ERR_INVALID_ARGUMENT, "gsx_workspace_bytes rejected the sizes")
+        private = dict(cap=cap, workspace=torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                       pinned=torch.zeros(ctypes.sizeof(_ffi.GsxFrameStats), dtype=torch.uint8).pin_memory())
         stream = torch.cuda.Stream(dev)
-        with torch.cuda.stream(stream):   # same call once on the capture stream: sizes its scratch buffer
-            self.render_image_hip(image_idx, **kw)
-        self._ensure_pinned_pool()                      # pinning memory is not allowed while capturing
+        with torch.cuda.stream(stream):   # the same call once on the capture stream, outside the capture
+            self.render_image_hip(image_idx, _private=private, **kw)
         torch.cuda.synchronize(dev)
-        before = len(self._pending)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
-            self.render_image_hip(image_idx, no_sync=True, **kw)
-        pinned, _, call = self._pending.pop(before)     # the graph owns this frame's count slot from now on
-        return CapturedFrame(self, graph, out, pinned, call, camera_buffer=cam_buf)
+            self.render_image_hip(image_idx, no_sync=True, _private=private, **kw)
+        call = dict(image_idx=image_idx, **kw)
+        return CapturedFrame(self, graph, out, private["pinned"], call, camera_buffer=cam_buf,
+                             workspace=private["workspace"], capacity=cap)
 
     def render_image(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:
         """(W,H,3) float32 indexed [x,y]; same result as the reference's pure-Python
@@ -442,18 +471,25 @@ class GaussianScene:
                                    pre.inverse_covariance_2d, pre.min_x, pre.max_x, pre.min_y, pre.max_y,
                                    pre.sigmoid_opacity, layout=layout, stats=stats)
 
-    # ------------------------------------------------------------------ debug helper
+    # ------------------------------------------------------------------ debug helpers
     def render_points_image(self, image_idx: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """Projected (x_pix, y_pix, ndc_z) of the in-view points and their colours
-        (gaussian_scene.py:44-51, image.py:72-89)."""
+        (gaussian_scene.py:44-51 -> image.py:72-89)."""
+        return self.images[image_idx].project_point_to_camera_perspective_projection(
+            self.gaussians.points, self.gaussians.colors)
+
+    def get_2d_covariance(self, image_idx: int, points: torch.Tensor, covariance_3d: torch.Tensor) -> torch.Tensor:
+        """(n,2,2) EWA covariance of ``points`` (n,3) with 3D covariances (n,3,3) under camera
+        ``image_idx`` (gaussian_scene.py:53-68 -> utils.py:320-354), computed by gsx_covariance_2d."""
         lib = _ffi.load()
-        dev, n, tensors = self._inputs()
+        dev = points.device
+        _require_gpu(dev)
+        n = int(points.shape[0])
+        pts = _check_f32("points", points.reshape(n, 3), dev)
+        cov = _check_f32("covariance_3d", covariance_3d.reshape(n, 3, 3), dev)
+        out = torch.empty((n, 2, 2), dtype=torch.float32, device=dev)
         cam = self.images[image_idx].gsx_camera()
-        pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        vis = torch.empty(n, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.gsx_project_points(ctypes.byref(cam), _ptr(tensors[0]), n, _ptr(pts), _ptr(vis),
-                                        _stream_handle(dev))
+            rc = lib.gsx_covariance_2d(ctypes.byref(cam), _ptr(pts), _ptr(cov), n, _ptr(out), _stream_handle(dev))
         _ffi.check(rc)
-        keep = vis.bool()
-        return pts[keep], self.gaussians.colors[keep]
+        return out

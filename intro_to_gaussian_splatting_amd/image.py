@@ -1,8 +1,9 @@
 """Camera model: COLMAP pose + PINHOLE intrinsics -> the float32 constants stage 1 reads.
 
 Mirrors the attribute surface of the reference's ``GaussianImage`` (splat/image.py:19-70):
-``f_x f_y c_x c_y R T height width fovX fovY tan_fovX tan_fovY znear zfar world2view
-projection_matrix full_proj_transform camera_center name``.  The constants are computed once on
+``f_x f_y c_x c_y intrinsic_matrix R T height width extrinsic_matrix fovX fovY tan_fovX tan_fovY znear
+zfar world2view projection_matrix full_proj_transform camera_center projection name`` and
+``project_point_to_camera_perspective_projection`` (splat/image.py:72-89).  The constants are computed once on
 the host with the same mix of double (``math.atan`` / ``math.tan``) and float32 tensor
 arithmetic as the reference (splat/utils.py:158-159, 162-172, 189-225), so they are bit-equal
 to it; the HIP kernels receive them ready-made in a ``GsxCamera`` and never re-derive them.
@@ -10,7 +11,9 @@ The principal point is carried but, as in the reference, not used by the render 
 """
 from __future__ import annotations
 
+import ctypes
 import math
+from typing import Tuple
 
 import torch
 
@@ -93,6 +96,15 @@ class GaussianImage:
         center = world2view.inverse()[3, :3]
         self.camera_center = center.to(dev)
         self.camera_center_host = tuple(float(v) for v in center)   # read per frame by the SH kernel's caller
+        # carried for users of the reference's attribute surface; the render path does not read them
+        # (splat/image.py:32-34, 39, 68-70; splat/utils.py:19-52)
+        intrinsic = torch.zeros((3, 4), dtype=f32)
+        intrinsic[0, 0], intrinsic[0, 2] = f_x[0], c_x[0]
+        intrinsic[1, 1], intrinsic[1, 2] = f_y[0], c_y[0]
+        intrinsic[2, 2] = 1.0
+        self.intrinsic_matrix = intrinsic.to(dev)
+        self.extrinsic_matrix = extrinsic.to(dev)
+        self.projection = (intrinsic @ extrinsic).to(dev)
 
         cam = _ffi.GsxCamera()
         cam.world2view[:] = world2view.reshape(-1).tolist()
@@ -101,6 +113,27 @@ class GaussianImage:
         cam.fx, cam.fy = float(f_x), float(f_y)
         cam.width, cam.height = int(camera.width), int(camera.height)
         self._gsx_camera = cam
+
+    def project_point_to_camera_perspective_projection(
+            self, points: torch.Tensor, colors: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(x_pix, y_pix, ndc_z) of the points with z_view >= 0.2, in input order, and their colours
+        (splat/image.py:72-89), computed by gsx_project_points on the GPU."""
+        lib = _ffi.load()
+        dev = points.device
+        if dev.type != "cuda":
+            raise RuntimeError("the points are on %s: this projection runs as a HIP kernel (no CPU fallback)" % dev)
+        n = int(points.shape[0])
+        pts = points.to(torch.float32).reshape(n, 3).contiguous()
+        out = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        vis = torch.empty(n, dtype=torch.uint8, device=dev)
+        cam = self.gsx_camera()
+        with torch.cuda.device(dev):
+            rc = lib.gsx_project_points(ctypes.byref(cam), ctypes.c_void_p(pts.data_ptr()), n,
+                                        ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(vis.data_ptr()),
+                                        ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _ffi.check(rc)
+        keep = vis.bool()
+        return out[keep], colors[keep]
 
     def gsx_camera(self) -> "_ffi.GsxCamera":
         """The C-ABI view of this camera (include/gsx.h: GsxCamera)."""

@@ -114,6 +114,10 @@ def capture(name: str, spec: dict, GaussianScene, Gaussians) -> None:
             depth_unsorted = (hom @ cam.world2view)[:, 2]
             perm = torch.argsort(depth_unsorted)
             assert torch.equal(depth_unsorted[perm], pre.depths), "argsort is not reproducible"
+            # the debug projection helper (gaussian_scene.py:44-51 -> image.py:72-89) and the Sigma2D wrapper
+            # (gaussian_scene.py:53-68) on the in-view points, in INPUT order
+            pts_img, pts_col = scene.render_points_image(1)
+            cov2d_wrapper = scene.get_2d_covariance(1, g.points[in_view], cov3d[in_view])
             t0 = time.time()
             image = scene.render_image(1, tile_size=tile)
             dt = time.time() - t0
@@ -126,6 +130,10 @@ def capture(name: str, spec: dict, GaussianScene, Gaussians) -> None:
         full_proj_transform=cam.full_proj_transform.numpy(),
         tan_fovX=cam.tan_fovX.numpy(), tan_fovY=cam.tan_fovY.numpy(),
         f_x=cam.f_x.numpy(), f_y=cam.f_y.numpy(),
+        intrinsic_matrix=cam.intrinsic_matrix.numpy(), extrinsic_matrix=cam.extrinsic_matrix.numpy(),
+        projection=cam.projection.numpy(), camera_center=cam.camera_center.numpy(),
+        points_image_xyz=pts_img.detach().numpy(), points_image_colors=pts_col.detach().numpy(),
+        get_2d_covariance=cov2d_wrapper.detach().numpy(),
         in_view=in_view.numpy(), covariance_3d=cov3d.numpy(),
         order=idx[perm.numpy()].astype(np.int64),
         pre_points=pre.points.numpy(), pre_colors=pre.colors.detach().numpy(),
@@ -143,9 +151,84 @@ def capture(name: str, spec: dict, GaussianScene, Gaussians) -> None:
         name, sc["points"].shape[0], idx.size, tuple(image.shape), dt, path, os.path.getsize(path) / 1024))
 
 
+def capture_colmap_model() -> None:
+    """A small COLMAP sparse model in both flavours (written here with ``struct`` / ``%r``, following the
+    published COLMAP file layout) parsed by the REFERENCE's readers (splat/read_colmap.py:87-239); the
+    files and what the reference read from them are the fixture for our own reader (colmap.py)."""
+    import struct
+
+    from splat import read_colmap as rc
+
+    rs = np.random.RandomState(41)
+    cams = [  # id, model id, model name, width, height, params
+        (1, 1, "PINHOLE", 1959, 1090, [1159.5880733038064, 1164.6601287484507, 979.5, 545.0]),
+        (2, 0, "SIMPLE_PINHOLE", 640, 480, [500.25, 320.0, 240.0]),
+        (7, 4, "OPENCV", 1280, 720, [900.125, 901.5, 640.0, 360.0, -0.1, 0.01, 1e-4, -2e-4]),
+        (9, 2, "SIMPLE_RADIAL", 800, 600, [610.0, 400.0, 300.0, 0.03125]),
+    ]
+    imgs = []
+    for k, (img_id, cam_id, name, npts) in enumerate([(1, 1, "_DSC8973.JPG", 5), (2, 2, "frame 002.png", 0),
+                                                       (100, 7, "sub/dir/a.jpg", 3), (31, 9, "z.JPG", 1)]):
+        q = rs.normal(size=4)
+        q /= np.linalg.norm(q)
+        t = rs.normal(size=3) * 3.0
+        xy = rs.uniform(0, 1000, (npts, 2))
+        ids = rs.randint(-1, 5000, npts).astype(np.int64)
+        imgs.append((img_id, q, t, cam_id, name, xy, ids))
+    out_dir = os.path.join(OUT_DIR, "colmap_model")
+    os.makedirs(os.path.join(out_dir, "bin"), exist_ok=True)
+    os.makedirs(os.path.join(out_dir, "txt"), exist_ok=True)
+    with open(os.path.join(out_dir, "bin", "cameras.bin"), "wb") as f:
+        f.write(struct.pack("<Q", len(cams)))
+        for cid, mid, _, w, h, prm in cams:
+            f.write(struct.pack("<iiQQ", cid, mid, w, h))
+            f.write(struct.pack("<" + "d" * len(prm), *prm))
+    with open(os.path.join(out_dir, "bin", "images.bin"), "wb") as f:
+        f.write(struct.pack("<Q", len(imgs)))
+        for img_id, q, t, cam_id, name, xy, ids in imgs:
+            f.write(struct.pack("<idddddddi", img_id, *q, *t, cam_id))
+            f.write(name.replace(" ", "_").encode("utf-8") + b"\x00")
+            f.write(struct.pack("<Q", len(ids)))
+            for (x, y), pid in zip(xy, ids):
+                f.write(struct.pack("<ddq", x, y, int(pid)))
+    with open(os.path.join(out_dir, "txt", "cameras.txt"), "w") as f:
+        f.write("# Camera list with one line of data per camera:\n#   CAMERA_ID, MODEL, WIDTH, HEIGHT, PARAMS[]\n")
+        for cid, _, mname, w, h, prm in cams:
+            f.write("%d %s %d %d %s\n" % (cid, mname, w, h, " ".join(repr(float(v)) for v in prm)))
+    with open(os.path.join(out_dir, "txt", "images.txt"), "w") as f:
+        f.write("# Image list with two lines of data per image:\n\n")
+        for img_id, q, t, cam_id, name, xy, ids in imgs:
+            f.write("%d %s %s %d %s\n" % (img_id, " ".join(repr(float(v)) for v in q),
+                                          " ".join(repr(float(v)) for v in t), cam_id, name.replace(" ", "_")))
+            f.write(" ".join("%r %r %d" % (float(x), float(y), int(pid)) for (x, y), pid in zip(xy, ids)) + "\n")
+    parsed = {}
+    for flavour, rcam, rimg, ext in (("bin", rc.read_cameras_binary, rc.read_images_binary, "bin"),
+                                     ("txt", rc.read_cameras_text, rc.read_images_text, "txt")):
+        cameras = rcam(os.path.join(out_dir, flavour, "cameras." + ext))
+        images = rimg(os.path.join(out_dir, flavour, "images." + ext))
+        parsed[flavour + "_camera_ids"] = np.array(sorted(cameras), dtype=np.int64)
+        for cid, c in cameras.items():
+            parsed["%s_cam%d_model" % (flavour, cid)] = np.array(c.model)
+            parsed["%s_cam%d_size" % (flavour, cid)] = np.array([c.width, c.height], dtype=np.int64)
+            parsed["%s_cam%d_params" % (flavour, cid)] = np.asarray(c.params, dtype=np.float64)
+        parsed[flavour + "_image_ids"] = np.array(sorted(images), dtype=np.int64)
+        for iid, im in images.items():
+            parsed["%s_img%d_qvec" % (flavour, iid)] = np.asarray(im.qvec, dtype=np.float64)
+            parsed["%s_img%d_tvec" % (flavour, iid)] = np.asarray(im.tvec, dtype=np.float64)
+            parsed["%s_img%d_camera_id" % (flavour, iid)] = np.int64(im.camera_id)
+            parsed["%s_img%d_name" % (flavour, iid)] = np.array(im.name)
+            parsed["%s_img%d_xys" % (flavour, iid)] = np.asarray(im.xys, dtype=np.float64).reshape(-1, 2)
+            parsed["%s_img%d_point3D_ids" % (flavour, iid)] = np.asarray(im.point3D_ids, dtype=np.int64)
+    path = os.path.join(OUT_DIR, "colmap_model.npz")
+    np.savez_compressed(path, **parsed)
+    print("colmap_model: %d cameras, %d images, both flavours parsed by the reference -> %s" % (len(cams), len(imgs), path))
+
+
 def main() -> None:
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     GaussianScene, Gaussians = _import_reference()
+    if only in "colmap_model":
+        capture_colmap_model()
     for name, spec in FIXTURES.items():
         if only in name:
             capture(name, spec, GaussianScene, Gaussians)

@@ -39,7 +39,7 @@ def test_struct_layouts():
     assert ctypes.sizeof(_ffi.GsxFrameStats) == 64
     p = _ffi.default_params()
     assert p.semantics == _ffi.GSX_SEM_REF_CPU and p.layout == _ffi.GSX_LAYOUT_WH3
-    assert p.tile_x1 == 0 and p.out_w == 0
+    assert p.tile_x1 == -1 and p.tile_y1 == -1 and p.out_w == 0
 
 
 def test_argument_errors_do_not_need_a_gpu():

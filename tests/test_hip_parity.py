@@ -426,7 +426,12 @@ def test_cuda_kernel_semantics_against_its_cpu_restatement(tmp_path, name):
     assert tuple(img.shape) == (h, w, 3)
     ref = c_oracle.render_cuda_semantics(golden_preprocessed(g), w, h)
     diff = np.abs(img.cpu().numpy() - ref).max(axis=2)
-    assert (diff > PIXEL_TOL).mean() < 1e-4 and np.median(diff) < 1e-6
+    n_over = int((diff > PIXEL_TOL).sum())
+    print("ref_cuda %s: %d of %d pixels above %g (largest %.3g), median %.3g" % (
+        name, n_over, diff.size, PIXEL_TOL, float(diff.max()), float(np.median(diff))))
+    # observed on MI355X (round 2): 0 pixels above tolerance for all three fixtures; the bound leaves room for
+    # a few 0.001-threshold flips, not for a regression
+    assert n_over <= max(2, int(1e-4 * diff.size)) and np.median(diff) < 1e-6
     assert ref[h - 16:, :, :].any() or ref[:, w - 16:, :].any() or name.startswith("small")  # edge tiles are rendered
     # the whole-path entry with the same semantics gives the same frame, and other tile sizes too
     full = scene.render_image_hip(1, layout="hw3", semantics="ref_cuda")
@@ -451,19 +456,93 @@ def test_covariance_3d_method(tmp_path, golden):
     assert cov.shape == ref.shape and np.all(np.abs(cov - ref) <= 1e-9 + 2e-6 * np.abs(ref).max(axis=(1, 2), keepdims=True))
 
 
-def test_points_projection_helper(tmp_path):
+def test_points_projection_helper_against_the_references_output(tmp_path, golden):
+    """GaussianScene.render_points_image (splat/gaussian_scene.py:44-51 -> splat/image.py:72-89): all three
+    columns (x_pix, y_pix, ndc_z) and the colours against what the REFERENCE returned for the same scene."""
     _need_gpu()
-    g = load_golden("cull_96x80_n400")
+    g = golden
     scene = _scene_from_golden(tmp_path, g)
     pts, cols = scene.render_points_image(1)
-    assert pts.shape[0] == int(g["in_view"].sum()) and cols.shape[0] == pts.shape[0]
-    # same pixels as stage 1 (unsorted vs sorted: compare as sets via the order)
+    ref = g["points_image_xyz"]
+    assert tuple(pts.shape) == ref.shape and pts.shape[0] == int(g["in_view"].sum())
+    got = pts.cpu().numpy()
+    assert np.max(np.abs(got[:, :2] - ref[:, :2])) <= 1e-4 * max(1.0, np.abs(ref[:, :2]).max() / 64.0)   # pixels
+    assert np.max(np.abs(got[:, 2] - ref[:, 2])) <= 2e-6                                              # ndc z in (0, 1)
+    assert np.array_equal(cols.cpu().numpy(), g["points_image_colors"])
+    # the method of the camera object is the same call (splat/image.py:72-89)
+    p2, c2 = scene.images[1].project_point_to_camera_perspective_projection(scene.gaussians.points, scene.gaussians.colors)
+    assert torch.equal(p2, pts) and torch.equal(c2, cols)
+
+
+def test_get_2d_covariance_wrapper_against_the_references_output(tmp_path, golden):
+    """GaussianScene.get_2d_covariance(image_idx, points, covariance_3d) (splat/gaussian_scene.py:53-68) on the
+    in-view points and the reference's own 3D covariances: within re-association distance of the reference's
+    result, bit-identical to the Sigma2D the stage-1 kernel computes inline."""
+    _need_gpu()
+    g = golden
+    scene = _scene_from_golden(tmp_path, g)
+    vis = torch.from_numpy(g["in_view"]).to("cuda:0")
+    pts = scene.gaussians.points[vis]
+    cov3 = torch.from_numpy(g["covariance_3d"]).to("cuda:0")[vis]
+    out = scene.get_2d_covariance(1, pts, cov3)
+    ref = g["get_2d_covariance"]
+    assert tuple(out.shape) == ref.shape
+    scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
+    assert np.all(np.abs(out.cpu().numpy() - ref) <= 1e-6 + 1e-5 * scale)
+    # with the kernel's own 3D covariances it is what preprocess() stores (depth-sorted there)
+    mine = scene.get_2d_covariance(1, pts, scene.gaussians.get_3d_covariance_matrix()[vis])
     pre = scene.preprocess(1)
-    order = scene.last_order.long()
-    vis_idx = torch.nonzero(torch.from_numpy(g["in_view"]).to("cuda:0")).squeeze(1)
     lookup = torch.full((g["points"].shape[0],), -1, dtype=torch.long, device="cuda:0")
-    lookup[vis_idx] = torch.arange(vis_idx.numel(), device="cuda:0")
-    assert torch.equal(pts[lookup[order], :2], pre.points)
+    lookup[torch.nonzero(vis).squeeze(1)] = torch.arange(int(vis.sum()), device="cuda:0")
+    assert torch.equal(mine[lookup[scene.last_order.long()]], pre.covariance_2d)
+
+
+def test_a_stopped_pixel_stays_stopped_when_a_later_alpha_is_not_finite(tmp_path):
+    """The reference RETURNS once T(1-alpha) < 1e-6 (gaussian_scene.py:166-167); the kernels instead keep a
+    stopped pixel at T = 0.  A later Gaussian whose conic overflowed (inf / NaN inverse covariance, bounding
+    box over the whole frame) must not revive it as 0 * inf = NaN.  `dense` fixture (a quarter of its pixels
+    stop) + three such Gaussians appended at the far end, through the stage-2 entry point; the C restatement
+    breaks out of the loop like the reference."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd.gaussian_scene import render_preprocessed
+    from oracle import c_oracle, cpu_ref
+
+    g = load_golden("dense_48x48_n1500")
+    pre = golden_preprocessed(g)
+    w, h = int(g["width"]), int(g["height"])
+    extra = 3
+    inf, nan = np.float32(np.inf), np.float32(np.nan)
+    cat = lambda a, b: np.concatenate([a, np.asarray(b, np.float32).reshape((extra,) + a.shape[1:])])   # noqa: E731
+    # exponent = -1/2 d Q d^T.  First Q = NaN: every pixel that is still live turns NaN on both sides (the
+    # reference's `NaN < 1e-6` is false, it accumulates).  Then Q = -inf (alpha = +inf) and a mixed one: a
+    # stopped pixel computes 0 * inf = NaN in the kernel's arithmetic and must still keep its colour.
+    bad_q = np.array([[[nan, nan], [nan, nan]], [[-inf, 0], [0, -inf]], [[-inf, inf], [-inf, -inf]]], np.float32)
+    pre2 = cpu_ref.Preprocessed(
+        cat(pre.points, [[24.3, 20.1]] * extra), cat(pre.colors, [[0.9, 0.8, 0.7]] * extra),
+        cat(pre.covariance_2d, np.ones((extra, 2, 2))), cat(pre.depths, [99.0, 99.5, 99.9]),
+        cat(pre.inverse_covariance_2d, bad_q), cat(pre.radius, [1e9] * extra), cat(pre.points_xy, [[24.3, 20.1]] * extra),
+        cat(pre.min_x, [-inf] * extra), cat(pre.min_y, [-inf] * extra), cat(pre.max_x, [inf] * extra),
+        cat(pre.max_y, [inf] * extra), cat(pre.sigmoid_opacity, [[0.7]] * extra),
+        np.concatenate([pre.order, pre.order.max() + 1 + np.arange(extra)]))
+    ref, _, inst = c_oracle.render(pre2, w, h, 16)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")   # noqa: E731
+    for generic in (False, True):
+        st = {}
+        if generic:     # the any-tile-size kernel at tile 8 covers the same pixels except the last 8-px rows
+            img = render_preprocessed(h, w, 8, t(pre2.points), t(pre2.colors), t(pre2.inverse_covariance_2d), t(pre2.min_x),
+                                      t(pre2.max_x), t(pre2.min_y), t(pre2.max_y), t(pre2.sigmoid_opacity), stats=st)
+            ref8, _, _ = c_oracle.render(pre2, w, h, 8)
+            got, want = img.cpu().numpy(), ref8
+        else:
+            img = render_preprocessed(h, w, 16, t(pre2.points), t(pre2.colors), t(pre2.inverse_covariance_2d), t(pre2.min_x),
+                                      t(pre2.max_x), t(pre2.min_y), t(pre2.max_y), t(pre2.sigmoid_opacity), stats=st)
+            assert st["n_instances"] == inst
+            got, want = img.cpu().numpy(), ref
+        # pixels that had stopped keep their finite colour; live pixels turn NaN / inf on both sides alike
+        assert np.array_equal(np.isfinite(got), np.isfinite(want))
+        fin = np.isfinite(want)
+        assert (fin & (np.abs(want) > 0)).any() and (~fin).any()      # stopped (finite, coloured) and live (NaN) pixels
+        assert np.max(np.abs(got[fin] - want[fin])) <= PIXEL_TOL
 
 
 def test_spherical_harmonics_kernel_and_trained_ply_pipeline(tmp_path):
@@ -584,6 +663,46 @@ def test_captured_frame_replays_in_a_hip_graph(tmp_path):
     half = scene.render_image_hip(1)
     assert torch.equal(frame.confirm(), half) and not torch.equal(half, ref)
     assert scene.confirm_frames() == 0
+
+
+def test_captured_frame_owns_its_capacity_scratch_and_count_slot(tmp_path):
+    """capture_frame(headroom=h) records launches sized for h x the pair count of the captured view, in a
+    scratch buffer and a pinned count slot that belong to that frame alone: later frames of the scene (more
+    than the 256 slots of the shared ring) must not disturb them, and two captured frames replayed on
+    different streams at the same time must not share scratch."""
+    _need_gpu()
+    import ctypes
+
+    from intro_to_gaussian_splatting_amd import _ffi
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    sc = make_scene(30_000, 480, 320, seed=12)
+    scene = _scene_from_arrays(tmp_path, sc)
+    st = {}
+    ref = scene.render_image_hip(1, stats=st).clone()
+    d = st["n_instances"]
+    a = scene.capture_frame(1, headroom=2.0)
+    b = scene.capture_frame(1, headroom=1.0)
+    assert a.capacity >= 2 * d and d <= b.capacity < a.capacity
+    assert a._workspace.data_ptr() != b._workspace.data_ptr() and a._pinned.data_ptr() != b._pinned.data_ptr()
+    a.replay()
+    a.confirm()
+    got = ctypes.cast(ctypes.c_void_p(a._pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents
+    assert got.reserved >= 2 * d and got.n_instances == d
+    out = torch.empty_like(ref)
+    for _ in range(300):                      # wraps the scene's 256-slot ring of pinned count slots
+        scene.render_image_hip(1, out=out, no_sync=True)
+    assert scene.confirm_frames() == 0
+    got = ctypes.cast(ctypes.c_void_p(a._pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents
+    assert got.reserved >= 2 * d and got.n_instances == d          # untouched by the ring
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            a.replay()
+        with torch.cuda.stream(s2):
+            b.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a.confirm(), ref) and torch.equal(b.confirm(), ref)
 
 
 def test_c_abi_rejects_bad_arguments(tmp_path):

@@ -188,3 +188,40 @@ def test_constructor_defaults_equal_the_references_bit_for_bit():
     assert np.array_equal(ours.quaternions.numpy(), g["quaternions"])
     assert np.array_equal(ours.opacity.numpy(), g["opacity"])
     assert np.array_equal(ours.colors.numpy(), g["colors"])
+
+
+def test_colmap_readers_equal_the_references_parse_of_a_committed_model():
+    """tests/golden/colmap_model/{bin,txt}: a 4-camera / 4-image sparse model (PINHOLE, SIMPLE_PINHOLE, OPENCV,
+    SIMPLE_RADIAL; images with 0..5 keypoints, a name with a directory) written by oracle/capture_golden.py;
+    tests/golden/colmap_model.npz: what the REFERENCE's readers (splat/read_colmap.py:87-239) returned for
+    those very files.  Our readers must return the same records, both flavours."""
+    from conftest import GOLDEN_DIR
+
+    g = np.load(os.path.join(GOLDEN_DIR, "colmap_model.npz"))
+    for fl in ("bin", "txt"):
+        model = os.path.join(GOLDEN_DIR, "colmap_model", fl)
+        cams, imgs = colmap.read_camera_file(model), colmap.read_image_file(model)
+        assert sorted(cams) == list(g[fl + "_camera_ids"]) and sorted(imgs) == list(g[fl + "_image_ids"])
+        for cid, c in cams.items():
+            assert c.id == cid and c.model == str(g["%s_cam%d_model" % (fl, cid)])
+            assert [c.width, c.height] == list(g["%s_cam%d_size" % (fl, cid)])
+            assert np.array_equal(c.params, g["%s_cam%d_params" % (fl, cid)])
+        for iid, im in imgs.items():
+            assert im.id == iid and im.name == str(g["%s_img%d_name" % (fl, iid)])
+            assert im.camera_id == int(g["%s_img%d_camera_id" % (fl, iid)])
+            assert np.array_equal(im.qvec, g["%s_img%d_qvec" % (fl, iid)])
+            assert np.array_equal(im.tvec, g["%s_img%d_tvec" % (fl, iid)])
+            assert np.array_equal(np.asarray(im.xys).reshape(-1, 2), g["%s_img%d_xys" % (fl, iid)])
+            assert np.array_equal(im.point3D_ids, g["%s_img%d_point3D_ids" % (fl, iid)])
+    # the binary flavour wins when both are present, as in the reference (splat/utils.py:269-290)
+    assert colmap.read_camera_file(os.path.join(GOLDEN_DIR, "colmap_model", "bin"))[7].model == "OPENCV"
+
+
+def test_unused_camera_matrices_equal_the_references(golden):
+    """intrinsic_matrix, extrinsic_matrix, projection and camera_center (splat/image.py:32-39, 66-70): carried
+    for users of the reference's attribute surface, bit-equal to what the reference computed."""
+    im = _camera_from_fixture(golden)
+    assert np.array_equal(im.intrinsic_matrix.numpy(), golden["intrinsic_matrix"])
+    assert np.array_equal(im.extrinsic_matrix.numpy(), golden["extrinsic_matrix"])
+    assert np.allclose(im.projection.numpy(), golden["projection"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(im.camera_center.numpy(), golden["camera_center"], rtol=1e-5, atol=1e-6)
