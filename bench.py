@@ -12,9 +12,12 @@ is sharded as strips of tile rows across the ranks (every rank holds the full Ga
 runs the projection; binning, sorting and compositing cover only its strip) and the frame is
 gathered on rank 0 over RCCL: total work is fixed, so "scaling" is "strong".
 
-On one GPU every frame is enqueued as ONE hipGraph launch (GaussianScene.capture_frame: all ~30
-kernel launches, the clears and the asynchronous count copy of a frame are recorded once and replayed;
---no-graphs enqueues them one by one) and 3 frames are in flight on 3 HIP streams (--streams).
+On one GPU every frame is enqueued as ONE hipGraph launch (GaussianScene.capture_frame: all ~23
+kernel launches of a frame are recorded once and replayed; --no-graphs enqueues them one by one).
+`value` follows SURVEY.md 8(d): W*H over the MEDIAN of hipEvent-bracketed single frames with one frame
+in flight (--repeats x --steps of them); `ms_per_step` is the contract's wall-clock region (K such
+frames between fences).  The rate with 3 frames in flight on 3 HIP streams (--streams) is reported
+beside it as `value_frames_in_flight`.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant kernel (tile compositing): algorithmic bytes per launch over its
@@ -51,7 +54,12 @@ WORKLOADS = {
     "c4": (5_000_000, 3840, 2160, "C4: synthetic 5M Gaussians, 3840x2160"),
     # not a BASELINE config: index-width / capacity stress (2.0e7 Gaussians, ~8.5e7 pairs, ~3 GB of workspace)
     "stress20m": (20_000_000, 3840, 2160, "stress: synthetic 20M Gaussians, 3840x2160"),
+    # not a BASELINE config: heavy-tailed tile lists, like a trained scene (half of the Gaussians inside 5 % of the
+    # frame, log-normal footprints with sigma_ln = 1.0): what one-wave-per-tile compositing has to survive
+    "c3_clustered": (1_000_000, 1920, 1080, "clustered: 1M Gaussians, half of them in 5 % of a 1920x1080 frame, "
+                     "footprint sigma_ln 1.0"),
 }
+GENERATOR_ARGS = {"c3_clustered": dict(cluster_fraction=0.5, cluster_area=0.05, sigma_ln=1.0)}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (unpacked VALU)
 # VALU lane-ops the compositing loop issues per (pixel, Gaussian) pair, counted in the gfx950 ISA of
@@ -85,7 +93,7 @@ def build_scene_from_ply(ply_path: str, colmap_dir, image_id: int, width: int, h
 
 def build_scene(workload: str, device: str):
     n, w, h, _ = WORKLOADS[workload]
-    sc = make_scene(n, w, h, seed=0)
+    sc = make_scene(n, w, h, seed=0, **GENERATOR_ARGS.get(workload, {}))
     with tempfile.TemporaryDirectory() as tmp:
         write_colmap_text(tmp, sc)
         g = Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"],
@@ -193,12 +201,23 @@ def cpu_baseline(sc, scene, gpu_frame: torch.Tensor, budget_s: float = 20.0, sem
     # the projection is whole-frame work; charge the sample its share
     mpix = sample_px / (t_render + t_pre * frac) / 1e6
     x0, x1, y0, y1 = window[0] * tile, window[1] * tile, window[2] * tile, window[3] * tile
-    err, psnr = 0.0, float("inf")
+    err, psnr, exact_info = 0.0, float("inf"), None
     if n_tiles:
-        diff = gpu_frame[x0:x1, y0:y1].cpu().numpy().astype(np.float64) - ref[x0:x1, y0:y1]
+        got = gpu_frame[x0:x1, y0:y1].cpu().numpy().astype(np.float64)
+        diff = got - ref[x0:x1, y0:y1]
         err = float(np.abs(diff).max())
         mse = float((diff * diff).mean())
         psnr = float("inf") if mse == 0.0 else 10.0 * np.log10(1.0 / mse)
+        if err > 1e-5:
+            # who is off?  the same rules in float64 from the same float32 stage-1 arrays (oracle exact mode):
+            # on ill-conditioned footprints (thin, rotated, seen far along their ridge) the REFERENCE's float32
+            # grouping of e Q e^T loses up to 1e-3 of alpha; the kernel completes the square and stays at 1e-6
+            exact, _, _ = c_oracle.render(pre, w, h, tile, nthreads=cores, window=window, exact=True)
+            ex = exact[x0:x1, y0:y1].astype(np.float64)
+            exact_info = {"gpu_vs_float64": float(np.abs(got - ex).max()),
+                          "cpu_float32_port_vs_float64": float(np.abs(ref[x0:x1, y0:y1] - ex).max()),
+                          "pixels_gpu_vs_port_above_1e-4": int((np.abs(diff).max(axis=2) > 1e-4).sum()),
+                          "pixels": int(diff.shape[0] * diff.shape[1])}
 
     # the reference's own loop is single-threaded pure Python: time the scalar restatement on one tile
     # first, then on as much of a 4x4-tile window as fits ~8 s
@@ -226,6 +245,7 @@ def cpu_baseline(sc, scene, gpu_frame: torch.Tensor, budget_s: float = 20.0, sem
         "sample": "oracle/raster_cpu.c (C restatement, %d threads) on %s: %.2f s render + %.2f s projection share; "
                   "%d (pixel,Gaussian) pairs" % (cores, label, t_render, t_pre * frac, pairs),
         "seconds": round(t_render + t_pre * frac, 3),
+        "exact_arithmetic_check": exact_info,
         "python_port": {"us_per_pair": round(us_per_pair, 3), "pairs": int(py_pairs), "cores": 1,
                         "extrapolated_mpixels_per_s": float("%.3g" % py_mpix),
                         "sample": "oracle/cpu_ref.py scalar loop on the %dx%d-tile window at tile (%d,%d)"
@@ -262,11 +282,16 @@ def main() -> None:
                     help="frames in flight: consecutive frames alternate over this many HIP streams, so one "
                          "frame's latency-bound sorts overlap another's VALU-bound compositing (N > 1: the strips of "
                          "consecutive frames, strips.StripPipeline)")
+    ap.add_argument("--repeats", type=int, default=25,
+                    help="the --steps hipEvent-bracketed single frames are repeated this many times; `value` is W*H over "
+                         "the MEDIAN frame time of all of them (SURVEY.md 8(d))")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed frames rendered during setup, before the --warmup steps, for this many ms")
     ap.add_argument("--no-graphs", action="store_true",
                     help="enqueue every frame as ~30 separate launches instead of replaying it as one hipGraph "
                          "(GaussianScene.capture_frame); 1 GPU only")
+    ap.add_argument("--no-balance", action="store_true",
+                    help="N > 1: equal strips instead of strips balanced by the per-tile-row pair counts of a planning frame")
     ap.add_argument("--sync-frames", action="store_true",
                     help="read the instance count back inside every frame instead of speculating on it")
     args = ap.parse_args()
@@ -294,6 +319,16 @@ def main() -> None:
         sc, scene = build_scene(args.workload, str(device))
     tile, layout, sem = 16, "wh3", args.semantics
 
+    # N > 1: every rank renders the frame once (untimed), reads the per-tile list lengths the library reports
+    # (GsxParams.tile_counts) and derives the same balanced strip plan from them -- no communication needed
+    strip_plan = None
+    if world > 1 and not args.no_balance:
+        ntx, nty = strips.tiles_along(width, tile, sem), strips.tiles_along(height, tile, sem)
+        counts = torch.zeros(max(1, ntx * nty), dtype=torch.int32, device=device)
+        scene.render_image_hip(1, tile_size=tile, layout=layout, tile_counts=counts, semantics=sem)
+        n_lead, n_other = (ntx, nty) if layout == "wh3" else (nty, ntx)
+        strip_plan = strips.balanced_plan(strips.tile_row_costs(counts, n_lead, n_other, lead_is_x=(layout == "wh3")), world)
+
     def render_strip(window, out, origin):
         scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=window, out=out, out_origin=origin,
                                no_sync=not args.sync_frames, semantics=sem)
@@ -319,7 +354,7 @@ def main() -> None:
         if pipeline is not None:
             return pipeline.submit()
         return strips.render_sharded(render_strip, width, height, tile, layout, device, cache=strip_cache,
-                                     semantics=sem)
+                                     semantics=sem, plan=strip_plan)
 
     step.count = 0
     strip_cache = {}
@@ -330,10 +365,22 @@ def main() -> None:
     pipeline = None
     if world > 1 and args.streams > 1 and not args.sync_frames:
         pipeline = strips.StripPipeline(render_strip, width, height, tile, layout, device, depth=args.streams,
-                                        semantics=sem)
+                                        semantics=sem, plan=strip_plan)
     use_graphs = world == 1 and not args.no_graphs and not args.sync_frames
     gstreams = (streams or [torch.cuda.Stream(device)]) if use_graphs else []
     graphs = {st: scene.capture_frame(1, tile_size=tile, layout=layout, semantics=sem) for st in gstreams}
+    lat_stream = torch.cuda.Stream(device)
+    one = scene.capture_frame(1, tile_size=tile, layout=layout, semantics=sem) if use_graphs else None
+
+    def single_frame():
+        """ONE frame, nothing else in flight: what SURVEY.md 8(d) times."""
+        if world > 1:
+            return strips.render_sharded(render_strip, width, height, tile, layout, device, cache=strip_cache,
+                                         semantics=sem, plan=strip_plan)
+        if one is not None:
+            return one.replay()
+        return scene.render_image_hip(1, tile_size=tile, layout=layout, out=single_out, no_sync=not args.sync_frames,
+                                      semantics=sem)
 
     def fence():
         if world > 1:
@@ -344,52 +391,73 @@ def main() -> None:
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
         for _ in range(8):
-            step()
+            single_frame()
         torch.cuda.synchronize()
     scene.confirm_frames()
+
+    # ---- the contract's region: W untimed steps, then EXACTLY K steps between fences, one frame in flight
     frame = None
-    for _ in range(args.warmup):
-        frame = step()
-    fence()
-    scene.confirm_frames()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    with torch.cuda.stream(lat_stream):
+        for _ in range(args.warmup):
+            frame = single_frame()
+        fence()
+        scene.confirm_frames()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            frame = single_frame()
+        fence()
+        elapsed = time.perf_counter() - t0
     respeculated = scene.confirm_frames()
-    for gf in graphs.values():
-        gf.confirm()            # raises if a replay needed more pairs than the graph was captured with
-    if world > 1:
-        flag = torch.tensor([respeculated], dtype=torch.int64, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        respeculated = int(flag.item())
-    if respeculated:
-        raise SystemExit("speculative frames missed their instance hint %d times: timing invalid" % respeculated)
+    if one is not None:
+        one.confirm()           # raises if a replay needed more pairs than the graph was captured with
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    mpix = width * height / (ms_per_step * 1e-3) / 1e6
 
-    # frame latency with ONE frame in flight (same process, same scene), for reference
-    latency_ms = None
+    # ---- median of hipEvent-bracketed single frames; the K-step batch is repeated so that a
+    #      fresh box's first milliseconds do not decide the number
+    frame_ms = []
+    with torch.cuda.stream(lat_stream):
+        for _ in range(args.repeats):
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+            for e0, e1 in evs:
+                e0.record()
+                single_frame()
+                e1.record()
+            fence()
+            respeculated += scene.confirm_frames()
+            frame_ms += [e0.elapsed_time(e1) for e0, e1 in evs]
+    frame_ms = np.sort(np.asarray(frame_ms, dtype=np.float64))
+    if world > 1:       # a frame is done when the slowest rank is: take every rank's median, report the largest
+        t = torch.tensor([float(np.median(frame_ms))], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        median_ms = float(t.item())
+    else:
+        median_ms = float(np.median(frame_ms))
+    mpix = width * height / (median_ms * 1e-3) / 1e6
+
+    # ---- for reference: several frames in flight (whole-job throughput of a stream of frames)
+    inflight_ms = None
     launches_ms = None
-    if world == 1 and (len(streams) > 1 or graphs):
-        lat_out = single_out            # preallocated: pending frames keep their output tensors alive
-        one = graphs[gstreams[0]] if graphs else None
-        torch.cuda.synchronize()
+    if (world == 1 and (len(streams) > 1)) or pipeline is not None:
+        for _ in range(args.warmup):
+            step()
+        fence()
+        respeculated += scene.confirm_frames()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            if one is not None:
-                one.replay()
-            else:
-                scene.render_image_hip(1, tile_size=tile, layout=layout, out=lat_out, no_sync=not args.sync_frames,
-                                       semantics=sem)
-        torch.cuda.synchronize()
-        latency_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        scene.confirm_frames()
+        for _ in range(args.steps * 3):
+            step()
+        fence()
+        inflight_ms = (time.perf_counter() - t1) / (args.steps * 3) * 1e3
+        respeculated += scene.confirm_frames()
+        for gf in graphs.values():
+            gf.confirm()
+        if world > 1:
+            t = torch.tensor([inflight_ms], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            inflight_ms = float(t.item())
     if graphs and len(streams) > 1:
         # for reference: the same frames in flight, every frame enqueued as separate launches
         for st in streams:              # untimed: this path's per-stream workspaces are allocated on first use
@@ -405,6 +473,12 @@ def main() -> None:
         torch.cuda.synchronize()
         launches_ms = (time.perf_counter() - t1) / args.steps * 1e3
         scene.confirm_frames()
+    if world > 1:
+        flag = torch.tensor([respeculated], dtype=torch.int64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        respeculated = int(flag.item())
+    if respeculated:
+        raise SystemExit("speculative frames missed their instance hint %d times: timing invalid" % respeculated)
 
     # per-stage HIP-event times of this rank's share (live, same process, separate loop)
     stage = {}
@@ -412,7 +486,7 @@ def main() -> None:
     reps = max(3, min(args.steps, 10))
     window = None
     if world > 1:
-        per, plan = strips.strip_plan(strips.tiles_along(width, tile, sem), world)
+        plan = strip_plan or strips.strip_plan(strips.tiles_along(width, tile, sem), world)[1]
         window = (plan[rank][0], plan[rank][1], 0, strips.tiles_along(height, tile, sem))
     for _ in range(reps):
         stats = {}
@@ -421,10 +495,21 @@ def main() -> None:
         for k, v in stats.get("stage_ms", {}).items():
             stage[k] = stage.get(k, 0.0) + v / reps
 
+    # how long the tile lists are (GsxParams.tile_counts): the compositing kernel lasts as long as its longest
+    tile_list = None
+    if world == 1:
+        ntx_, nty_ = strips.tiles_along(width, tile, sem), strips.tiles_along(height, tile, sem)
+        if ntx_ * nty_ > 0:
+            tc = torch.zeros(ntx_ * nty_, dtype=torch.int32, device=device)
+            scene.render_image_hip(1, tile_size=tile, layout=layout, tile_counts=tc, semantics=sem)
+            tcs = torch.sort(tc.to(torch.float64)).values
+            tile_list = {"mean": round(float(tcs.mean()), 1), "p50": float(tcs[len(tcs) // 2]),
+                         "p99": float(tcs[int(0.99 * (len(tcs) - 1))]), "max": float(tcs[-1]), "tiles": int(len(tcs))}
+
     strips_ok = None
     if world > 1:
         # the gathered frame must equal the single-GPU frame bit for bit
-        last = step()
+        last = single_frame()
         torch.cuda.synchronize()
         scene.confirm_frames()
         if rank == 0:
@@ -443,36 +528,53 @@ def main() -> None:
         pairs = 256.0 * d
         valu = pairs * VALU_OPS_PER_PAIR / (blend_ms * 1e-3) / FP32_LANE_OPS_PER_S if blend_ms > 0 else 0.0
         ref_rules = sem == "ref_cpu"
+        pmc_traffic, pmc_valu = pmc_record(args.workload, world) if ref_rules else (None, None)
         out = {
             "metric": "Mpixels/sec forward raster (1M Gaussians, 1080p) + max |dpixel| vs CPU ref",
+            # W*H over the MEDIAN of hipEvent-bracketed single frames, one frame in flight
             "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "user-supplied .ply" if args.ply else "synthetic",
+            "frame_ms": {"median": round(median_ms, 4), "min": round(float(frame_ms[0]), 4),
+                         "max": round(float(frame_ms[-1]), 4), "p90": round(float(frame_ms[int(0.9 * (len(frame_ms) - 1))]), 4),
+                         "frames": int(len(frame_ms)),
+                         "how": "hipEvent pair around every frame, one frame in flight, %d x %d frames%s" % (
+                             args.repeats, args.steps, "; largest per-rank median" if world > 1 else "")},
+            # whole-job rate with several frames in flight on separate HIP streams (not the contract's number)
+            "value_frames_in_flight": None if inflight_ms is None else round(width * height / (inflight_ms * 1e-3) / 1e6, 2),
             "config": {"workload": desc, "n_gaussians": n, "width": width, "height": height, "tile": tile,
                        "semantics": sem, "layout": layout, "n_visible": nvis, "tile_instances": d,
-                       "frames_in_flight": max(1, len(streams)) if world == 1 else (pipeline.depth if pipeline else 1),
-                       "launch": "one hipGraph replay per frame" if graphs else "separate kernel launches",
-                       "ms_per_frame_one_in_flight": None if latency_ms is None else round(latency_ms, 4),
+                       "frames_in_flight": 1,
+                       "launch": "one hipGraph replay per frame" if one is not None else "separate kernel launches",
+                       "ms_per_frame_in_flight": None if inflight_ms is None else round(inflight_ms, 4),
+                       "frames_in_flight_for_that": (max(1, len(streams)) if world == 1 else (pipeline.depth if pipeline else 1)),
                        "ms_per_frame_separate_launches": None if launches_ms is None else round(launches_ms, 4),
                        "frame_sync": "host reads instance count every frame" if args.sync_frames
                        else "speculative (GSX_FLAG_NO_SYNC), counts confirmed after the timed region",
-                       "parallelism": "1 GPU" if world == 1 else "%d column strips + RCCL gather" % world},
-            "fps": round(1e3 / ms_per_step, 2),
+                       "parallelism": "1 GPU" if world == 1 else "%d column strips + RCCL gather" % world,
+                       "strip_plan": None if world == 1 else (strip_plan or "equal")},
+            "fps": round(1e3 / median_ms, 2),
             "roofline": {"bound": "hbm", "kernel": "blend_tile16_kernel" if ref_rules else "blend_rules_kernel",
                          "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": pmc_record(args.workload, world)[0] if ref_rules else None,
+                         "traffic": pmc_traffic,
                          "bytes_per_launch": blend_bytes,
                          "avg_ms": round(blend_ms, 4), "valu_frac": round(valu, 4) if ref_rules else None,
-                         "valu_busy_pmc": pmc_record(args.workload, world)[1] if ref_rules else None,
+                         "valu_busy_pmc": pmc_valu,
+                         "source": {"achieved": "live: hipEvent pair around the launch on its stream (GSX_FLAG_TIMING), this run",
+                                    "traffic": None if pmc_traffic is None else "replayed from %s (rocprofv3 --pmc passes "
+                                    "of an earlier run of this command)" % os.path.relpath(PMC_FILE, ROOT),
+                                    "valu_busy_pmc": None if pmc_valu is None else os.path.relpath(PMC_FILE, ROOT)},
                          "note": "compositing under reference CPU semantics is VALU-bound (256 evaluations per "
                                  "36-B record); valu_frac = 256*D*%.2f lane-ops / t / (256 CU x 4 SIMD x 32 lanes x "
                                  "2.4 GHz); valu_busy_pmc = SQ_ACTIVE_INST_VALU share of kernel cycles; traffic = "
-                                 "HBM-side bytes per launch; both from rocprofv3 PMC passes (profiles/r1_pmc_c3.json)"
-                                 % VALU_OPS_PER_PAIR},
-            "frame_roofline": {"bytes": frame_bytes, "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                               "unit": "GB/s", "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                                 "HBM-side bytes per launch" % VALU_OPS_PER_PAIR},
+            # the whole frame against the HBM roofline, at the one-frame-in-flight median (SURVEY.md 8(d) B_alg)
+            "frame_roofline": {"bytes": frame_bytes, "ms": round(median_ms, 4),
+                               "achieved": round(frame_bytes / (median_ms * 1e-3) / 1e9, 2),
+                               "unit": "GB/s", "frac": round(frame_bytes / (median_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+            "tile_list_length": tile_list,
         }
         if stage.get("project", 0.0) > 0.0 and world == 1:
             # the HBM-bound stage: 56 B read + 68 B written per Gaussian (record 48, keys/values 8, rectangle 8,
@@ -490,7 +592,11 @@ def main() -> None:
             out["max_abs_dpixel"] = err
             out["psnr_db"] = None if psnr in (None, float("inf")) else round(psnr, 2)
             if ref_rules:
-                out["parity_ok"] = bool(err <= 1e-4 and inst == d)
+                ex = base.get("exact_arithmetic_check")
+                # within 1e-4 of the float32 restatement -- or, where that restatement is itself further than that from
+                # exact arithmetic (ill-conditioned footprints of the heavy-tailed stress scene), within 1e-5 of float64
+                out["parity_ok"] = bool(inst == d and (err <= 1e-4 or (ex is not None and ex["gpu_vs_float64"] <= 1e-5 and
+                                                                       err <= ex["cpu_float32_port_vs_float64"] + 1e-5)))
             else:   # 1/255-threshold flips are counted apart (tests/test_hip_std3dgs.py states the bar)
                 # the default binning drops (Gaussian, tile) pairs that cannot reach alpha = 1/255: D <= published D
                 out["parity_ok"] = bool(err <= 1e-4 and (inst is None or d <= inst) and

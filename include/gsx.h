@@ -101,6 +101,10 @@ typedef struct GsxParams {
      * moment, e.g. a camera that moves between replays of a captured frame.  `camera` must still be
      * given: its width / height size the frame on the host and must equal the buffer's. */
     const GsxCamera *camera_device;
+    /* Optional DEVICE array of one uint32 per tile of the window (window-local id = (tx - tile_x0) *
+     * window_height_in_tiles + (ty - tile_y0)): the length of every tile's Gaussian list, written by the
+     * frame.  What a multi-GPU caller balances its strips with (strips.balanced_plan).  NULL: not reported. */
+    uint32_t *tile_counts;
 } GsxParams;
 
 /* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call
@@ -130,6 +134,13 @@ typedef struct GsxParams {
  * no tile at all).  This flag bins with the published rectangles instead, e.g. to compare
  * GsxFrameStats.n_instances with another implementation of the published algorithm. */
 #define GSX_FLAG_PUBLISHED_RECTS 8
+
+/* GSX_SEM_REF_CPU, tile 16.  By default a tile whose Gaussian list is more than 4x the frame's average (and
+ * more than 1024 entries) long is composited by four waves -- a quarter of its pixels each, one pixel per
+ * lane -- instead of one, so that a few very long lists (trained scenes are heavy-tailed) do not outlast
+ * the rest of the frame.  Same arithmetic, same pixels bit for bit; this flag keeps every tile on one wave,
+ * for tests that hold the two paths against each other. */
+#define GSX_FLAG_NO_LONG_TILE_SPLIT 16
 
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
 enum {

@@ -28,6 +28,7 @@ GSX_FLAG_TIMING = 1
 GSX_FLAG_NO_SYNC = 2
 GSX_FLAG_GENERIC_KERNELS = 4
 GSX_FLAG_PUBLISHED_RECTS = 8
+GSX_FLAG_NO_LONG_TILE_SPLIT = 16
 STAGE_NAMES = ("project", "depth_sort", "scan", "bin", "blend", "total")
 
 
@@ -41,7 +42,8 @@ class GsxParams(ctypes.Structure):
     _fields_ = [("semantics", c_int32), ("layout", c_int32),
                 ("tile_x0", c_int32), ("tile_x1", c_int32), ("tile_y0", c_int32), ("tile_y1", c_int32),
                 ("out_x0", c_int32), ("out_y0", c_int32), ("out_w", c_int32), ("out_h", c_int32),
-                ("flags", c_int32), ("background", c_float * 3), ("camera_device", c_void_p)]
+                ("flags", c_int32), ("background", c_float * 3), ("camera_device", c_void_p),
+                ("tile_counts", c_void_p)]
 
 
 class GsxFrameStats(ctypes.Structure):

@@ -42,14 +42,14 @@ struct Carve {
     size_t keys0, keys1, vals0, vals1;      // n x u32: depth keys / original indices (ping-pong)
     size_t rec, rect, rrect, bbox;          // per Gaussian: record, tile rectangle by index / by depth rank
     size_t tkeys0, tkeys1, tvals0, tvals1;  // cap x u32: tile ids / Gaussian indices (ping-pong)
-    size_t ranges, counters, temp, temp_bytes, total;
+    size_t ranges, longs, counters, temp, temp_bytes, total;
 };
 
 // The 64-byte `counters` block: what the kernels of one frame hand to each other on the device.
 //   u32 [0] Gaussians behind the cull plane   [1] Gaussians kept by the depth sort (M)
-//       [2] min(D, 2^32 - 1)                   [3] spare
+//       [2] min(D, 2^32 - 1)                   [3] long tiles found (LongTiles.count)
 //   i64 at byte 16: n_visible, D (the first two fields of a GsxFrameStats)
-enum { kCtrCulled = 0, kCtrKept = 1, kCtrPairs = 2 };
+enum { kCtrCulled = 0, kCtrKept = 1, kCtrPairs = 2, kCtrLong = 3 };
 
 Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes) {
     Carve c;
@@ -67,6 +67,7 @@ Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes) {
     c.bbox = take(nn * sizeof(float4));
     c.tkeys0 = take(cc * 4); c.tkeys1 = take(cc * 4); c.tvals0 = take(cc * 4); c.tvals1 = take(cc * 4);
     c.ranges = take((size_t)(max_tiles > 0 ? max_tiles : 1) * sizeof(uint2));
+    c.longs = take(gsx::kMaxLongTiles * sizeof(uint32_t));
     c.counters = take(64);
     c.temp = take(temp_bytes);
     c.temp_bytes = temp_bytes;
@@ -100,7 +101,9 @@ struct Plan {
     bool no_sync;  // GSX_FLAG_NO_SYNC: nothing waits for the device
     bool generic;  // GSX_FLAG_GENERIC_KERNELS
     bool tight;    // GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS
+    bool split;    // long tiles on four waves (not GSX_FLAG_NO_LONG_TILE_SPLIT)
     const GsxCamera *camera_device;
+    uint32_t *tile_counts;
     float background[3];
 };
 
@@ -153,6 +156,7 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
         return fail(GSX_ERR_UNSUPPORTED, "unknown semantics %d", d.semantics);
     for (int i = 0; i < 3; ++i) p.background[i] = d.background[i];
     p.camera_device = d.camera_device;
+    p.tile_counts = d.tile_counts;
     if (d.layout != GSX_LAYOUT_WH3 && d.layout != GSX_LAYOUT_HW3) return fail(GSX_ERR_INVALID_ARGUMENT, "unknown layout %d", d.layout);
     if (!out_image) return fail(GSX_ERR_INVALID_ARGUMENT, "out_image is NULL");
     p.semantics = d.semantics;
@@ -160,6 +164,7 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     p.no_sync = (d.flags & GSX_FLAG_NO_SYNC) != 0 && !p.timing;
     p.generic = (d.flags & GSX_FLAG_GENERIC_KERNELS) != 0;
     p.tight = d.semantics == GSX_SEM_STD_3DGS && (d.flags & GSX_FLAG_PUBLISHED_RECTS) == 0;
+    p.split = (d.flags & GSX_FLAG_NO_LONG_TILE_SPLIT) == 0;
     gsx::TileGrid &g = p.grid;
     g.tile = tile;
     g.ntx = tiles_along(width, tile, d.semantics);
@@ -258,14 +263,15 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
         tm.mark();  // 3: scan + emit
         GSX_HIP(gsx::launch_zero_words((uint32_t *)ranges, (size_t)p.grid.count() * 2, s));
         GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), nullptr, (const uint32_t *)(ws + c.tvals0), ranges,
-                                  p.grid, p.out, p.semantics, p.background, p.generic, make_clear_plan(p, false), s));
+                                  p.grid, p.out, p.semantics, p.background, p.generic, make_clear_plan(p, false),
+                                  gsx::LongTiles{nullptr, nullptr, 0u}, s));
     } else if (n == 0) {
         tm.mark();
         GSX_HIP(gsx::launch_clear(make_clear_plan(p, true), p.out.ptr, s));
     } else {
         // the counts are produced by the emit kernel even when no tile is rendered (an empty window
         // still reports n_visible; its pair count is 0 because every rectangle was clamped away)
-        gsx::BinCounts bc{dev2, nullptr, counters + kCtrPairs, culled_dev, n};
+        gsx::BinCounts bc{dev2, nullptr, counters + kCtrPairs, counters + kCtrLong, culled_dev, n};
         if (p.no_sync && stats) {
             // pinned host memory is device-visible: the emit kernel stores the two counts there itself
             void *alias = nullptr;
@@ -284,12 +290,15 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             GSX_HIP(gsx::launch_clear(make_clear_plan(p, true), p.out.ptr, s));
         } else {
             const uint32_t *sorted_vals = nullptr;
+            const bool split = p.split && cap > 0 && gsx::blend_splits_long_tiles(p.grid, p.semantics, p.generic);
+            const gsx::LongTiles lt{counters + kCtrLong, (uint32_t *)(ws + c.longs), split ? gsx::kMaxLongTiles : 0u};
             GSX_HIP(gsx::sort_instances(temp, cap, p.grid, ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0),
-                                        (uint32_t *)(ws + c.tvals1), ranges, counters + kCtrPairs, &sorted_vals, s));
+                                        (uint32_t *)(ws + c.tvals1), ranges, counters + kCtrPairs, lt, &sorted_vals, s));
+            if (p.tile_counts) GSX_HIP(gsx::launch_tile_counts(ranges, p.grid.count(), p.tile_counts, s));
             tm.mark();  // 4: tile sort
             GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
                                       ranges, p.grid, p.out, p.semantics, p.background, p.generic,
-                                      make_clear_plan(p, false), s));
+                                      make_clear_plan(p, false), lt, s));
             tm.mark();  // 5: blend
         }
     }
@@ -454,7 +463,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     tm.begin(p.timing, s);
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
     uint32_t *counters = (uint32_t *)(ws + c.counters);
-    GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, k0, v0, (gsx::Record *)(ws + c.rec),
+    GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, k0, (gsx::Record *)(ws + c.rec),
                                      (gsx::TileRect *)(ws + c.rect), counters,
                                      p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 1: project (+ depth keys)

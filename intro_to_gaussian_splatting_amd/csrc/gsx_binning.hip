@@ -134,6 +134,7 @@ struct EmitCounts {
     int64_t *stats2;
     int64_t *stats2_host;        // device-visible alias of pinned host memory, or null
     uint32_t *d32;
+    uint32_t *long_count;
     const uint32_t *culled_dev;  // Gaussians behind the cull plane (whole-path entry), or null
     int64_t n_total;             // n_visible = n_total - *culled_dev
 };
@@ -210,6 +211,7 @@ __global__ void __launch_bounds__(kBlock)
             ec.stats2_host[1] = (int64_t)d;
         }
         *ec.d32 = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d;
+        *ec.long_count = 0u;
     }
 
     // ---- pair by pair: p-th pair of the chunk -> its Gaussian (largest rank with offs <= p) -> its tile
@@ -254,15 +256,19 @@ __global__ void __launch_bounds__(kBlock)
 // ranges[t] = [first, last+1) of tile t inside the tile-sorted pair list; untouched (zeroed by
 // the emit kernel) for tiles with no entries.  8 consecutive keys per thread.
 // The grid covers the workspace capacity; the true pair count is read from device memory.
+// The thread that closes a tile's run also decides whether the tile is LONG (more entries than
+// long_tile_threshold: the key that many positions back is still this tile's), appends it to lt.list and
+// flags it in bit 31 of ranges[t].y -- see LongTiles in gsx_internal.h.
 template <typename Key>
 __global__ void __launch_bounds__(kBlock)
     tile_ranges_kernel(const Key *__restrict__ keys, const uint32_t *__restrict__ d_dev, uint32_t cap,
-                       uint2 *__restrict__ ranges) {
+                       uint2 *__restrict__ ranges, LongTiles lt, uint32_t ntiles) {
     constexpr int kPer = 8;
     const uint32_t d = min(*d_dev, cap);
     const uint32_t j0 = (blockIdx.x * (uint32_t)kBlock + threadIdx.x) * kPer;
     if (j0 >= d) return;
-    Key k[kPer + 1];                 // k[0] = the key before this thread's run
+    const uint32_t long_len = long_tile_threshold(d, ntiles);
+    Key k[kPer + 2];                 // k[0] = the key before this thread's run, k[kPer + 1] = the one after it
     k[0] = j0 > 0 ? keys[j0 - 1] : (Key)0;
     const uint32_t cnt = min((uint32_t)kPer, d - j0);
     if (cnt == kPer && sizeof(Key) == 2) {
@@ -277,21 +283,42 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
         for (int e = 0; e < kPer; ++e) k[1 + e] = (uint32_t)e < cnt ? keys[j0 + e] : (Key)0;
     }
+    k[kPer + 1] = j0 + kPer < d ? keys[j0 + kPer] : (Key)0;
 #pragma unroll
     for (int e = 0; e < kPer; ++e) {
         if ((uint32_t)e >= cnt) break;
         const uint32_t j = j0 + e;
-        if (j == 0 || k[e] != k[e + 1]) {
-            ranges[k[e + 1]].x = j;
-            if (j > 0) ranges[k[e]].y = j;
+        const Key cur = k[e + 1];
+        if (j == 0 || k[e] != cur) ranges[cur].x = j;
+        if (j == d - 1 || k[e + 2] != cur) {           // j closes the run of tile `cur`
+            uint32_t end = j + 1;
+            if (lt.max && j >= long_len && keys[j - long_len] == cur) {
+                const uint32_t slot = atomicAdd(lt.count, 1u);
+                if (slot < lt.max) {
+                    lt.list[slot] = (uint32_t)cur;
+                    end |= kLongFlag;
+                }
+            }
+            ranges[cur].y = end;
         }
-        if (j == d - 1) ranges[k[e + 1]].y = d;
     }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    tile_counts_kernel(const uint2 *__restrict__ ranges, int64_t nt, uint32_t *__restrict__ counts) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t < nt) counts[t] = (ranges[t].y & ~kLongFlag) - ranges[t].x;
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
+
+hipError_t launch_tile_counts(const uint2 *ranges, int64_t nt, uint32_t *counts, hipStream_t s) {
+    if (nt <= 0) return hipSuccess;
+    tile_counts_kernel<<<blocks_for(nt), kBlock, 0, s>>>(ranges, nt, counts);
+    return hipGetLastError();
+}
 
 size_t binning_temp_bytes(int64_t n, int64_t cap) {
     const size_t nchunks = (size_t)((n + kChunk - 1) / kChunk) + 2;
@@ -317,7 +344,7 @@ hipError_t emit_impl(void *temp, const TileRect *rrect, const uint32_t *order, c
     const int nchunks = (int)((n + kChunk - 1) / kChunk);
     uint64_t *sums = sums_of(temp, n, cap);
     chunk_sums_kernel<<<nchunks, kBlock, 0, s>>>(rrect, m_dev, (uint32_t)n, sums);
-    const EmitCounts ec{bc.stats2, bc.stats2_host, bc.d32, bc.culled_dev, bc.n_total};
+    const EmitCounts ec{bc.stats2, bc.stats2_host, bc.d32, bc.long_count, bc.culled_dev, bc.n_total};
     const unsigned tiles_grid = blocks_for(nt);
     const unsigned egrid = (unsigned)nchunks > tiles_grid ? (unsigned)nchunks : tiles_grid;
     if (nchunks <= kSelfScanChunks) {
@@ -334,7 +361,8 @@ hipError_t emit_impl(void *temp, const TileRect *rrect, const uint32_t *order, c
 // Stable sort of the pairs by tile id + every tile's [first, last) range.
 template <typename Key>
 hipError_t sort_impl(void *temp, int64_t cap, void *keys0, void *keys1, uint32_t *vals0, uint32_t *vals1, uint2 *ranges,
-                     int key_bits, const uint32_t *d32, const uint32_t **sorted_vals, hipStream_t s) {
+                     int key_bits, const uint32_t *d32, const LongTiles &lt, uint32_t ntiles,
+                     const uint32_t **sorted_vals, hipStream_t s) {
     Key *kc = (Key *)keys0, *ka = (Key *)keys1;
     uint32_t *vc = vals0, *va = vals1;
     hipError_t e;
@@ -343,7 +371,7 @@ hipError_t sort_impl(void *temp, int64_t cap, void *keys0, void *keys1, uint32_t
     else
         e = radix_sort_pairs_u32(temp, (uint32_t *&)kc, (uint32_t *&)ka, vc, va, d32, cap, key_bits, s);
     if (e != hipSuccess) return e;
-    tile_ranges_kernel<Key><<<blocks_for((cap + 7) / 8), kBlock, 0, s>>>(kc, d32, (uint32_t)cap, ranges);
+    tile_ranges_kernel<Key><<<blocks_for((cap + 7) / 8), kBlock, 0, s>>>(kc, d32, (uint32_t)cap, ranges, lt, ntiles);
     *sorted_vals = vc;
     return hipGetLastError();
 }
@@ -357,15 +385,16 @@ hipError_t emit_instances(void *temp, const TileRect *rrect, const uint32_t *ord
 }
 
 hipError_t sort_instances(void *temp, int64_t cap, const TileGrid &grid, void *keys0, void *keys1, uint32_t *vals0,
-                          uint32_t *vals1, uint2 *ranges, const uint32_t *d32, const uint32_t **sorted_vals,
-                          hipStream_t s) {
+                          uint32_t *vals1, uint2 *ranges, const uint32_t *d32, const LongTiles &lt,
+                          const uint32_t **sorted_vals, hipStream_t s) {
     *sorted_vals = vals0;
     if (cap <= 0) return hipSuccess;           // nothing fits: every range stays empty
     const int64_t nt = grid.count();
     int bits = 1;
     while (((int64_t)1 << bits) < nt) ++bits;
-    if (nt <= 65536) return sort_impl<uint16_t>(temp, cap, keys0, keys1, vals0, vals1, ranges, bits, d32, sorted_vals, s);
-    return sort_impl<uint32_t>(temp, cap, keys0, keys1, vals0, vals1, ranges, bits, d32, sorted_vals, s);
+    if (nt <= 65536)
+        return sort_impl<uint16_t>(temp, cap, keys0, keys1, vals0, vals1, ranges, bits, d32, lt, (uint32_t)nt, sorted_vals, s);
+    return sort_impl<uint32_t>(temp, cap, keys0, keys1, vals0, vals1, ranges, bits, d32, lt, (uint32_t)nt, sorted_vals, s);
 }
 
 }  // namespace gsx

@@ -32,8 +32,18 @@
 // contracted each template instance: both output layouts give bit-identical pixels.  With
 // Q'' = -1/2 log2(e) Q (packed by the projection kernels), e = mean - pixel:
 //     alpha = exp2(e0^2 Q''00 + e0 e1 (Q''01 + Q''10) + e1^2 Q''11 + log2 op)    (one v_exp_f32)
-// which is the reference's exp(-1/2 e Q e^T) * op with the four products re-associated; the
-// difference is a few ulp of the largest product, like the reference's own float32 rounding.
+// which is the reference's exp(-1/2 e Q e^T) * op.  The three products are NOT summed as they stand: for a
+// long, thin, rotated footprint seen from 100 px along its ridge they are ~1e4 each and cancel to O(1), and
+// float32 then loses up to 1e-3 of alpha (found on the heavy-tailed workload: 7.7e-4 on a pixel).  With
+// M = -Q'' (symmetrised like the reference's e Q e^T does) the square is completed in y:
+//     e M e^T = D1 e0^2 + (r11 e1 + h e0)^2,   r11 = sqrt(M11), h = M01 / r11, D1 = M00 - h^2 = det M / M11
+//     exponent = fma(-w, w, s0),  w = fma(r11, e1, h e0),  s0 = fma(-(D1 e0), e0, log2 op)
+// D1, h, r11 come from the projection kernels (float64 from the float32 Q'' entries, rounded once).  Along
+// the ridge w is a small difference of terms of size sqrt(1e4), so the absolute error of the exponent drops
+// from eps * 1e4 to eps * 2 |w| * 1e2; for round footprints nothing changes.  Cost: the same 4 operations per
+// lane and record for the x-only part and the same 2 FMAs per pixel as the monomial form.  A record whose
+// M11 is not positive and finite (only possible for caller-given inverse covariances on the stage-2 entry)
+// keeps the monomial coefficients and is flagged; a batch holding one takes the unpacked loop.
 // T(1 - alpha) is evaluated as T - T alpha (1 ulp).
 #include <stdlib.h>
 
@@ -77,30 +87,46 @@ __global__ void __launch_bounds__(64) clear_kernel(ClearPlan cp, float *__restri
     clear_block(blockIdx.x, cp, base);
 }
 
-struct Splat {  // one record, unpacked (wave-uniform values); lop = log2(opacity factor)
-    float mx, my, q00, qs, q11, lop, cr, cg, cb;
+struct Splat {  // one record, unpacked (wave-uniform values); mono: monomial coefficients in (d1, h, r11)
+    float mx, my, d1, h, r11, lop, cr, cg, cb;
+    bool mono;
 };
 
+// Record: a = (x, y, D1, h)  b = (r11, log2 op, r, g)  c = (b, depth, monomial flag, -)
 __device__ __forceinline__ Splat read_splat(const float4 (*sh)[64], uint32_t k) {
     const float4 A = sh[0][k], B = sh[1][k];
-    const float cb = sh[2][k].x;
-    return Splat{A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, cb};
+    const float2 C = *reinterpret_cast<const float2 *>(&sh[2][k]);
+    const float flag = sh[2][k].z;
+    return Splat{A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, flag != 0.0f};
 }
 
-// NPX pixels of one lane against one Gaussian.  The lane's pixels share x (e_s = e_x) and differ in
-// y (e_p[j] = e_y); callers always pass (q_ss, q_pp) = (Q''00, Q''11), so the association is fixed:
-//   exponent = e_x^2 Q''00 + e_x e_y qs + e_y^2 Q''11 = fma(e_y, fma(e_y, Q''11, e_x qs), e_x^2 Q''00)
+// Exponent of one pixel: e_s = mean_x - pixel_x (shared by the lane's pixels), e_p = mean_y - pixel_y.
+// The association is fixed; every REF_CPU kernel evaluates exactly this.
+__device__ __forceinline__ void exponent_x(const Splat &g, float e_s, float &s0, float &t0) {
+    if (g.mono) {   // monomial fallback: s0 = e_s^2 Q''00 + log2 op, t0 = e_s Qs
+        s0 = __builtin_fmaf(e_s * e_s, g.d1, g.lop);
+        t0 = e_s * g.h;
+    } else {
+        s0 = __builtin_fmaf(-(g.d1 * e_s), e_s, g.lop);
+        t0 = g.h * e_s;
+    }
+}
+__device__ __forceinline__ float exponent_y(const Splat &g, float e_p, float s0, float t0) {
+    if (g.mono) return __builtin_fmaf(e_p, __builtin_fmaf(e_p, g.r11, t0), s0);
+    const float w = __builtin_fmaf(g.r11, e_p, t0);
+    return __builtin_fmaf(-w, w, s0);
+}
+
+// NPX pixels of one lane against one Gaussian.  The lane's pixels share x (e_s) and differ in y (e_p[j]).
 template <int NPX>
-__device__ __forceinline__ void composite(float e_s, const float (&e_p)[NPX], float q_ss, float qs, float q_pp,
-                                          const Splat &g, float (&T)[NPX], float (&c0)[NPX], float (&c1)[NPX],
-                                          float (&c2)[NPX]) {
-    const float a0 = __builtin_fmaf(e_s * e_s, q_ss, g.lop);  // opacity rides in the exponent
-    const float b0 = e_s * qs;
+__device__ __forceinline__ void composite(float e_s, const float (&e_p)[NPX], const Splat &g, float (&T)[NPX],
+                                          float (&c0)[NPX], float (&c1)[NPX], float (&c2)[NPX]) {
+    float s0, t0;
+    exponent_x(g, e_s, s0, t0);
     float ta[NPX], test[NPX];
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
-        const float pw = __builtin_fmaf(e_p[j], __builtin_fmaf(e_p[j], q_pp, b0), a0);
-        const float alpha = __builtin_amdgcn_exp2f(pw);
+        const float alpha = __builtin_amdgcn_exp2f(exponent_y(g, e_p[j], s0, t0));
         ta[j] = T[j] * alpha;
         test[j] = T[j] - ta[j];
     }
@@ -132,6 +158,21 @@ __device__ __forceinline__ void composite(float e_s, const float (&e_p)[NPX], fl
     }
 }
 
+// Gathers one record per lane into LDS; returns (wave-uniform) whether the batch holds a monomial record.
+__device__ __forceinline__ bool stage_batch(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
+                                            uint32_t base, uint32_t nb, float4 (*sh)[64], int lane) {
+    bool mono = false;
+    if ((uint32_t)lane < nb) {
+        const Record *q = rec + vals[base + lane];
+        const float4 c = q->c;
+        sh[0][lane] = q->a;
+        sh[1][lane] = q->b;
+        sh[2][lane] = c;
+        mono = c.z != 0.0f;
+    }
+    return __any(mono) != 0;
+}
+
 // ---- packed-math form of the same arithmetic (two pixels per VGPR pair) ----------------------
 // The lane's 4 pixels are kept as two float2 and every per-pixel operation except v_exp_f32 is issued
 // as v_pk_{fma,mul,add}_f32.  On gfx950 a packed instruction takes the issue time of two plain ones
@@ -144,16 +185,17 @@ __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_el
 __device__ __forceinline__ v2f pk_exp2(v2f p) { return v2f{__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)}; }
 __device__ __forceinline__ v2f splat2(float v) { return v2f{v, v}; }
 
-// alpha of one record at the lane's 4 pixels (pairs a = (y0,y1), b = (y2,y3)); independent of T.
-// A = (x, y, Q''00, Q''01+Q''10), q11 = Q''11, lop = log2(opacity factor).
-__device__ __forceinline__ void alphas(float4 A, float q11, float lop, float cx, v2f cya, v2f cyb, v2f &al_a,
+// alpha of one (completed-square) record at the lane's 4 pixels (pairs a = (y0,y1), b = (y2,y3)); independent
+// of T.  A = (x, y, D1, h), r11, lop = log2(opacity factor).  Same operations as exponent_x / exponent_y.
+__device__ __forceinline__ void alphas(float4 A, float r11, float lop, float cx, v2f cya, v2f cyb, v2f &al_a,
                                        v2f &al_b) {
     const float e_x = A.x - cx;
-    const float a0 = __builtin_fmaf(e_x * e_x, A.z, lop);
-    const float b0 = e_x * A.w;
+    const float s0 = __builtin_fmaf(-(A.z * e_x), e_x, lop);
+    const float t0 = A.w * e_x;
     const v2f ea = splat2(A.y) - cya, eb = splat2(A.y) - cyb;
-    al_a = pk_exp2(pk_fma(ea, pk_fma(ea, splat2(q11), splat2(b0)), splat2(a0)));
-    al_b = pk_exp2(pk_fma(eb, pk_fma(eb, splat2(q11), splat2(b0)), splat2(a0)));
+    const v2f wa = pk_fma(splat2(r11), ea, splat2(t0)), wb = pk_fma(splat2(r11), eb, splat2(t0));
+    al_a = pk_exp2(pk_fma(-wa, wa, splat2(s0)));
+    al_b = pk_exp2(pk_fma(-wb, wb, splat2(s0)));
 }
 
 #define GSX_ACCUMULATE(ta_a, ta_b, cr, cg, cb)          \
@@ -182,6 +224,85 @@ __device__ __forceinline__ void checked_pair(v2f alpha, v2f &T, v2f &ta) {
 
 __device__ __forceinline__ float min4(v2f a, v2f b) { return fminf(fminf(a.x, a.y), fminf(b.x, b.y)); }
 
+// ---- long tiles: a quarter of the tile per wave, one pixel per lane, eight records per trip ----------
+// Same per-(pixel, record) arithmetic as the kernels above (bit-identical frames, tested): what changes is
+// the shape of the loop.  A lone wave spends ~430 cycles per record in the two-records-per-trip loop (LDS
+// wait, the dependent exponent -> exp2 -> T chain); with the eight alphas of a trip computed independently
+// and only the T / colour chains sequential, and four such waves per tile, a 20 000-entry tile takes about as
+// long as 700 entries did.  The four workgroups of a tile are placed on one XCD (block ids congruent mod 8),
+// so the records they all gather are fetched into that XCD's L2 once.
+__device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
+                                                        const uint2 *__restrict__ ranges, const TileGrid &g,
+                                                        const OutDesc &out, uint32_t t, int quarter,
+                                                        float4 (*sh)[64]) {
+    const int lane = threadIdx.x;
+    const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
+    const bool y_contig = out.stride_y < out.stride_x;
+    // WH3: a quarter = 4 columns of x, lanes run along y (192 contiguous bytes per column);
+    // HW3: a quarter = 4 rows of y, lanes run along x
+    const int px = tx * 16 + (y_contig ? 4 * quarter + (lane >> 4) : (lane & 15));
+    const int py = ty * 16 + (y_contig ? (lane & 15) : 4 * quarter + (lane >> 4));
+    const float cx = (float)px, cy = (float)py;
+    float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+    bool checked = false;   // wave-uniform: some pixel of this quarter has saturated
+    uint2 rg = ranges[t];
+    rg.y &= ~kLongFlag;
+    constexpr int kTrip = 8;
+    for (uint32_t base = rg.x; base < rg.y; base += 64) {
+        const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
+        const bool mono = stage_batch(rec, vals, base, nb, sh, lane);
+        __syncthreads();
+        uint32_t k = 0;
+        if (!checked && !mono) {
+            for (; k + kTrip <= nb; k += kTrip) {
+                float alpha[kTrip];
+#pragma unroll
+                for (int u = 0; u < kTrip; ++u) {
+                    const float4 A = sh[0][k + u];
+                    const float2 Bq = *reinterpret_cast<const float2 *>(&sh[1][k + u]);   // (r11, log2 op)
+                    const float e_x = A.x - cx, e_y = A.y - cy;
+                    const float s0 = __builtin_fmaf(-(A.z * e_x), e_x, Bq.y);
+                    const float w = __builtin_fmaf(Bq.x, e_y, A.w * e_x);
+                    alpha[u] = __builtin_amdgcn_exp2f(__builtin_fmaf(-w, w, s0));
+                }
+                float ta[kTrip], Tt = T, m = T;
+#pragma unroll
+                for (int u = 0; u < kTrip; ++u) {
+                    ta[u] = Tt * alpha[u];
+                    Tt = Tt - ta[u];
+                    m = fminf(m, Tt);
+                }
+                if (__builtin_expect(__any(m < kStopRefCpu), 0)) {
+                    checked = true;
+                    break;
+                }
+#pragma unroll
+                for (int u = 0; u < kTrip; ++u) {
+                    const float2 rg_ = *reinterpret_cast<const float2 *>(&sh[1][k + u].z);    // (r, g)
+                    const float cb = sh[2][k + u].x;
+                    c0 = __builtin_fmaf(ta[u], rg_.x, c0);
+                    c1 = __builtin_fmaf(ta[u], rg_.y, c1);
+                    c2 = __builtin_fmaf(ta[u], cb, c2);
+                }
+                T = Tt;
+            }
+        }
+        for (; k < nb; ++k) {   // tail of the batch, or the checked path (exact stop rule, see composite<>)
+            const Splat s = read_splat(sh, k);
+            const float e_p[1] = {s.my - cy};
+            float T1[1] = {T}, a0[1] = {c0}, a1[1] = {c1}, a2[1] = {c2};
+            composite<1>(s.mx - cx, e_p, s, T1, a0, a1, a2);
+            T = T1[0]; c0 = a0[0]; c1 = a1[0]; c2 = a2[0];
+        }
+        __syncthreads();
+        if (__ballot(T > 0.0f) == 0ull) break;
+    }
+    float *o = out.ptr + (int64_t)(px - out.x0) * out.stride_x + (int64_t)(py - out.y0) * out.stride_y;
+    o[0] = c0;
+    o[1] = c1;
+    o[2] = c2;
+}
+
 // Fast path, tile = 16: one wave per tile, 4 pixels per lane.  A lane owns pixels
 // (x, y..y+3): x is the coordinate its pixels share, so the x-only terms of the exponent are
 // computed once per record.  The assignment (and therefore every bit of the result) is the same
@@ -193,14 +314,25 @@ __device__ __forceinline__ float min4(v2f a, v2f b) { return fminf(fminf(a.x, a.
 template <int VARIANT>
 __global__ void __launch_bounds__(64)
     blend_tile16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
-                        const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp) {
+                        const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
+                        uint32_t nhelpers) {
     __shared__ float4 sh[3][64];
-    if (blockIdx.x >= (uint32_t)g.count()) {
-        clear_block(blockIdx.x - (uint32_t)g.count(), cp, out.ptr);
+    // block order: [helpers of long tiles (dispatched first: they have the most to do)] [tiles] [clears]
+    if (blockIdx.x < nhelpers) {
+        // 32 consecutive blocks serve 8 long tiles; the 4 quarters of a tile share b % 8, i.e. an XCD
+        const uint32_t b = blockIdx.x, slot = (b >> 5) * 8u + (b & 7u);
+        const int quarter = (int)((b >> 3) & 3u);
+        if (slot >= min(*lt.count, lt.max)) return;
+        blend_long_tile_quarter(rec, vals, ranges, g, out, lt.list[slot], quarter, sh);
+        return;
+    }
+    const uint32_t bid = blockIdx.x - nhelpers;
+    if (bid >= (uint32_t)g.count()) {
+        clear_block(bid - (uint32_t)g.count(), cp, out.ptr);
         return;
     }
     const int lane = threadIdx.x;
-    const uint32_t t = xcd_remap(blockIdx.x, (uint32_t)g.count());
+    const uint32_t t = xcd_remap(bid, (uint32_t)g.count());
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     // WH3: lanes 4q..4q+3 cover one x (contiguous 192 B); HW3: lanes 16q..16q+15 cover one y-quad
     const bool y_contig = out.stride_y < out.stride_x;
@@ -219,16 +351,18 @@ __global__ void __launch_bounds__(64)
 
     bool checked = false;  // wave-uniform: some pixel of this tile has saturated
     const uint2 rg = ranges[t];
+    if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
         const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
-        if ((uint32_t)lane < nb) {
-            const Record *q = rec + vals[base + lane];
-            sh[0][lane] = q->a;
-            sh[1][lane] = q->b;
-            sh[2][lane] = q->c;
-        }
+        const bool mono = stage_batch(rec, vals, base, nb, sh, lane);
         __syncthreads();
-        if (VARIANT == 0) {
+        if (VARIANT == 0 || mono) {
+            if (VARIANT != 0) {   // a batch with a monomial record (stage-2 entry only): unpack the state
+                T[0] = Ta.x; T[1] = Ta.y; T[2] = Tb.x; T[3] = Tb.y;
+                c0[0] = c0a.x; c0[1] = c0a.y; c0[2] = c0b.x; c0[3] = c0b.y;
+                c1[0] = c1a.x; c1[1] = c1a.y; c1[2] = c1b.x; c1[3] = c1b.y;
+                c2[0] = c2a.x; c2[1] = c2a.y; c2[2] = c2b.x; c2[3] = c2b.y;
+            }
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
                 // e = mean - pixel, the pixel coordinate formed first, as the reference does
@@ -236,7 +370,13 @@ __global__ void __launch_bounds__(64)
                 float e_y[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) e_y[j] = s.my - cy[j];
-                composite<4>(e_x, e_y, s.q00, s.qs, s.q11, s, T, c0, c1, c2);
+                composite<4>(e_x, e_y, s, T, c0, c1, c2);
+            }
+            if (VARIANT != 0) {
+                Ta = v2f{T[0], T[1]}; Tb = v2f{T[2], T[3]};
+                c0a = v2f{c0[0], c0[1]}; c0b = v2f{c0[2], c0[3]};
+                c1a = v2f{c1[0], c1[1]}; c1b = v2f{c1[2], c1[3]};
+                c2a = v2f{c2[0], c2[1]}; c2b = v2f{c2[2], c2[3]};
             }
         } else {
             // Common path: two records per trip, ONE wave-level saturation test, no per-pixel
@@ -332,17 +472,12 @@ __global__ void __launch_bounds__(64)
         float T[1] = {1.0f}, c0[1] = {0.0f}, c1[1] = {0.0f}, c2[1] = {0.0f};
         for (uint32_t base = rg.x; base < rg.y; base += 64) {
             const uint32_t nb = min(64u, rg.y - base);
-            if ((uint32_t)lane < nb) {
-                const Record *q = rec + vals[base + lane];
-                sh[0][lane] = q->a;
-                sh[1][lane] = q->b;
-                sh[2][lane] = q->c;
-            }
+            (void)stage_batch(rec, vals, base, nb, sh, lane);
             __syncthreads();
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
                 const float e_p[1] = {s.my - fy};
-                composite<1>(s.mx - fx, e_p, s.q00, s.qs, s.q11, s, T, c0, c1, c2);
+                composite<1>(s.mx - fx, e_p, s, T, c0, c1, c2);
             }
             __syncthreads();
             if (__ballot(valid && T[0] > 0.0f) == 0ull) break;
@@ -570,9 +705,13 @@ int clear_blocks_for(int64_t rows, int64_t fw) {
     return (int)((floats + kClearFloats - 1) / kClearFloats);
 }
 
+bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic) {
+    return semantics == GSX_SEM_REF_CPU && grid.tile == 16 && !generic;
+}
+
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
-                        bool generic, const ClearPlan &cp, hipStream_t s) {
+                        bool generic, const ClearPlan &cp, const LongTiles &lt, hipStream_t s) {
     const int64_t nt = grid.count();
     if (nt <= 0) return launch_clear(cp, out.ptr, s);
     const unsigned nb = (unsigned)nt + (unsigned)(cp.n > 0 ? cp.first[cp.n] : 0);
@@ -597,10 +736,11 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             const char *e = getenv("GSX_BLEND_VARIANT");
             return e ? atoi(e) : 1;
         }();
+        const unsigned nh = lt.max ? 4u * lt.max : 0u;
         if (variant == 0)
-            blend_tile16_kernel<0><<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp);
+            blend_tile16_kernel<0><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh);
         else
-            blend_tile16_kernel<1><<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp);
+            blend_tile16_kernel<1><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh);
     } else {
         blend_generic_kernel<<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp);
     }

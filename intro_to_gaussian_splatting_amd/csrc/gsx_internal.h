@@ -14,7 +14,11 @@ constexpr uint32_t kEmptyKey = 0xFFFFFFFEu;   // visible, but it reaches no tile
 
 // Stage-1 -> stage-2 record, 48 B, three 16-B loads, indexed by the Gaussian's index (original
 // index on the whole-path entry, row index on the stage-2 entry).  With Q'' = Q * (-1/2 log2 e):
-//   a = (x_pix, y_pix, Q''00, Q''01 + Q''10)   b = (Q''11, log2(opacity factor), r, g)   c = (b, depth, -, -)
+//   GSX_SEM_REF_CPU (square completed in y, M = -Q'': r11 = sqrt(M11), h = M01 / r11, D1 = M00 - h^2):
+//     a = (x_pix, y_pix, D1, h)   b = (r11, log2(opacity factor), r, g)   c = (b, depth, 0, -)
+//     or, when that factorisation does not exist, the monomial form below with c.z = 1
+//   other semantics:
+//     a = (x_pix, y_pix, Q''00, Q''01 + Q''10)   b = (Q''11, log2(opacity factor) | opacity, r, g)   c = (b, depth, 0, -)
 struct __attribute__((aligned(16))) Record {
     float4 a, b, c;
 };
@@ -53,6 +57,24 @@ struct ClearPlan {
     int64_t pitch;
 };
 
+// Tiles whose list is much longer than the frame's average are composited by FOUR waves (a quarter of the
+// tile's pixels each, one pixel per lane, eight records per trip) instead of one: a lone wave walks its list
+// at ~430 cycles per record, so one 20 000-entry tile would outlast the rest of the frame several times over.
+// The list of such tiles is built on the device by tile_ranges_kernel (count: zeroed by the emit kernel) and
+// flagged in bit 31 of ranges[t].y; the compositing launch carries 4 * kMaxLongTiles helper workgroups.
+constexpr uint32_t kMaxLongTiles = 512;
+constexpr uint32_t kLongFlag = 0x80000000u;
+struct LongTiles {
+    uint32_t *count;   // number of long tiles found (may exceed max)
+    uint32_t *list;    // window-local tile ids, max entries
+    uint32_t max;      // 0: the split is off for this frame
+};
+__host__ __device__ inline uint32_t long_tile_threshold(uint32_t pairs, uint32_t tiles) {
+    const uint32_t mean = tiles ? pairs / tiles : 0u;
+    const uint32_t four = mean > 0x3FFFFFFFu ? 0xFFFFFFFFu : 4u * mean;
+    return four > 1024u ? four : 1024u;
+}
+
 struct StageOneOut {  // PreprocessedScene arrays (splat/schema.py:13-25), depth-sorted
     float *points_xy, *colors, *cov2d, *depths, *inv_cov, *radius, *min_x, *max_x, *min_y, *max_y, *sig_op;
     int32_t *order;
@@ -71,14 +93,15 @@ hipError_t launch_depth_keys(const GsxCamera &cam, const float *means3d, int64_t
                              uint32_t *vals, hipStream_t s);
 hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t *n_visible, hipStream_t s);
 // Original order: depth keys (kCulledKey behind the cull plane, kEmptyKey when no tile of the window is
-// reached) + identity values for the sort, records / rects indexed by the ORIGINAL Gaussian index.
+// reached), records / rects indexed by the ORIGINAL Gaussian index (only written for the Gaussians that
+// reach a tile; the depth sort generates the identity values itself).
 // bbox (REF_CUDA only, else may be null): (min_x, max_x, min_y, max_y) per Gaussian for the
 // per-pixel cull of splat/c/render.cu:55-60.
 // tight_rects: GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS (see include/gsx.h).
 // cam_device (may be null): GsxParams.camera_device, read by the kernel instead of `cam`.
 // counters: 4 words this kernel zeroes for the depth sort (culled count, kept count, ...).
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
-                               const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys, uint32_t *vals,
+                               const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys,
                                Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s);
 hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
                                const uint32_t *sorted_idx, int64_t n, const StageOneOut &out, hipStream_t s);
@@ -97,6 +120,7 @@ struct BinCounts {
     int64_t *stats2;             // [0] = visible Gaussians, [1] = D: the first two fields of a GsxFrameStats
     int64_t *stats2_host;        // device-visible alias of a pinned GsxFrameStats, or null
     uint32_t *d32;               // min(D, 2^32 - 1): element count of the tile sort
+    uint32_t *long_count;        // zeroed by the emit kernel for tile_ranges_kernel (LongTiles.count)
     const uint32_t *culled_dev;  // Gaussians behind the cull plane (counted by the depth sort), or null
     int64_t n_total;             // n_visible = n_total - *culled_dev
 };
@@ -110,8 +134,10 @@ hipError_t emit_instances(void *temp, const TileRect *rrect, const uint32_t *ord
 // Stable sort of the emitted pairs by tile id and ranges[t] = [first, last) for every tile of the
 // window; *sorted_vals points at the sorted Gaussian indices.  The pair count is read from *d32.
 hipError_t sort_instances(void *temp, int64_t cap, const TileGrid &grid, void *keys0, void *keys1, uint32_t *vals0,
-                          uint32_t *vals1, uint2 *ranges, const uint32_t *d32, const uint32_t **sorted_vals,
-                          hipStream_t s);
+                          uint32_t *vals1, uint2 *ranges, const uint32_t *d32, const LongTiles &lt,
+                          const uint32_t **sorted_vals, hipStream_t s);
+// counts[t] = length of tile t's list (GsxParams.tile_counts).
+hipError_t launch_tile_counts(const uint2 *ranges, int64_t nt, uint32_t *counts, hipStream_t s);
 // ---- gsx_sort.hip: stable LSD radix sort, up to 8 bits per pass, key bits [0, key_bits).  The element
 // count is min(*n_dev, bound) (n_dev == nullptr: bound); grids are sized by `bound`.  Buffers
 // ping-pong; on return keys_cur / vals_cur point at the sorted data.  temp: radix_temp_bytes(bound).
@@ -125,7 +151,8 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
 // Depth sort of the whole-path entry point: all 32 key bits, dropping keys >= kEmptyKey in the first
 // pass (*m_dev = Gaussians kept, *culled_dev += keys == kCulledKey; culled_dev must hold 0 when the
 // first kernel runs) and gathering rect[index] into rrect[rank] in the last one.  On return
-// vals_cur[0 .. *m_dev) = Gaussian index of each depth rank (ties: original index).
+// vals_cur[0 .. *m_dev) = Gaussian index of each depth rank (ties: original index).  The values of the
+// first pass are the item positions themselves (vals_cur need not be initialised).
 hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
                               hipStream_t s);
@@ -137,9 +164,11 @@ hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, i
 // ---- gsx_blend.hip
 // background: 3 floats, read on the host (GSX_SEM_STD_3DGS only); generic: GSX_FLAG_GENERIC_KERNELS.
 // cp: what the launch zeroes besides compositing its tiles (extra workgroups of the same kernel).
+// lt: long tiles split over four waves (GSX_SEM_REF_CPU, tile 16 only; lt.max == 0 otherwise).
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
-                        bool generic, const ClearPlan &cp, hipStream_t s);
+                        bool generic, const ClearPlan &cp, const LongTiles &lt, hipStream_t s);
+bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic);
 hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s);   // the zero fill alone
 hipError_t launch_zero_words(uint32_t *p, size_t n, hipStream_t s);
 int clear_blocks_for(int64_t rows, int64_t fw);                              // workgroups for rows x fw pixels

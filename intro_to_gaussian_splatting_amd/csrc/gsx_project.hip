@@ -323,19 +323,41 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
         y = trunc_to_int(y);
         q10 = q01;
     }
-    out.a = make_float4(x, y, q00 * k, (q01 + q10) * k);
+    const float Q00 = q00 * k, Qs = (q01 + q10) * k, Q11 = q11 * k;     // Q'' = -1/2 log2(e) Q, float32
+    if (semantics == GSX_SEM_REF_CPU) {
+        // gsx_blend.hip evaluates e Q'' e^T with the square completed in y (see there):
+        //   M = -Q'',  r11 = sqrt(M11),  h = M01 / r11,  D1 = M00 - h^2   (float64 from the float32 entries)
+        // Whenever that does not exist as finite numbers (M11 <= 0, NaN, inf: caller-given inverse
+        // covariances on the stage-2 entry) the record keeps the monomial coefficients, flagged in c.z.
+        // from the UNSCALED float32 entries: a thin footprint's conic is nearly singular (det ~ 1e-4 of the
+        // product of its diagonal), and rounding each entry of Q'' = k Q separately already moves the flat
+        // direction's curvature by a part in 1e3 -- the scale factor is applied in float64 instead
+        const double kd = 0.5 * 1.44269504088896340736;
+        const double m00 = kd * (double)q00, m01 = kd * 0.5 * ((double)q01 + (double)q10), m11 = kd * (double)q11;
+        const double r11 = sqrt(m11), h = m01 / r11, d1 = m00 - h * h;
+        const float fr = (float)r11, fh = (float)h, fd = (float)d1;
+        const bool ok = m11 > 0.0 && isfinite(fr) && isfinite(fh) && isfinite(fd) && fr > 0.0f;
+        out.a = ok ? make_float4(x, y, fd, fh) : make_float4(x, y, Q00, Qs);
+        out.b = make_float4(ok ? fr : Q11, log2f(op), cr, cg);
+        out.c = make_float4(cb, depth, ok ? 0.0f : 1.0f, 0.0f);
+        return;
+    }
+    out.a = make_float4(x, y, Q00, Qs);
     // STD_3DGS multiplies by the opacity after the exponential (its exponent is tested on its own)
-    out.b = make_float4(q11 * k, semantics == GSX_SEM_STD_3DGS ? op : log2f(op), cr, cg);
+    out.b = make_float4(Q11, semantics == GSX_SEM_STD_3DGS ? op : log2f(op), cr, cg);
     out.c = make_float4(cb, depth, 0.0f, 0.0f);
 }
 
 // One thread per Gaussian, ORIGINAL order (coalesced reads of the parameter arrays, coalesced
-// writes): depth key for the sort, compositing record, tile rectangle and tile count.
+// writes): depth key for the sort, compositing record and tile rectangle.  A Gaussian that reaches no
+// tile of the window (culled, off screen, or -- on a rank that owns a strip of the frame -- in another
+// rank's strip) only gets its key written: no record, no rectangle, and its opacity and colour are
+// never read (40 B in + 4 B out instead of 56 B in + 60 B out; 7/8 of the Gaussians on an 8-GPU rank).
 template <bool DEVICE_CAMERA>
 __global__ void __launch_bounds__(kBlock)
     project_pack_kernel(GsxCamera cam_arg, const GsxCamera *__restrict__ cam_dev, GaussiansIn in, int64_t n,
                         TileGrid grid, int semantics, bool tight,
-                        uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, Record *__restrict__ rec,
+                        uint32_t *__restrict__ keys, Record *__restrict__ rec,
                         TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox) {
     int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (g < 4) counters[g] = 0u;   // the depth sort's culled / kept counts start from zero (no memset node)
@@ -345,31 +367,26 @@ __global__ void __launch_bounds__(kBlock)
     const float *p = in.means3d + 3 * g;
     float p0 = p[0], p1 = p[1], p2 = p[2];
     float tz = row4(p0, p1, p2, cam.world2view, 2);
-    vals[g] = (uint32_t)g;
     const bool std3dgs = semantics == GSX_SEM_STD_3DGS;
     if (std3dgs ? !(tz > 0.2f) : !(tz >= 0.2f)) {               // utils.py:293-310
-        TileRect e;
-        e.x0 = 1; e.x1 = 0; e.y0 = 1; e.y1 = 0;
         keys[g] = kCulledKey;
-        rect[g] = e;
         return;
     }
-    const float *s = in.scales + 3 * g, *q = in.quats + 4 * g, *c = in.colors + 3 * g;
+    const float *s = in.scales + 3 * g, *q = in.quats + 4 * g;
     Projected o;
     bool keep = true;
     if (std3dgs)
         keep = project_std(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
     else
         project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
-    float op = sigmoidf(in.opacity_logit[g]);
-    if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);
-    Record out;
-    pack_record(semantics, o.x, o.y, o.q00, o.q01, o.q10, o.q11, op, c[0], c[1], c[2], o.depth, out);
-    rec[g] = out;
-    if (bbox) bbox[g] = make_float4(o.min_x, o.max_x, o.min_y, o.max_y);
     TileRect tr;
     uint32_t cnt = std3dgs ? tile_rect(o.x, o.radius, o.y, o.radius, grid, semantics, tr)
                            : tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, semantics, tr);
+    float op = 0.0f;
+    if (keep && cnt) {
+        op = sigmoidf(in.opacity_logit[g]);
+        if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);
+    }
     if (std3dgs && tight && keep && cnt) {
         // alpha = op exp(power) >= 1/255  <=>  -power <= log(255 op); on the level set of a Gaussian with
         // covariance (ca, cb; cb, cd) the coordinates reach sqrt(2 log(255 op) ca) and sqrt(... cd).
@@ -389,12 +406,17 @@ __global__ void __launch_bounds__(kBlock)
             }
         }
     }
-    if (!keep) {
-        tr.x0 = 1; tr.x1 = 0; tr.y0 = 1; tr.y1 = 0;
-        cnt = 0u;
+    if (!keep || cnt == 0u) {
+        // reaches no tile of the window: it needs no depth rank, the sort drops it in its first pass
+        keys[g] = kEmptyKey;
+        return;
     }
-    // a Gaussian that reaches no tile of the window needs no depth rank: the sort drops it in its first pass
-    keys[g] = cnt ? __float_as_uint(tz) : kEmptyKey;
+    keys[g] = __float_as_uint(tz);
+    const float *c = in.colors + 3 * g;
+    Record out;
+    pack_record(semantics, o.x, o.y, o.q00, o.q01, o.q10, o.q11, op, c[0], c[1], c[2], o.depth, out);
+    rec[g] = out;
+    if (bbox) bbox[g] = make_float4(o.min_x, o.max_x, o.min_y, o.max_y);
     rect[g] = tr;
 }
 
@@ -524,15 +546,15 @@ hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t
 }
 
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
-                               const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys, uint32_t *vals,
+                               const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys,
                                Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s) {
     if (n == 0) return hipSuccess;
     if (cam_device)
         project_pack_kernel<true><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics, tight_rects,
-                                                                   keys, vals, rec, rect, counters, bbox);
+                                                                   keys, rec, rect, counters, bbox);
     else
         project_pack_kernel<false><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics,
-                                                                    tight_rects, keys, vals, rec, rect, counters, bbox);
+                                                                    tight_rects, keys, rec, rect, counters, bbox);
     return hipGetLastError();
 }
 

@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(kThreads)
         const uint32_t i = wave_base + (uint32_t)r * 64 + lane;
         ok[r] = i < n;
         key[r] = ok[r] ? kin[i] : (Key)0;
-        val[r] = ok[r] ? vin[i] : 0u;
+        // FIRST: the value of an item is its position (the Gaussian index): nothing to read
+        val[r] = (MODE & kModeFirst) ? i : (ok[r] ? vin[i] : 0u);
         if (MODE & kModeFirst) ok[r] = ok[r] && (uint32_t)key[r] < kEmptyKey;
     }
     uint16_t rank[kRounds];

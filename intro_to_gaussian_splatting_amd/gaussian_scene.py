@@ -241,6 +241,7 @@ class GaussianScene:
                          background: Tuple[float, float, float] = (0.0, 0.0, 0.0),
                          generic_kernels: bool = False, published_rects: bool = False,
                          camera_buffer: Optional[torch.Tensor] = None,
+                         tile_counts: Optional[torch.Tensor] = None, split_long_tiles: bool = True,
                          _private: Optional[dict] = None) -> torch.Tensor:
         """Full forward render in libgsx (gsx_render_forward).
 
@@ -254,6 +255,8 @@ class GaussianScene:
         ``out`` may then be a strip-sized buffer whose pixel (0,0) is frame pixel ``out_origin``.
         ``timing`` asks the library for per-stage HIP-event times (``stats["stage_ms"]``); the call
         then waits for the frame.
+        ``tile_counts`` (int32 / uint32 device tensor, one entry per tile of the window, x-major) receives
+        the length of every tile's Gaussian list (GsxParams.tile_counts; ``strips.balanced_plan``).
         ``no_sync`` (GSX_FLAG_NO_SYNC) enqueues the frame without waiting for the device at all: the
         counts arrive later in pinned memory and ``confirm_frames()`` must be called (it
         synchronises) before the images are trusted -- it re-renders, on the normal path, any frame
@@ -271,6 +274,8 @@ class GaussianScene:
             params.flags |= _ffi.GSX_FLAG_TIMING
         if generic_kernels:     # tests: the any-tile-size kernels also at tile 16 (same pixels)
             params.flags |= _ffi.GSX_FLAG_GENERIC_KERNELS
+        if not split_long_tiles:   # tests: every tile on one wave (same pixels as the four-wave path of long tiles)
+            params.flags |= _ffi.GSX_FLAG_NO_LONG_TILE_SPLIT
         if published_rects:     # std_3dgs: bin with the published 3-sigma squares (same pixels, longer lists)
             params.flags |= _ffi.GSX_FLAG_PUBLISHED_RECTS
         if camera_buffer is not None:   # GsxParams.camera_device: the kernels read the camera from this buffer
@@ -280,6 +285,18 @@ class GaussianScene:
             params.camera_device = camera_buffer.data_ptr()
         if tile_window is not None:
             params.tile_x0, params.tile_x1, params.tile_y0, params.tile_y1 = [int(v) for v in tile_window]
+        if tile_counts is not None:
+            if tile_counts.device != dev or tile_counts.dtype not in (torch.int32, torch.uint32) or \
+                    not tile_counts.is_contiguous():
+                raise ValueError("tile_counts must be a contiguous int32 tensor on %s" % dev)
+            from .strips import tiles_along
+            ntx, nty = tiles_along(width, tile_size, semantics), tiles_along(height, tile_size, semantics)
+            wx0, wx1, wy0, wy1 = (0, ntx, 0, nty) if tile_window is None else [int(v) for v in tile_window]
+            wx1, wy1 = (ntx if wx1 < 0 else min(wx1, ntx)), (nty if wy1 < 0 else min(wy1, nty))
+            if tile_counts.numel() < max(0, wx1 - wx0) * max(0, wy1 - wy0):
+                raise ValueError("tile_counts holds %d entries, the window has %d tiles"
+                                 % (tile_counts.numel(), max(0, wx1 - wx0) * max(0, wy1 - wy0)))
+            params.tile_counts = tile_counts.data_ptr()
         if out is None:
             shape = (width, height, 3) if layout == "wh3" else (height, width, 3)
             out = torch.empty(shape, dtype=torch.float32, device=dev)
@@ -342,7 +359,8 @@ class GaussianScene:
             self._pending.append((pinned, cap_key, dict(
                 image_idx=image_idx, tile_size=tile_size, layout=layout, tile_window=tile_window, out=out,
                 out_origin=out_origin, semantics=semantics, background=background,
-                generic_kernels=generic_kernels, published_rects=published_rects, camera_buffer=camera_buffer)))
+                generic_kernels=generic_kernels, published_rects=published_rects, camera_buffer=camera_buffer,
+                tile_counts=tile_counts, split_long_tiles=split_long_tiles)))
             if stats is not None:
                 stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
             return out

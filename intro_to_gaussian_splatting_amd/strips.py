@@ -14,7 +14,7 @@ the gathered frame equals the single-GPU frame bit for bit.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -40,10 +40,69 @@ def strip_plan(n_tiles: int, world_size: int) -> Tuple[int, List[Tuple[int, int]
     return per, plan
 
 
+def balanced_plan(row_cost: Sequence[float], world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous strips of tile rows whose LARGEST cost is as small as possible ("optional
+    balance by prefix-sum of per-tile-row D").  ``row_cost[t]`` = cost of tile row ``t`` of the leading axis,
+    e.g. ``tile_row_costs(tile_counts)``.  Returns [(t0, t1) per rank]; trailing ranks may get no rows.
+    Exact for the cost given: binary search on the bottleneck, greedy fill (the classic linear partition)."""
+    cost = [max(0.0, float(c)) for c in row_cost]
+    n = len(cost)
+    if n == 0 or world_size <= 0:
+        return [(0, 0)] * max(world_size, 0)
+
+    def cut(limit: float):
+        plan, t0, acc = [], 0, 0.0
+        for t in range(n):
+            if acc + cost[t] > limit and t > t0:
+                plan.append((t0, t))
+                t0, acc = t, 0.0
+            acc += cost[t]
+        plan.append((t0, n))
+        return plan
+
+    lo, hi = max(cost), sum(cost)
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if len(cut(mid)) <= world_size:
+            hi = mid
+        else:
+            lo = mid
+    plan = cut(hi)
+    return plan + [(n, n)] * (world_size - len(plan))
+
+
+def tile_row_costs(tile_counts, n_lead: int, n_other: int, lead_is_x: bool = True, per_tile: float = 8.0) -> List[float]:
+    """Cost of every tile row of the leading axis from the per-tile list lengths a frame reported
+    (GsxParams.tile_counts, x-major: index = tx * n_tiles_y + ty): the compositing and the pair sort cost
+    one unit per (Gaussian, tile) pair, every tile a small constant more (``per_tile`` pairs' worth)."""
+    c = tile_counts.reshape(-1).to("cpu").to(torch.float64)
+    grid = c.reshape(n_lead, n_other) if lead_is_x else c.reshape(n_other, n_lead).t()
+    return (grid.sum(dim=1) + per_tile * n_other).tolist()
+
+
+def _gather_strips(strip, frame, pixel_ranges, rank, world, group, all_ranks) -> None:
+    """Unequal strips: every rank sends its strip straight into its place in rank 0's frame (grouped
+    point-to-point operations: ncclSend / ncclRecv pairs under RCCL, each over its own xGMI link)."""
+    ops = []
+    if rank == 0:
+        for r in range(1, world):
+            a, b = pixel_ranges[r]
+            if b > a:
+                ops.append(dist.P2POp(dist.irecv, frame[a:b], r, group))
+    elif strip.shape[0] > 0:
+        ops.append(dist.P2POp(dist.isend, strip, 0, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if all_ranks:
+        dist.broadcast(frame, src=0, group=group)
+
+
 def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor, Tuple[int, int]], None],
                    width: int, height: int, tile: int, layout: str, device: torch.device,
                    group: Optional[dist.ProcessGroup] = None, all_ranks: bool = False,
-                   cache: Optional[dict] = None, semantics: str = "ref_cpu") -> Optional[torch.Tensor]:
+                   cache: Optional[dict] = None, semantics: str = "ref_cpu",
+                   plan: Optional[List[Tuple[int, int]]] = None) -> Optional[torch.Tensor]:
     """Renders this rank's strip with ``render_fn(tile_window, out_strip, out_origin)`` and gathers
     the frame on rank 0 (or on every rank with ``all_ranks``).
 
@@ -54,12 +113,18 @@ def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor,
     instead of allocating them per call; the returned frame is then overwritten by the next call.
     ``semantics`` only decides how many tile rows exist (see ``tiles_along``); with partial edge tiles
     the last strip's buffer extends past the frame and the surplus rows are cut off after the gather.
+    ``plan`` ([(t0, t1) per rank], e.g. from ``balanced_plan``; the same on every rank) replaces the equal
+    strips: each rank then renders straight into (a buffer the size of) its own rows and the strips travel
+    point to point instead of through one equal-sized gather.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lead, other = (width, height) if layout == "wh3" else (height, width)
     n_lead = tiles_along(lead, tile, semantics)
     n_other = tiles_along(other, tile, semantics)
+    if plan is not None:
+        return _render_planned(render_fn, plan, lead, other, n_other, tile, layout, device, group, all_ranks, cache,
+                               rank, world)
     per, plan = strip_plan(n_lead, world)
     rows = per * tile                                  # strip extent in pixels, tile aligned
     t0, t1 = plan[rank]
@@ -97,6 +162,42 @@ def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor,
     return None
 
 
+def _render_planned(render_fn, plan, lead, other, n_other, tile, layout, device, group, all_ranks, cache, rank, world):
+    if len(plan) != world:
+        raise ValueError("the strip plan has %d entries for %d ranks" % (len(plan), world))
+    pixel_ranges = [(min(t0 * tile, lead), min(t1 * tile, lead)) for t0, t1 in plan]
+    is_dst = all_ranks or rank == 0 or world == 1
+
+    def buffer(name, shape):
+        if cache is None:
+            return torch.empty(shape, dtype=torch.float32, device=device)
+        key = (name, shape, str(device))
+        if key not in cache:
+            cache[key] = torch.empty(shape, dtype=torch.float32, device=device)
+        return cache[key]
+
+    frame = buffer("frame", (lead, other, 3)) if is_dst else None
+    if is_dst:      # rows no strip owns (REF_CPU: the never-rendered last tile row) stay zero
+        covered = sorted(r for r in pixel_ranges if r[1] > r[0])
+        edge = 0
+        for a, b in covered:
+            if a > edge:
+                frame[edge:a].zero_()
+            edge = max(edge, b)
+        if edge < lead:
+            frame[edge:].zero_()
+    a, b = pixel_ranges[rank]
+    t0, t1 = plan[rank]
+    strip = frame[a:b] if is_dst else buffer("strip", (b - a, other, 3))
+    if b > a:
+        window = (t0, t1, 0, n_other) if layout == "wh3" else (0, n_other, t0, t1)
+        origin = (a, 0) if layout == "wh3" else (0, a)
+        render_fn(window, strip, origin)
+    if world > 1:
+        _gather_strips(strip, frame, pixel_ranges, rank, world, group, all_ranks)
+    return frame
+
+
 class StripPipeline:
     """Consecutive frames of one camera, sharded as strips, with up to ``depth`` frames in flight.
 
@@ -113,18 +214,29 @@ class StripPipeline:
     """
 
     def __init__(self, render_fn, width: int, height: int, tile: int, layout: str, device: torch.device,
-                 depth: int = 3, group: Optional[dist.ProcessGroup] = None, semantics: str = "ref_cpu") -> None:
+                 depth: int = 3, group: Optional[dist.ProcessGroup] = None, semantics: str = "ref_cpu",
+                 plan: Optional[List[Tuple[int, int]]] = None) -> None:
         self.render_fn, self.group, self.device = render_fn, group, torch.device(device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         lead, other = (width, height) if layout == "wh3" else (height, width)
         n_lead, n_other = tiles_along(lead, tile, semantics), tiles_along(other, tile, semantics)
-        per, plan = strip_plan(n_lead, self.world)
-        self.rows, self.lead = per * tile, lead
-        t0, t1 = plan[self.rank]
+        self.pixel_ranges = None
+        if plan is not None:      # unequal strips (balanced_plan): point-to-point gather, strips of their own size
+            if len(plan) != self.world:
+                raise ValueError("the strip plan has %d entries for %d ranks" % (len(plan), self.world))
+            self.pixel_ranges = [(min(a * tile, lead), min(b * tile, lead)) for a, b in plan]
+            per = max((b - a) for a, b in plan) if plan else 0
+            t0, t1 = plan[self.rank]
+            self.rows, self.lead = self.pixel_ranges[self.rank][1] - self.pixel_ranges[self.rank][0], lead
+            self.origin = (self.pixel_ranges[self.rank][0], 0) if layout == "wh3" else (0, self.pixel_ranges[self.rank][0])
+        else:
+            per, eq = strip_plan(n_lead, self.world)
+            self.rows, self.lead = per * tile, lead
+            t0, t1 = eq[self.rank]
+            self.origin = (self.rank * self.rows, 0) if layout == "wh3" else (0, self.rank * self.rows)
         self.window = (t0, t1, 0, n_other) if layout == "wh3" else (0, n_other, t0, t1)
-        self.origin = (self.rank * self.rows, 0) if layout == "wh3" else (0, self.rank * self.rows)
-        covered = self.world * self.rows
+        covered = self.world * self.rows if plan is None else lead
         self.on_gpu = self.device.type == "cuda"
         self.depth = max(1, depth) if self.on_gpu else 1
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -137,7 +249,8 @@ class StripPipeline:
     def submit(self) -> Optional[torch.Tensor]:
         k = self.count % self.depth
         self.count += 1
-        strip = self.strips[k]
+        strip = self.strips[k][:self.rows]
+        planned = self.pixel_ranges is not None
         if self.rows > 0:
             if self.on_gpu:
                 main = torch.cuda.current_stream(self.device)
@@ -151,8 +264,14 @@ class StripPipeline:
                 main.wait_event(side.record_event())
             else:
                 self.render_fn(self.window, strip, self.origin)
+        if self.rows > 0 or (planned and self.world > 1):
             if self.world == 1:
                 self.frame[:self.rows].copy_(strip)
+            elif planned:                              # unequal strips: every rank takes part, also with no rows
+                if self.rank == 0 and self.rows > 0:
+                    a, b = self.pixel_ranges[0]
+                    self.frame[a:b].copy_(strip)
+                _gather_strips(strip, self.frame, self.pixel_ranges, self.rank, self.world, self.group, False)
             elif self.rank == 0:
                 dist.gather(strip, [self.frame[r * self.rows:(r + 1) * self.rows] for r in range(self.world)], dst=0,
                             group=self.group)

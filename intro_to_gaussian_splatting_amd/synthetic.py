@@ -27,7 +27,8 @@ def _rotation(qvec) -> np.ndarray:
 
 def make_scene(n: int, width: int, height: int, seed: int = 0, behind_fraction: float = 0.0,
                qvec=TREEHILL_QVEC, tvec=TREEHILL_TVEC, spread: float = 1.0,
-               sigma_scale: float = 1.0) -> Dict[str, np.ndarray]:
+               sigma_scale: float = 1.0, cluster_fraction: float = 0.0, cluster_area: float = 0.05,
+               cluster_center=(0.35, -0.2), sigma_ln: float = 0.5) -> Dict[str, np.ndarray]:
     """Returns float32 arrays ``points (n,3)``, ``colors_0_255 (n,3)``, ``scales (n,3)`` (linear),
     ``quaternions (n,4)`` (w,x,y,z, unnormalised), ``opacity (n,1)`` (logit) plus the camera
     ``qvec, tvec, fx, fy, cx, cy, width, height``.
@@ -37,6 +38,12 @@ def make_scene(n: int, width: int, height: int, seed: int = 0, behind_fraction: 
     the default stream is unchanged).  ``spread`` > 1 places points up to that multiple of the
     frustum's half-width off axis (beyond 1.3 the EWA clamp of splat/utils.py:336-337 is active),
     ``sigma_scale`` scales the footprints; both leave the random stream untouched.
+
+    Heavy-tailed variant (not a BASELINE config; trained scenes are never uniform): ``cluster_fraction`` of
+    the Gaussians (chosen by one more uniform draw, after everything else) are moved into a window of
+    ``cluster_area`` of the frame around ``cluster_center`` (in [-1,1]^2 frame coordinates), and ``sigma_ln``
+    stretches the log-normal footprint distribution from its default 0.5 (same draws, exponent rescaled) --
+    ``cluster_fraction=0.5, cluster_area=0.05, sigma_ln=1.0`` gives tile lists whose longest is ~20x the mean.
     """
     rs = np.random.RandomState(seed)
     fx = fy = 0.75 * width
@@ -51,6 +58,13 @@ def make_scene(n: int, width: int, height: int, seed: int = 0, behind_fraction: 
     if behind_fraction > 0.0:
         behind = rs.uniform(0.0, 1.0, n) < behind_fraction
         z = np.where(behind, -z * 0.5 + 0.15, z)
+    if sigma_ln != 0.5:     # same normal draws, another log-standard-deviation
+        sigma_px = np.exp(np.log(1.5) + (np.log(sigma_px) - np.log(1.5)) * (sigma_ln / 0.5))
+    if cluster_fraction > 0.0:
+        inside = rs.uniform(0.0, 1.0, n) < cluster_fraction
+        half = np.sqrt(cluster_area)        # the window's half-extent in [-1,1] frame coordinates
+        u = np.where(inside, cluster_center[0] + half * u, u)
+        v = np.where(inside, cluster_center[1] + half * v, v)
     u, v, sigma_px = u * spread, v * spread, sigma_px * sigma_scale
     p_cam = np.stack([u * tanx * np.abs(z), v * tany * np.abs(z), z], axis=1)
     R, t = _rotation(qvec), np.asarray(tvec, dtype=np.float64)

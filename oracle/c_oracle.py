@@ -80,8 +80,10 @@ def preprocess(points, colors, scales, quats, opacity_logit, cam: Camera) -> Pre
 
 
 def render(pre, width: int, height: int, tile: int = 16, nthreads: Optional[int] = None,
-           window: Optional[Tuple[int, int, int, int]] = None):
-    """Returns (image (W,H,3) indexed [x,y], pairs, instances)."""
+           window: Optional[Tuple[int, int, int, int]] = None, exact: bool = False):
+    """Returns (image (W,H,3) indexed [x,y], pairs, instances).  ``exact``: the same rules evaluated in
+    float64 from the same float32 stage-1 arrays (the exact-arithmetic limit of the reference's formulas, not
+    its float32 behaviour): tells which side is off when kernel and restatement disagree."""
     f = lambda a: np.ascontiguousarray(np.asarray(a, np.float32))  # noqa: E731
     means, colors, inv = f(pre.points), f(pre.colors), f(pre.inverse_covariance_2d)
     mnx, mxx, mny, mxy, sop = f(pre.min_x), f(pre.max_x), f(pre.min_y), f(pre.max_y), f(pre.sigmoid_opacity)
@@ -93,9 +95,13 @@ def render(pre, width: int, height: int, tile: int = 16, nthreads: Optional[int]
         win = (ctypes.c_int32 * 4)(*[int(v) for v in window])
     if nthreads is None:
         nthreads = os.cpu_count() or 1
-    rc = lib().orc_render(int(height), int(width), int(tile), _fp(means), _fp(colors), _fp(inv),
-                          _fp(mnx), _fp(mxx), _fp(mny), _fp(mxy), _fp(sop), ctypes.c_int64(n), _fp(image),
-                          int(nthreads), win, ctypes.byref(pairs), ctypes.byref(inst))
+    lib().orc_set_exact(1 if exact else 0)
+    try:
+        rc = lib().orc_render(int(height), int(width), int(tile), _fp(means), _fp(colors), _fp(inv),
+                              _fp(mnx), _fp(mxx), _fp(mny), _fp(mxy), _fp(sop), ctypes.c_int64(n), _fp(image),
+                              int(nthreads), win, ctypes.byref(pairs), ctypes.byref(inst))
+    finally:
+        lib().orc_set_exact(0)
     assert rc == 0
     return image, pairs.value, inst.value
 

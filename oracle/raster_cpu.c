@@ -206,7 +206,42 @@ typedef struct {
     char pad1[128];
 } RenderJob;
 
+/* orc_set_exact(1): the same rule set evaluated in float64 from the same float32 stage-1 arrays -- not the
+ * reference's arithmetic (that is float32, below) but its exact-arithmetic limit.  Used to tell WHICH side is
+ * off when the float32 restatement and the kernel disagree on ill-conditioned footprints (a 200:1 ellipse seen
+ * 70 px along its ridge: the three products of e Q e^T are ~5e4 each and cancel to ~3; float32 loses 1e-3). */
+static int g_exact = 0;
+void orc_set_exact(int on) { g_exact = on; }
+
+static void render_one_tile_exact(RenderJob *jb, int tix, int tiy) {
+    int T = jb->tile, x0 = tix * T, y0 = tiy * T, H = jb->H;
+    int64_t b = jb->tile_start[tix * jb->nty + tiy], e = jb->tile_start[tix * jb->nty + tiy + 1];
+    if (b == e) return;
+    for (int px = x0; px < x0 + T; ++px)
+        for (int py = y0; py < y0 + T; ++py) {
+            double Tw = 1.0, C0 = 0.0, C1 = 0.0, C2 = 0.0;
+            for (int64_t k = b; k < e; ++k) {
+                int32_t g = jb->tile_items[k];
+                const float *Q = jb->inv + 4 * (int64_t)g;
+                double e0 = (double)jb->means[2 * (int64_t)g] - px, e1 = (double)jb->means[2 * (int64_t)g + 1] - py;
+                double d0 = -0.5 * e0, d1 = -0.5 * e1;
+                double t0 = d0 * Q[0] + d1 * Q[2], t1 = d0 * Q[1] + d1 * Q[3];
+                double sig = 1.0 / (1.0 + exp(-(double)jb->op2[g]));     /* op2 holds sigmoid_opacity in this mode */
+                double alpha = exp(t0 * e0 + t1 * e1) * sig;
+                double test = Tw * (1.0 - alpha);
+                if (test < 0.000001) break;
+                double ta = Tw * alpha;
+                const float *c = jb->colors + 3 * (int64_t)g;
+                C0 += ta * c[0]; C1 += ta * c[1]; C2 += ta * c[2];
+                Tw = test;
+            }
+            float *o = jb->image + ((int64_t)px * H + py) * 3;
+            o[0] = (float)C0; o[1] = (float)C1; o[2] = (float)C2;
+        }
+}
+
 static void render_one_tile(RenderJob *jb, int tix, int tiy) {
+    if (g_exact) { render_one_tile_exact(jb, tix, tiy); return; }
     int T = jb->tile, x0 = tix * T, y0 = tiy * T, H = jb->H;
     int64_t b = jb->tile_start[tix * jb->nty + tiy], e = jb->tile_start[tix * jb->nty + tiy + 1];
     if (b == e) return;                                    /* gaussian_scene.py:219-220 */
@@ -292,7 +327,7 @@ int orc_render(int H, int W, int tile, const float *means, const float *colors, 
         rect[4 * i] = lx; rect[4 * i + 1] = hx; rect[4 * i + 2] = ly; rect[4 * i + 3] = hy;
         for (int a = lx; a <= hx; ++a)
             for (int b = ly; b <= hy; ++b) start[(int64_t)a * nty + b + 1]++;
-        op2[i] = sigmoidf_(sig_op[i]);
+        op2[i] = g_exact ? sig_op[i] : sigmoidf_(sig_op[i]);
     }
     for (int64_t t = 0; t < ntiles; ++t) start[t + 1] += start[t];
     int64_t D = start[ntiles];

@@ -321,6 +321,87 @@ def test_4k_5m_stress_properties(tmp_path):
     assert stats["n_instances"] == inst
     got = a[1600:1760, 960:1120].cpu().numpy()
     assert np.max(np.abs(got - win[1600:1760, 960:1120])) <= PIXEL_TOL
+    # the per-tile list lengths the frame reports add up to D, and strips balanced by them (8 ranks'
+    # worth, rendered one after the other on this GPU) assemble to the same frame bit for bit
+    from intro_to_gaussian_splatting_amd import strips
+
+    ntx, nty = strips.tiles_along(3840, 16), strips.tiles_along(2160, 16)
+    counts = torch.zeros(ntx * nty, dtype=torch.int32, device="cuda:0")
+    c = scene.render_image_hip(1, tile_counts=counts)
+    assert torch.equal(c, a) and int(counts.sum().item()) == inst
+    plan = strips.balanced_plan(strips.tile_row_costs(counts, ntx, nty), 8)
+    assert plan[0][0] == 0 and plan[-1][1] == ntx and len({b - a_ for a_, b in plan}) > 1      # not the equal split
+    frame = torch.full_like(a, 7.0)
+    frame[ntx * 16:].zero_()
+    per_rank = []
+    for t0, t1 in plan:
+        st = {}
+        scene.render_image_hip(1, tile_window=(t0, t1, 0, nty), out=frame[t0 * 16:t1 * 16], out_origin=(t0 * 16, 0),
+                               stats=st, timing=True)
+        per_rank.append((st["n_instances"], st["stage_ms"]))
+    assert torch.equal(frame, a)
+    assert sum(p[0] for p in per_rank) >= inst               # a Gaussian on a strip border is binned by both ranks
+    worst = max(p[0] for p in per_rank)
+    assert worst <= 1.15 * inst / 8 + 0.02 * inst            # balanced: no rank far above its share
+    # the replicated share of a rank: projection of all N + ONE pass over N keys; everything after it is M ~ N/8
+    full_ms = stats_timing = None
+    st = {}
+    scene.render_image_hip(1, stats=st, timing=True)
+    full_ms = st["stage_ms"]
+    strip_ms = per_rank[3][1]
+    print("C4 full frame stage ms: %s" % {k: round(v, 3) for k, v in full_ms.items()})
+    print("C4 1/8 strip stage ms:  %s" % {k: round(v, 3) for k, v in strip_ms.items()})
+    assert strip_ms["depth_sort"] + strip_ms["scan"] <= 0.5 * (full_ms["depth_sort"] + full_ms["scan"])
+
+
+def test_long_tiles_on_four_waves_equal_the_single_wave_path(tmp_path):
+    """Heavy-tailed scene (half of the Gaussians inside 5 % of the frame, footprint sigma_ln 1.0): the longest
+    tile lists are ~20x the mean.  Tiles above long_tile_threshold are composited by four waves, one pixel per
+    lane, eight records per trip; the frame must equal the one-wave-per-tile frame bit for bit (both layouts),
+    the count of such tiles must be what the per-tile list lengths imply, and the pixels must match the oracle."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import strips
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+    from oracle import c_oracle
+
+    w, h = 640, 400
+    sc = make_scene(150_000, w, h, seed=4, cluster_fraction=0.5, cluster_area=0.05, sigma_ln=1.0)
+    scene = _scene_from_arrays(tmp_path, sc)
+    ntx, nty = strips.tiles_along(w, 16), strips.tiles_along(h, 16)
+    counts = torch.zeros(ntx * nty, dtype=torch.int32, device="cuda:0")
+    st = {}
+    split = scene.render_image_hip(1, tile_counts=counts, stats=st)
+    single = scene.render_image_hip(1, split_long_tiles=False)
+    assert torch.equal(split, single)
+    d = st["n_instances"]
+    threshold = max(1024, 4 * (d // (ntx * nty)))
+    n_long = int((counts > threshold).sum().item())
+    print("clustered 150k: D = %d, mean list %.0f, longest %d, threshold %d, %d long tiles" % (
+        d, d / (ntx * nty), int(counts.max().item()), threshold, n_long))
+    assert 0 < n_long < 512 and int(counts.max().item()) > 8 * d / (ntx * nty)
+    a = scene.render_image_hip(1, layout="hw3")
+    b = scene.render_image_hip(1, layout="hw3", split_long_tiles=False)
+    assert torch.equal(a, b) and torch.equal(a.permute(1, 0, 2), split)
+    pre, ref, inst = _oracle_frame(scene, sc)
+    assert inst == d
+    assert np.max(np.abs(split.cpu().numpy() - ref)) <= PIXEL_TOL
+    # a tile window and a captured frame go through the same split
+    part = scene.render_image_hip(1, tile_window=(10, 30, 2, 20))
+    assert torch.equal(part[160:480, 32:320], split[160:480, 32:320])
+    frame = scene.capture_frame(1)
+    frame.out.fill_(3.0)
+    frame.replay()
+    assert torch.equal(frame.confirm(), split)
+    # more long tiles than helper slots: the rest stay on one wave, the frame is still the same
+    sc2 = make_scene(400_000, 1280, 800, seed=5, cluster_fraction=0.9, cluster_area=0.4, sigma_ln=0.2)
+    scene2 = _scene_from_arrays(tmp_path / "b", sc2)
+    ntx2, nty2 = strips.tiles_along(1280, 16), strips.tiles_along(800, 16)
+    counts2 = torch.zeros(ntx2 * nty2, dtype=torch.int32, device="cuda:0")
+    st2 = {}
+    s2 = scene2.render_image_hip(1, tile_counts=counts2, stats=st2)
+    thr2 = max(1024, 4 * (st2["n_instances"] // (ntx2 * nty2)))
+    print("many long tiles: %d above %d" % (int((counts2 > thr2).sum().item()), thr2))
+    assert torch.equal(s2, scene2.render_image_hip(1, split_long_tiles=False))
 
 
 # ----------------------------------------------------------------------------- error behaviour

@@ -160,3 +160,63 @@ def test_strip_pipeline_equals_single_frame(tmp_path, name, layout, world):
     full, _, _ = c_oracle.render(golden_preprocessed(g), int(g["width"]), int(g["height"]), int(g["tile"]))
     full = full if layout == "wh3" else full.transpose(1, 0, 2)
     assert np.array_equal(np.load(tmp_path / "pipe_0.npy"), full)
+
+
+# ---- balanced (unequal) strips: point-to-point gather straight into place
+
+def test_balanced_plan_minimises_the_largest_strip():
+    plan = strips.balanced_plan([1, 1, 1, 1, 10, 1, 1, 1], 3)
+    assert plan == [(0, 4), (4, 5), (5, 8)]
+    assert strips.balanced_plan([5.0] * 8, 4) == [(0, 2), (2, 4), (4, 6), (6, 8)]
+    assert strips.balanced_plan([3, 0, 0], 4) == [(0, 1), (1, 3), (3, 3), (3, 3)] or \
+        strips.balanced_plan([3, 0, 0], 4)[0] == (0, 3)
+    for cost, world in (([7, 2, 9, 4, 4, 1, 8, 3, 3, 6], 4), ([0, 0, 0, 5], 2), ([1], 3), ([2, 2], 5)):
+        plan = strips.balanced_plan(cost, world)
+        assert len(plan) == world and plan[0][0] == 0 and plan[-1][1] == len(cost)
+        assert all(a[1] == b[0] for a, b in zip(plan, plan[1:])) and all(t0 <= t1 for t0, t1 in plan)
+        best = max(sum(cost[a:b]) for a, b in plan)
+        # no contiguous partition into `world` parts does better (brute force over the cut positions)
+        import itertools
+        n = len(cost)
+        others = []
+        for cuts in itertools.combinations_with_replacement(range(n + 1), world - 1):
+            edges = (0,) + cuts + (n,)
+            others.append(max(sum(cost[a:b]) for a, b in zip(edges, edges[1:])))
+        assert best <= min(others) + 1e-9
+    counts = torch.arange(12, dtype=torch.int32).reshape(4, 3)          # x-major: 4 tile columns x 3 tile rows
+    assert strips.tile_row_costs(counts, 4, 3, lead_is_x=True, per_tile=0.0) == [3.0, 12.0, 21.0, 30.0]
+    assert strips.tile_row_costs(counts, 3, 4, lead_is_x=False, per_tile=1.0) == [22.0, 26.0, 30.0]
+
+
+def _planned_worker(rank, world, port, name, layout, plan, all_ranks, pipeline, result_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden(name)
+        w, h, t = int(g["width"]), int(g["height"]), int(g["tile"])
+        fn = _oracle_strip_renderer(golden_preprocessed(g), w, h, t, layout)
+        if pipeline:
+            pipe = strips.StripPipeline(fn, w, h, t, layout, torch.device("cpu"), depth=2, plan=plan)
+            frame = [pipe.submit() for _ in range(3)][-1]
+        else:
+            frame = strips.render_sharded(fn, w, h, t, layout, torch.device("cpu"), all_ranks=all_ranks, plan=plan)
+        if frame is not None:
+            np.save(os.path.join(result_dir, "frame_%d.npy" % rank), frame.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,layout,plan,all_ranks,pipeline", [
+    ("c1_256x256_n2000", "wh3", [(0, 3), (3, 4), (4, 15)], False, False),
+    ("c1_256x256_n2000", "hw3", [(0, 11), (11, 15), (15, 15)], True, False),      # a rank without rows
+    ("pose_70x50_n250", "wh3", [(0, 1), (1, 4)], False, True),
+])
+def test_unequal_strips_equal_single_frame(tmp_path, name, layout, plan, all_ranks, pipeline):
+    world = len(plan)
+    mp.spawn(_planned_worker, args=(world, _free_port(), name, layout, plan, all_ranks, pipeline, str(tmp_path)),
+             nprocs=world, join=True)
+    g = load_golden(name)
+    full, _, _ = c_oracle.render(golden_preprocessed(g), int(g["width"]), int(g["height"]), int(g["tile"]))
+    full = full if layout == "wh3" else full.transpose(1, 0, 2)
+    for r in (range(world) if all_ranks else [0]):
+        assert np.array_equal(np.load(tmp_path / ("frame_%d.npy" % r)), full)

@@ -1,0 +1,87 @@
+"""Where does the kernel-vs-oracle difference on very long tile lists come from?  For the worst pixel of a
+clustered scene: GPU value, C oracle value, and float64 recomputations of that pixel from the oracle's
+stage-1 arrays (a) exactly as the reference orders its float32 operations, but in float64, (b) in the
+kernel's exp2 formulation in float64."""
+import os, sys, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians
+from intro_to_gaussian_splatting_amd.synthetic import make_scene, write_colmap_text
+from oracle import c_oracle, cpu_ref
+
+w, h = 640, 400
+sc = make_scene(150_000, w, h, seed=4, cluster_fraction=0.5, cluster_area=0.05, sigma_ln=1.0)
+with tempfile.TemporaryDirectory() as tmp:
+    write_colmap_text(tmp, sc)
+    g = Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"], sc["opacity"], device="cuda:0")
+    scene = GaussianScene(tmp, g)
+img = scene.render_image_hip(1).cpu().numpy()
+im = scene.images[1]; c = im.gsx_camera()
+cam = cpu_ref.Camera(im.world2view.cpu().numpy(), im.full_proj_transform.cpu().numpy(), np.float32(c.tan_fovx),
+                     np.float32(c.tan_fovy), np.float32(c.fx), np.float32(c.fy), c.width, c.height)
+pre = c_oracle.preprocess(sc["points"], g.colors.cpu().numpy(), sc["scales"], sc["quaternions"], sc["opacity"], cam)
+ref, _, inst = c_oracle.render(pre, w, h, 16)
+diff = np.abs(img - ref)
+print("max |d| %.3g, pixels > 1e-4: %d, > 1e-5: %d of %d" % (diff.max(), (diff.max(axis=2) > 1e-4).sum(), (diff.max(axis=2) > 1e-5).sum(), w * h))
+x, y, ch = np.unravel_index(np.argmax(diff), diff.shape)
+print("worst pixel", x, y, ch, "gpu", img[x, y], "oracle", ref[x, y])
+T0 = 16
+x0, y0 = (x // T0) * T0, (y // T0) * T0
+m = (pre.min_x <= x0 + T0) & (pre.max_x >= x0) & (pre.min_y <= y0 + T0) & (pre.max_y >= y0)
+idx = np.nonzero(m)[0]
+print("tile list length", idx.size)
+def run(dtype, form):
+    T = dtype(1); C = np.zeros(3, dtype)
+    px, py = dtype(x), dtype(y)
+    stop_at = None
+    for n_, i in enumerate(idx):
+        mx, my = dtype(pre.points_xy[i, 0]), dtype(pre.points_xy[i, 1])
+        Q = pre.inverse_covariance_2d[i].astype(dtype)
+        op = dtype(1) / (dtype(1) + np.exp(-dtype(pre.sigmoid_opacity[i, 0])))
+        e0, e1 = mx - px, my - py
+        if form == "ref":
+            d0, d1 = dtype(-0.5) * e0, dtype(-0.5) * e1
+            t0 = d0 * Q[0, 0] + d1 * Q[1, 0]; t1 = d0 * Q[0, 1] + d1 * Q[1, 1]
+            a = np.exp(t0 * e0 + t1 * e1) * op
+        else:
+            k = dtype(-0.5) * dtype(1.4426950408889634)
+            a = np.exp2(e1 * (e1 * (Q[1, 1] * k) + e0 * ((Q[0, 1] + Q[1, 0]) * k)) + (e0 * e0 * (Q[0, 0] * k) + np.log2(op)))
+        test = T * (dtype(1) - a)
+        if test < dtype(1e-6):
+            stop_at = n_
+            break
+        C = C + T * a * pre.colors[i].astype(dtype)
+        T = test
+    return C, T, stop_at
+for dtype in (np.float64, np.float32):
+    for form in ("ref", "exp2"):
+        C, T, s = run(dtype, form)
+        print(dtype.__name__, form, C, "T", T, "stopped at", s)
+
+# ---- which records make this pixel sensitive?  alpha of every record in float64 and in the reference's float32
+# order; records whose two values disagree by more than 1e-3 relative, or whose alpha exceeds 1 (a conic that is
+# indefinite after rounding: the exponent is positive along its ridge)
+print("records with alpha > 1 or |alpha32/alpha64 - 1| > 1e-3 (only those with alpha64 > 1e-6):")
+T64 = 1.0
+shown = 0
+for n_, i in enumerate(idx):
+    Q = pre.inverse_covariance_2d[i]
+    out = []
+    for dtype in (np.float64, np.float32):
+        mx, my = dtype(pre.points_xy[i, 0]), dtype(pre.points_xy[i, 1])
+        Qd = Q.astype(dtype)
+        op = dtype(1) / (dtype(1) + np.exp(-dtype(pre.sigmoid_opacity[i, 0])))
+        e0, e1 = mx - dtype(x), my - dtype(y)
+        d0, d1 = dtype(-0.5) * e0, dtype(-0.5) * e1
+        t0 = d0 * Qd[0, 0] + d1 * Qd[1, 0]; t1 = d0 * Qd[0, 1] + d1 * Qd[1, 1]
+        out.append(float(np.exp(t0 * e0 + t1 * e1) * op))
+    a64, a32 = out
+    if a64 > 1e-6 and (a64 > 1.0 or abs(a32 / a64 - 1) > 1e-3) and shown < 12:
+        shown += 1
+        det = float(Q[0, 0]) * float(Q[1, 1]) - 0.25 * (float(Q[0, 1]) + float(Q[1, 0])) ** 2
+        print("  #%d T=%.3g alpha64=%.6g alpha32=%.6g  Q=%s det(sym Q)=%.3g cov2d=%s e=(%.2f,%.2f)" % (
+            n_, T64, a64, a32, Q.reshape(-1), det, pre.covariance_2d[i].reshape(-1), pre.points_xy[i, 0] - x, pre.points_xy[i, 1] - y))
+    if T64 * (1 - a64) < 1e-6:
+        print("  float64 stops at #%d (T=%.4g, alpha=%.4g)" % (n_, T64, a64))
+        break
+    T64 *= (1 - a64)
