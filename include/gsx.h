@@ -78,6 +78,7 @@ typedef struct GsxCamera {
     float fy;             /* splat/image.py:29     */
     int32_t width;        /* splat/image.py:38     */
     int32_t height;       /* splat/image.py:37     */
+    float camera_center[3]; /* splat/image.py:66 (world2view.inverse()[3,:3]); read only when GsxParams.sh is set */
 } GsxCamera;
 
 /*
@@ -105,6 +106,14 @@ typedef struct GsxParams {
      * window_height_in_tiles + (ty - tile_y0)): the length of every tile's Gaussian list, written by the
      * frame.  What a multi-GPU caller balances its strips with (strips.balanced_plan).  NULL: not reported. */
     uint32_t *tile_counts;
+    /* gsx_render_forward only, build extension (the reference has no spherical harmonics).  NULL (default): the
+     * `colors` argument is (n,3) RGB.  Otherwise DEVICE coefficients (n, (sh_degree+1)^2, 3), sh_degree in 0..3,
+     * in the published 3DGS convention (see gsx_sh_to_rgb); the view-dependent colour is evaluated inside the
+     * projection kernel with GsxCamera.camera_center (of `camera`, or of camera_device when that is set), the
+     * `colors` argument is ignored and may be NULL. */
+    const float *sh;
+    int32_t sh_degree;
+    int32_t reserved0;
 } GsxParams;
 
 /* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call

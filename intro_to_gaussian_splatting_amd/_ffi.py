@@ -35,7 +35,7 @@ STAGE_NAMES = ("project", "depth_sort", "scan", "bin", "blend", "total")
 class GsxCamera(ctypes.Structure):
     _fields_ = [("world2view", c_float * 16), ("full_proj", c_float * 16),
                 ("tan_fovx", c_float), ("tan_fovy", c_float), ("fx", c_float), ("fy", c_float),
-                ("width", c_int32), ("height", c_int32)]
+                ("width", c_int32), ("height", c_int32), ("camera_center", c_float * 3)]
 
 
 class GsxParams(ctypes.Structure):
@@ -43,7 +43,7 @@ class GsxParams(ctypes.Structure):
                 ("tile_x0", c_int32), ("tile_x1", c_int32), ("tile_y0", c_int32), ("tile_y1", c_int32),
                 ("out_x0", c_int32), ("out_y0", c_int32), ("out_w", c_int32), ("out_h", c_int32),
                 ("flags", c_int32), ("background", c_float * 3), ("camera_device", c_void_p),
-                ("tile_counts", c_void_p)]
+                ("tile_counts", c_void_p), ("sh", c_void_p), ("sh_degree", c_int32), ("reserved0", c_int32)]
 
 
 class GsxFrameStats(ctypes.Structure):

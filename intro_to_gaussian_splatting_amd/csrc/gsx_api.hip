@@ -104,6 +104,8 @@ struct Plan {
     bool split;    // long tiles on four waves (not GSX_FLAG_NO_LONG_TILE_SPLIT)
     const GsxCamera *camera_device;
     uint32_t *tile_counts;
+    const float *sh;
+    int sh_degree;   // -1: RGB colours
     float background[3];
 };
 
@@ -157,6 +159,9 @@ int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, con
     for (int i = 0; i < 3; ++i) p.background[i] = d.background[i];
     p.camera_device = d.camera_device;
     p.tile_counts = d.tile_counts;
+    p.sh = d.sh;
+    p.sh_degree = d.sh ? d.sh_degree : -1;
+    if (d.sh && (d.sh_degree < 0 || d.sh_degree > 3)) return fail(GSX_ERR_INVALID_ARGUMENT, "SH degree %d outside [0,3]", d.sh_degree);
     if (d.layout != GSX_LAYOUT_WH3 && d.layout != GSX_LAYOUT_HW3) return fail(GSX_ERR_INVALID_ARGUMENT, "unknown layout %d", d.layout);
     if (!out_image) return fail(GSX_ERR_INVALID_ARGUMENT, "out_image is NULL");
     p.semantics = d.semantics;
@@ -451,7 +456,8 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     int rc = make_plan(camera->width, camera->height, tile_size, out_image, params, p);
     if (rc != GSX_OK) return rc;
     if (n < 0 || n >= (int64_t)1 << 31) return fail(GSX_ERR_INVALID_ARGUMENT, "n = %lld out of range", (long long)n);
-    if (n > 0 && (!means3d || !scales || !quats || !opacity_logit || !colors)) return fail(GSX_ERR_INVALID_ARGUMENT, "an input array is NULL");
+    if (n > 0 && (!means3d || !scales || !quats || !opacity_logit || (!colors && !p.sh)))
+        return fail(GSX_ERR_INVALID_ARGUMENT, "an input array is NULL");
     Carve c;
     int64_t cap;
     rc = check_workspace(workspace, workspace_bytes, n, max_tiles_of(camera->width, camera->height, tile_size), c, cap);
@@ -461,9 +467,9 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     uint32_t *v0 = (uint32_t *)(ws + c.vals0), *v1 = (uint32_t *)(ws + c.vals1);
     StageTimer tm;
     tm.begin(p.timing, s);
-    gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
+    gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, p.sh ? p.sh : colors};
     uint32_t *counters = (uint32_t *)(ws + c.counters);
-    GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, k0, (gsx::Record *)(ws + c.rec),
+    GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, p.sh_degree, k0, (gsx::Record *)(ws + c.rec),
                                      (gsx::TileRect *)(ws + c.rect), counters,
                                      p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 1: project (+ depth keys)

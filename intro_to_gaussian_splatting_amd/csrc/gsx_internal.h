@@ -99,9 +99,10 @@ hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t
 // per-pixel cull of splat/c/render.cu:55-60.
 // tight_rects: GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS (see include/gsx.h).
 // cam_device (may be null): GsxParams.camera_device, read by the kernel instead of `cam`.
+// sh_degree >= 0: in.colors holds spherical-harmonics coefficients, evaluated inline (GsxParams.sh).
 // counters: 4 words this kernel zeroes for the depth sort (culled count, kept count, ...).
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
-                               const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys,
+                               const TileGrid &grid, int semantics, bool tight_rects, int sh_degree, uint32_t *keys,
                                Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s);
 hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
                                const uint32_t *sorted_idx, int64_t n, const StageOneOut &out, hipStream_t s);

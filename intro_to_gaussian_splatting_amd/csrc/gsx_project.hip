@@ -17,11 +17,13 @@
 //   splat/utils.py:409-423          r = ceil(3 sqrt(lambda_max)), discriminant floored at 0.1
 //   splat/gaussian_scene.py:209-217 tile membership test (min <= x0 + T and max >= x0)
 #include "gsx_internal.h"
+#include "gsx_sh_device.h"
 
 namespace gsx {
 namespace {
 
 constexpr int kBlock = 256;
+static_assert(kBlock == sh::kBlock, "the projection kernel stages SH coefficients with the SH kernel's block size");
 
 struct Projected {
     float x, y;            // pixel position
@@ -353,14 +355,40 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
 // tile of the window (culled, off screen, or -- on a rank that owns a strip of the frame -- in another
 // rank's strip) only gets its key written: no record, no rectangle, and its opacity and colour are
 // never read (40 B in + 4 B out instead of 56 B in + 60 B out; 7/8 of the Gaussians on an 8-GPU rank).
-template <bool DEVICE_CAMERA>
+// SHDEG >= 0 (GsxParams.sh, build extension): the colour is evaluated here from spherical harmonics of that
+// degree (gsx_sh_device.h: the workgroup streams its 256 Gaussians' coefficients through LDS) with the camera
+// centre of the GsxCamera the kernel reads -- no colour array, no colour launch, and a captured frame follows
+// a moving camera with SH colours too.  SHDEG = -1: in.colors holds RGB, as in the reference.
+template <bool DEVICE_CAMERA, int SHDEG>
 __global__ void __launch_bounds__(kBlock)
     project_pack_kernel(GsxCamera cam_arg, const GsxCamera *__restrict__ cam_dev, GaussiansIn in, int64_t n,
                         TileGrid grid, int semantics, bool tight,
                         uint32_t *__restrict__ keys, Record *__restrict__ rec,
-                        TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox) {
+                        TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox,
+                        bool sh_vec) {
+    constexpr int DEG = SHDEG >= 0 ? SHDEG : 0;
+    using L = sh::Layout<DEG>;
+    __shared__ float sh_lds[SHDEG >= 0 ? L::kRows * L::STRIDE : 1];
     int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (g < 4) counters[g] = 0u;   // the depth sort's culled / kept counts start from zero (no memset node)
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    if (SHDEG >= 0) {
+        // colour of every Gaussian of the workgroup first (all threads take part in the staging rounds)
+        const float *cc = DEVICE_CAMERA ? cam_dev->camera_center : cam_arg.camera_center;
+        const float c0 = cc[0], c1 = cc[1], c2 = cc[2];
+        // a part's coefficient block starts 16-byte aligned only if the whole array is and kRows * W * 4 is a multiple of 16
+        const bool vec = sh_vec && (L::kRows * L::W) % 4 == 0;
+#pragma unroll
+        for (int part = 0; part < L::kParts; ++part) {
+            if (part) __syncthreads();
+            sh::stage<DEG, L::kRows>(in.colors, n, (int64_t)blockIdx.x * kBlock + part * L::kRows, sh_lds, vec);
+            const int row = (int)threadIdx.x - part * L::kRows;
+            if (row >= 0 && row < L::kRows && g < n) {
+                const float *pp = in.means3d + 3 * g;
+                sh::eval<DEG>(sh_lds + row * L::STRIDE, pp[0] - c0, pp[1] - c1, pp[2] - c2, cr, cg, cb);
+            }
+        }
+    }
     if (g >= n) return;
     // GsxParams.camera_device: the constants as they are in device memory now (uniform scalar loads)
     const GsxCamera &cam = DEVICE_CAMERA ? *cam_dev : cam_arg;
@@ -412,9 +440,12 @@ __global__ void __launch_bounds__(kBlock)
         return;
     }
     keys[g] = __float_as_uint(tz);
-    const float *c = in.colors + 3 * g;
+    if (SHDEG < 0) {
+        const float *c = in.colors + 3 * g;
+        cr = c[0]; cg = c[1]; cb = c[2];
+    }
     Record out;
-    pack_record(semantics, o.x, o.y, o.q00, o.q01, o.q10, o.q11, op, c[0], c[1], c[2], o.depth, out);
+    pack_record(semantics, o.x, o.y, o.q00, o.q01, o.q10, o.q11, op, cr, cg, cb, o.depth, out);
     rec[g] = out;
     if (bbox) bbox[g] = make_float4(o.min_x, o.max_x, o.min_y, o.max_y);
     rect[g] = tr;
@@ -545,16 +576,31 @@ hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t
     return hipGetLastError();
 }
 
+template <int SHDEG>
+static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
+                                    const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys, Record *rec,
+                                    TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s) {
+    const bool vec = (reinterpret_cast<uintptr_t>(in.colors) & 15u) == 0;
+    if (cam_device)
+        project_pack_kernel<true, SHDEG><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics,
+                                                                          tight_rects, keys, rec, rect, counters, bbox, vec);
+    else
+        project_pack_kernel<false, SHDEG><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics,
+                                                                           tight_rects, keys, rec, rect, counters, bbox, vec);
+}
+
+// sh_degree < 0: in.colors is (n,3) RGB; 0..3: in.colors is (n, (degree+1)^2, 3) spherical harmonics.
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
-                               const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys,
+                               const TileGrid &grid, int semantics, bool tight_rects, int sh_degree, uint32_t *keys,
                                Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    if (cam_device)
-        project_pack_kernel<true><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics, tight_rects,
-                                                                   keys, rec, rect, counters, bbox);
-    else
-        project_pack_kernel<false><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics,
-                                                                    tight_rects, keys, rec, rect, counters, bbox);
+    switch (sh_degree) {
+        case 0: launch_project_pack_deg<0>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, s); break;
+        case 1: launch_project_pack_deg<1>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, s); break;
+        case 2: launch_project_pack_deg<2>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, s); break;
+        case 3: launch_project_pack_deg<3>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, s); break;
+        default: launch_project_pack_deg<-1>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, s); break;
+    }
     return hipGetLastError();
 }
 

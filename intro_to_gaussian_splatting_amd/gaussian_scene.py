@@ -192,19 +192,25 @@ class GaussianScene:
         _ffi.check(rc)
         return out
 
-    def _inputs(self, image_idx: Optional[int] = None):
+    def _inputs(self, image_idx: Optional[int] = None, inline_sh: bool = False):
+        """The five parameter tensors the library reads.  With ``inline_sh`` and an SH scene the last one is
+        None: the whole-path entry evaluates the colour itself from ``gaussians.sh`` (GsxParams.sh)."""
         g = self.gaussians
         dev = g.points.device
         _require_gpu(dev)
         n = int(g.points.shape[0])
-        colors = g.colors if image_idx is None else self._colors(image_idx)
+        has_sh = getattr(g, "sh", None) is not None
         tensors = [
             _check_f32("points", g.points.reshape(n, 3), dev),
             _check_f32("scales", g.scales.reshape(n, 3), dev),
             _check_f32("quaternions", g.quaternions.reshape(n, 4), dev),
             _check_f32("opacity", g.opacity.reshape(n, 1), dev),
-            _check_f32("colors", colors.reshape(n, 3), dev),
         ]
+        if has_sh and inline_sh:
+            tensors.append(None)
+        else:
+            colors = g.colors if (image_idx is None or not has_sh) else self._colors(image_idx)
+            tensors.append(_check_f32("colors", colors.reshape(n, 3), dev))
         return dev, n, tensors
 
     # ------------------------------------------------------------------ stage 1
@@ -263,10 +269,15 @@ class GaussianScene:
         whose pair count exceeded the workspace capacity it was enqueued with.
         """
         lib = _ffi.load()
-        dev, n, tensors = self._inputs(image_idx)
+        dev, n, tensors = self._inputs(image_idx, inline_sh=True)
         cam = self.images[image_idx].gsx_camera()
         width, height = cam.width, cam.height
         params = _ffi.default_params()
+        if tensors[4] is None:      # SH scene: the projection kernel evaluates the view-dependent colour itself
+            g = self.gaussians
+            k = (int(g.sh_degree) + 1) ** 2
+            self._sh_flat = _check_f32("sh", g.sh.reshape(n, k, 3), dev)
+            params.sh, params.sh_degree = self._sh_flat.data_ptr(), int(g.sh_degree)
         params.layout = _ffi.GSX_LAYOUT_WH3 if layout == "wh3" else _ffi.GSX_LAYOUT_HW3
         params.semantics = _SEMANTICS[semantics]
         params.background[0], params.background[1], params.background[2] = [float(v) for v in background]
@@ -417,8 +428,8 @@ class GaussianScene:
         Gaussian tensors -- all buffer addresses are baked in, and so are the camera constants unless
         ``movable_camera`` is set: then the projection kernel reads them from a device buffer
         (GsxParams.camera_device) that ``frame.set_camera(other_image_idx)`` rewrites between replays
-        (same frame size; stored-RGB scenes only, the SH colour kernel takes the camera centre by
-        value).  The graph holds room for ``headroom`` x the pair count of the captured view; a replay
+        (same frame size; SH scenes too: the colour is evaluated inside the projection kernel with the
+        camera centre of that buffer).  The graph holds room for ``headroom`` x the pair count of the captured view; a replay
         that needs more (another camera may) is reported by ``confirm()``.  Possible because the
         no-sync frame has no host dependency at all."""
         dev = self.gaussians.points.device
@@ -428,8 +439,6 @@ class GaussianScene:
         out = torch.empty(shape, dtype=torch.float32, device=dev)
         cam_buf = None
         if movable_camera:
-            if getattr(self.gaussians, "sh", None) is not None:
-                raise RuntimeError("movable_camera needs stored RGB colours (the SH kernel takes the camera centre by value)")
             cam_buf = torch.frombuffer(bytearray(bytes(cam)), dtype=torch.uint8).to(dev)
         kw = dict(tile_size=tile_size, layout=layout, out=out, semantics=semantics, camera_buffer=cam_buf)
         st = {}

@@ -112,6 +112,7 @@ class GaussianImage:
         cam.tan_fovx, cam.tan_fovy = float(tan_fovX), float(tan_fovY)
         cam.fx, cam.fy = float(f_x), float(f_y)
         cam.width, cam.height = int(camera.width), int(camera.height)
+        cam.camera_center[:] = [float(v) for v in center]
         self._gsx_camera = cam
 
     def project_point_to_camera_perspective_projection(

@@ -34,8 +34,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts():
-    assert ctypes.sizeof(_ffi.GsxCamera) == 16 * 4 * 2 + 4 * 4 + 2 * 4
-    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8
+    assert ctypes.sizeof(_ffi.GsxCamera) == 16 * 4 * 2 + 4 * 4 + 2 * 4 + 3 * 4
+    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16
     assert ctypes.sizeof(_ffi.GsxFrameStats) == 64
     p = _ffi.default_params()
     assert p.semantics == _ffi.GSX_SEM_REF_CPU and p.layout == _ffi.GSX_LAYOUT_WH3

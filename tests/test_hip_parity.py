@@ -652,6 +652,12 @@ def test_spherical_harmonics_kernel_and_trained_ply_pipeline(tmp_path):
         ref = cpu_ref.sh_to_rgb(sc["points"], sh, deg, scene.images[1].camera_center.cpu().numpy())
         assert np.max(np.abs(cols - ref)) <= 2e-6
         img = scene.render_image(1)
+        # the colour is evaluated INSIDE the projection kernel (GsxParams.sh): same code as the standalone kernel,
+        # so feeding that kernel's colours through the RGB path gives the same frame bit for bit
+        g_cols = Gaussians.from_arrays(g.points.cpu().numpy(), np.zeros_like(sc["colors_0_255"]), g.scales.cpu().numpy(),
+                                       g.quaternions.cpu().numpy(), g.opacity.cpu().numpy(), device="cuda:0")
+        g_cols.colors = scene._colors(1).clone()
+        assert torch.equal(GaussianScene(str(tmp_path), g_cols).render_image_hip(1).cpu(), img)
         # the same frame through the pinned RGB path with those colours (colors = rgb/256 convention)
         g_rgb = Gaussians.from_arrays(sc["points"], ref * 256.0, np.exp(np.log(sc["scales"])), sc["quaternions"],
                                       sc["opacity"], device="cuda:0")
@@ -1028,3 +1034,23 @@ def test_captured_frame_follows_a_moving_camera(tmp_path):
     with pytest.raises(RuntimeError, match="movable_camera"):
         baked.set_camera(2)
     assert first is scene.images[1]
+    # a trained-.ply style scene (degree-3 spherical harmonics): the colour depends on the camera centre, which the
+    # recorded projection kernel reads from the same device buffer
+    from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians, ply
+
+    rs = np.random.RandomState(3)
+    sh = np.zeros((20000, 16, 3), np.float32)
+    sh[:, 0, :] = (sc["colors_0_255"] / 256.0 - 0.5) / 0.28209479177387814
+    sh[:, 1:, :] = rs.normal(0, 0.25, size=(20000, 15, 3))
+    path = str(tmp_path / "trained.ply")
+    ply.save_trained(path, sc["points"], sh, sc["scales"], sc["quaternions"], sc["opacity"])
+    sh_scene = GaussianScene(str(tmp_path), Gaussians.from_ply(path, device="cuda:0"))
+    for idx in (2, 3):
+        sh_scene.images[idx] = scene.images[idx]
+    sh_refs = {i: sh_scene.render_image_hip(i).clone() for i in (1, 2, 3)}
+    assert not torch.equal(sh_refs[1], refs[1])                      # the view-dependent part is there
+    sh_frame = sh_scene.capture_frame(1, movable_camera=True, headroom=1.5)
+    for i in (2, 1, 3, 3, 1):
+        sh_frame.set_camera(i)
+        sh_frame.replay()
+        assert torch.equal(sh_frame.confirm(), sh_refs[i]), i
