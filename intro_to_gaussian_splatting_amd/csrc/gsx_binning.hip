@@ -31,6 +31,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kPerThread = 4;
 constexpr int kChunk = kBlock * kPerThread;   // depth ranks per workgroup in chunk_sums / emit
+static_assert(kChunk == kEmitChunk, "gsx_plan.h sizes the chunk sums with this");
 // Up to this many chunks (2M Gaussians) the emit kernel adds up the raw chunk sums itself; beyond,
 // scan_sums_kernel turns them into prefixes first (one more launch where frames take milliseconds).
 constexpr int kSelfScanChunks = 2048;
@@ -320,16 +321,8 @@ hipError_t launch_tile_counts(const uint2 *ranges, int64_t nt, uint32_t *counts,
     return hipGetLastError();
 }
 
-size_t binning_temp_bytes(int64_t n, int64_t cap) {
-    const size_t nchunks = (size_t)((n + kChunk - 1) / kChunk) + 2;
-    // two regions: [radix digit table for max(n, cap) items] [chunk sums]
-    const size_t r = (radix_temp_bytes(n > cap ? n : cap) + 255) & ~(size_t)255;
-    return r + ((nchunks * sizeof(uint64_t) + 255) & ~(size_t)255);
-}
-
 static uint64_t *sums_of(void *temp, int64_t n, int64_t cap) {
-    const size_t r = (radix_temp_bytes(n > cap ? n : cap) + 255) & ~(size_t)255;
-    return (uint64_t *)((char *)temp + r);
+    return (uint64_t *)((char *)temp + binning_sums_offset(n, cap));
 }
 
 // (tile id, Gaussian index) pairs in rank order.  Tile ids fit 16 bits for any frame up to 65536 tiles

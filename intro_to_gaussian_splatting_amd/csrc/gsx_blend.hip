@@ -66,7 +66,6 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 // compositing launch itself (blockIdx >= number of tiles): no memset nodes on the frame path -- they cost
 // a 5 us dispatch each, and a hipGraph memset node replayed on another stream than the one it was
 // captured on left the border untouched on ROCm 7.2 (tools/debug_border.py).
-constexpr int kClearFloats = 6144;   // floats zeroed per extra workgroup
 
 __device__ __forceinline__ void clear_block(uint32_t cb, const ClearPlan &cp, float *__restrict__ base) {
     int i = 0;
@@ -698,11 +697,6 @@ hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s) {
     if (cp.n <= 0 || cp.first[cp.n] <= 0) return hipSuccess;
     clear_kernel<<<(unsigned)cp.first[cp.n], 64, 0, s>>>(cp, base);
     return hipGetLastError();
-}
-
-int clear_blocks_for(int64_t rows, int64_t fw) {
-    const int64_t floats = rows * fw * 3;
-    return (int)((floats + kClearFloats - 1) / kClearFloats);
 }
 
 bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic) {

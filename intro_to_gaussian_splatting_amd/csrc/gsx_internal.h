@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "gsx.h"
+#include "gsx_plan.h"
 
 namespace gsx {
 
@@ -22,47 +23,20 @@ constexpr uint32_t kEmptyKey = 0xFFFFFFFEu;   // visible, but it reaches no tile
 struct __attribute__((aligned(16))) Record {
     float4 a, b, c;
 };
-
-// Which tiles exist and which of them this call renders.
-//   ntx, nty : number of tiles in the frame along x / y (REF_CPU: the last row/column is absent)
-//   wx0..wy1 : window [wx0,wx1) x [wy0,wy1) rendered by this call
-// Window-local tile id = (tx - wx0) * (wy1 - wy0) + (ty - wy0).
-struct TileGrid {
-    int32_t tile, ntx, nty;
-    int32_t wx0, wx1, wy0, wy1;
-    int32_t width, height;  // frame size in pixels (REF_CUDA has partial edge tiles)
-    __host__ __device__ int32_t nwx() const { return wx1 - wx0; }
-    __host__ __device__ int32_t nwy() const { return wy1 - wy0; }
-    __host__ __device__ int64_t count() const { return (int64_t)nwx() * nwy(); }
-};
+static_assert(sizeof(Record) == kRecordBytes, "gsx_plan.h sizes the workspace with this");
 
 // Tile rectangle of one Gaussian, inclusive, already clamped to the window; empty when x0 > x1.
 struct TileRect {
     uint16_t x0, x1, y0, y1;
 };
-
-struct OutDesc {
-    float *ptr;
-    int64_t stride_x, stride_y;  // in floats; the channel stride is 1
-    int32_t x0, y0, w, h;        // frame pixel of out(0,0) and the buffer extent in pixels
-};
-
-// Up to four rectangles of the output buffer that a frame zeroes (everything no rendered tile covers), in
-// buffer-local pixels along the (slow, fast) memory axes; first[i] = first clear workgroup of rectangle i,
-// first[n] = their total.  pitch: floats per slow-axis step.
-struct ClearPlan {
-    int32_t n;
-    int32_t first[5];
-    int32_t s0[4], f0[4], rows[4], fw[4];
-    int64_t pitch;
-};
+static_assert(sizeof(TileRect) == kTileRectBytes && sizeof(float4) == kBboxBytes && sizeof(uint2) == kRangeBytes,
+              "gsx_plan.h sizes the workspace with these");
 
 // Tiles whose list is much longer than the frame's average are composited by FOUR waves (a quarter of the
 // tile's pixels each, one pixel per lane, eight records per trip) instead of one: a lone wave walks its list
 // at ~430 cycles per record, so one 20 000-entry tile would outlast the rest of the frame several times over.
 // The list of such tiles is built on the device by tile_ranges_kernel (count: zeroed by the emit kernel) and
 // flagged in bit 31 of ranges[t].y; the compositing launch carries 4 * kMaxLongTiles helper workgroups.
-constexpr uint32_t kMaxLongTiles = 512;
 constexpr uint32_t kLongFlag = 0x80000000u;
 struct LongTiles {
     uint32_t *count;   // number of long tiles found (may exceed max)
@@ -115,7 +89,6 @@ hipError_t launch_project_points(const GsxCamera &cam, const float *means3d, int
                                  uint8_t *in_view, hipStream_t s);
 
 // ---- gsx_binning.hip
-size_t binning_temp_bytes(int64_t n, int64_t cap);
 // Where a frame's counts go on the device (and, optionally, straight into pinned host memory).
 struct BinCounts {
     int64_t *stats2;             // [0] = visible Gaussians, [1] = D: the first two fields of a GsxFrameStats
@@ -142,7 +115,6 @@ hipError_t launch_tile_counts(const uint2 *ranges, int64_t nt, uint32_t *counts,
 // ---- gsx_sort.hip: stable LSD radix sort, up to 8 bits per pass, key bits [0, key_bits).  The element
 // count is min(*n_dev, bound) (n_dev == nullptr: bound); grids are sized by `bound`.  Buffers
 // ping-pong; on return keys_cur / vals_cur point at the sorted data.  temp: radix_temp_bytes(bound).
-size_t radix_temp_bytes(int64_t max_items);
 hipError_t radix_sort_pairs_u32(void *temp, uint32_t *&keys_cur, uint32_t *&keys_alt, uint32_t *&vals_cur,
                                 uint32_t *&vals_alt, const uint32_t *n_dev, int64_t bound, int key_bits,
                                 hipStream_t s);
@@ -172,6 +144,5 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
 bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic);
 hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s);   // the zero fill alone
 hipError_t launch_zero_words(uint32_t *p, size_t n, hipStream_t s);
-int clear_blocks_for(int64_t rows, int64_t fw);                              // workgroups for rows x fw pixels
 
 }  // namespace gsx

@@ -1,0 +1,294 @@
+// Host-side planning of a frame: tile grid and window, output descriptor, workspace carving and capacity,
+// the rectangles a frame zeroes.  Pure integer arithmetic with no HIP type in it, so that the same code is
+// (a) what libgsx.so runs and (b) what tests/host/plan_sanitize.cpp compiles with g++ under
+// -fsanitize=address,undefined and sweeps to the 2^31 limits (GSX_HD is empty there).
+#pragma once
+
+#include <stdarg.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gsx.h"
+
+#if defined(__HIPCC__)
+#define GSX_HD __host__ __device__
+#else
+#define GSX_HD
+#endif
+
+namespace gsx {
+
+// ---- sizes the kernels and the workspace agree on
+constexpr int kSortItems = 2048;       // a radix-sort chunk: items of one scatter workgroup (gsx_sort.hip)
+constexpr int kSortQuad = 4;           // chunks per count workgroup
+constexpr int kSortBins = 256;         // digit-table rows
+constexpr int kEmitChunk = 1024;       // depth ranks per workgroup of chunk_sums / emit (gsx_binning.hip)
+constexpr uint32_t kMaxLongTiles = 512;
+constexpr int kClearFloats = 6144;     // floats zeroed per clear workgroup (gsx_blend.hip)
+constexpr size_t kRecordBytes = 48, kTileRectBytes = 8, kBboxBytes = 16, kRangeBytes = 8;
+
+// Which tiles exist and which of them this call renders.
+//   ntx, nty : number of tiles in the frame along x / y (REF_CPU: the last row/column is absent)
+//   wx0..wy1 : window [wx0,wx1) x [wy0,wy1) rendered by this call
+// Window-local tile id = (tx - wx0) * (wy1 - wy0) + (ty - wy0).
+struct TileGrid {
+    int32_t tile, ntx, nty;
+    int32_t wx0, wx1, wy0, wy1;
+    int32_t width, height;  // frame size in pixels (REF_CUDA has partial edge tiles)
+    GSX_HD int32_t nwx() const { return wx1 - wx0; }
+    GSX_HD int32_t nwy() const { return wy1 - wy0; }
+    GSX_HD int64_t count() const { return (int64_t)nwx() * nwy(); }
+};
+
+struct OutDesc {
+    float *ptr;
+    int64_t stride_x, stride_y;  // in floats; the channel stride is 1
+    int32_t x0, y0, w, h;        // frame pixel of out(0,0) and the buffer extent in pixels
+};
+
+// Up to four rectangles of the output buffer that a frame zeroes (everything no rendered tile covers), in
+// buffer-local pixels along the (slow, fast) memory axes; first[i] = first clear workgroup of rectangle i,
+// first[n] = their total.  pitch: floats per slow-axis step.
+struct ClearPlan {
+    int32_t n;
+    int32_t first[5];
+    int32_t s0[4], f0[4], rows[4], fw[4];
+    int64_t pitch;
+};
+
+
+// Digit table [256][chunks rounded up to a multiple of 4] + 256 row totals.
+inline size_t radix_temp_bytes(int64_t max_items) {
+    const size_t nblocks = (size_t)((max_items + kSortItems - 1) / kSortItems) + kSortQuad;
+    return ((size_t)kSortBins * (nblocks + kSortQuad) + kSortBins) * sizeof(uint32_t);
+}
+// Where the 64-bit chunk sums start inside `temp`: behind the radix table for max(n, cap) items.
+inline size_t binning_sums_offset(int64_t n, int64_t cap) {
+    const int64_t items = n > cap ? n : cap;
+    return (radix_temp_bytes(items > 1 ? items : 1) + 255) & ~(size_t)255;   // a request for 0 pairs is sized like 1
+}
+inline size_t binning_temp_bytes(int64_t n, int64_t cap) {
+    const size_t nchunks = (size_t)((n + kEmitChunk - 1) / kEmitChunk) + 2;
+    return binning_sums_offset(n, cap) + ((nchunks * sizeof(uint64_t) + 255) & ~(size_t)255);
+}
+inline int clear_blocks_for(int64_t rows, int64_t fw) {
+    const int64_t floats = rows * fw * 3;
+    return (int)((floats + kClearFloats - 1) / kClearFloats);
+}
+
+namespace plan {
+
+constexpr size_t kAlign = 256;
+constexpr int64_t kMaxPairs = ((int64_t)1 << 31) - 1;
+inline size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
+
+inline void default_params(GsxParams *params) {
+    memset(params, 0, sizeof *params);
+    params->semantics = GSX_SEM_REF_CPU;
+    params->layout = GSX_LAYOUT_WH3;
+    params->tile_x1 = -1;
+    params->tile_y1 = -1;
+}
+
+// Number of tiles along an axis.  REF_CPU iterates range(0, extent - tile, tile)
+// (splat/gaussian_scene.py:208,214): the last row/column is never rendered.
+// REF_CUDA covers the frame (splat/c/render.cu:119-120).
+inline int32_t tiles_along(int32_t extent, int32_t tile, int semantics) {
+    if (semantics == GSX_SEM_REF_CPU) return extent > tile ? (extent - tile + tile - 1) / tile : 0;
+    return (extent + tile - 1) / tile;
+}
+
+struct Carve {
+    size_t keys0, keys1, vals0, vals1;      // n x u32: depth keys / original indices (ping-pong)
+    size_t rec, rect, rrect, bbox;          // per Gaussian: record, tile rectangle by index / by depth rank
+    size_t tkeys0, tkeys1, tvals0, tvals1;  // cap x u32: tile ids / Gaussian indices (ping-pong)
+    size_t ranges, longs, counters, temp, temp_bytes, total;
+};
+
+// The 64-byte `counters` block: what the kernels of one frame hand to each other on the device.
+//   u32 [0] Gaussians behind the cull plane   [1] Gaussians kept by the depth sort (M)
+//       [2] min(D, 2^32 - 1)                   [3] long tiles found (LongTiles.count)
+//   i64 at byte 16: n_visible, D (the first two fields of a GsxFrameStats)
+enum { kCtrCulled = 0, kCtrKept = 1, kCtrPairs = 2, kCtrLong = 3 };
+
+inline Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes) {
+    Carve c;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = off;
+        off = align_up(off + bytes);
+        return at;
+    };
+    size_t nn = (size_t)(n > 0 ? n : 1), cc = (size_t)(cap > 0 ? cap : 1);
+    c.keys0 = take(nn * 4); c.keys1 = take(nn * 4); c.vals0 = take(nn * 4); c.vals1 = take(nn * 4);
+    c.rec = take(nn * kRecordBytes);
+    c.rect = take(nn * kTileRectBytes);
+    c.rrect = take(nn * kTileRectBytes);
+    c.bbox = take(nn * kBboxBytes);
+    c.tkeys0 = take(cc * 4); c.tkeys1 = take(cc * 4); c.tvals0 = take(cc * 4); c.tvals1 = take(cc * 4);
+    c.ranges = take((size_t)(max_tiles > 0 ? max_tiles : 1) * kRangeBytes);
+    c.longs = take(kMaxLongTiles * sizeof(uint32_t));
+    c.counters = take(64);
+    c.temp = take(temp_bytes);
+    c.temp_bytes = temp_bytes;
+    c.total = off;
+    return c;
+}
+
+inline int64_t max_tiles_of(int32_t width, int32_t height, int32_t tile) {
+    return (int64_t)((width + tile - 1) / tile) * ((height + tile - 1) / tile);
+}
+
+// Largest pair capacity whose carve fits `bytes` (the size of a carve grows monotonically with the capacity:
+// bisection, exact -- what gsx_workspace_bytes(n, .., cap) asks for always yields at least cap); -1 when not
+// even the per-Gaussian part fits.  The kernels index pairs with 32 bits and gsx_workspace_bytes sizes for
+// < 2^31 pairs: a larger buffer (a 288 GB part can hand over 68 GB and more) does not raise the capacity
+// beyond that.
+inline int64_t capacity_for(size_t bytes, int64_t n, int64_t max_tiles) {
+    auto fits = [&](int64_t cap) { return carve(n, cap, max_tiles, binning_temp_bytes(n, cap)).total <= bytes; };
+    if (!fits(1)) return -1;
+    int64_t lo = 1, hi = kMaxPairs;       // invariant: fits(lo), and hi is an upper bound of the answer
+    if (fits(hi)) return hi;
+    while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (fits(mid))
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+struct Plan {
+    TileGrid grid;
+    OutDesc out;
+    int semantics;
+    bool timing;
+    bool no_sync;  // GSX_FLAG_NO_SYNC: nothing waits for the device
+    bool generic;  // GSX_FLAG_GENERIC_KERNELS
+    bool tight;    // GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS
+    bool split;    // long tiles on four waves (not GSX_FLAG_NO_LONG_TILE_SPLIT)
+    const GsxCamera *camera_device;
+    uint32_t *tile_counts;
+    const float *sh;
+    int sh_degree;   // -1: RGB colours
+    float background[3];
+};
+
+inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, const GsxParams *params, Plan &p,
+                     char *msg, size_t msg_bytes) {
+    auto fail = [&](int code, const char *fmt, ...) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(msg, msg_bytes, fmt, ap);
+        va_end(ap);
+        return code;
+    };
+    GsxParams d;
+    default_params(&d);
+    if (params) d = *params;
+    if (width <= 0 || height <= 0) return fail(GSX_ERR_INVALID_ARGUMENT, "image size %dx%d is not positive", width, height);
+    if (tile <= 0 || tile > 1024) return fail(GSX_ERR_INVALID_ARGUMENT, "tile size %d out of range [1,1024]", tile);
+    if (d.semantics != GSX_SEM_REF_CPU && d.semantics != GSX_SEM_REF_CUDA && d.semantics != GSX_SEM_STD_3DGS)
+        return fail(GSX_ERR_UNSUPPORTED, "unknown semantics %d", d.semantics);
+    for (int i = 0; i < 3; ++i) p.background[i] = d.background[i];
+    p.camera_device = d.camera_device;
+    p.tile_counts = d.tile_counts;
+    p.sh = d.sh;
+    p.sh_degree = d.sh ? d.sh_degree : -1;
+    if (d.sh && (d.sh_degree < 0 || d.sh_degree > 3)) return fail(GSX_ERR_INVALID_ARGUMENT, "SH degree %d outside [0,3]", d.sh_degree);
+    if (d.layout != GSX_LAYOUT_WH3 && d.layout != GSX_LAYOUT_HW3) return fail(GSX_ERR_INVALID_ARGUMENT, "unknown layout %d", d.layout);
+    if (!out_image) return fail(GSX_ERR_INVALID_ARGUMENT, "out_image is NULL");
+    p.semantics = d.semantics;
+    p.timing = (d.flags & GSX_FLAG_TIMING) != 0;
+    p.no_sync = (d.flags & GSX_FLAG_NO_SYNC) != 0 && !p.timing;
+    p.generic = (d.flags & GSX_FLAG_GENERIC_KERNELS) != 0;
+    p.tight = d.semantics == GSX_SEM_STD_3DGS && (d.flags & GSX_FLAG_PUBLISHED_RECTS) == 0;
+    p.split = (d.flags & GSX_FLAG_NO_LONG_TILE_SPLIT) == 0;
+    TileGrid &g = p.grid;
+    g.tile = tile;
+    g.ntx = tiles_along(width, tile, d.semantics);
+    g.nty = tiles_along(height, tile, d.semantics);
+    g.width = width;
+    g.height = height;
+    if (g.ntx > 65535 || g.nty > 65535) return fail(GSX_ERR_UNSUPPORTED, "more than 65535 tiles along an axis");
+    g.wx0 = d.tile_x0 < 0 ? 0 : d.tile_x0;
+    g.wy0 = d.tile_y0 < 0 ? 0 : d.tile_y0;
+    // tile_x1 / tile_y1 < 0: "to the end" (the default); x1 == x0 is an EMPTY window, also at tile 0
+    g.wx1 = (d.tile_x1 < 0 || d.tile_x1 > g.ntx) ? g.ntx : d.tile_x1;
+    g.wy1 = (d.tile_y1 < 0 || d.tile_y1 > g.nty) ? g.nty : d.tile_y1;
+    if (g.wx0 > g.wx1) g.wx0 = g.wx1;
+    if (g.wy0 > g.wy1) g.wy0 = g.wy1;
+    OutDesc &o = p.out;
+    o.ptr = out_image;
+    o.x0 = d.out_w > 0 ? d.out_x0 : 0;
+    o.y0 = d.out_h > 0 ? d.out_y0 : 0;
+    o.w = d.out_w > 0 ? d.out_w : width;
+    o.h = d.out_h > 0 ? d.out_h : height;
+    // the kernels that zero and write the buffer index its floats with 32 bits per rectangle: 2^30 pixels
+    // (a 12.9 GB float frame, e.g. 32768 x 32768) is the most one call renders into
+    if ((int64_t)o.w * o.h > ((int64_t)1 << 30))
+        return fail(GSX_ERR_UNSUPPORTED, "output buffer of %dx%d pixels is larger than 2^30 pixels", o.w, o.h);
+    if (d.layout == GSX_LAYOUT_WH3) {
+        o.stride_x = (int64_t)o.h * 3;
+        o.stride_y = 3;
+    } else {
+        o.stride_x = 3;
+        o.stride_y = (int64_t)o.w * 3;
+    }
+    if (g.count() > 0) {
+        // every rendered tile must lie inside the output buffer
+        int64_t px0 = (int64_t)g.wx0 * tile, px1 = (int64_t)g.wx1 * tile, py0 = (int64_t)g.wy0 * tile, py1 = (int64_t)g.wy1 * tile;
+        px1 = px1 > width ? width : px1;   // partial edge tiles (REF_CUDA) end at the frame border
+        py1 = py1 > height ? height : py1;
+        if (px0 < o.x0 || px1 > (int64_t)o.x0 + o.w || py0 < o.y0 || py1 > (int64_t)o.y0 + o.h)
+            return fail(GSX_ERR_INVALID_ARGUMENT, "tile window [%d,%d)x[%d,%d) does not fit the %dx%d output buffer at (%d,%d)",
+                        g.wx0, g.wx1, g.wy0, g.wy1, o.w, o.h, o.x0, o.y0);
+    }
+    return GSX_OK;
+}
+
+// The pixels of the output buffer that no tile of the window covers (the compositing kernel writes every
+// pixel of every tile it owns, empty tiles included): up to four rectangles, zeroed by extra workgroups
+// of the compositing launch instead of a whole-frame memset (25 MB at 1080p).  whole = true: the entire
+// buffer (nothing is rendered).
+inline ClearPlan make_clear_plan(const Plan &p, bool whole) {
+    const OutDesc &o = p.out;
+    const int T = p.grid.tile;
+    ClearPlan cp;
+    memset(&cp, 0, sizeof cp);
+    // window in buffer-local pixel coordinates along (slow, fast) memory axes
+    const bool wh3 = o.stride_y < o.stride_x;  // x is the slow axis
+    const int64_t slow_n = wh3 ? o.w : o.h, fast_n = wh3 ? o.h : o.w;
+    cp.pitch = fast_n * 3;
+    auto rect = [&](int64_t s0, int64_t s1, int64_t f0, int64_t f1) {
+        if (s1 <= s0 || f1 <= f0) return;
+        const int i = cp.n++;
+        cp.s0[i] = (int32_t)s0; cp.rows[i] = (int32_t)(s1 - s0);
+        cp.f0[i] = (int32_t)f0; cp.fw[i] = (int32_t)(f1 - f0);
+        cp.first[i + 1] = cp.first[i] + clear_blocks_for(s1 - s0, f1 - f0);
+    };
+    if (whole || p.grid.count() == 0) {
+        // row by row blocks of at most 2^31 floats each: one rectangle per quarter keeps 32-bit indices safe
+        const int64_t q = (slow_n + 3) / 4;
+        for (int k = 0; k < 4; ++k) rect(k * q, (k + 1) * q < slow_n ? (k + 1) * q : slow_n, 0, fast_n);
+        return cp;
+    }
+    int64_t ws0 = (int64_t)(wh3 ? p.grid.wx0 : p.grid.wy0) * T - (wh3 ? o.x0 : o.y0);
+    int64_t ws1 = (int64_t)(wh3 ? p.grid.wx1 : p.grid.wy1) * T;
+    int64_t wf1 = (int64_t)(wh3 ? p.grid.wy1 : p.grid.wx1) * T;
+    ws1 = (ws1 > (wh3 ? p.grid.width : p.grid.height) ? (wh3 ? p.grid.width : p.grid.height) : ws1) - (wh3 ? o.x0 : o.y0);
+    wf1 = (wf1 > (wh3 ? p.grid.height : p.grid.width) ? (wh3 ? p.grid.height : p.grid.width) : wf1) - (wh3 ? o.y0 : o.x0);
+    int64_t wf0 = (int64_t)(wh3 ? p.grid.wy0 : p.grid.wx0) * T - (wh3 ? o.y0 : o.x0);
+    rect(0, ws0, 0, fast_n);
+    rect(ws1, slow_n, 0, fast_n);
+    rect(ws0, ws1, 0, wf0);
+    rect(ws0, ws1, wf1, fast_n);
+    return cp;
+}
+
+
+}  // namespace plan
+}  // namespace gsx

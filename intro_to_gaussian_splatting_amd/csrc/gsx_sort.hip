@@ -39,10 +39,11 @@ namespace gsx {
 namespace {
 
 constexpr int kThreads = 256;                      // 4 wavefronts
-constexpr int kBins = 256;                         // table rows; a pass uses the first 1 << bits of them
+constexpr int kBins = kSortBins;                   // table rows; a pass uses the first 1 << bits of them
 constexpr int kRounds = 8;                         // items per lane
 constexpr int kItems = kThreads * kRounds;         // a chunk: 2048 consecutive items, one scatter workgroup
-constexpr int kQuad = 4;                           // chunks per count workgroup
+constexpr int kQuad = kSortQuad;                   // chunks per count workgroup
+static_assert(kItems == kSortItems, "gsx_plan.h sizes the digit table with this");
 // Up to this many chunks (131 072 items) a pass has no row-scan launch: the count kernel writes the
 // table chunk-major and every scatter workgroup adds up the counts before its own chunk (measured
 // round 1, one frame in flight: 2 000 Gaussians 96 -> 85 us, 100 000 Gaussians 166 -> 161 us; beyond
@@ -395,11 +396,6 @@ hipError_t sort_impl(void *temp, Key *&kc, Key *&ka, uint32_t *&vc, uint32_t *&v
 }
 
 }  // namespace
-
-size_t radix_temp_bytes(int64_t max_items) {
-    const size_t nblocks = (size_t)((max_items + kItems - 1) / kItems) + kQuad;
-    return (kBins * (nblocks + kQuad) + kBins) * sizeof(uint32_t);
-}
 
 hipError_t radix_sort_pairs_u32(void *temp, uint32_t *&keys_cur, uint32_t *&keys_alt, uint32_t *&vals_cur,
                                 uint32_t *&vals_alt, const uint32_t *n_dev, int64_t bound, int key_bits,
