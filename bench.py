@@ -66,7 +66,7 @@ FP32_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 
 # blend_tile16_kernel: per trip (2 records x 4 pixels of a lane) 18 unpacked +
 # 32 packed (2 lane-ops each) + 8 v_exp_f32 = 90 lane-ops in 58 issue slots, i.e. 11.25 per pair.
 VALU_OPS_PER_PAIR = 11.25
-PMC_FILE = os.path.join(ROOT, "profiles", "r1_pmc_c3.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_c3.json")
 
 
 def build_scene_from_ply(ply_path: str, colmap_dir, image_id: int, width: int, height: int, device: str):
@@ -577,9 +577,9 @@ def main() -> None:
             "tile_list_length": tile_list,
         }
         if stage.get("project", 0.0) > 0.0 and world == 1:
-            # the HBM-bound stage: 56 B read + 68 B written per Gaussian (record 48, keys/values 8, rectangle 8,
-            # count 4); the HIP-event bracket includes the launch, the kernel alone is ~5 us shorter (profiles/)
-            pb = 124.0 * n
+            # the HBM-bound stage: 56 B read + 60 B written per Gaussian that reaches a tile (record 48, key 4,
+            # rectangle 8); the HIP-event bracket includes the launch, the kernel alone is ~3 us shorter (profiles/)
+            pb = 116.0 * n
             out["project_roofline"] = {"bound": "hbm", "kernel": "project_pack_kernel", "bytes_per_launch": pb,
                                        "avg_ms": round(stage["project"], 4),
                                        "achieved": round(pb / (stage["project"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
