@@ -359,7 +359,7 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
 // degree (gsx_sh_device.h: the workgroup streams its 256 Gaussians' coefficients through LDS) with the camera
 // centre of the GsxCamera the kernel reads -- no colour array, no colour launch, and a captured frame follows
 // a moving camera with SH colours too.  SHDEG = -1: in.colors holds RGB, as in the reference.
-template <bool DEVICE_CAMERA, int SHDEG>
+template <bool DEVICE_CAMERA, int SHDEG, bool WINDOWED>
 __global__ void __launch_bounds__(kBlock)
     project_pack_kernel(GsxCamera cam_arg, const GsxCamera *__restrict__ cam_dev, GaussiansIn in, int64_t n,
                         TileGrid grid, int semantics, bool tight,
@@ -389,24 +389,99 @@ __global__ void __launch_bounds__(kBlock)
             }
         }
     }
-    if (g >= n) return;
     // GsxParams.camera_device: the constants as they are in device memory now (uniform scalar loads)
     const GsxCamera &cam = DEVICE_CAMERA ? *cam_dev : cam_arg;
-    const float *p = in.means3d + 3 * g;
-    float p0 = p[0], p1 = p[1], p2 = p[2];
-    float tz = row4(p0, p1, p2, cam.world2view, 2);
     const bool std3dgs = semantics == GSX_SEM_STD_3DGS;
-    if (std3dgs ? !(tz > 0.2f) : !(tz >= 0.2f)) {               // utils.py:293-310
+
+    // ---- phase 1 (WINDOWED: the call renders a strict part of the frame, e.g. one rank's strip), every
+    // Gaussian of the workgroup: cull plane, then a cheap conservative window test.  What survives is
+    // compacted inside the workgroup, so that the covariance arithmetic below (~400 instructions, correctly
+    // rounded divisions and square roots) runs on dense waves: on a rank that owns 1/8 of the frame 7/8 of
+    // the Gaussians end here, having cost 24 B of reads and one key.  A whole-frame call skips the phase
+    // (measured: +8 us at 1M Gaussians when nearly everything survives anyway).
+    __shared__ uint16_t s_list[WINDOWED ? kBlock : 1];
+    __shared__ float s_col[(WINDOWED && SHDEG >= 0) ? kBlock * 3 : 1];
+    __shared__ uint32_t s_wcnt[kBlock / 64];
+    if (WINDOWED) {
+    bool survives = false;
+    if (g < n) {
+        const float *p = in.means3d + 3 * g;
+        const float p0 = p[0], p1 = p[1], p2 = p[2];
+        const float tz = row4(p0, p1, p2, cam.world2view, 2);
+        if (std3dgs ? !(tz > 0.2f) : !(tz >= 0.2f)) {               // utils.py:293-310
+            keys[g] = kCulledKey;
+        } else {
+            survives = true;
+            if (!std3dgs) {
+                // (approximate reciprocal / square root: the margins below absorb their last bits)
+                // The exact radius is ceil(3 sqrt(lam)) with lam <= trace(Sigma2D) + sqrt(0.1), trace(Sigma2D) <=
+                // (|J row 0|^2 + |J row 1|^2) max(scale)^2 and |J row 0|^2 = (fx / z)^2 (1 + clamp(x/z)^2) <=
+                // (fx / z)^2 (1 + (1.3 tan_x)^2) -- 2 % and two pixels are added for the rounding of everything
+                // involved.  A Gaussian is dropped only if that generous box misses the window; whatever passes
+                // goes through the exact test of phase 2 (NaNs pass: comparisons are false).
+                const float *s = in.scales + 3 * g;
+                const float *F = cam.full_proj;
+                const float icw = __builtin_amdgcn_rcpf(row4(p0, p1, p2, F, 3)), itz = __builtin_amdgcn_rcpf(tz);
+                const float xe = (row4(p0, p1, p2, F, 0) * icw + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
+                const float ye = (row4(p0, p1, p2, F, 1) * icw + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
+                const float lx = 1.3f * cam.tan_fovx, ly = 1.3f * cam.tan_fovy;
+                const float smax = fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fabsf(s[2]));
+                const float jn = (cam.fx * cam.fx) * (1.0f + lx * lx) + (cam.fy * cam.fy) * (1.0f + ly * ly);
+                const float rb = 3.0f * __builtin_amdgcn_sqrtf(jn * (smax * smax) * (itz * itz) + 0.32f) * 1.02f + 2.0f;
+                const float T = (float)grid.tile;
+                if (xe - rb > (float)grid.wx1 * T || xe + rb < (float)grid.wx0 * T || ye - rb > (float)grid.wy1 * T ||
+                    ye + rb < (float)grid.wy0 * T) {
+                    keys[g] = kEmptyKey;
+                    survives = false;
+                }
+            }
+        }
+    }
+    if (SHDEG >= 0) {
+        s_col[3 * threadIdx.x] = cr;
+        s_col[3 * threadIdx.x + 1] = cg;
+        s_col[3 * threadIdx.x + 2] = cb;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // (indentation: still inside `if (WINDOWED)`)
+    const unsigned long long mask = __ballot(survives);
+    if (lane == 0) s_wcnt[w] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock / 64; ++k) {
+        before += k < w ? s_wcnt[k] : 0u;
+        total += s_wcnt[k];
+    }
+    if (survives) s_list[before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    if (threadIdx.x >= total) return;
+    const uint32_t src = s_list[threadIdx.x];
+    g = (int64_t)blockIdx.x * kBlock + src;
+    if (SHDEG >= 0) {
+        cr = s_col[3 * src];
+        cg = s_col[3 * src + 1];
+        cb = s_col[3 * src + 2];
+    }
+    } else if (g >= n) {
+        return;
+    }
+
+    // ---- phase 2 (WINDOWED: survivors only, dense): the exact projection
+    const float *p = in.means3d + 3 * g;
+    const float p0 = p[0], p1 = p[1], p2 = p[2];
+    const float tz = row4(p0, p1, p2, cam.world2view, 2);
+    if (!WINDOWED && (std3dgs ? !(tz > 0.2f) : !(tz >= 0.2f))) {               // utils.py:293-310
         keys[g] = kCulledKey;
         return;
     }
     const float *s = in.scales + 3 * g, *q = in.quats + 4 * g;
+    const float s0 = s[0], s1 = s[1], s2 = s[2];
     Projected o;
     bool keep = true;
     if (std3dgs)
-        keep = project_std(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
+        keep = project_std(cam, p0, p1, p2, tz, s0, s1, s2, q[0], q[1], q[2], q[3], o);
     else
-        project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
+        project(cam, p0, p1, p2, tz, s0, s1, s2, q[0], q[1], q[2], q[3], o);
     TileRect tr;
     uint32_t cnt = std3dgs ? tile_rect(o.x, o.radius, o.y, o.radius, grid, semantics, tr)
                            : tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, semantics, tr);
@@ -581,12 +656,17 @@ static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_d
                                     const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys, Record *rec,
                                     TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s) {
     const bool vec = (reinterpret_cast<uintptr_t>(in.colors) & 15u) == 0;
-    if (cam_device)
-        project_pack_kernel<true, SHDEG><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics,
-                                                                          tight_rects, keys, rec, rect, counters, bbox, vec);
-    else
-        project_pack_kernel<false, SHDEG><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics,
-                                                                           tight_rects, keys, rec, rect, counters, bbox, vec);
+    // a strict part of the frame (a rank's strip, a tile window): most Gaussians miss it -> two-phase kernel
+    const bool windowed = grid.wx0 > 0 || grid.wy0 > 0 || grid.wx1 < grid.ntx || grid.wy1 < grid.nty;
+#define GSX_LAUNCH_PP(DC, WIN)                                                                                          \
+    project_pack_kernel<DC, SHDEG, WIN><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics,      \
+                                                                         tight_rects, keys, rec, rect, counters, bbox, vec)
+    if (cam_device) {
+        if (windowed) GSX_LAUNCH_PP(true, true); else GSX_LAUNCH_PP(true, false);
+    } else {
+        if (windowed) GSX_LAUNCH_PP(false, true); else GSX_LAUNCH_PP(false, false);
+    }
+#undef GSX_LAUNCH_PP
 }
 
 // sh_degree < 0: in.colors is (n,3) RGB; 0..3: in.colors is (n, (degree+1)^2, 3) spherical harmonics.
