@@ -291,8 +291,12 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
                                      (gsx::TileRect *)(ws + c.rect), counters,
                                      p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 1: project (+ depth keys)
-    GSX_HIP(gsx::sort_depth_compact(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
-                                    (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s));
+    if (gsx::depth_sort_is_sampled(n))
+        GSX_HIP(gsx::sort_depth_sampled(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
+                                        (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), 0, s));
+    else
+        GSX_HIP(gsx::sort_depth_compact(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
+                                        (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s));
     tm.mark();  // 2: depth sort (drops what reaches no tile, leaves the rectangles in rank order)
     return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rrect), v0, counters + kCtrKept,
                          counters + kCtrCulled, stats_host, tm, s);
@@ -322,6 +326,40 @@ int gsx_debug_sort_pairs(void *keys, uint32_t *vals, int64_t n, int32_t key_bits
         if (kc != (uint32_t *)keys) GSX_HIP(hipMemcpyAsync(keys, kc, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     }
     if (vc != vals) GSX_HIP(hipMemcpyAsync(vals, vc, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    return GSX_OK;
+}
+
+// Test hook (not part of include/gsx.h): the depth sort of the whole-path entry on caller-provided keys.
+// keys (n, device; >= 0xFFFFFFFE = dropped; overwritten), rect / rrect (n x 4 uint16), order_out (n): on return
+// order_out[0 .. counts_host[0]) = index of each rank, rrect[rank] = rect[index]; counts_host = {kept, culled}.
+// mode 0: four LSD passes, 1: sample-partitioned; lds_cap: see sort_depth_sampled.  scratch: 16 n + 64 +
+// gsx_workspace_bytes(n, 16, 16, 16, 1) bytes.  Synchronises.
+int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, void *rrect, uint32_t *order_out, int32_t mode,
+                         uint32_t lds_cap, int64_t *counts_host, void *scratch, size_t scratch_bytes, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 0 || !keys || !rect || !rrect || !order_out || !scratch) return fail(GSX_ERR_INVALID_ARGUMENT, "bad arguments");
+    const size_t words = align_up((size_t)n * 4);
+    const size_t need = 3 * words + 256 + binning_temp_bytes(n, 1);
+    if (scratch_bytes < need) return fail(GSX_ERR_WORKSPACE_TOO_SMALL, "scratch needs %zu bytes", need);
+    char *sc = (char *)scratch;
+    uint32_t *k1 = (uint32_t *)sc, *v0 = (uint32_t *)(sc + words), *v1 = (uint32_t *)(sc + 2 * words);
+    uint32_t *counters = (uint32_t *)(sc + 3 * words);
+    void *temp = sc + 3 * words + 256;
+    GSX_HIP(hipMemsetAsync(counters, 0, 64, s));
+    if (mode == 1)
+        GSX_HIP(gsx::sort_depth_sampled(temp, keys, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
+                                        (const gsx::TileRect *)rect, (gsx::TileRect *)rrect, lds_cap, s));
+    else
+        GSX_HIP(gsx::sort_depth_compact(temp, keys, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
+                                        (const gsx::TileRect *)rect, (gsx::TileRect *)rrect, s));
+    uint32_t host[4] = {0, 0, 0, 0};
+    GSX_HIP(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, s));
+    GSX_HIP(hipMemcpyAsync(order_out, v0, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    GSX_HIP(hipStreamSynchronize(s));
+    if (counts_host) {
+        counts_host[0] = host[kCtrKept];
+        counts_host[1] = host[kCtrCulled];
+    }
     return GSX_OK;
 }
 

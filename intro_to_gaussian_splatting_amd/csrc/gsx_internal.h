@@ -130,6 +130,14 @@ hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
                               hipStream_t s);
 
+// The same contract with 6 kernels instead of 12: sample 8192 keys -> 255 splitters, ONE stable partition
+// pass, one in-LDS sort per bucket (gsx_sort.hip).  Used when depth_sort_is_sampled(n).  lds_cap: 0 = the
+// kernel's capacity; tests pass a small value to drive buckets through the global-memory path.
+bool depth_sort_is_sampled(int64_t n);
+hipError_t sort_depth_sampled(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
+                              int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
+                              uint32_t lds_cap, hipStream_t s);
+
 // ---- gsx_sh.hip
 hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, int64_t n, const float *center,
                             float *colors, hipStream_t s);

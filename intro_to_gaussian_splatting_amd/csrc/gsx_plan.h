@@ -59,10 +59,12 @@ struct ClearPlan {
 };
 
 
-// Digit table [256][chunks rounded up to a multiple of 4] + 256 row totals.
+// Digit table [256][chunks rounded up to a multiple of 4] + 256 row totals + 256 splitters + 2048 samples
+// and their 2048 ranks (sample-partitioned depth sort).
+constexpr int kSortSamples = 2048;
 inline size_t radix_temp_bytes(int64_t max_items) {
     const size_t nblocks = (size_t)((max_items + kSortItems - 1) / kSortItems) + kSortQuad;
-    return ((size_t)kSortBins * (nblocks + kSortQuad) + kSortBins) * sizeof(uint32_t);
+    return ((size_t)kSortBins * (nblocks + kSortQuad) + 2 * kSortBins + 2 * kSortSamples) * sizeof(uint32_t);
 }
 // Where the 64-bit chunk sums start inside `temp`: behind the radix table for max(n, cap) items.
 inline size_t binning_sums_offset(int64_t n, int64_t cap) {

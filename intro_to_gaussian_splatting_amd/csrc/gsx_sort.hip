@@ -33,6 +33,8 @@
 //          gathers its 8-byte tile rectangle into rank order on the way (the scan and the pair
 //          emission then read coalesced arrays; round 1 gathered counts and rectangles by index
 //          in two later kernels, 5-8x the algorithmic traffic); the sorted keys are not written.
+#include <stdlib.h>
+
 #include "gsx_internal.h"
 
 namespace gsx {
@@ -51,11 +53,47 @@ static_assert(kItems == kSortItems, "gsx_plan.h sizes the digit table with this"
 constexpr int kSelfScanBlocks = 64;
 
 constexpr int kModePlain = 0, kModeFirst = 1, kModeFinal = 2;
+constexpr int kSamples = kSortSamples;   // sample keys of the sample-partitioned depth sort (8 per bucket)
 
 __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t bound) {
     if (!n_dev) return bound;
     uint32_t n = *n_dev;
     return n < bound ? n : bound;
+}
+
+// SPLIT passes (sort_depth_sampled): the "digit" of a key is its bucket among 255 sorted splitters,
+// bucket(k) = #{j in 1..255 : spl[j] <= k}, spl[0] = 0 -- monotone in k, equal keys share a bucket.
+__device__ __forceinline__ uint32_t bucket_of(const uint32_t *spl, uint32_t k) {
+    uint32_t lo = 0, hi = 256;          // spl[lo] <= k < spl[hi], spl[256] = +inf
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const bool right = spl[mid] <= k;
+        lo = right ? mid : lo;
+        hi = right ? hi : mid;
+    }
+    return lo;
+}
+
+// Every consumer workgroup of the partition pass derives the 255 splitters itself: scatter the samples to
+// their ranks in LDS, count the valid ones (dropped keys sort to the end), take regular quantiles.
+// spl[0] = 0; `sorted`: kSamples words of LDS scratch.  All threads of the workgroup must call this.
+__device__ __forceinline__ void derive_splitters(const uint32_t *__restrict__ samples, const uint32_t *__restrict__ ranks,
+                                                 uint32_t *sorted, uint32_t *spl, uint32_t *s_valid, int nthreads) {
+    if (threadIdx.x == 0) *s_valid = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int k = threadIdx.x; k < kSamples; k += nthreads) {
+        const uint32_t v = samples[k];
+        sorted[ranks[k]] = v;
+        mine += v < kEmptyKey;
+    }
+    if (mine) atomicAdd(s_valid, mine);
+    __syncthreads();
+    const uint32_t sv = *s_valid;
+    if (threadIdx.x < kBins)
+        spl[threadIdx.x] = (threadIdx.x && sv) ? sorted[(uint32_t)(((uint64_t)threadIdx.x * sv) / kBins)] : 0u;
+    __syncthreads();
 }
 
 // Each thread owns kRounds CONSECUTIVE items of one chunk (one or two 16-byte loads) -- the histogram does
@@ -65,13 +103,23 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t b
 // four waves), table[digit][chunk .. chunk+3] stored as ONE 16-byte word per digit (nbp = row pitch, a
 // multiple of 4).  FIRST: keys >= kEmptyKey are not counted (they are dropped by this pass) and the
 // culled ones among them (== kCulledKey) are added to *culled (zeroed by an earlier kernel).
-template <typename Key, bool CHUNK_MAJOR, bool FIRST>
+template <typename Key, bool CHUNK_MAJOR, bool FIRST, bool SPLIT = false>
 __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     count_kernel(const Key *__restrict__ keys, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
-                 uint32_t mask, uint32_t *__restrict__ table, int nbp, uint32_t *__restrict__ culled) {
+                 uint32_t mask, uint32_t *__restrict__ table, int nbp, uint32_t *__restrict__ culled,
+                 const uint32_t *__restrict__ splitters = nullptr) {
     constexpr int kLanes = CHUNK_MAJOR ? 1 : kQuad;   // chunks per workgroup
     __shared__ uint32_t h[kLanes][kBins];
     __shared__ uint32_t s_culled;
+    __shared__ uint32_t spl[SPLIT ? kBins : 1];
+    __shared__ uint32_t s_sorted[SPLIT ? kSamples : 1];
+    __shared__ uint32_t s_valid;
+    if (SPLIT) {   // splitters: (samples, ranks) follow the 256 splitter words; workgroup 0 publishes the splitters
+        derive_splitters(splitters + kBins, splitters + kBins + kSamples, s_sorted, spl, &s_valid,
+                         CHUNK_MAJOR ? kThreads : kQuad * kThreads);
+        if (blockIdx.x == 0 && threadIdx.x < kBins) const_cast<uint32_t *>(splitters)[threadIdx.x] = spl[threadIdx.x];
+    }
+    auto digit = [&](uint32_t k) -> uint32_t { return SPLIT ? bucket_of(spl, k) : ((k >> shift) & mask); };
     const uint32_t n = load_count(n_dev, bound);
     const int c = CHUNK_MAJOR ? 0 : (int)(threadIdx.x >> 8);
     const uint32_t t = threadIdx.x & 255u;
@@ -97,7 +145,7 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
                     if (FIRST && w4[e] >= kEmptyKey)
                         my_culled += w4[e] == kCulledKey;
                     else
-                        atomicAdd(&h[c][(w4[e] >> shift) & mask], 1u);
+                        atomicAdd(&h[c][digit(w4[e])], 1u);
                 } else {
                     atomicAdd(&h[c][((w4[e] & 0xFFFFu) >> shift) & mask], 1u);
                     atomicAdd(&h[c][((w4[e] >> 16) >> shift) & mask], 1u);
@@ -111,7 +159,7 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
                 if (FIRST && k >= kEmptyKey)
                     my_culled += k == kCulledKey;
                 else
-                    atomicAdd(&h[c][(k >> shift) & mask], 1u);
+                    atomicAdd(&h[c][digit(k)], 1u);
             }
     }
     if (FIRST && my_culled) atomicAdd(&s_culled, my_culled);
@@ -180,13 +228,17 @@ __global__ void __launch_bounds__(kThreads) row_scan_kernel(uint32_t *__restrict
 // MODE: kModeFirst / kModeFinal, see the head of this file.  m_out (FIRST): number of items this pass
 // keeps, i.e. the element count of every later pass.  rect / rrect (FINAL): per-Gaussian tile
 // rectangles by index / by depth rank.
-template <typename Key, bool SELF_SCAN, int MODE, int BITS>
+template <typename Key, bool SELF_SCAN, int MODE, int BITS, bool SPLIT = false>
 __global__ void __launch_bounds__(kThreads)
     scatter_kernel(const Key *__restrict__ kin, const uint32_t *__restrict__ vin, Key *__restrict__ kout,
                    uint32_t *__restrict__ vout, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
                    const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nbp,
-                   uint32_t *__restrict__ m_out, const TileRect *__restrict__ rect, TileRect *__restrict__ rrect) {
+                   uint32_t *__restrict__ m_out, const TileRect *__restrict__ rect, TileRect *__restrict__ rrect,
+                   const uint32_t *__restrict__ splitters = nullptr) {
     constexpr int kWaveItems = kItems / 4;
+    __shared__ uint32_t spl[SPLIT ? kBins : 1];
+    __shared__ uint8_t sdig[SPLIT ? kItems : 1];     // SPLIT: the bucket of every parked item (not derivable by a shift)
+    if (SPLIT) spl[threadIdx.x] = threadIdx.x ? splitters[threadIdx.x] : 0u;   // visible after the barrier below
     __shared__ uint32_t cnt[4][kBins];   // per-wave running digit counts, then per-wave LDS bases
     __shared__ uint32_t gbase[kBins];    // global address of parked item j of digit d = gbase[d] + j
     __shared__ uint32_t wsum[4], lsum[4];
@@ -222,10 +274,12 @@ __global__ void __launch_bounds__(kThreads)
         if (MODE & kModeFirst) ok[r] = ok[r] && (uint32_t)key[r] < kEmptyKey;
     }
     uint16_t rank[kRounds];
+    uint8_t dig[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
         const bool valid = ok[r];
-        const uint32_t d = ((uint32_t)key[r] >> shift) & mask;
+        const uint32_t d = SPLIT ? bucket_of(spl, (uint32_t)key[r]) : (((uint32_t)key[r] >> shift) & mask);
+        dig[r] = (uint8_t)d;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < BITS; ++b) {
@@ -311,10 +365,11 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
         if (ok[r]) {
-            const uint32_t d = ((uint32_t)key[r] >> shift) & mask;
+            const uint32_t d = dig[r];
             const uint32_t pos = cnt[w][d] + rank[r];
             skey[pos] = key[r];
             sval[pos] = val[r];
+            if (SPLIT) sdig[pos] = dig[r];
         }
     }
     __syncthreads();
@@ -323,10 +378,298 @@ __global__ void __launch_bounds__(kThreads)
     for (uint32_t j = threadIdx.x; j < live; j += kThreads) {
         const Key k = skey[j];
         const uint32_t v = sval[j];
-        const uint32_t dst = gbase[((uint32_t)k >> shift) & mask] + j;
+        const uint32_t dst = gbase[SPLIT ? (uint32_t)sdig[j] : (((uint32_t)k >> shift) & mask)] + j;
         if (!(MODE & kModeFinal)) kout[dst] = k;
         vout[dst] = v;
         if (MODE & kModeFinal) rrect[dst] = rect[v];   // the one gather by Gaussian index on the binning path
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// Sample-partitioned depth sort (sort_depth_sampled): 6 kernels instead of the 12 of four LSD passes.
+//   sample    the rank of each of 2048 regularly spaced keys among them (sample_rank_kernel, all CUs); every
+//             workgroup of the partition's count kernel turns (samples, ranks) into 255 splitters in LDS;
+//   partition ONE stable pass of the count / row_scan / scatter machinery above with the bucket among the
+//             splitters as the "digit" (FIRST mode: drops what reaches no tile, values = positions);
+//   buckets   one 1024-thread workgroup per bucket sorts its items in LDS -- only over the key bytes that
+//             vary inside the bucket -- and streams them out with the rank-ordered rectangle gather.
+// A bucket larger than the LDS capacity (possible, never seen: the samples keep the sizes within
+// a few 10 % of the mean -- with 8 samples per bucket a bucket 4x the mean, which is what the LDS holds at 1M
+// keys, has probability ~1e-9; adversarial key layouts are tested) is sorted by the same workgroup through
+// global memory, tile by tile.  Equal keys share a bucket and every step is stable: ties keep index order.
+constexpr int kBigThreads = 1024, kBigWaves = kBigThreads / 64;
+constexpr int kBucketRounds = 16, kBucketCap = kBigThreads * kBucketRounds;   // 16 384 items in LDS
+
+struct RankShared {
+    uint32_t cnt[kBigWaves][kBins];   // per-wave running digit counts, then per-wave positions
+    uint32_t lstart[kBins + 1];       // first position of every digit in the digit-major order
+    uint32_t wsum[4];
+};
+
+// Stable digit-major positions of up to ROUNDS x 1024 items held in registers: item (wave w, round r, lane)
+// is the (w * L + r * 64 + lane)-th of the tile (L = the per-wave slice, a multiple of 64).  All 1024 threads
+// must call this (barriers inside).  On return pos[r] is the item's position, sh.lstart[d] the first
+// position of digit d, sh.lstart[256] the number of valid items.
+template <int ROUNDS>
+__device__ __forceinline__ void rank_items(const uint32_t (&key)[ROUNDS], const bool (&ok)[ROUNDS], int shift,
+                                           RankShared &sh, uint32_t (&pos)[ROUNDS]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int k = threadIdx.x; k < kBigWaves * kBins; k += kBigThreads) (&sh.cnt[0][0])[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const bool valid = ok[r];
+        const uint32_t d = (key[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+        if (peers == 0ull) {   // wave-uniform: nothing left in this wave's slice
+            pos[r] = 0;
+            continue;
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        uint32_t old = 0;
+        if (valid) {
+            const int leader = __ffsll((long long)peers) - 1;
+            if (lane == leader) {
+                old = sh.cnt[w][d];
+                sh.cnt[w][d] = old + (uint32_t)__popcll(peers);
+            }
+            old = (uint32_t)__shfl((int)old, leader);
+        }
+        pos[r] = old + (uint32_t)__popcll(peers & lt);
+    }
+    __syncthreads();
+    uint32_t total = 0, x = 0;
+    if (threadIdx.x < kBins) {   // thread d: exclusive prefix of digit d over the waves, then over the digits
+        const int d = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < kBigWaves; ++k) {
+            const uint32_t c = sh.cnt[k][d];
+            sh.cnt[k][d] = total;
+            total += c;
+        }
+        x = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) sh.wsum[w] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < kBins) {
+        uint32_t before = 0;
+        for (int k = 0; k < w; ++k) before += sh.wsum[k];
+        const uint32_t start = before + x - total;
+        sh.lstart[threadIdx.x] = start;
+        if (threadIdx.x == kBins - 1) sh.lstart[kBins] = start + total;
+#pragma unroll
+        for (int k = 0; k < kBigWaves; ++k) sh.cnt[k][threadIdx.x] += start;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+        if (ok[r]) pos[r] += sh.cnt[w][(key[r] >> shift) & 255u];
+}
+
+// ranks[i] = position of sample i (key at index i n / 2048) in the stable ascending order of the 2048 samples.
+// A single workgroup sorting them took 41 us (one CU doing 4 LDS radix passes); here every sample's rank is
+// counted directly -- #{j : s[j] < s[i]} + #{j < i : s[j] == s[i]} -- by 16 lanes that share the 2048
+// comparisons, 16 samples per workgroup, 128 workgroups: ~350 instructions per lane.
+constexpr int kRankLanes = 16, kRankPerGroup = kThreads / kRankLanes;   // 16 samples per 256-thread workgroup
+__global__ void __launch_bounds__(kThreads)
+    sample_rank_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ samples,
+                       uint32_t *__restrict__ ranks) {
+    __shared__ uint32_t sm[kSamples];
+    for (int k = threadIdx.x; k < kSamples; k += kThreads) sm[k] = keys[(uint32_t)(((uint64_t)k * n) / kSamples)];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * (uint32_t)kRankPerGroup + (threadIdx.x / kRankLanes);
+    const uint32_t part = threadIdx.x % kRankLanes;
+    const uint32_t v = sm[i];
+    uint32_t c = 0;
+    // lane `part` compares against samples part, part + 16, part + 32, ... (conflict-free across the 16 lanes)
+    for (uint32_t j = part; j < kSamples; j += kRankLanes) {
+        const uint32_t x = sm[j];
+        c += (x < v) | ((x == v) & (j < i));
+    }
+#pragma unroll
+    for (int o = kRankLanes / 2; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if (part == 0) {
+        ranks[i] = c;
+        samples[i] = v;
+    }
+}
+
+// One workgroup per bucket of the partition pass.  in: (kin, vin) partitioned by bucket, bucket sizes = the
+// row totals of that pass.  out: vout[rank] = Gaussian index, rrect[rank] = rect[index] for the bucket's
+// ranks.  kalt: the other key buffer (scratch of the through-memory path).
+__global__ void __launch_bounds__(kBigThreads)
+    bucket_sort_kernel(const uint32_t *__restrict__ totals, const uint32_t *__restrict__ table_cm, int nblocks_cm,
+                       uint32_t *kin, uint32_t *vin, uint32_t *kalt, uint32_t *vout,
+                       const TileRect *__restrict__ rect, TileRect *__restrict__ rrect, uint32_t lds_cap) {
+    __shared__ RankShared sh;
+    __shared__ uint32_t skey[kBucketCap];
+    __shared__ uint32_t sval[kBucketCap];
+    __shared__ uint32_t s_tot[kBins];
+    __shared__ uint32_t s_or, s_start, s_key0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x < kBins) {
+        // bucket sizes: the row totals of the partition pass, or (small inputs: chunk-major table, no row scan)
+        // the column sums of the raw counts
+        uint32_t t = 0;
+        if (nblocks_cm > 0) {
+            int b = 0;
+            for (; b + 8 <= nblocks_cm; b += 8) {     // 8 independent loads in flight
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = table_cm[(size_t)(b + u) * kBins + threadIdx.x];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t += v[u];
+            }
+            for (; b < nblocks_cm; ++b) t += table_cm[(size_t)b * kBins + threadIdx.x];
+        } else {
+            t = totals[threadIdx.x];
+        }
+        s_tot[threadIdx.x] = t;
+    }
+    if (threadIdx.x == 0) {
+        s_or = 0;
+        s_start = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < kBins) {   // first rank of this bucket = sizes of the buckets before it
+        uint32_t c = (uint32_t)threadIdx.x < blockIdx.x ? s_tot[threadIdx.x] : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+        if (lane == 0 && c) atomicAdd(&s_start, c);
+    }
+    __syncthreads();
+    const uint32_t start = s_start, size = s_tot[blockIdx.x];
+    if (size == 0) return;
+    if (size <= lds_cap) {
+        // ---- in LDS: items wave-striped, L per wave
+        const uint32_t L = (((size + kBigWaves - 1) / kBigWaves) + 63u) & ~63u;
+        uint32_t key[kBucketRounds], val[kBucketRounds];
+        bool ok[kBucketRounds];
+#pragma unroll
+        for (int r = 0; r < kBucketRounds; ++r) {
+            const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+            ok[r] = (uint32_t)r * 64 < L && i < size;
+            key[r] = ok[r] ? kin[start + i] : 0u;
+            val[r] = ok[r] ? vin[start + i] : 0u;
+        }
+        if (threadIdx.x == 0) s_key0 = key[0];      // item 0 of the bucket (size > 0)
+        __syncthreads();
+        const uint32_t key0 = s_key0;
+        uint32_t diff = 0;
+#pragma unroll
+        for (int r = 0; r < kBucketRounds; ++r) diff |= ok[r] ? key[r] ^ key0 : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, o);
+        if (lane == 0 && diff) atomicOr(&s_or, diff);
+        __syncthreads();
+        const uint32_t varying = s_or;
+        for (int shift = 0; shift < 32; shift += 8) {
+            if (((varying >> shift) & 255u) == 0) continue;      // every key of the bucket has this byte: nothing to sort by
+            uint32_t pos[kBucketRounds];
+            rank_items<kBucketRounds>(key, ok, shift, sh, pos);
+#pragma unroll
+            for (int r = 0; r < kBucketRounds; ++r)
+                if (ok[r]) {
+                    skey[pos[r]] = key[r];
+                    sval[pos[r]] = val[r];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < kBucketRounds; ++r) {
+                const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+                if (ok[r]) {
+                    key[r] = skey[i];
+                    val[r] = sval[i];
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < kBucketRounds; ++r) {
+            const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+            if (ok[r]) {
+                vout[start + i] = val[r];
+                rrect[start + i] = rect[val[r]];
+            }
+        }
+        return;
+    }
+    // ---- through global memory (a bucket that does not fit): LSD passes over the varying bytes, tile by tile
+    const uint32_t key0 = kin[start];
+    uint32_t diff = 0;
+    for (uint32_t i = threadIdx.x; i < size; i += kBigThreads) diff |= kin[start + i] ^ key0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, o);
+    if (lane == 0 && diff) atomicOr(&s_or, diff);
+    __syncthreads();
+    const uint32_t varying = s_or;
+    uint32_t *sk = kin + start, *sv = vin + start, *dk = kalt + start, *dv = vout + start;
+    uint32_t *gbase = skey;      // 256 running digit bases (the LDS item buffers are free on this path)
+    for (int shift = 0; shift < 32; shift += 8) {
+        if (((varying >> shift) & 255u) == 0) continue;
+        if (threadIdx.x < kBins) s_tot[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < size; i += kBigThreads) atomicAdd(&s_tot[(sk[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int d = 0; d < kBins; ++d) {
+                gbase[d] = run;
+                run += s_tot[d];
+            }
+        }
+        __syncthreads();
+        for (uint32_t t0 = 0; t0 < size; t0 += lds_cap) {
+            const uint32_t tsize = min(lds_cap, size - t0);
+            const uint32_t L = (((tsize + kBigWaves - 1) / kBigWaves) + 63u) & ~63u;
+            uint32_t key[kBucketRounds], val[kBucketRounds], pos[kBucketRounds];
+            bool ok[kBucketRounds];
+#pragma unroll
+            for (int r = 0; r < kBucketRounds; ++r) {
+                const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+                ok[r] = (uint32_t)r * 64 < L && i < tsize;
+                key[r] = ok[r] ? sk[t0 + i] : 0u;
+                val[r] = ok[r] ? sv[t0 + i] : 0u;
+            }
+            rank_items<kBucketRounds>(key, ok, shift, sh, pos);
+#pragma unroll
+            for (int r = 0; r < kBucketRounds; ++r)
+                if (ok[r]) {
+                    const uint32_t d = (key[r] >> shift) & 255u;
+                    const uint32_t dst = gbase[d] + (pos[r] - sh.lstart[d]);
+                    dk[dst] = key[r];
+                    dv[dst] = val[r];
+                }
+            __syncthreads();
+            if (threadIdx.x < kBins) {
+                const uint32_t d = threadIdx.x;
+                const uint32_t next = d + 1 < kBins ? sh.lstart[d + 1] : sh.lstart[kBins];
+                gbase[d] += next - sh.lstart[d];
+            }
+            __syncthreads();
+        }
+        __threadfence_block();   // the next pass of this workgroup reads what this one wrote
+        __syncthreads();
+        uint32_t *tk = sk; sk = dk; dk = tk;
+        uint32_t *tv = sv; sv = dv; dv = tv;
+    }
+    // the sorted values now sit in sv: they belong in vout, with their rectangles beside them
+    for (uint32_t i = threadIdx.x; i < size; i += kBigThreads) {
+        const uint32_t v = sv[i];
+        if (sv != vout + start) vout[start + i] = v;
+        rrect[start + i] = rect[v];
     }
 }
 
@@ -407,6 +750,50 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
                                 uint32_t *&vals_alt, const uint32_t *n_dev, int64_t bound, int key_bits,
                                 hipStream_t s) {
     return sort_impl<uint16_t>(temp, keys_cur, keys_alt, vals_cur, vals_alt, n_dev, bound, key_bits, s);
+}
+
+
+// Up to this many keys the depth sort is sample-partitioned (one partition pass + one bucket sort); beyond,
+// the average bucket would not fit the bucket kernel's LDS and the four LSD passes are used.
+constexpr int64_t kSampledMin = 8 * kSamples, kSampledMax = (int64_t)1 << 20;
+
+bool depth_sort_is_sampled(int64_t n) {
+    static const int force = [] {
+        const char *e = getenv("GSX_DEPTH_SORT");   // measurement knob: "lsd" / "sampled" (default: by size)
+        return !e ? 0 : (e[0] == 'l' ? 1 : 2);
+    }();
+    if (force == 1) return false;
+    return n >= kSampledMin && (force == 2 || n <= kSampledMax);
+}
+
+// Same contract as sort_depth_compact.  keys0 / keys1 / vals: n words each; on return vals_cur[0 .. *m_dev)
+// = Gaussian index of each depth rank, rrect[rank] = rect[index].  lds_cap: bucket size above which the
+// through-memory path is taken (tests shrink it).
+hipError_t sort_depth_sampled(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
+                              int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
+                              uint32_t lds_cap, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const PassPlan p = plan_for(temp, n);
+    uint32_t *splitters = p.totals + kBins;            // behind the row totals: 256 splitters, 2048 samples, 2048 ranks
+    sample_rank_kernel<<<kSamples / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, splitters + kBins,
+                                                                     splitters + kBins + kSamples);
+    // partition: keys0 -> (keys1, vals_alt), values generated (FIRST)
+    if (p.self_scan) {
+        count_kernel<uint32_t, true, true, true><<<p.nblocks, kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u, p.table,
+                                                                                p.nbp, culled_dev, splitters);
+        scatter_kernel<uint32_t, true, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
+            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, nullptr, nullptr, splitters);
+    } else {
+        count_kernel<uint32_t, false, true, true><<<p.nquads, kQuad * kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u,
+                                                                                        p.table, p.nbp, culled_dev, splitters);
+        row_scan_kernel<<<kBins, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
+        scatter_kernel<uint32_t, false, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
+            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, nullptr, nullptr, splitters);
+    }
+    if (lds_cap == 0 || lds_cap > (uint32_t)kBucketCap) lds_cap = kBucketCap;
+    bucket_sort_kernel<<<kBins, kBigThreads, 0, s>>>(p.totals, p.table, p.self_scan ? p.nblocks : 0, keys1, vals_alt, keys0,
+                                                    vals_cur, rect, rrect, lds_cap);
+    return hipGetLastError();
 }
 
 // The depth sort of the whole-path entry point: 4 passes over the IEEE bits of z_view.  Pass 0 keeps only

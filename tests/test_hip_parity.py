@@ -404,6 +404,67 @@ def test_long_tiles_on_four_waves_equal_the_single_wave_path(tmp_path):
     assert torch.equal(s2, scene2.render_image_hip(1, split_long_tiles=False))
 
 
+@pytest.mark.parametrize("n,mode,lds_cap,kind", [
+    (16_384, 1, 0, "random"), (20_001, 1, 0, "random"), (100_003, 1, 0, "depth"), (131_072, 1, 0, "random"),
+    (131_073, 1, 0, "depth"), (1_000_000, 1, 0, "depth"), (1_000_000, 0, 0, "depth"), (2_200_000, 1, 0, "random"),
+    (300_000, 1, 0, "equal"), (300_000, 1, 0, "two"), (300_000, 1, 0, "sorted"), (300_000, 1, 0, "reverse"),
+    (300_000, 1, 0, "adversarial"), (60_000, 1, 64, "depth"), (400_000, 1, 1024, "depth"), (400_000, 1, 1000, "two"),
+    (50_000, 0, 0, "random"), (3_000, 0, 0, "depth")])
+def test_depth_sort_paths_are_the_stable_argsort(n, mode, lds_cap, kind):
+    """The depth sort of the whole-path entry (gsx_debug_depth_sort): four compacting LSD passes (mode 0) and the
+    sample-partitioned sort (mode 1: 2048 samples -> 255 splitters, one partition pass, one in-LDS sort per
+    bucket).  Both must return the STABLE argsort of the keys that are kept (< 0xFFFFFFFE), the rectangles
+    gathered into rank order, and the kept / culled counts.  lds_cap > 0 shrinks the bucket kernel's LDS
+    capacity so that buckets go through its global-memory path; "adversarial" puts all small keys on the
+    sampled positions, so that one bucket receives almost everything."""
+    _need_gpu()
+    import ctypes
+
+    from intro_to_gaussian_splatting_amd import _ffi
+
+    lib = _ffi.load()
+    fn = lib.gsx_debug_depth_sort
+    fn.restype = ctypes.c_int
+    rs = np.random.RandomState(n % 9973 + mode)
+    if kind == "random":
+        keys = rs.randint(0, 2 ** 32 - 2, size=n, dtype=np.uint64).astype(np.uint32)
+        keys[rs.uniform(size=n) < 0.1] = rs.randint(0, 50, size=int((rs.uniform(size=n) < 0.1).sum()) or 1)[0]   # duplicates
+    elif kind == "depth":
+        keys = rs.uniform(0.2, 40.0, n).astype(np.float32).view(np.uint32).copy()
+        keys[::7] = keys[3]                                              # ties: index order decides
+    elif kind == "equal":
+        keys = np.full(n, 0x40490FDB, np.uint32)
+    elif kind == "two":
+        keys = np.where(rs.uniform(size=n) < 0.5, 0x3F800000, 0x3F800001).astype(np.uint32)
+    elif kind in ("sorted", "reverse"):
+        keys = np.sort(rs.uniform(0.2, 40.0, n).astype(np.float32)).view(np.uint32).copy()
+        keys = keys[::-1].copy() if kind == "reverse" else keys
+    else:   # adversarial: the 2048 sampled positions hold tiny keys, everything else is large and distinct-ish
+        keys = (0x41000000 + rs.randint(0, 2 ** 22, size=n)).astype(np.uint32)
+        keys[(np.arange(2048, dtype=np.uint64) * n // 2048).astype(np.int64)] = rs.randint(1, 1000, 2048)
+    drop = rs.uniform(size=n)
+    keys[drop < 0.08] = 0xFFFFFFFF
+    keys[(drop >= 0.08) & (drop < 0.2)] = 0xFFFFFFFE
+    kept = np.nonzero(keys < 0xFFFFFFFE)[0]
+    expect = kept[np.argsort(keys[kept], kind="stable")]
+    rect = rs.randint(0, 65535, size=(n, 4)).astype(np.uint16)
+    d_keys = torch.from_numpy(keys.view(np.int32).copy()).cuda()
+    d_rect = torch.from_numpy(rect.view(np.int16).copy()).cuda()
+    d_rrect = torch.zeros_like(d_rect)
+    d_order = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    nbytes = 16 * n + 4096 + lib.gsx_workspace_bytes(n, 16, 16, 16, 1)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+    counts = (ctypes.c_int64 * 2)()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    rc = fn(p(d_keys), ctypes.c_int64(n), p(d_rect), p(d_rrect), p(d_order), ctypes.c_int32(mode), ctypes.c_uint32(lds_cap),
+            counts, p(scratch), ctypes.c_size_t(nbytes), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _ffi.check(rc)
+    assert counts[0] == kept.size and counts[1] == int((keys == 0xFFFFFFFF).sum())
+    got = d_order[:kept.size].cpu().numpy().astype(np.int64)
+    assert np.array_equal(got, expect)
+    assert np.array_equal(d_rrect[:kept.size].cpu().numpy().view(np.uint16), rect[expect])
+
+
 # ----------------------------------------------------------------------------- error behaviour
 
 def test_wrong_dtype_and_device_raise(tmp_path):
@@ -693,9 +754,8 @@ def test_radix_sort_is_a_stable_sort(n, bits, key16):
     if bits > 16:
         keys64 = keys64 * 65537 % (hi + 1)
     vals = torch.arange(n, device="cuda:0", dtype=torch.int32)
-    blocks = n // 2048 + 2
-    scratch = torch.empty(2 * ((n * 4 + 255) // 256 * 256) + (256 * blocks + 256 * (blocks // 32 + 2) * 4) * 4 + 4096,
-                          dtype=torch.uint8, device="cuda:0")
+    # two ping-pong arrays + the sort's digit table: gsx_workspace_bytes(n, .., n) holds more than that
+    scratch = torch.empty(lib.gsx_workspace_bytes(n, 16, 16, 16, n), dtype=torch.uint8, device="cuda:0")
     for live in (n, max(1, (2 * n) // 3)):
         keys = keys64.to(torch.int16 if key16 else torch.int32).clone()
         v = vals.clone()
