@@ -673,6 +673,91 @@ __global__ void __launch_bounds__(kBigThreads)
     }
 }
 
+// Up to kBucketCap keys (the reference's own scenes: 2 000 .. 52 000 Gaussians fit or nearly fit) ONE workgroup
+// does the whole depth sort in LDS: drop what reaches no tile, count the culled, LSD passes over the key bytes
+// that vary, rank-ordered rectangle gather.  One launch instead of eight.
+__global__ void __launch_bounds__(kBigThreads)
+    small_depth_sort_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ vout,
+                            const TileRect *__restrict__ rect, TileRect *__restrict__ rrect, uint32_t *__restrict__ m_out,
+                            uint32_t *__restrict__ culled_out) {
+    __shared__ RankShared sh;
+    __shared__ uint32_t skey[kBucketCap];
+    __shared__ uint32_t sval[kBucketCap];
+    __shared__ uint32_t s_or, s_and, s_culled;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        s_or = 0;
+        s_and = 0xFFFFFFFFu;
+        s_culled = 0;
+    }
+    __syncthreads();
+    const uint32_t L = (((n + kBigWaves - 1) / kBigWaves) + 63u) & ~63u;
+    uint32_t key[kBucketRounds], val[kBucketRounds];
+    bool ok[kBucketRounds];
+    uint32_t o_ = 0, a_ = 0xFFFFFFFFu, culled = 0;
+#pragma unroll
+    for (int r = 0; r < kBucketRounds; ++r) {
+        const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+        const bool in = (uint32_t)r * 64 < L && i < n;
+        key[r] = in ? keys[i] : 0u;
+        val[r] = i;
+        ok[r] = in && key[r] < kEmptyKey;
+        culled += in && key[r] == kCulledKey;
+        o_ |= ok[r] ? key[r] : 0u;
+        a_ &= ok[r] ? key[r] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        o_ |= (uint32_t)__shfl_xor((int)o_, o);
+        a_ &= (uint32_t)__shfl_xor((int)a_, o);
+        culled += (uint32_t)__shfl_xor((int)culled, o);
+    }
+    if (lane == 0) {
+        atomicOr(&s_or, o_);
+        atomicAnd(&s_and, a_);
+        if (culled) atomicAdd(&s_culled, culled);
+    }
+    __syncthreads();
+    uint32_t varying = s_or & ~s_and;          // bits in which two kept keys differ
+    if (varying == 0) varying = 1;             // one pass at least: it is also what compacts
+    uint32_t m = 0;
+    for (int shift = 0; shift < 32; shift += 8) {
+        if (((varying >> shift) & 255u) == 0) continue;
+        uint32_t pos[kBucketRounds];
+        rank_items<kBucketRounds>(key, ok, shift, sh, pos);
+        m = sh.lstart[kBins];
+#pragma unroll
+        for (int r = 0; r < kBucketRounds; ++r)
+            if (ok[r]) {
+                skey[pos[r]] = key[r];
+                sval[pos[r]] = val[r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kBucketRounds; ++r) {
+            const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+            ok[r] = (uint32_t)r * 64 < L && i < m;     // the kept items are dense now
+            if (ok[r]) {
+                key[r] = skey[i];
+                val[r] = sval[i];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < kBucketRounds; ++r) {
+        const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+        if (ok[r]) {
+            vout[i] = val[r];
+            rrect[i] = rect[val[r]];
+        }
+    }
+    if (threadIdx.x == 0) {
+        *m_out = m;
+        *culled_out = s_culled;
+    }
+}
+
 struct PassPlan {
     int nblocks, nbp, nquads;
     bool self_scan;
@@ -763,6 +848,7 @@ bool depth_sort_is_sampled(int64_t n) {
         return !e ? 0 : (e[0] == 'l' ? 1 : 2);
     }();
     if (force == 1) return false;
+    if (n <= kBucketCap) return true;      // one workgroup sorts it all (sort_depth_sampled's small path)
     return n >= kSampledMin && (force == 2 || n <= kSampledMax);
 }
 
@@ -773,6 +859,10 @@ hipError_t sort_depth_sampled(void *temp, uint32_t *keys0, uint32_t *keys1, uint
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
                               uint32_t lds_cap, hipStream_t s) {
     if (n <= 0) return hipSuccess;
+    if (n <= kBucketCap && lds_cap == 0) {   // everything fits one workgroup's LDS: one launch
+        small_depth_sort_kernel<<<1, kBigThreads, 0, s>>>(keys0, (uint32_t)n, vals_cur, rect, rrect, m_dev, culled_dev);
+        return hipGetLastError();
+    }
     const PassPlan p = plan_for(temp, n);
     uint32_t *splitters = p.totals + kBins;            // behind the row totals: 256 splitters, 2048 samples, 2048 ranks
     sample_rank_kernel<<<kSamples / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, splitters + kBins,

@@ -409,7 +409,9 @@ def test_long_tiles_on_four_waves_equal_the_single_wave_path(tmp_path):
     (131_073, 1, 0, "depth"), (1_000_000, 1, 0, "depth"), (1_000_000, 0, 0, "depth"), (2_200_000, 1, 0, "random"),
     (300_000, 1, 0, "equal"), (300_000, 1, 0, "two"), (300_000, 1, 0, "sorted"), (300_000, 1, 0, "reverse"),
     (300_000, 1, 0, "adversarial"), (60_000, 1, 64, "depth"), (400_000, 1, 1024, "depth"), (400_000, 1, 1000, "two"),
-    (50_000, 0, 0, "random"), (3_000, 0, 0, "depth")])
+    (50_000, 0, 0, "random"), (3_000, 0, 0, "depth"),
+    (1, 1, 0, "random"), (63, 1, 0, "random"), (2_000, 1, 0, "depth"), (9_999, 1, 0, "equal"), (16_384, 1, 0, "two"),
+    (16_000, 1, 0, "random")])
 def test_depth_sort_paths_are_the_stable_argsort(n, mode, lds_cap, kind):
     """The depth sort of the whole-path entry (gsx_debug_depth_sort): four compacting LSD passes (mode 0) and the
     sample-partitioned sort (mode 1: 2048 samples -> 255 splitters, one partition pass, one in-LDS sort per
@@ -439,6 +441,8 @@ def test_depth_sort_paths_are_the_stable_argsort(n, mode, lds_cap, kind):
     elif kind in ("sorted", "reverse"):
         keys = np.sort(rs.uniform(0.2, 40.0, n).astype(np.float32)).view(np.uint32).copy()
         keys = keys[::-1].copy() if kind == "reverse" else keys
+    elif n < 2048:
+        keys = rs.randint(0, 2 ** 31, size=n).astype(np.uint32)
     else:   # adversarial: the 2048 sampled positions hold tiny keys, everything else is large and distinct-ish
         keys = (0x41000000 + rs.randint(0, 2 ** 22, size=n)).astype(np.uint32)
         keys[(np.arange(2048, dtype=np.uint64) * n // 2048).astype(np.int64)] = rs.randint(1, 1000, 2048)
