@@ -401,34 +401,37 @@ __global__ void __launch_bounds__(kThreads)
 constexpr int kBigThreads = 1024, kBigWaves = kBigThreads / 64;
 constexpr int kBucketRounds = 16, kBucketCap = kBigThreads * kBucketRounds;   // 16 384 items in LDS
 
+constexpr int kLocalBits = 9, kLocalBins = 1 << kLocalBits;   // digits of the in-LDS passes: 17 varying bits = 2 passes
 struct RankShared {
-    uint32_t cnt[kBigWaves][kBins];   // per-wave running digit counts, then per-wave positions
-    uint32_t lstart[kBins + 1];       // first position of every digit in the digit-major order
-    uint32_t wsum[4];
+    uint16_t cnt[kBigWaves][kLocalBins];   // per-wave running digit counts, then per-wave positions (< 2^16)
+    uint32_t lstart[kLocalBins + 1];       // first position of every digit in the digit-major order
+    uint32_t wsum[kLocalBins / 64];
 };
 
 // Stable digit-major positions of up to ROUNDS x 1024 items held in registers: item (wave w, round r, lane)
-// is the (w * L + r * 64 + lane)-th of the tile (L = the per-wave slice, a multiple of 64).  All 1024 threads
-// must call this (barriers inside).  On return pos[r] is the item's position, sh.lstart[d] the first
-// position of digit d, sh.lstart[256] the number of valid items.
-template <int ROUNDS>
+// is the (w * L + r * 64 + lane)-th of the tile (L = the per-wave slice, a multiple of 64).  Digit = DBITS bits
+// of the key from `shift`.  All 1024 threads must call this (barriers inside).  On return pos[r] is the
+// item's position, sh.lstart[d] the first position of digit d, sh.lstart[1 << DBITS] the number of valid items.
+template <int ROUNDS, int DBITS>
 __device__ __forceinline__ void rank_items(const uint32_t (&key)[ROUNDS], const bool (&ok)[ROUNDS], int shift,
                                            RankShared &sh, uint32_t (&pos)[ROUNDS]) {
+    constexpr int NB = 1 << DBITS;
+    constexpr uint32_t DM = NB - 1;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int k = threadIdx.x; k < kBigWaves * kBins; k += kBigThreads) (&sh.cnt[0][0])[k] = 0;
+    for (int k = threadIdx.x; k < kBigWaves * kLocalBins / 2; k += kBigThreads) reinterpret_cast<uint32_t *>(&sh.cnt[0][0])[k] = 0;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const bool valid = ok[r];
-        const uint32_t d = (key[r] >> shift) & 255u;
+        const uint32_t d = (key[r] >> shift) & DM;
         unsigned long long peers = __ballot(valid);
         if (peers == 0ull) {   // wave-uniform: nothing left in this wave's slice
             pos[r] = 0;
             continue;
         }
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < DBITS; ++b) {
             const bool bit = (d >> b) & 1u;
             const unsigned long long m = __ballot(bit);
             peers &= bit ? m : ~m;
@@ -438,7 +441,7 @@ __device__ __forceinline__ void rank_items(const uint32_t (&key)[ROUNDS], const 
             const int leader = __ffsll((long long)peers) - 1;
             if (lane == leader) {
                 old = sh.cnt[w][d];
-                sh.cnt[w][d] = old + (uint32_t)__popcll(peers);
+                sh.cnt[w][d] = (uint16_t)(old + (uint32_t)__popcll(peers));
             }
             old = (uint32_t)__shfl((int)old, leader);
         }
@@ -446,12 +449,12 @@ __device__ __forceinline__ void rank_items(const uint32_t (&key)[ROUNDS], const 
     }
     __syncthreads();
     uint32_t total = 0, x = 0;
-    if (threadIdx.x < kBins) {   // thread d: exclusive prefix of digit d over the waves, then over the digits
+    if (threadIdx.x < NB) {   // thread d: exclusive prefix of digit d over the waves, then over the digits
         const int d = threadIdx.x;
 #pragma unroll
         for (int k = 0; k < kBigWaves; ++k) {
             const uint32_t c = sh.cnt[k][d];
-            sh.cnt[k][d] = total;
+            sh.cnt[k][d] = (uint16_t)total;
             total += c;
         }
         x = total;
@@ -463,19 +466,19 @@ __device__ __forceinline__ void rank_items(const uint32_t (&key)[ROUNDS], const 
         if (lane == 63) sh.wsum[w] = x;
     }
     __syncthreads();
-    if (threadIdx.x < kBins) {
+    if (threadIdx.x < NB) {
         uint32_t before = 0;
         for (int k = 0; k < w; ++k) before += sh.wsum[k];
         const uint32_t start = before + x - total;
         sh.lstart[threadIdx.x] = start;
-        if (threadIdx.x == kBins - 1) sh.lstart[kBins] = start + total;
+        if (threadIdx.x == NB - 1) sh.lstart[NB] = start + total;
 #pragma unroll
-        for (int k = 0; k < kBigWaves; ++k) sh.cnt[k][threadIdx.x] += start;
+        for (int k = 0; k < kBigWaves; ++k) sh.cnt[k][threadIdx.x] = (uint16_t)(sh.cnt[k][threadIdx.x] + start);
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
-        if (ok[r]) pos[r] += sh.cnt[w][(key[r] >> shift) & 255u];
+        if (ok[r]) pos[r] += sh.cnt[w][(key[r] >> shift) & DM];
 }
 
 // ranks[i] = position of sample i (key at index i n / 2048) in the stable ascending order of the 2048 samples.
@@ -574,11 +577,13 @@ __global__ void __launch_bounds__(kBigThreads)
         for (int o = 32; o > 0; o >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, o);
         if (lane == 0 && diff) atomicOr(&s_or, diff);
         __syncthreads();
+        // only the bits in which two keys of the bucket differ need sorting: 9 of them per pass, from the lowest
+        // such bit up (a bucket holds 1/256 of the keys: ~17 varying bits of a float depth = 2 passes)
         const uint32_t varying = s_or;
-        for (int shift = 0; shift < 32; shift += 8) {
-            if (((varying >> shift) & 255u) == 0) continue;      // every key of the bucket has this byte: nothing to sort by
+        const int lo_bit = varying ? __ffs((int)varying) - 1 : 0, hi_bit = varying ? 32 - __clz((int)varying) : 0;
+        for (int shift = lo_bit; shift < hi_bit; shift += kLocalBits) {
             uint32_t pos[kBucketRounds];
-            rank_items<kBucketRounds>(key, ok, shift, sh, pos);
+            rank_items<kBucketRounds, kLocalBits>(key, ok, shift, sh, pos);
 #pragma unroll
             for (int r = 0; r < kBucketRounds; ++r)
                 if (ok[r]) {
@@ -643,7 +648,7 @@ __global__ void __launch_bounds__(kBigThreads)
                 key[r] = ok[r] ? sk[t0 + i] : 0u;
                 val[r] = ok[r] ? sv[t0 + i] : 0u;
             }
-            rank_items<kBucketRounds>(key, ok, shift, sh, pos);
+            rank_items<kBucketRounds, 8>(key, ok, shift, sh, pos);
 #pragma unroll
             for (int r = 0; r < kBucketRounds; ++r)
                 if (ok[r]) {
@@ -720,12 +725,12 @@ __global__ void __launch_bounds__(kBigThreads)
     __syncthreads();
     uint32_t varying = s_or & ~s_and;          // bits in which two kept keys differ
     if (varying == 0) varying = 1;             // one pass at least: it is also what compacts
+    const int lo_bit = __ffs((int)varying) - 1, hi_bit = 32 - __clz((int)varying);
     uint32_t m = 0;
-    for (int shift = 0; shift < 32; shift += 8) {
-        if (((varying >> shift) & 255u) == 0) continue;
+    for (int shift = lo_bit; shift < hi_bit; shift += kLocalBits) {
         uint32_t pos[kBucketRounds];
-        rank_items<kBucketRounds>(key, ok, shift, sh, pos);
-        m = sh.lstart[kBins];
+        rank_items<kBucketRounds, kLocalBits>(key, ok, shift, sh, pos);
+        m = sh.lstart[kLocalBins];
 #pragma unroll
         for (int r = 0; r < kBucketRounds; ++r)
             if (ok[r]) {
