@@ -59,6 +59,9 @@ ALG = {   # algorithmic bytes per launch at C3
     "scatter_kernel<u32,first>": (4 * N, 8 * N),
     "scatter_kernel<u32>": (8 * N, 8 * N),
     "scatter_kernel<u32,final>": (16 * N, 12 * N),
+    "sample_rank_kernel": (8192, 16384),
+    "count_kernel<u32,split>": (4 * N, 0.5e6),
+    "bucket_sort_kernel": (16 * N, 12 * N),
     "chunk_sums_kernel": (8 * N, 0),
     "emit_kernel": (12 * N, 6 * D),
     "count_kernel<u16>": (2 * D, 1.2e6),
@@ -71,12 +74,14 @@ ALG = {   # algorithmic bytes per launch at C3
 def k2(n):
     n = re.sub(r"\(anonymous namespace\)::|gsx::|void ", "", n)
     for key in ("blend_tile16_kernel", "project_pack_kernel", "emit_kernel", "tile_ranges_kernel", "chunk_sums_kernel",
-                "row_scan_kernel"):
+                "row_scan_kernel", "sample_rank_kernel", "bucket_sort_kernel", "small_depth_sort_kernel"):
         if key in n:
             return key
     m = re.match(r"(count|scatter)_kernel<(unsigned short|unsigned int), (?:true|false), (\w+)", n)
     if m:
         kind, key, mode = m.group(1), "u16" if "short" in m.group(2) else "u32", m.group(3)
+        if kind == "count" and n.rstrip(">").endswith("true") and key == "u32":
+            return "count_kernel<u32,split>"
         if kind == "scatter" and mode == "1":
             return "scatter_kernel<u32,first>"
         if kind == "scatter" and mode == "2":
