@@ -95,7 +95,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
         GSX_HIP(gsx::launch_zero_words((uint32_t *)ranges, (size_t)p.grid.count() * 2, s));
         GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), nullptr, (const uint32_t *)(ws + c.tvals0), ranges,
                                   p.grid, p.out, p.semantics, p.background, p.generic, make_clear_plan(p, false),
-                                  gsx::LongTiles{nullptr, nullptr, 0u}, s));
+                                  gsx::LongTiles{nullptr, nullptr, 0u}, nullptr, s));
     } else if (n == 0) {
         tm.mark();
         GSX_HIP(gsx::launch_clear(make_clear_plan(p, true), p.out.ptr, s));
@@ -126,10 +126,15 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             GSX_HIP(gsx::sort_instances(temp, cap, p.grid, ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0),
                                         (uint32_t *)(ws + c.tvals1), ranges, counters + kCtrPairs, lt, &sorted_vals, s));
             if (p.tile_counts) GSX_HIP(gsx::launch_tile_counts(ranges, p.grid.count(), p.tile_counts, s));
-            tm.mark();  // 4: tile sort
+            uint32_t *sched = nullptr;
+            if (cap > 0 && gsx::blend_uses_schedule(p.grid, p.semantics, p.generic, n)) {
+                sched = (uint32_t *)(ws + c.sched);
+                GSX_HIP(gsx::launch_tile_schedule(ranges, p.grid.count(), sched, s));
+            }
+            tm.mark();  // 4: tile sort (+ the compositing schedule)
             GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
                                       ranges, p.grid, p.out, p.semantics, p.background, p.generic,
-                                      make_clear_plan(p, false), lt, s));
+                                      make_clear_plan(p, false), lt, sched, s));
             tm.mark();  // 5: blend
         }
     }

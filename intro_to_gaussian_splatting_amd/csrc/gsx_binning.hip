@@ -311,9 +311,107 @@ __global__ void __launch_bounds__(kBlock)
     if (t < nt) counts[t] = (ranges[t].y & ~kLongFlag) - ranges[t].x;
 }
 
+// sched[k] = the tile with the k-th longest list (ties and near-ties in any order: lists are ranked by
+// 1024 length classes between the shortest and the longest list of the frame).  The compositing kernel
+// hands the tiles out so that every SIMD of the chip gets the same share of every length class (see
+// blend_tile16_kernel): with the tiles in index order the busiest SIMD of a 1M-Gaussian 1080p frame had 11 %
+// more list entries than the average one and the kernel waited for it (298 -> 261 us).  Long tiles
+// (composited by helper workgroups) count as empty.  One workgroup; a thread keeps its first 32 lengths in
+// registers (all loads in flight at once; a loop of dependent trips to memory cost 1 us per 1024 tiles).  (Run by the last workgroup of tile_ranges_kernel instead, this cost 100+ us: every workgroup of
+// that kernel then needs a device-scope release fence, an L2 write-back on this part.)
+constexpr int kSchedThreads = 1024, kSchedClasses = 1024, kSchedKeep = 32;   // 32 768 tiles (a 4K frame) in registers
+__global__ void __launch_bounds__(kSchedThreads)
+    tile_schedule_kernel(const uint2 *__restrict__ ranges, uint32_t nt, uint32_t *__restrict__ sched) {
+    __shared__ uint32_t hist[kSchedClasses];
+    __shared__ uint32_t wsum[kSchedThreads / 64];
+    __shared__ uint32_t s_min, s_max;
+    // the order is put together in LDS and written out in one coalesced sweep: 4-byte stores scattered straight
+    // to memory are one 64-byte transaction each, and a single CU issues about one per clock (15 us at 32 768 tiles)
+    __shared__ uint32_t staged[kSchedKeep * kSchedThreads];
+    const bool stage = nt <= (uint32_t)(kSchedKeep * kSchedThreads);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    auto length = [&](uint32_t t) -> uint32_t {
+        const uint2 r = ranges[t];
+        return (r.y & kLongFlag) ? 0u : r.y - r.x;
+    };
+    uint32_t len[kSchedKeep];
+    uint32_t mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+    for (int k = 0; k < kSchedKeep; ++k) {
+        const uint32_t t = (uint32_t)k * kSchedThreads + threadIdx.x;
+        len[k] = t < nt ? length(t) : 0u;
+        if (t < nt) {
+            mn = min(mn, len[k]);
+            mx = max(mx, len[k]);
+        }
+    }
+    for (uint32_t t = (uint32_t)kSchedKeep * kSchedThreads + threadIdx.x; t < nt; t += kSchedThreads) {
+        const uint32_t l = length(t);
+        mn = min(mn, l);
+        mx = max(mx, l);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    }
+    hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        s_min = 0xFFFFFFFFu;
+        s_max = 0;
+    }
+    __syncthreads();
+    if (lane == 0 && mn <= mx) {
+        atomicMin(&s_min, mn);
+        atomicMax(&s_max, mx);
+    }
+    __syncthreads();
+    const uint32_t shortest = s_min;
+    const float per_entry = (float)(kSchedClasses - 1) / (float)max(s_max - shortest, 1u);
+    auto cls = [&](uint32_t l) -> uint32_t {   // class 0 = the longest lists
+        return (uint32_t)(kSchedClasses - 1) - min((uint32_t)((float)(l - shortest) * per_entry), (uint32_t)(kSchedClasses - 1));
+    };
+#pragma unroll
+    for (int k = 0; k < kSchedKeep; ++k)
+        if ((uint32_t)k * kSchedThreads + threadIdx.x < nt) atomicAdd(&hist[cls(len[k])], 1u);
+    for (uint32_t t = (uint32_t)kSchedKeep * kSchedThreads + threadIdx.x; t < nt; t += kSchedThreads)
+        atomicAdd(&hist[cls(length(t))], 1u);
+    __syncthreads();
+    const uint32_t mine = hist[threadIdx.x];
+    uint32_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int k = 0; k < w; ++k) before += wsum[k];
+    hist[threadIdx.x] = before + x - mine;   // first slot of this class
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSchedKeep; ++k) {
+        const uint32_t t = (uint32_t)k * kSchedThreads + threadIdx.x;
+        if (t < nt) (stage ? staged : sched)[atomicAdd(&hist[cls(len[k])], 1u)] = t;
+    }
+    for (uint32_t t = (uint32_t)kSchedKeep * kSchedThreads + threadIdx.x; t < nt; t += kSchedThreads)
+        sched[atomicAdd(&hist[cls(length(t))], 1u)] = t;
+    if (stage) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < nt; k += kSchedThreads) sched[k] = staged[k];
+    }
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
+
+hipError_t launch_tile_schedule(const uint2 *ranges, int64_t nt, uint32_t *sched, hipStream_t s) {
+    if (nt <= 0) return hipSuccess;
+    tile_schedule_kernel<<<1, kSchedThreads, 0, s>>>(ranges, (uint32_t)nt, sched);
+    return hipGetLastError();
+}
 
 hipError_t launch_tile_counts(const uint2 *ranges, int64_t nt, uint32_t *counts, hipStream_t s) {
     if (nt <= 0) return hipSuccess;

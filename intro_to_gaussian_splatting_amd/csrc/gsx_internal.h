@@ -112,6 +112,8 @@ hipError_t sort_instances(void *temp, int64_t cap, const TileGrid &grid, void *k
                           const uint32_t **sorted_vals, hipStream_t s);
 // counts[t] = length of tile t's list (GsxParams.tile_counts).
 hipError_t launch_tile_counts(const uint2 *ranges, int64_t nt, uint32_t *counts, hipStream_t s);
+// sched[k] = tile with the k-th longest list (1024 length classes), for launch_blend's balanced hand-out.
+hipError_t launch_tile_schedule(const uint2 *ranges, int64_t nt, uint32_t *sched, hipStream_t s);
 // ---- gsx_sort.hip: stable LSD radix sort, up to 8 bits per pass, key bits [0, key_bits).  The element
 // count is min(*n_dev, bound) (n_dev == nullptr: bound); grids are sized by `bound`.  Buffers
 // ping-pong; on return keys_cur / vals_cur point at the sorted data.  temp: radix_temp_bytes(bound).
@@ -146,9 +148,11 @@ hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, i
 // background: 3 floats, read on the host (GSX_SEM_STD_3DGS only); generic: GSX_FLAG_GENERIC_KERNELS.
 // cp: what the launch zeroes besides compositing its tiles (extra workgroups of the same kernel).
 // lt: long tiles split over four waves (GSX_SEM_REF_CPU, tile 16 only; lt.max == 0 otherwise).
+// sched: launch_tile_schedule's order, or nullptr (tiles in index order); used by the tile-16 REF_CPU kernel.
+bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int64_t n);
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
-                        bool generic, const ClearPlan &cp, const LongTiles &lt, hipStream_t s);
+                        bool generic, const ClearPlan &cp, const LongTiles &lt, const uint32_t *sched, hipStream_t s);
 bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic);
 hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s);   // the zero fill alone
 hipError_t launch_zero_words(uint32_t *p, size_t n, hipStream_t s);

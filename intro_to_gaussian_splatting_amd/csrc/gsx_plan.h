@@ -106,7 +106,7 @@ struct Carve {
     size_t keys0, keys1, vals0, vals1;      // n x u32: depth keys / original indices (ping-pong)
     size_t rec, rect, rrect, bbox;          // per Gaussian: record, tile rectangle by index / by depth rank
     size_t tkeys0, tkeys1, tvals0, tvals1;  // cap x u32: tile ids / Gaussian indices (ping-pong)
-    size_t ranges, longs, counters, temp, temp_bytes, total;
+    size_t ranges, longs, sched, counters, temp, temp_bytes, total;
 };
 
 // The 64-byte `counters` block: what the kernels of one frame hand to each other on the device.
@@ -132,6 +132,7 @@ inline Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes)
     c.tkeys0 = take(cc * 4); c.tkeys1 = take(cc * 4); c.tvals0 = take(cc * 4); c.tvals1 = take(cc * 4);
     c.ranges = take((size_t)(max_tiles > 0 ? max_tiles : 1) * kRangeBytes);
     c.longs = take(kMaxLongTiles * sizeof(uint32_t));
+    c.sched = take((size_t)(max_tiles > 0 ? max_tiles : 1) * sizeof(uint32_t));   // tiles by falling list length
     c.counters = take(64);
     c.temp = take(temp_bytes);
     c.temp_bytes = temp_bytes;

@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(kThreads)
     __shared__ uint32_t gbase[kBins];    // global address of parked item j of digit d = gbase[d] + j
     __shared__ uint32_t wsum[4], lsum[4];
     __shared__ Key skey[kItems];
-    __shared__ uint32_t sval[kItems];
+    __shared__ __attribute__((aligned(16))) uint32_t sval[kItems];   // 8 KB: also the 4 x 256 match words of the ranking
+    static_assert(kItems * 4 == 4 * kBins * 8, "sval doubles as the per-wave match words");
     const uint32_t n = load_count(n_dev, bound);
     const uint32_t block_base = blockIdx.x * (uint32_t)kItems;
     if (block_base >= n) return;
@@ -256,6 +257,7 @@ __global__ void __launch_bounds__(kThreads)
         before_pre = table[(size_t)threadIdx.x * nbp + blockIdx.x];
     }
     for (int k = threadIdx.x; k < 4 * kBins; k += kThreads) (&cnt[0][0])[k] = 0;
+    for (int k = threadIdx.x; k < kItems / 4; k += kThreads) reinterpret_cast<uint4 *>(sval)[k] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     // ---- stable rank of every item among the same-digit items of its wave's consecutive slice
@@ -273,30 +275,33 @@ __global__ void __launch_bounds__(kThreads)
         val[r] = (MODE & kModeFirst) ? i : (ok[r] ? vin[i] : 0u);
         if (MODE & kModeFirst) ok[r] = ok[r] && (uint32_t)key[r] < kEmptyKey;
     }
+    // The lanes of a wave that hold the same digit find each other through the LDS: every lane ORs its bit
+    // into the wave's 64-bit word of the digit, reads the word back and clears it -- three DS operations that
+    // one wave executes in issue order -- instead of BITS ballots at ~6 VALU instructions each.  The words
+    // live in sval, which is dead until the items are parked.
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u64 *wm = (lds_u64 *)(reinterpret_cast<unsigned long long *>(sval) + (size_t)w * kBins);
+    lds_u32 *wc = (lds_u32 *)&cnt[w][0];
+    const unsigned long long me = 1ull << lane;
     uint16_t rank[kRounds];
     uint8_t dig[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
-        const bool valid = ok[r];
         const uint32_t d = SPLIT ? bucket_of(spl, (uint32_t)key[r]) : (((uint32_t)key[r] >> shift) & mask);
         dig[r] = (uint8_t)d;
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < BITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long m = __ballot(bit);
-            peers &= bit ? m : ~m;
+        rank[r] = 0;
+        if (ok[r]) {
+            __hip_atomic_fetch_or(&wm[d], me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long peers = wm[d];
+            const uint32_t before = wc[d];
+            __builtin_amdgcn_wave_barrier();
+            wm[d] = 0ull;
+            if ((peers & lt) == 0ull) wc[d] = before + (uint32_t)__popcll(peers);   // the first of them
+            __builtin_amdgcn_wave_barrier();
+            rank[r] = (uint16_t)(before + (uint32_t)__popcll(peers & lt));
         }
-        uint32_t old = 0;
-        if (valid) {
-            const int leader = __ffsll((long long)peers) - 1;
-            if (lane == leader) {
-                old = cnt[w][d];
-                cnt[w][d] = old + (uint32_t)__popcll(peers);
-            }
-            old = (uint32_t)__shfl((int)old, leader);
-        }
-        rank[r] = (uint16_t)(old + (uint32_t)__popcll(peers & lt));
     }
     __syncthreads();
 
@@ -375,13 +380,41 @@ __global__ void __launch_bounds__(kThreads)
     __syncthreads();
 
     // ---- stream out: consecutive j of one digit -> consecutive addresses
-    for (uint32_t j = threadIdx.x; j < live; j += kThreads) {
-        const Key k = skey[j];
-        const uint32_t v = sval[j];
-        const uint32_t dst = gbase[SPLIT ? (uint32_t)sdig[j] : (((uint32_t)k >> shift) & mask)] + j;
-        if (!(MODE & kModeFinal)) kout[dst] = k;
-        vout[dst] = v;
-        if (MODE & kModeFinal) rrect[dst] = rect[v];   // the one gather by Gaussian index on the binning path
+    constexpr bool with_rect = (MODE & kModeFinal) || SPLIT;
+    if (with_rect) {
+        // FINAL: the one gather by Gaussian index of the LSD depth sort.  SPLIT (the partition pass of the sampled
+        // sort): v lies in this chunk's own 2048 indices -- 16 KB of rect, read once -- and the rectangles travel
+        // with their items, so that the bucket sort finds them side by side.  All gathers are issued before
+        // the first store.
+        uint32_t dst[kRounds], v[kRounds];
+        Key k[kRounds];
+        TileRect t[kRounds];
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const uint32_t j = (uint32_t)r * kThreads + threadIdx.x;
+            if (j < live) {
+                k[r] = skey[j];
+                v[r] = sval[j];
+                dst[r] = gbase[SPLIT ? (uint32_t)sdig[j] : (((uint32_t)k[r] >> shift) & mask)] + j;
+                t[r] = rect[v[r]];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const uint32_t j = (uint32_t)r * kThreads + threadIdx.x;
+            if (j < live) {
+                if (!(MODE & kModeFinal)) kout[dst[r]] = k[r];
+                vout[dst[r]] = v[r];
+                rrect[dst[r]] = t[r];
+            }
+        }
+    } else {
+        for (uint32_t j = threadIdx.x; j < live; j += kThreads) {
+            const Key k = skey[j];
+            const uint32_t dst = gbase[((uint32_t)k >> shift) & mask] + j;
+            kout[dst] = k;
+            vout[dst] = sval[j];
+        }
     }
 }
 
@@ -412,40 +445,50 @@ struct RankShared {
 // is the (w * L + r * 64 + lane)-th of the tile (L = the per-wave slice, a multiple of 64).  Digit = DBITS bits
 // of the key from `shift`.  All 1024 threads must call this (barriers inside).  On return pos[r] is the
 // item's position, sh.lstart[d] the first position of digit d, sh.lstart[1 << DBITS] the number of valid items.
+//
+// The lanes of a wave that hold the same digit find each other through the LDS, not through DBITS ballots
+// (6 VALU instructions per bit and round; a wave64 instruction occupies the SIMD for 4 cycles): every lane ORs
+// its bit into the wave's 64-bit word of the digit, reads the word back, and clears it for the next round --
+// three LDS operations.  The DS instructions of one wave execute in issue order, so the read sees the ORs of
+// all 64 lanes and the clear comes after every read.  `masks`: kBigWaves x kLocalBins 64-bit words (64 KB),
+// scratch that callers alias with the item buffers (dead while positions are being computed).
 template <int ROUNDS, int DBITS>
 __device__ __forceinline__ void rank_items(const uint32_t (&key)[ROUNDS], const bool (&ok)[ROUNDS], int shift,
-                                           RankShared &sh, uint32_t (&pos)[ROUNDS]) {
+                                           RankShared &sh, unsigned long long *masks, uint32_t (&pos)[ROUNDS]) {
     constexpr int NB = 1 << DBITS;
     constexpr uint32_t DM = NB - 1;
+    static_assert(NB <= kLocalBins, "the tables hold kLocalBins digits");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int k = threadIdx.x; k < kBigWaves * kLocalBins / 2; k += kBigThreads) reinterpret_cast<uint32_t *>(&sh.cnt[0][0])[k] = 0;
+    const unsigned long long me = 1ull << lane, lt = me - 1ull;
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(masks);
+        for (int k = threadIdx.x; k < kBigWaves * kLocalBins * 8 / 16; k += kBigThreads) z[k] = make_uint4(0, 0, 0, 0);
+        uint4 *c = reinterpret_cast<uint4 *>(&sh.cnt[0][0]);
+        for (int k = threadIdx.x; k < kBigWaves * kLocalBins * 2 / 16; k += kBigThreads) c[k] = make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
+    // explicit LDS pointers: the DS instructions below must stay DS instructions, in this order
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    lds_u64 *wm = (lds_u64 *)(masks + (size_t)w * kLocalBins);
+    lds_u16 *wc = (lds_u16 *)&sh.cnt[w][0];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const bool valid = ok[r];
         const uint32_t d = (key[r] >> shift) & DM;
-        unsigned long long peers = __ballot(valid);
-        if (peers == 0ull) {   // wave-uniform: nothing left in this wave's slice
-            pos[r] = 0;
-            continue;
-        }
-#pragma unroll
-        for (int b = 0; b < DBITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        uint32_t old = 0;
+        pos[r] = 0;
+        if (__ballot(valid) == 0ull) continue;   // wave-uniform: nothing left in this wave's slice
         if (valid) {
-            const int leader = __ffsll((long long)peers) - 1;
-            if (lane == leader) {
-                old = sh.cnt[w][d];
-                sh.cnt[w][d] = (uint16_t)(old + (uint32_t)__popcll(peers));
-            }
-            old = (uint32_t)__shfl((int)old, leader);
+            __hip_atomic_fetch_or(&wm[d], me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long peers = wm[d];
+            const uint32_t before = wc[d];
+            __builtin_amdgcn_wave_barrier();
+            wm[d] = 0ull;
+            if ((peers & lt) == 0ull) wc[d] = (uint16_t)(before + (uint32_t)__popcll(peers));   // the first of them
+            __builtin_amdgcn_wave_barrier();
+            pos[r] = before + (uint32_t)__popcll(peers & lt);
         }
-        pos[r] = old + (uint32_t)__popcll(peers & lt);
     }
     __syncthreads();
     uint32_t total = 0, x = 0;
@@ -479,6 +522,162 @@ __device__ __forceinline__ void rank_items(const uint32_t (&key)[ROUNDS], const 
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
         if (ok[r]) pos[r] += sh.cnt[w][(key[r] >> shift) & DM];
+}
+
+// The in-LDS LSD passes over the bits set in [lo_bit, hi_bit) for up to R x 1024 items held in registers
+// (item (wave w, round r, lane) = the (w * L + r * 64 + lane)-th): 9 bits per pass, items parked in digit-major
+// order in (skey, sval) and read back position-major.  COMPACT: invalid items are dropped by the first pass and
+// the count of valid ones is returned (the kept items are dense afterwards).  R is a template parameter
+// because every round costs instructions at 6 code sites whether the wave has items in it or not: a bucket
+// of 3 000 items (4 rounds) through the 16-round code took 11 us per pass, through the 4-round code 5.
+template <int R, bool COMPACT>
+__device__ __forceinline__ uint32_t lds_passes(uint32_t (&key)[R], uint32_t (&val)[R], bool (&ok)[R], uint32_t L,
+                                               int lo_bit, int hi_bit, RankShared &sh, uint32_t *skey, uint32_t *sval) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t m = 0;
+    for (int shift = lo_bit; shift < hi_bit; shift += kLocalBits) {
+        uint32_t pos[R];
+        rank_items<R, kLocalBits>(key, ok, shift, sh, reinterpret_cast<unsigned long long *>(skey), pos);
+        m = sh.lstart[kLocalBins];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (ok[r]) {
+                skey[pos[r]] = key[r];
+                sval[pos[r]] = val[r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+            if (COMPACT) ok[r] = (uint32_t)r * 64 < L && i < m;
+            if (ok[r]) {
+                key[r] = skey[i];
+                val[r] = sval[i];
+            }
+        }
+        __syncthreads();
+    }
+    return m;
+}
+
+// vout[first + i] = val, rrect[first + i] = rect[val] for the items in registers.  All the rectangle loads
+// are issued before the first store: with load and store of one item back to back the compiler waits for
+// every gather in turn (15 us of a 43 us kernel at 1M keys).
+template <int R>
+__device__ __forceinline__ void store_ranked(const uint32_t (&val)[R], const bool (&ok)[R], uint32_t L, uint32_t first,
+                                             uint32_t *__restrict__ vout, const TileRect *__restrict__ rect,
+                                             TileRect *__restrict__ rrect) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    TileRect rc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (ok[r]) rc[r] = rect[val[r]];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+        if (ok[r]) {
+            vout[first + i] = val[r];
+            rrect[first + i] = rc[r];
+        }
+    }
+}
+
+// Minimum and maximum of the valid keys over the workgroup (s_min / s_max preset to ~0 / 0 before a barrier).
+template <int R>
+__device__ __forceinline__ void key_span(const uint32_t (&key)[R], const bool (&ok)[R], uint32_t *s_min, uint32_t *s_max) {
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mn = ok[r] ? min(mn, key[r]) : mn;
+        mx = ok[r] ? max(mx, key[r]) : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    }
+    if ((threadIdx.x & 63) == 0 && mn <= mx) {
+        atomicMin(s_min, mn);
+        atomicMax(s_max, mx);
+    }
+    __syncthreads();
+}
+
+// A bucket that fits the LDS: load, sort over the bits of (key - smallest key), stream out.  (All 1024 threads.)
+// The offset from the smallest key, not the bits in which keys differ: a bucket holds 1/256 of the keys, a span
+// of 2^15 .. 2^18 float-depth codes at 1M Gaussians = two 9-bit passes, where one bucket that straddles a
+// power of two differs in 20+ bits (and the slowest bucket is the kernel's duration).
+//
+// What is sorted is (key, position in the bucket).  The partition pass left the bucket's Gaussian indices in
+// vin[start ..) and their rectangles in rrect[start ..) (partition order); both are staged in LDS with
+// coalesced loads, permuted there, and written back -- the rectangles in place.  (A gather rect[index] from
+// here, 1M random 8-byte reads of an 8 MB table that no XCD's L2 holds, was 11 of the kernel's 38 us.)
+// `items`: the 2 x kBucketCap words of LDS item buffer.
+template <int R>
+__device__ __forceinline__ void bucket_in_lds(uint32_t start, uint32_t size, uint32_t L, const uint32_t *kin,
+                                              const uint32_t *vin, uint32_t *vout, TileRect *rrect, RankShared &sh,
+                                              uint32_t *items, uint32_t *s_min, uint32_t *s_max) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t key[R], val[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+        ok[r] = (uint32_t)r * 64 < L && i < size;
+        key[r] = ok[r] ? kin[start + i] : 0u;
+        val[r] = i;
+    }
+    key_span<R>(key, ok, s_min, s_max);
+    const uint32_t kmin = *s_min, span = *s_max - kmin;
+#pragma unroll
+    for (int r = 0; r < R; ++r) key[r] -= kmin;
+    lds_passes<R, false>(key, val, ok, L, 0, span ? 32 - __clz((int)span) : 0, sh, items, items + kBucketCap);
+    // val[r] = position in the bucket of the item of rank (w, r, lane).  Thread-strided staging: item j = r * 1024 + tid.
+    uint2 *lrect = reinterpret_cast<uint2 *>(items);
+    const uint2 *grect = reinterpret_cast<const uint2 *>(rrect + start);
+    const bool together = size * 3u <= 2u * (uint32_t)kBucketCap;   // 12 bytes per item fit the buffer at once
+    uint32_t *lval = together ? items + 2 * size : items;
+    uint2 t[R];
+    uint32_t v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t j = (uint32_t)r * kBigThreads + threadIdx.x;
+        if (j < size) {
+            t[r] = grect[j];
+            v[r] = vin[start + j];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t j = (uint32_t)r * kBigThreads + threadIdx.x;
+        if (j < size) {
+            lrect[j] = t[r];
+            if (together) lval[j] = v[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+        if (ok[r]) {
+            reinterpret_cast<uint2 *>(rrect + start)[i] = lrect[val[r]];
+            if (together) vout[start + i] = lval[val[r]];
+        }
+    }
+    if (R == kBucketRounds && !together) {   // a bucket beyond 2/3 of the buffer: the indices take a second trip
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t j = (uint32_t)r * kBigThreads + threadIdx.x;
+            if (j < size) lval[j] = v[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+            if (ok[r]) vout[start + i] = lval[val[r]];
+        }
+    }
 }
 
 // ranks[i] = position of sample i (key at index i n / 2048) in the stable ascending order of the 2048 samples.
@@ -515,12 +714,12 @@ __global__ void __launch_bounds__(kThreads)
 __global__ void __launch_bounds__(kBigThreads)
     bucket_sort_kernel(const uint32_t *__restrict__ totals, const uint32_t *__restrict__ table_cm, int nblocks_cm,
                        uint32_t *kin, uint32_t *vin, uint32_t *kalt, uint32_t *vout,
-                       const TileRect *__restrict__ rect, TileRect *__restrict__ rrect, uint32_t lds_cap) {
+                       const TileRect *__restrict__ rect, TileRect *rrect, uint32_t lds_cap) {
     __shared__ RankShared sh;
-    __shared__ uint32_t skey[kBucketCap];
-    __shared__ uint32_t sval[kBucketCap];
+    __shared__ __attribute__((aligned(16))) uint32_t sitems[2 * kBucketCap];
+    uint32_t *skey = sitems;
     __shared__ uint32_t s_tot[kBins];
-    __shared__ uint32_t s_or, s_start, s_key0;
+    __shared__ uint32_t s_or, s_start, s_min, s_max;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x < kBins) {
         // bucket sizes: the row totals of the partition pass, or (small inputs: chunk-major table, no row scan)
@@ -544,6 +743,8 @@ __global__ void __launch_bounds__(kBigThreads)
     if (threadIdx.x == 0) {
         s_or = 0;
         s_start = 0;
+        s_min = 0xFFFFFFFFu;
+        s_max = 0;
     }
     __syncthreads();
     if (threadIdx.x < kBins) {   // first rank of this bucket = sizes of the buckets before it
@@ -556,59 +757,16 @@ __global__ void __launch_bounds__(kBigThreads)
     const uint32_t start = s_start, size = s_tot[blockIdx.x];
     if (size == 0) return;
     if (size <= lds_cap) {
-        // ---- in LDS: items wave-striped, L per wave
+        // ---- in LDS: items wave-striped, L per wave, as few rounds of 64 per wave as hold them
         const uint32_t L = (((size + kBigWaves - 1) / kBigWaves) + 63u) & ~63u;
-        uint32_t key[kBucketRounds], val[kBucketRounds];
-        bool ok[kBucketRounds];
-#pragma unroll
-        for (int r = 0; r < kBucketRounds; ++r) {
-            const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
-            ok[r] = (uint32_t)r * 64 < L && i < size;
-            key[r] = ok[r] ? kin[start + i] : 0u;
-            val[r] = ok[r] ? vin[start + i] : 0u;
-        }
-        if (threadIdx.x == 0) s_key0 = key[0];      // item 0 of the bucket (size > 0)
-        __syncthreads();
-        const uint32_t key0 = s_key0;
-        uint32_t diff = 0;
-#pragma unroll
-        for (int r = 0; r < kBucketRounds; ++r) diff |= ok[r] ? key[r] ^ key0 : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, o);
-        if (lane == 0 && diff) atomicOr(&s_or, diff);
-        __syncthreads();
-        // only the bits in which two keys of the bucket differ need sorting: 9 of them per pass, from the lowest
-        // such bit up (a bucket holds 1/256 of the keys: ~17 varying bits of a float depth = 2 passes)
-        const uint32_t varying = s_or;
-        const int lo_bit = varying ? __ffs((int)varying) - 1 : 0, hi_bit = varying ? 32 - __clz((int)varying) : 0;
-        for (int shift = lo_bit; shift < hi_bit; shift += kLocalBits) {
-            uint32_t pos[kBucketRounds];
-            rank_items<kBucketRounds, kLocalBits>(key, ok, shift, sh, pos);
-#pragma unroll
-            for (int r = 0; r < kBucketRounds; ++r)
-                if (ok[r]) {
-                    skey[pos[r]] = key[r];
-                    sval[pos[r]] = val[r];
-                }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < kBucketRounds; ++r) {
-                const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
-                if (ok[r]) {
-                    key[r] = skey[i];
-                    val[r] = sval[i];
-                }
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int r = 0; r < kBucketRounds; ++r) {
-            const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
-            if (ok[r]) {
-                vout[start + i] = val[r];
-                rrect[start + i] = rect[val[r]];
-            }
-        }
+        if (L <= 2 * 64)
+            bucket_in_lds<2>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max);
+        else if (L <= 4 * 64)
+            bucket_in_lds<4>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max);
+        else if (L <= 8 * 64)
+            bucket_in_lds<8>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max);
+        else
+            bucket_in_lds<kBucketRounds>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max);
         return;
     }
     // ---- through global memory (a bucket that does not fit): LSD passes over the varying bytes, tile by tile
@@ -621,7 +779,7 @@ __global__ void __launch_bounds__(kBigThreads)
     __syncthreads();
     const uint32_t varying = s_or;
     uint32_t *sk = kin + start, *sv = vin + start, *dk = kalt + start, *dv = vout + start;
-    uint32_t *gbase = skey;      // 256 running digit bases (the LDS item buffers are free on this path)
+    uint32_t *gbase = s_tot;     // 256 running digit bases (skey is rank_items' scratch)
     for (int shift = 0; shift < 32; shift += 8) {
         if (((varying >> shift) & 255u) == 0) continue;
         if (threadIdx.x < kBins) s_tot[threadIdx.x] = 0;
@@ -630,9 +788,10 @@ __global__ void __launch_bounds__(kBigThreads)
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t run = 0;
-            for (int d = 0; d < kBins; ++d) {
+            for (int d = 0; d < kBins; ++d) {   // in place: counts -> first destinations
+                const uint32_t c = s_tot[d];
                 gbase[d] = run;
-                run += s_tot[d];
+                run += c;
             }
         }
         __syncthreads();
@@ -648,7 +807,7 @@ __global__ void __launch_bounds__(kBigThreads)
                 key[r] = ok[r] ? sk[t0 + i] : 0u;
                 val[r] = ok[r] ? sv[t0 + i] : 0u;
             }
-            rank_items<kBucketRounds, 8>(key, ok, shift, sh, pos);
+            rank_items<kBucketRounds, 8>(key, ok, shift, sh, reinterpret_cast<unsigned long long *>(skey), pos);
 #pragma unroll
             for (int r = 0; r < kBucketRounds; ++r)
                 if (ok[r]) {
@@ -679,8 +838,43 @@ __global__ void __launch_bounds__(kBigThreads)
 }
 
 // Up to kBucketCap keys (the reference's own scenes: 2 000 .. 52 000 Gaussians fit or nearly fit) ONE workgroup
-// does the whole depth sort in LDS: drop what reaches no tile, count the culled, LSD passes over the key bytes
-// that vary, rank-ordered rectangle gather.  One launch instead of eight.
+// does the whole depth sort in LDS: drop what reaches no tile, count the culled, LSD passes over the bits of
+// (key - smallest key), rank-ordered rectangle gather.  One launch instead of eight.
+template <int R>
+__device__ __forceinline__ void small_sort_in_lds(const uint32_t *__restrict__ keys, uint32_t n, uint32_t L,
+                                                  uint32_t *__restrict__ vout, const TileRect *__restrict__ rect,
+                                                  TileRect *__restrict__ rrect, uint32_t *__restrict__ m_out,
+                                                  uint32_t *__restrict__ culled_out, RankShared &sh, uint32_t *skey,
+                                                  uint32_t *sval, uint32_t *s_min, uint32_t *s_max, uint32_t *s_culled) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t key[R], val[R];
+    bool ok[R];
+    uint32_t culled = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
+        const bool in = (uint32_t)r * 64 < L && i < n;
+        key[r] = in ? keys[i] : 0u;
+        val[r] = i;
+        ok[r] = in && key[r] < kEmptyKey;
+        culled += in && key[r] == kCulledKey;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) culled += (uint32_t)__shfl_xor((int)culled, o);
+    if (lane == 0 && culled) atomicAdd(s_culled, culled);
+    key_span<R>(key, ok, s_min, s_max);
+    const uint32_t kmin = *s_min, span = *s_max - kmin;
+#pragma unroll
+    for (int r = 0; r < R; ++r) key[r] -= kmin;
+    // one pass at least: the first pass is also what compacts
+    const uint32_t m = lds_passes<R, true>(key, val, ok, L, 0, span ? 32 - __clz((int)span) : 1, sh, skey, sval);
+    store_ranked<R>(val, ok, L, 0u, vout, rect, rrect);
+    if (threadIdx.x == 0) {
+        *m_out = m;
+        *culled_out = *s_culled;
+    }
+}
+
 __global__ void __launch_bounds__(kBigThreads)
     small_depth_sort_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ vout,
                             const TileRect *__restrict__ rect, TileRect *__restrict__ rrect, uint32_t *__restrict__ m_out,
@@ -688,79 +882,23 @@ __global__ void __launch_bounds__(kBigThreads)
     __shared__ RankShared sh;
     __shared__ uint32_t skey[kBucketCap];
     __shared__ uint32_t sval[kBucketCap];
-    __shared__ uint32_t s_or, s_and, s_culled;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ uint32_t s_min, s_max, s_culled;
     if (threadIdx.x == 0) {
-        s_or = 0;
-        s_and = 0xFFFFFFFFu;
+        s_min = 0xFFFFFFFFu;
+        s_max = 0;
         s_culled = 0;
     }
     __syncthreads();
     const uint32_t L = (((n + kBigWaves - 1) / kBigWaves) + 63u) & ~63u;
-    uint32_t key[kBucketRounds], val[kBucketRounds];
-    bool ok[kBucketRounds];
-    uint32_t o_ = 0, a_ = 0xFFFFFFFFu, culled = 0;
-#pragma unroll
-    for (int r = 0; r < kBucketRounds; ++r) {
-        const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
-        const bool in = (uint32_t)r * 64 < L && i < n;
-        key[r] = in ? keys[i] : 0u;
-        val[r] = i;
-        ok[r] = in && key[r] < kEmptyKey;
-        culled += in && key[r] == kCulledKey;
-        o_ |= ok[r] ? key[r] : 0u;
-        a_ &= ok[r] ? key[r] : 0xFFFFFFFFu;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        o_ |= (uint32_t)__shfl_xor((int)o_, o);
-        a_ &= (uint32_t)__shfl_xor((int)a_, o);
-        culled += (uint32_t)__shfl_xor((int)culled, o);
-    }
-    if (lane == 0) {
-        atomicOr(&s_or, o_);
-        atomicAnd(&s_and, a_);
-        if (culled) atomicAdd(&s_culled, culled);
-    }
-    __syncthreads();
-    uint32_t varying = s_or & ~s_and;          // bits in which two kept keys differ
-    if (varying == 0) varying = 1;             // one pass at least: it is also what compacts
-    const int lo_bit = __ffs((int)varying) - 1, hi_bit = 32 - __clz((int)varying);
-    uint32_t m = 0;
-    for (int shift = lo_bit; shift < hi_bit; shift += kLocalBits) {
-        uint32_t pos[kBucketRounds];
-        rank_items<kBucketRounds, kLocalBits>(key, ok, shift, sh, pos);
-        m = sh.lstart[kLocalBins];
-#pragma unroll
-        for (int r = 0; r < kBucketRounds; ++r)
-            if (ok[r]) {
-                skey[pos[r]] = key[r];
-                sval[pos[r]] = val[r];
-            }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kBucketRounds; ++r) {
-            const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
-            ok[r] = (uint32_t)r * 64 < L && i < m;     // the kept items are dense now
-            if (ok[r]) {
-                key[r] = skey[i];
-                val[r] = sval[i];
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int r = 0; r < kBucketRounds; ++r) {
-        const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
-        if (ok[r]) {
-            vout[i] = val[r];
-            rrect[i] = rect[val[r]];
-        }
-    }
-    if (threadIdx.x == 0) {
-        *m_out = m;
-        *culled_out = s_culled;
-    }
+    if (L <= 2 * 64)
+        small_sort_in_lds<2>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled);
+    else if (L <= 4 * 64)
+        small_sort_in_lds<4>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled);
+    else if (L <= 8 * 64)
+        small_sort_in_lds<8>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled);
+    else
+        small_sort_in_lds<kBucketRounds>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max,
+                                         &s_culled);
 }
 
 struct PassPlan {
@@ -877,13 +1015,13 @@ hipError_t sort_depth_sampled(void *temp, uint32_t *keys0, uint32_t *keys1, uint
         count_kernel<uint32_t, true, true, true><<<p.nblocks, kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u, p.table,
                                                                                 p.nbp, culled_dev, splitters);
         scatter_kernel<uint32_t, true, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
-            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, nullptr, nullptr, splitters);
+            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters);
     } else {
         count_kernel<uint32_t, false, true, true><<<p.nquads, kQuad * kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u,
                                                                                         p.table, p.nbp, culled_dev, splitters);
         row_scan_kernel<<<kBins, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
         scatter_kernel<uint32_t, false, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
-            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, nullptr, nullptr, splitters);
+            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters);
     }
     if (lds_cap == 0 || lds_cap > (uint32_t)kBucketCap) lds_cap = kBucketCap;
     bucket_sort_kernel<<<kBins, kBigThreads, 0, s>>>(p.totals, p.table, p.self_scan ? p.nblocks : 0, keys1, vals_alt, keys0,

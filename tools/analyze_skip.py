@@ -1,0 +1,89 @@
+"""How many (Gaussian, tile) pairs of a bench scene contribute nothing anywhere in their tile -- at the
+16x16 tile of the binning and at 8x8 quadrants of it?  CPU only (oracle projection + numpy):
+    python tools/analyze_skip.py [workload]
+A pair is negligible when ln(alpha) = ln(opacity) + max over the pixel block of the exponent < -26 ln 2
+(the staging test of blend_tile16_kernel)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from intro_to_gaussian_splatting_amd.synthetic import make_scene  # noqa: E402
+from oracle import c_oracle, cpu_ref  # noqa: E402
+
+
+def min_quadratic_over_box(a, b, c, mx, my, x0, x1, y0, y1):
+    """min over [x0,x1]x[y0,y1] of a ex^2 + 2 b ex ey + c ey^2, (ex, ey) = (x - mx, y - my); PSD."""
+    cx = np.clip(mx, x0, x1)
+    cy = np.clip(my, y0, y1)
+    inside = (cx == mx) & (cy == my)
+    best = np.full(a.shape, np.inf)
+    for fixed_x in (x0, x1):      # vertical edges: x fixed, minimise over y
+        ex = fixed_x - mx
+        ey = np.clip(-b * ex / np.maximum(c, 1e-30), y0 - my, y1 - my)
+        best = np.minimum(best, a * ex * ex + 2 * b * ex * ey + c * ey * ey)
+    for fixed_y in (y0, y1):
+        ey = fixed_y - my
+        ex = np.clip(-b * ey / np.maximum(a, 1e-30), x0 - mx, x1 - mx)
+        best = np.minimum(best, a * ex * ex + 2 * b * ex * ey + c * ey * ey)
+    return np.where(inside, 0.0, best)
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+    n, w, h, _ = bench.WORKLOADS[wl]
+    sc = make_scene(n, w, h, seed=0, **bench.GENERATOR_ARGS.get(wl, {}))
+    cam = cpu_ref.build_camera(sc["qvec"], sc["tvec"], sc["fx"], sc["fy"], w, h)
+    pre = c_oracle.preprocess(sc["points"], sc["colors_0_255"] / 255.0, sc["scales"], sc["quaternions"], sc["opacity"], cam)
+    tile = 16
+    ntx, nty = len(cpu_ref.tile_origins(w, tile)), len(cpu_ref.tile_origins(h, tile))
+    inv = pre.inverse_covariance_2d.astype(np.float64)
+    a, b, c = inv[:, 0, 0], 0.5 * (inv[:, 0, 1] + inv[:, 1, 0]), inv[:, 1, 1]
+    mx, my = pre.points_xy[:, 0].astype(np.float64), pre.points_xy[:, 1].astype(np.float64)
+    ln_op = -np.log1p(np.exp(-pre.sigmoid_opacity[:, 0].astype(np.float64)))
+    # tile rectangle of every Gaussian: x0 = 16 i with min_x <= x0 + 16 and max_x >= x0
+    tx0 = np.maximum(np.ceil((pre.min_x.astype(np.float64) - tile) / tile), 0).astype(np.int64)
+    tx1 = np.minimum(np.floor(pre.max_x.astype(np.float64) / tile), ntx - 1).astype(np.int64)
+    ty0 = np.maximum(np.ceil((pre.min_y.astype(np.float64) - tile) / tile), 0).astype(np.int64)
+    ty1 = np.minimum(np.floor(pre.max_y.astype(np.float64) / tile), nty - 1).astype(np.int64)
+    nx, ny = np.maximum(tx1 - tx0 + 1, 0), np.maximum(ty1 - ty0 + 1, 0)
+    cnt = nx * ny
+    D = int(cnt.sum())
+    g = np.repeat(np.arange(len(cnt)), cnt)
+    k = np.arange(D) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    px = (tx0[g] + k % np.maximum(nx[g], 1)) * tile
+    py = (ty0[g] + k // np.maximum(nx[g], 1)) * tile
+    thr = -26.0 * np.log(2.0)
+
+    def negligible(x0, y0, side, side_y=None):
+        side_y = side if side_y is None else side_y
+        q = min_quadratic_over_box(a[g], b[g], c[g], mx[g], my[g], x0, x0 + side - 1, y0, y0 + side_y - 1)
+        return ln_op[g] - 0.5 * q < thr
+
+    neg16 = negligible(px, py, 16)
+    print("%s: %d Gaussians kept, %d pairs (%.2f per Gaussian)" % (wl, len(cnt), D, D / max(len(cnt), 1)))
+    print("negligible in the whole 16x16 tile: %.1f %% of pairs" % (100.0 * neg16.mean()))
+    for side in (8, 4):
+        live = 0
+        m = 16 // side
+        for qy in range(m):
+            for qx in range(m):
+                live += int((~negligible(px + side * qx, py + side * qy, side)).sum())
+        print("%dx%d blocks: %.1f %% of the pixel work of the pairs is in non-negligible blocks" %
+              (side, side, 100.0 * live / (D * m * m)))
+    for bw, bh in ((16, 8), (8, 16), (16, 4), (16, 2), (16, 1)):
+        live = 0
+        for qy in range(16 // bh):
+            for qx in range(16 // bw):
+                live += int((~negligible(px + bw * qx, py + bh * qy, bw, bh)).sum())
+        print("%dx%d blocks (w x h): %.1f %% of the pixel work is in non-negligible blocks" %
+              (bw, bh, 100.0 * live / (D * (256 // (bw * bh)))))
+    # the same with a 1/255-style cut, for orientation
+    thr = np.log(1.0 / 255.0)
+    print("(pairs whose alpha stays below 1/255 in the whole tile: %.1f %%)" % (100.0 * negligible(px, py, 16).mean()))
+
+
+if __name__ == "__main__":
+    main()
