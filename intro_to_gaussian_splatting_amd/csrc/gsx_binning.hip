@@ -140,6 +140,13 @@ struct EmitCounts {
     int64_t n_total;             // n_visible = n_total - *culled_dev
 };
 
+// What the walk below needs of one Gaussian of the chunk, in one 16-byte LDS word.
+struct EmitSlot {
+    uint32_t xs, ys;   // x0 | x1 << 16, y0 | y1 << 16 (tile rectangle)
+    uint32_t index;    // Gaussian index (the value of its pairs)
+    uint32_t end;      // local offset of its last pair + 1 (= offs[g + 1])
+};
+
 template <typename Key, bool PREFIXED>
 __global__ void __launch_bounds__(kBlock)
     emit_kernel(const TileRect *__restrict__ rrect, const uint32_t *__restrict__ order,
@@ -148,18 +155,25 @@ __global__ void __launch_bounds__(kBlock)
                 uint2 *__restrict__ ranges, EmitCounts ec) {
     __shared__ uint64_t wsum[4];
     __shared__ uint32_t offs[kChunk + 1];
-    __shared__ TileRect srect[kChunk];
-    __shared__ uint32_t sgi[kChunk];
+    __shared__ __attribute__((aligned(16))) EmitSlot slot[kChunk + 2];
     {   // tiles without pairs keep an empty range
         const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
         if (t < g.count()) ranges[t] = make_uint2(0u, 0u);
     }
     if ((int)blockIdx.x >= nchunks) return;
-    const uint32_t m = load_count(m_dev, bound);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t first = blockIdx.x * (uint32_t)kChunk + threadIdx.x * (uint32_t)kPerThread;
 
-    // ---- pairs before this chunk (and, in the last workgroup, the frame's counts)
+    // ---- everything this workgroup reads from memory is requested at once -- the kept count, the chunk sums
+    //      before this chunk, its rectangles and indices (bounded by the host-known `bound`; what lies beyond
+    //      the kept count is masked afterwards): one trip to memory instead of three dependent ones.  With one
+    //      workgroup per 1024 ranks and all of them resident the kernel's duration IS that chain.
+    TileRect r[kPerThread];
+    uint32_t gidx[kPerThread];
+    load_rects(rrect, first, bound, r);
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) gidx[k] = first + k < bound ? (order ? order[first + k] : first + k) : 0u;
+    const uint32_t m = load_count(m_dev, bound);
     uint64_t base;
     const bool last = (int)blockIdx.x == nchunks - 1;
     if (PREFIXED) {
@@ -170,17 +184,13 @@ __global__ void __launch_bounds__(kBlock)
         base = block_sum64(before, wsum);
     }
 
-    // ---- this chunk's rectangles, counts and local offsets
-    TileRect r[kPerThread];
+    // ---- this chunk's counts and local offsets
     uint32_t c[kPerThread];
     uint64_t mine = 0;
-    load_rects(rrect, first, m, r);
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
         c[k] = first + k < m ? tiles_of(r[k]) : 0u;
         mine += c[k];
-        srect[threadIdx.x * kPerThread + k] = r[k];
-        sgi[threadIdx.x * kPerThread + k] = first + k < m ? (order ? order[first + k] : first + k) : 0u;
     }
     uint64_t x = mine;  // inclusive scan over the wave, then over the workgroup
 #pragma unroll
@@ -194,12 +204,16 @@ __global__ void __launch_bounds__(kBlock)
     for (int k = 0; k < w; ++k) run += wsum[k];
     const uint64_t chunk_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     // local offsets saturate at 2^32 - 1: whatever lies beyond is beyond the pair capacity anyway
+    auto sat = [](uint64_t v) -> uint32_t { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; };
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
-        offs[threadIdx.x * kPerThread + k] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
+        offs[threadIdx.x * kPerThread + k] = sat(run);
         run += c[k];
+        slot[threadIdx.x * kPerThread + k] = EmitSlot{(uint32_t)r[k].x0 | ((uint32_t)r[k].x1 << 16),
+                                                      (uint32_t)r[k].y0 | ((uint32_t)r[k].y1 << 16), gidx[k], sat(run)};
     }
-    if (threadIdx.x == kBlock - 1) offs[kChunk] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
+    if (threadIdx.x == kBlock - 1) offs[kChunk] = sat(run);
+    if (threadIdx.x < 2) slot[kChunk + threadIdx.x] = EmitSlot{0u, 0u, 0u, 0xFFFFFFFFu};   // the walk stops here
     __syncthreads();
 
     if (last && threadIdx.x == 0) {
@@ -215,41 +229,94 @@ __global__ void __launch_bounds__(kBlock)
         *ec.long_count = 0u;
     }
 
-    // ---- pair by pair: p-th pair of the chunk -> its Gaussian (largest rank with offs <= p) -> its tile
+    // ---- the chunk's pairs: every thread takes ONE run of consecutive pairs (8 L of them, L the same for the
+    //      whole workgroup), finds the Gaussian of its first pair by binary search (largest rank with offs <= p)
+    //      and then walks -- next row of the rectangle, next column, next Gaussian (one 16-byte LDS word, fetched
+    //      one Gaussian ahead) -- at ~8 instructions per pair.  (A search and an integer division per pair, as in
+    //      the first version of this kernel, were ~100.)  Runs are aligned in the GLOBAL pair index, so every 8
+    //      keys and 8 values are whole 16-byte words: wide stores, every byte written once.
     if (base >= (uint64_t)limit) return;   // speculative mode: the pair count exceeded the caller's hint
     const uint64_t room = (uint64_t)limit - base;
     const uint32_t npairs = (uint32_t)(chunk_total < room ? chunk_total : room);
-    const uint32_t out0 = (uint32_t)base;
+    if (npairs == 0) return;
+    const uint32_t out0 = (uint32_t)base, out1 = out0 + npairs;      // limit < 2^32: no wrap
     const uint32_t nwy = (uint32_t)g.nwy();
-    constexpr int kIlp = 4;                    // four searches in flight per thread: LDS latency overlaps
-    for (uint32_t p0 = threadIdx.x; p0 < npairs; p0 += kBlock * kIlp) {
-        uint32_t lo[kIlp], hi[kIlp];
+    const uint32_t q_first = out0 & ~7u;
+    const uint32_t run_len = 8u * (((out1 - q_first + (uint32_t)kBlock - 1u) / (uint32_t)kBlock + 7u) / 8u);
+    const uint32_t qb = q_first + threadIdx.x * run_len;
+    if (qb >= out1) return;
+    const uint32_t qa = max(qb, out0), qe = min(qb + run_len, out1);   // this thread's pairs: global [qa, qe)
+    uint32_t p = qa - out0;
+    uint32_t lo = 0, hi = kChunk;            // invariant: offs[lo] <= p < offs[hi]
 #pragma unroll
-        for (int u = 0; u < kIlp; ++u) {
-            lo[u] = 0;                         // invariant: offs[lo] <= p < offs[hi]
-            hi[u] = kChunk;
-        }
+    for (int s_ = 0; s_ < 10; ++s_) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const bool right = offs[mid] <= p;
+        lo = right ? mid : lo;
+        hi = right ? hi : mid;
+    }
+    const uint4 *slots = reinterpret_cast<const uint4 *>(slot);
+    uint4 cur = slots[lo], ahead = slots[lo + 1];     // (xs, ys, index, end)
+    uint32_t x0 = cur.x & 0xFFFFu, y0 = cur.y & 0xFFFFu, y1 = cur.y >> 16;
+    uint32_t tx, ty;
+    {
+        const uint32_t k = p - offs[lo], h = y1 - y0 + 1u;
+        tx = x0 + k / h;
+        ty = y0 + k % h;
+    }
+    uint32_t key = (tx - (uint32_t)g.wx0) * nwy + (ty - (uint32_t)g.wy0);
+    for (uint32_t q8 = qb; q8 < qe; q8 += 8u) {
+        uint32_t kk[8], vv[8];
 #pragma unroll
-        for (int s = 0; s < 10; ++s) {
-#pragma unroll
-            for (int u = 0; u < kIlp; ++u) {
-                const uint32_t p = min(p0 + (uint32_t)u * kBlock, npairs - 1u);
-                const uint32_t mid = (lo[u] + hi[u]) >> 1;
-                const bool right = offs[mid] <= p;
-                lo[u] = right ? mid : lo[u];
-                hi[u] = right ? hi[u] : mid;
+        for (uint32_t i = 0; i < 8u; ++i) {
+            const uint32_t q = q8 + i;
+            kk[i] = key;
+            vv[i] = cur.z;
+            if (q >= qa && q + 1u < qe) {        // step to pair p + 1 (there is one)
+                ++p;
+                if (p >= cur.w) {                // the next Gaussian that has tiles
+                    do {
+                        cur = ahead;
+                        ++lo;
+                        ahead = slots[lo + 1];
+                    } while (p >= cur.w);
+                    x0 = cur.x & 0xFFFFu;
+                    y0 = cur.y & 0xFFFFu;
+                    y1 = cur.y >> 16;
+                    tx = x0;
+                    ty = y0;
+                    key = (tx - (uint32_t)g.wx0) * nwy + (ty - (uint32_t)g.wy0);
+                } else if (ty == y1) {           // next column of the rectangle
+                    ty = y0;
+                    ++tx;
+                    key += nwy - (y1 - y0);
+                } else {
+                    ++ty;
+                    ++key;
+                }
             }
         }
+        if (q8 >= qa && q8 + 8u <= qe) {
+            if (sizeof(Key) == 2) {
+                *reinterpret_cast<uint4 *>(keys + q8) =
+                    make_uint4(kk[0] | (kk[1] << 16), kk[2] | (kk[3] << 16), kk[4] | (kk[5] << 16), kk[6] | (kk[7] << 16));
+            } else {
+                uint4 *dk = reinterpret_cast<uint4 *>(keys + q8);
+                dk[0] = make_uint4(kk[0], kk[1], kk[2], kk[3]);
+                dk[1] = make_uint4(kk[4], kk[5], kk[6], kk[7]);
+            }
+            uint4 *dv = reinterpret_cast<uint4 *>(vals + q8);
+            dv[0] = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+            dv[1] = make_uint4(vv[4], vv[5], vv[6], vv[7]);
+        } else {                                  // the ragged first / last 8 of the chunk
 #pragma unroll
-        for (int u = 0; u < kIlp; ++u) {
-            const uint32_t p = p0 + (uint32_t)u * kBlock;
-            if (p >= npairs) break;
-            const TileRect tr = srect[lo[u]];
-            const uint32_t k = p - offs[lo[u]];
-            const uint32_t h = (uint32_t)(tr.y1 - tr.y0 + 1);
-            const uint32_t tx = tr.x0 + k / h, ty = tr.y0 + k % h;
-            keys[out0 + p] = (Key)((tx - (uint32_t)g.wx0) * nwy + (ty - (uint32_t)g.wy0));
-            vals[out0 + p] = sgi[lo[u]];
+            for (uint32_t i = 0; i < 8u; ++i) {
+                const uint32_t q = q8 + i;
+                if (q >= qa && q < qe) {
+                    keys[q] = (Key)kk[i];
+                    vals[q] = vv[i];
+                }
+            }
         }
     }
 }
