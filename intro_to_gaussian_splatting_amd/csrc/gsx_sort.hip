@@ -75,25 +75,28 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t *spl, uint32_t k) {
     return lo;
 }
 
-// Every consumer workgroup of the partition pass derives the 255 splitters itself: scatter the samples to
-// their ranks in LDS, count the valid ones (dropped keys sort to the end), take regular quantiles.
-// spl[0] = 0; `sorted`: kSamples words of LDS scratch.  All threads of the workgroup must call this.
-__device__ __forceinline__ void derive_splitters(const uint32_t *__restrict__ samples, const uint32_t *__restrict__ ranks,
-                                                 uint32_t *sorted, uint32_t *spl, uint32_t *s_valid, int nthreads) {
-    if (threadIdx.x == 0) *s_valid = 0;
-    __syncthreads();
-    uint32_t mine = 0;
-    for (int k = threadIdx.x; k < kSamples; k += nthreads) {
-        const uint32_t v = samples[k];
-        sorted[ranks[k]] = v;
-        mine += v < kEmptyKey;
+// The same for N keys at once: the N searches advance in lock step, so their LDS reads are in flight together
+// (eight dependent reads in a row per key otherwise).
+template <int N>
+__device__ __forceinline__ void buckets_of(const uint32_t *spl, const uint32_t (&k)[N], uint32_t (&b)[N]) {
+    uint32_t lo[N], hi[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        lo[i] = 0;
+        hi[i] = 256;
     }
-    if (mine) atomicAdd(s_valid, mine);
-    __syncthreads();
-    const uint32_t sv = *s_valid;
-    if (threadIdx.x < kBins)
-        spl[threadIdx.x] = (threadIdx.x && sv) ? sorted[(uint32_t)(((uint64_t)threadIdx.x * sv) / kBins)] : 0u;
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const uint32_t mid = (lo[i] + hi[i]) >> 1;
+            const bool right = spl[mid] <= k[i];
+            lo[i] = right ? mid : lo[i];
+            hi[i] = right ? hi[i] : mid;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) b[i] = lo[i];
 }
 
 // Each thread owns kRounds CONSECUTIVE items of one chunk (one or two 16-byte loads) -- the histogram does
@@ -109,43 +112,43 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
                  uint32_t mask, uint32_t *__restrict__ table, int nbp, uint32_t *__restrict__ culled,
                  const uint32_t *__restrict__ splitters = nullptr) {
     constexpr int kLanes = CHUNK_MAJOR ? 1 : kQuad;   // chunks per workgroup
-    __shared__ uint32_t h[kLanes][kBins];
-    __shared__ uint32_t s_culled;
-    __shared__ uint32_t spl[SPLIT ? kBins : 1];
-    __shared__ uint32_t s_sorted[SPLIT ? kSamples : 1];
-    __shared__ uint32_t s_valid;
-    if (SPLIT) {   // splitters: (samples, ranks) follow the 256 splitter words; workgroup 0 publishes the splitters
-        derive_splitters(splitters + kBins, splitters + kBins + kSamples, s_sorted, spl, &s_valid,
-                         CHUNK_MAJOR ? kThreads : kQuad * kThreads);
-        if (blockIdx.x == 0 && threadIdx.x < kBins) const_cast<uint32_t *>(splitters)[threadIdx.x] = spl[threadIdx.x];
-    }
-    auto digit = [&](uint32_t k) -> uint32_t { return SPLIT ? bucket_of(spl, k) : ((k >> shift) & mask); };
-    const uint32_t n = load_count(n_dev, bound);
+    constexpr int kPerVec = 16 / sizeof(Key), kVecs = kRounds / kPerVec;   // 8 x u16 or 4 x u32 per 16 B
+    static_assert(kRounds % kPerVec == 0, "a thread's items must fill whole 16-byte vectors");
     const int c = CHUNK_MAJOR ? 0 : (int)(threadIdx.x >> 8);
     const uint32_t t = threadIdx.x & 255u;
     const uint32_t chunk = blockIdx.x * (uint32_t)kLanes + (uint32_t)c;
-    constexpr int kPerVec = 16 / sizeof(Key), kVecs = kRounds / kPerVec;   // 8 x u16 or 4 x u32 per 16 B
-    static_assert(kRounds % kPerVec == 0, "a thread's items must fill whole 16-byte vectors");
+    const uint32_t first = chunk * (uint32_t)kItems + t * (uint32_t)kRounds;
+    // the keys are requested first of all, before the element count is looked at (the grid covers the
+    // capacity `bound`) and before the splitters are put together: one trip to memory, not three in a row
+    uint4 q[kVecs];
+    if (first + kRounds <= bound) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(keys + first);   // first is a multiple of kRounds
+#pragma unroll
+        for (int v = 0; v < kVecs; ++v) q[v] = src[v];
+    }
+    __shared__ uint32_t h[kLanes][kBins];
+    __shared__ uint32_t s_culled;
+    __shared__ uint32_t spl[SPLIT ? kBins : 1];
+    if (SPLIT && threadIdx.x < kBins) spl[threadIdx.x] = splitters[threadIdx.x];   // visible after the barrier below
+    auto digit = [&](uint32_t k) -> uint32_t { return SPLIT ? bucket_of(spl, k) : ((k >> shift) & mask); };
     h[c][t] = 0;
     if (FIRST && threadIdx.x == 0) s_culled = 0;
     __syncthreads();
-    const uint32_t first = chunk * (uint32_t)kItems + t * (uint32_t)kRounds;
     uint32_t my_culled = 0;
+    const uint32_t n = load_count(n_dev, bound);
     if (first + kRounds <= n) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(keys + first);   // first is a multiple of kRounds
-        uint4 q[kVecs];
-#pragma unroll
-        for (int v = 0; v < kVecs; ++v) q[v] = src[v];
 #pragma unroll
         for (int v = 0; v < kVecs; ++v) {
             const uint32_t w4[4] = {q[v].x, q[v].y, q[v].z, q[v].w};
+            uint32_t d4[4] = {0, 0, 0, 0};
+            if (sizeof(Key) == 4 && SPLIT) buckets_of<4>(spl, w4, d4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (sizeof(Key) == 4) {
                     if (FIRST && w4[e] >= kEmptyKey)
                         my_culled += w4[e] == kCulledKey;
                     else
-                        atomicAdd(&h[c][digit(w4[e])], 1u);
+                        atomicAdd(&h[c][SPLIT ? d4[e] : digit(w4[e])], 1u);
                 } else {
                     atomicAdd(&h[c][((w4[e] & 0xFFFFu) >> shift) & mask], 1u);
                     atomicAdd(&h[c][((w4[e] >> 16) >> shift) & mask], 1u);
@@ -245,34 +248,42 @@ __global__ void __launch_bounds__(kThreads)
     __shared__ Key skey[kItems];
     __shared__ __attribute__((aligned(16))) uint32_t sval[kItems];   // 8 KB: also the 4 x 256 match words of the ranking
     static_assert(kItems * 4 == 4 * kBins * 8, "sval doubles as the per-wave match words");
-    const uint32_t n = load_count(n_dev, bound);
     const uint32_t block_base = blockIdx.x * (uint32_t)kItems;
-    if (block_base >= n) return;
+    if (block_base >= bound) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     constexpr uint32_t nbins = 1u << BITS, mask = nbins - 1u;
-    // this digit's row total and row prefix: issued now, needed after the ranking
-    uint32_t t_pre = 0, before_pre = 0;
-    if (!SELF_SCAN && (uint32_t)threadIdx.x < nbins) {
-        t_pre = totals[threadIdx.x];
-        before_pre = table[(size_t)threadIdx.x * nbp + blockIdx.x];
-    }
-    for (int k = threadIdx.x; k < 4 * kBins; k += kThreads) (&cnt[0][0])[k] = 0;
-    for (int k = threadIdx.x; k < kItems / 4; k += kThreads) reinterpret_cast<uint4 *>(sval)[k] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-
-    // ---- stable rank of every item among the same-digit items of its wave's consecutive slice
+    // Everything the workgroup reads is requested before the element count is looked at (the grid covers the
+    // capacity `bound`; what lies beyond the count is masked below): one trip to memory, not two in a row.
     const uint32_t wave_base = block_base + (uint32_t)w * kWaveItems;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     Key key[kRounds];
     uint32_t val[kRounds];
     bool ok[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
         const uint32_t i = wave_base + (uint32_t)r * 64 + lane;
-        ok[r] = i < n;
+        ok[r] = i < bound;
         key[r] = ok[r] ? kin[i] : (Key)0;
         // FIRST: the value of an item is its position (the Gaussian index): nothing to read
         val[r] = (MODE & kModeFirst) ? i : (ok[r] ? vin[i] : 0u);
+    }
+    // this digit's row total and row prefix: needed after the ranking
+    uint32_t t_pre = 0, before_pre = 0;
+    if (!SELF_SCAN && (uint32_t)threadIdx.x < nbins) {
+        t_pre = totals[threadIdx.x];
+        before_pre = table[(size_t)threadIdx.x * nbp + blockIdx.x];
+    }
+    const uint32_t n = load_count(n_dev, bound);
+    if (block_base >= n) return;
+    for (int k = threadIdx.x; k < 4 * kBins; k += kThreads) (&cnt[0][0])[k] = 0;
+    for (int k = threadIdx.x; k < kItems / 4; k += kThreads) reinterpret_cast<uint4 *>(sval)[k] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    // ---- stable rank of every item among the same-digit items of its wave's consecutive slice
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const uint32_t i = wave_base + (uint32_t)r * 64 + lane;
+        ok[r] = i < n;
         if (MODE & kModeFirst) ok[r] = ok[r] && (uint32_t)key[r] < kEmptyKey;
     }
     // The lanes of a wave that hold the same digit find each other through the LDS: every lane ORs its bit
@@ -286,10 +297,20 @@ __global__ void __launch_bounds__(kThreads)
     const unsigned long long me = 1ull << lane;
     uint16_t rank[kRounds];
     uint8_t dig[kRounds];
+    {
+        uint32_t kq[kRounds], dq[kRounds];
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            kq[r] = (uint32_t)key[r];
+            dq[r] = ((uint32_t)key[r] >> shift) & mask;
+        }
+        if (SPLIT) buckets_of<kRounds>(spl, kq, dq);
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) dig[r] = (uint8_t)dq[r];
+    }
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
-        const uint32_t d = SPLIT ? bucket_of(spl, (uint32_t)key[r]) : (((uint32_t)key[r] >> shift) & mask);
-        dig[r] = (uint8_t)d;
+        const uint32_t d = dig[r];
         rank[r] = 0;
         if (ok[r]) {
             __hip_atomic_fetch_or(&wm[d], me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -421,8 +442,8 @@ __global__ void __launch_bounds__(kThreads)
 
 // ------------------------------------------------------------------------------------------------------
 // Sample-partitioned depth sort (sort_depth_sampled): 6 kernels instead of the 12 of four LSD passes.
-//   sample    the rank of each of 2048 regularly spaced keys among them (sample_rank_kernel, all CUs); every
-//             workgroup of the partition's count kernel turns (samples, ranks) into 255 splitters in LDS;
+//   sample    2048 regularly spaced keys are ranked among themselves on all CUs (sample_rank_kernel); the
+//             samples that sit on the 255 regular quantiles are the splitters;
 //   partition ONE stable pass of the count / row_scan / scatter machinery above with the bucket among the
 //             splitters as the "digit" (FIRST mode: drops what reaches no tile, values = positions);
 //   buckets   one 1024-thread workgroup per bucket sorts its items in LDS -- only over the key bytes that
@@ -627,24 +648,39 @@ __device__ __forceinline__ void bucket_in_lds(uint32_t start, uint32_t size, uin
         key[r] = ok[r] ? kin[start + i] : 0u;
         val[r] = i;
     }
+    // what is staged after the sort is requested now (up to 8 rounds: 24 registers), so that its trip to memory
+    // runs under the passes
+    constexpr bool kEarly = R <= 8;
+    uint2 *lrect = reinterpret_cast<uint2 *>(items);
+    const uint2 *grect = reinterpret_cast<const uint2 *>(rrect + start);
+    uint2 t[R];
+    uint32_t v[R];
+    if (kEarly) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t j = (uint32_t)r * kBigThreads + threadIdx.x;
+            if (j < size) {
+                t[r] = grect[j];
+                v[r] = vin[start + j];
+            }
+        }
+    }
     key_span<R>(key, ok, s_min, s_max);
     const uint32_t kmin = *s_min, span = *s_max - kmin;
 #pragma unroll
     for (int r = 0; r < R; ++r) key[r] -= kmin;
     lds_passes<R, false>(key, val, ok, L, 0, span ? 32 - __clz((int)span) : 0, sh, items, items + kBucketCap);
     // val[r] = position in the bucket of the item of rank (w, r, lane).  Thread-strided staging: item j = r * 1024 + tid.
-    uint2 *lrect = reinterpret_cast<uint2 *>(items);
-    const uint2 *grect = reinterpret_cast<const uint2 *>(rrect + start);
     const bool together = size * 3u <= 2u * (uint32_t)kBucketCap;   // 12 bytes per item fit the buffer at once
     uint32_t *lval = together ? items + 2 * size : items;
-    uint2 t[R];
-    uint32_t v[R];
+    if (!kEarly) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t j = (uint32_t)r * kBigThreads + threadIdx.x;
-        if (j < size) {
-            t[r] = grect[j];
-            v[r] = vin[start + j];
+        for (int r = 0; r < R; ++r) {
+            const uint32_t j = (uint32_t)r * kBigThreads + threadIdx.x;
+            if (j < size) {
+                t[r] = grect[j];
+                v[r] = vin[start + j];
+            }
         }
     }
 #pragma unroll
@@ -680,17 +716,34 @@ __device__ __forceinline__ void bucket_in_lds(uint32_t start, uint32_t size, uin
     }
 }
 
-// ranks[i] = position of sample i (key at index i n / 2048) in the stable ascending order of the 2048 samples.
-// A single workgroup sorting them took 41 us (one CU doing 4 LDS radix passes); here every sample's rank is
-// counted directly -- #{j : s[j] < s[i]} + #{j < i : s[j] == s[i]} -- by 16 lanes that share the 2048
-// comparisons, 16 samples per workgroup, 128 workgroups: ~350 instructions per lane.
+// The 255 splitters of the partition pass: regular quantiles of 2048 regularly spaced keys (key at index
+// i n / 2048), splitters[j] = the valid sample of rank floor(j V / 256), V = number of valid samples (dropped keys
+// sort to the end), splitters[0] = 0.  A single workgroup sorting the samples took 41 us (one CU doing 4 LDS radix
+// passes); here every sample's rank is counted directly -- #{j : s[j] < s[i]} + #{j < i : s[j] == s[i]} -- by 16
+// lanes that share the 2048 comparisons, 16 samples per workgroup, 128 workgroups: ~350 instructions per lane;
+// the sample that finds itself on a quantile writes the splitter(s) it is.
 constexpr int kRankLanes = 16, kRankPerGroup = kThreads / kRankLanes;   // 16 samples per 256-thread workgroup
 __global__ void __launch_bounds__(kThreads)
-    sample_rank_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ samples,
-                       uint32_t *__restrict__ ranks) {
+    sample_rank_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ splitters) {
     __shared__ uint32_t sm[kSamples];
-    for (int k = threadIdx.x; k < kSamples; k += kThreads) sm[k] = keys[(uint32_t)(((uint64_t)k * n) / kSamples)];
+    __shared__ uint32_t s_valid;
+    if (threadIdx.x == 0) s_valid = 0;
     __syncthreads();
+    uint32_t mine = 0;
+    for (int k = threadIdx.x; k < kSamples; k += kThreads) {
+        const uint32_t v = keys[(uint32_t)(((uint64_t)k * n) / kSamples)];
+        sm[k] = v;
+        mine += v < kEmptyKey;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_valid, mine);
+    __syncthreads();
+    const uint32_t valid = s_valid;
+    if (valid == 0) {       // nothing reaches a tile: every key goes to bucket 0 (and is dropped there)
+        if (blockIdx.x == 0 && threadIdx.x < kBins) splitters[threadIdx.x] = 0u;
+        return;
+    }
     const uint32_t i = blockIdx.x * (uint32_t)kRankPerGroup + (threadIdx.x / kRankLanes);
     const uint32_t part = threadIdx.x % kRankLanes;
     const uint32_t v = sm[i];
@@ -702,10 +755,12 @@ __global__ void __launch_bounds__(kThreads)
     }
 #pragma unroll
     for (int o = kRankLanes / 2; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
-    if (part == 0) {
-        ranks[i] = c;
-        samples[i] = v;
+    if (part == 0 && c < valid) {
+        // the quantiles j with floor(j valid / 256) == c (none, one, or several when valid < 256)
+        for (uint32_t j = (c * (uint32_t)kBins + valid - 1u) / valid; j < (uint32_t)kBins && (j * valid) / kBins == c; ++j)
+            splitters[j] = j ? v : 0u;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) splitters[0] = 0u;
 }
 
 // One workgroup per bucket of the partition pass.  in: (kin, vin) partitioned by bucket, bucket sizes = the
@@ -1007,9 +1062,8 @@ hipError_t sort_depth_sampled(void *temp, uint32_t *keys0, uint32_t *keys1, uint
         return hipGetLastError();
     }
     const PassPlan p = plan_for(temp, n);
-    uint32_t *splitters = p.totals + kBins;            // behind the row totals: 256 splitters, 2048 samples, 2048 ranks
-    sample_rank_kernel<<<kSamples / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, splitters + kBins,
-                                                                     splitters + kBins + kSamples);
+    uint32_t *splitters = p.totals + kBins;            // behind the row totals: 256 splitters
+    sample_rank_kernel<<<kSamples / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, splitters);
     // partition: keys0 -> (keys1, vals_alt), values generated (FIRST)
     if (p.self_scan) {
         count_kernel<uint32_t, true, true, true><<<p.nblocks, kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u, p.table,
