@@ -82,8 +82,8 @@ int make_plan_or_fail(int32_t width, int32_t height, int32_t tile, float *out_im
 // synchronises ONCE, after the last launch, to report the counts and to detect D > capacity;
 // GSX_FLAG_NO_SYNC skips even that (the counts then arrive in pinned memory on their own).
 int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t cap, const gsx::TileRect *rrect,
-                  const uint32_t *order, const uint32_t *m_dev, const uint32_t *culled_dev, GsxFrameStats *stats,
-                  StageTimer &tm, hipStream_t s) {
+                  const uint32_t *order, const uint32_t *m_dev, const uint32_t *culled_dev, bool sums_ready,
+                  GsxFrameStats *stats, StageTimer &tm, hipStream_t s) {
     uint32_t *counters = (uint32_t *)(ws + c.counters);
     void *temp = ws + c.temp;
     int64_t *dev2 = (int64_t *)(counters + 4);
@@ -114,7 +114,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             }
         }
         GSX_HIP(gsx::emit_instances(temp, rrect, order, m_dev, n, cap, p.grid, ws + c.tkeys0, (uint32_t *)(ws + c.tvals0),
-                                    ranges, bc, s));
+                                    ranges, bc, sums_ready, s));
         counts_on_device = true;
         tm.mark();  // 3: scan + emit
         if (p.grid.count() == 0) {
@@ -265,7 +265,7 @@ int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t t
                                           p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 2: pack
     // rows are already in compositing order: the rectangles by row ARE the rectangles by rank
-    return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rect), nullptr, nullptr, nullptr, stats_host,
+    return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rect), nullptr, nullptr, nullptr, false, stats_host,
                          tm, s);
 }
 
@@ -296,15 +296,18 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
                                      (gsx::TileRect *)(ws + c.rect), counters,
                                      p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 1: project (+ depth keys)
-    if (gsx::depth_sort_is_sampled(n))
+    // the sampled sort also leaves the per-chunk tile counts the pair emission starts from (one kernel less)
+    const bool sampled = gsx::depth_sort_is_sampled(n);
+    if (sampled)
         GSX_HIP(gsx::sort_depth_sampled(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
-                                        (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), 0, s));
+                                        (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), 0,
+                                        gsx::emit_chunk_sums(ws + c.temp, n, cap), s));
     else
         GSX_HIP(gsx::sort_depth_compact(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
                                         (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s));
     tm.mark();  // 2: depth sort (drops what reaches no tile, leaves the rectangles in rank order)
     return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rrect), v0, counters + kCtrKept,
-                         counters + kCtrCulled, stats_host, tm, s);
+                         counters + kCtrCulled, sampled, stats_host, tm, s);
 }
 
 // Test hook (not part of include/gsx.h): the pipeline's radix sort on caller-provided pairs.
@@ -353,7 +356,7 @@ int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, void *rrec
     GSX_HIP(hipMemsetAsync(counters, 0, 64, s));
     if (mode == 1)
         GSX_HIP(gsx::sort_depth_sampled(temp, keys, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
-                                        (const gsx::TileRect *)rect, (gsx::TileRect *)rrect, lds_cap, s));
+                                        (const gsx::TileRect *)rect, (gsx::TileRect *)rrect, lds_cap, nullptr, s));
     else
         GSX_HIP(gsx::sort_depth_compact(temp, keys, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
                                         (const gsx::TileRect *)rect, (gsx::TileRect *)rrect, s));

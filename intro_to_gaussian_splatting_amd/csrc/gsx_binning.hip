@@ -497,11 +497,11 @@ static uint64_t *sums_of(void *temp, int64_t n, int64_t cap) {
 template <typename Key>
 hipError_t emit_impl(void *temp, const TileRect *rrect, const uint32_t *order, const uint32_t *m_dev, int64_t n,
                      int64_t cap, const TileGrid &grid, void *keys0, uint32_t *vals0, uint2 *ranges, const BinCounts &bc,
-                     hipStream_t s) {
+                     bool sums_ready, hipStream_t s) {
     const int64_t nt = grid.count();
     const int nchunks = (int)((n + kChunk - 1) / kChunk);
     uint64_t *sums = sums_of(temp, n, cap);
-    chunk_sums_kernel<<<nchunks, kBlock, 0, s>>>(rrect, m_dev, (uint32_t)n, sums);
+    if (!sums_ready) chunk_sums_kernel<<<nchunks, kBlock, 0, s>>>(rrect, m_dev, (uint32_t)n, sums);
     const EmitCounts ec{bc.stats2, bc.stats2_host, bc.d32, bc.long_count, bc.culled_dev, bc.n_total};
     const unsigned tiles_grid = blocks_for(nt);
     const unsigned egrid = (unsigned)nchunks > tiles_grid ? (unsigned)nchunks : tiles_grid;
@@ -536,11 +536,14 @@ hipError_t sort_impl(void *temp, int64_t cap, void *keys0, void *keys1, uint32_t
 
 hipError_t emit_instances(void *temp, const TileRect *rrect, const uint32_t *order, const uint32_t *m_dev, int64_t n,
                           int64_t cap, const TileGrid &grid, void *keys0, uint32_t *vals0, uint2 *ranges,
-                          const BinCounts &bc, hipStream_t s) {
+                          const BinCounts &bc, bool sums_ready, hipStream_t s) {
     if (n <= 0) return hipErrorInvalidValue;   // callers handle the empty scene themselves
-    if (grid.count() <= 65536) return emit_impl<uint16_t>(temp, rrect, order, m_dev, n, cap, grid, keys0, vals0, ranges, bc, s);
-    return emit_impl<uint32_t>(temp, rrect, order, m_dev, n, cap, grid, keys0, vals0, ranges, bc, s);
+    if (grid.count() <= 65536)
+        return emit_impl<uint16_t>(temp, rrect, order, m_dev, n, cap, grid, keys0, vals0, ranges, bc, sums_ready, s);
+    return emit_impl<uint32_t>(temp, rrect, order, m_dev, n, cap, grid, keys0, vals0, ranges, bc, sums_ready, s);
 }
+
+uint64_t *emit_chunk_sums(void *temp, int64_t n, int64_t cap) { return sums_of(temp, n, cap); }
 
 hipError_t sort_instances(void *temp, int64_t cap, const TileGrid &grid, void *keys0, void *keys1, uint32_t *vals0,
                           uint32_t *vals1, uint2 *ranges, const uint32_t *d32, const LongTiles &lt,

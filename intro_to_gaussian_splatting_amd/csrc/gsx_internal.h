@@ -101,10 +101,11 @@ struct BinCounts {
 // One (tile id, Gaussian index) pair per covered tile, in rank order, from the rank-ordered tile
 // rectangles rrect[0 .. m) (m = min(*m_dev, n); m_dev == nullptr: n).  order[r] = Gaussian index of rank
 // r (nullptr: the identity).  Also zeroes ranges[] and delivers the frame's counts (bc).  keys0 / vals0
-// hold cap 32-bit words each; pairs beyond cap are dropped.
+// hold cap 32-bit words each; pairs beyond cap are dropped.  sums_ready: emit_chunk_sums(temp, n, cap) already
+// holds the chunk sums (the sampled depth sort left them there).
 hipError_t emit_instances(void *temp, const TileRect *rrect, const uint32_t *order, const uint32_t *m_dev, int64_t n,
                           int64_t cap, const TileGrid &grid, void *keys0, uint32_t *vals0, uint2 *ranges,
-                          const BinCounts &bc, hipStream_t s);
+                          const BinCounts &bc, bool sums_ready, hipStream_t s);
 // Stable sort of the emitted pairs by tile id and ranges[t] = [first, last) for every tile of the
 // window; *sorted_vals points at the sorted Gaussian indices.  The pair count is read from *d32.
 hipError_t sort_instances(void *temp, int64_t cap, const TileGrid &grid, void *keys0, void *keys1, uint32_t *vals0,
@@ -138,7 +139,9 @@ hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint
 bool depth_sort_is_sampled(int64_t n);
 hipError_t sort_depth_sampled(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
-                              uint32_t lds_cap, hipStream_t s);
+                              uint32_t lds_cap, uint64_t *chunk_sums, hipStream_t s);
+// Where emit_instances keeps its chunk sums inside `temp` (for sort_depth_sampled to fill them in).
+uint64_t *emit_chunk_sums(void *temp, int64_t n, int64_t cap);
 
 // ---- gsx_sh.hip
 hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, int64_t n, const float *center,

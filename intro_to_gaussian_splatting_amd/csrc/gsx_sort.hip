@@ -581,26 +581,58 @@ __device__ __forceinline__ uint32_t lds_passes(uint32_t (&key)[R], uint32_t (&va
     return m;
 }
 
+// chunk_sums[c] += tile counts of the ranks of chunk c (kEmitChunk consecutive depth ranks: what the pair
+// emission needs of the rank-ordered rectangles before it can start; fused into the sort's last kernel it saves
+// the frame a launch).  A wave's ranks are the L <= 1024 consecutive ones from `wave_first`, i.e. at most two
+// chunks: every lane adds up its own rounds (ChunkTally::add), then ONE pair of wave reductions and at most two
+// atomics per wave (ChunkTally::flush; a reduction per round cost 4 us in dependent cross-lane steps).
+struct ChunkTally {
+    uint32_t chunk0, a, b;      // 64 x 16 x 65 535 tiles fit 32 bits
+    __device__ __forceinline__ explicit ChunkTally(uint32_t wave_first) : chunk0(wave_first / (uint32_t)kEmitChunk), a(0), b(0) {}
+    __device__ __forceinline__ void add(uint32_t rank, bool have, uint2 rc) {
+        const uint32_t x0 = rc.x & 0xFFFFu, x1 = rc.x >> 16, y0 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
+        const uint32_t tiles = (have && x0 <= x1) ? (x1 - x0 + 1u) * (y1 - y0 + 1u) : 0u;
+        const bool in0 = rank / (uint32_t)kEmitChunk == chunk0;
+        a += in0 ? tiles : 0u;
+        b += in0 ? 0u : tiles;
+    }
+    __device__ __forceinline__ void flush(unsigned long long *__restrict__ chunk_sums) {   // all 64 lanes
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += (uint32_t)__shfl_xor((int)a, o);
+            b += (uint32_t)__shfl_xor((int)b, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (a) atomicAdd(&chunk_sums[chunk0], (unsigned long long)a);
+            if (b) atomicAdd(&chunk_sums[chunk0 + 1u], (unsigned long long)b);
+        }
+    }
+};
+
 // vout[first + i] = val, rrect[first + i] = rect[val] for the items in registers.  All the rectangle loads
 // are issued before the first store: with load and store of one item back to back the compiler waits for
 // every gather in turn (15 us of a 43 us kernel at 1M keys).
 template <int R>
 __device__ __forceinline__ void store_ranked(const uint32_t (&val)[R], const bool (&ok)[R], uint32_t L, uint32_t first,
                                              uint32_t *__restrict__ vout, const TileRect *__restrict__ rect,
-                                             TileRect *__restrict__ rrect) {
+                                             TileRect *__restrict__ rrect, unsigned long long *__restrict__ chunk_sums) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     TileRect rc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (ok[r]) rc[r] = rect[val[r]];
+    ChunkTally tally(first + (uint32_t)w * L);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
         if (ok[r]) {
             vout[first + i] = val[r];
             rrect[first + i] = rc[r];
+            tally.add(first + i, true, make_uint2((uint32_t)rc[r].x0 | ((uint32_t)rc[r].x1 << 16),
+                                                  (uint32_t)rc[r].y0 | ((uint32_t)rc[r].y1 << 16)));
         }
     }
+    if (chunk_sums) tally.flush(chunk_sums);
 }
 
 // Minimum and maximum of the valid keys over the workgroup (s_min / s_max preset to ~0 / 0 before a barrier).
@@ -637,7 +669,8 @@ __device__ __forceinline__ void key_span(const uint32_t (&key)[R], const bool (&
 template <int R>
 __device__ __forceinline__ void bucket_in_lds(uint32_t start, uint32_t size, uint32_t L, const uint32_t *kin,
                                               const uint32_t *vin, uint32_t *vout, TileRect *rrect, RankShared &sh,
-                                              uint32_t *items, uint32_t *s_min, uint32_t *s_max) {
+                                              uint32_t *items, uint32_t *s_min, uint32_t *s_max,
+                                              unsigned long long *chunk_sums) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t key[R], val[R];
     bool ok[R];
@@ -692,14 +725,18 @@ __device__ __forceinline__ void bucket_in_lds(uint32_t start, uint32_t size, uin
         }
     }
     __syncthreads();
+    ChunkTally tally(start + (uint32_t)w * L);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
         if (ok[r]) {
-            reinterpret_cast<uint2 *>(rrect + start)[i] = lrect[val[r]];
+            const uint2 rc = lrect[val[r]];
+            reinterpret_cast<uint2 *>(rrect + start)[i] = rc;
             if (together) vout[start + i] = lval[val[r]];
+            tally.add(start + i, true, rc);
         }
     }
+    if (chunk_sums) tally.flush(chunk_sums);
     if (R == kBucketRounds && !together) {   // a bucket beyond 2/3 of the buffer: the indices take a second trip
         __syncthreads();
 #pragma unroll
@@ -724,9 +761,13 @@ __device__ __forceinline__ void bucket_in_lds(uint32_t start, uint32_t size, uin
 // the sample that finds itself on a quantile writes the splitter(s) it is.
 constexpr int kRankLanes = 16, kRankPerGroup = kThreads / kRankLanes;   // 16 samples per 256-thread workgroup
 __global__ void __launch_bounds__(kThreads)
-    sample_rank_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ splitters) {
+    sample_rank_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ splitters,
+                       unsigned long long *__restrict__ chunk_sums, uint32_t nsums) {
     __shared__ uint32_t sm[kSamples];
     __shared__ uint32_t s_valid;
+    // the chunk sums the bucket kernel adds to start from zero (the first kernel of the sort has threads to spare)
+    for (uint32_t k = blockIdx.x * (uint32_t)kThreads + threadIdx.x; chunk_sums && k < nsums; k += gridDim.x * (uint32_t)kThreads)
+        chunk_sums[k] = 0ull;
     if (threadIdx.x == 0) s_valid = 0;
     __syncthreads();
     uint32_t mine = 0;
@@ -769,7 +810,8 @@ __global__ void __launch_bounds__(kThreads)
 __global__ void __launch_bounds__(kBigThreads)
     bucket_sort_kernel(const uint32_t *__restrict__ totals, const uint32_t *__restrict__ table_cm, int nblocks_cm,
                        uint32_t *kin, uint32_t *vin, uint32_t *kalt, uint32_t *vout,
-                       const TileRect *__restrict__ rect, TileRect *rrect, uint32_t lds_cap) {
+                       const TileRect *__restrict__ rect, TileRect *rrect, uint32_t lds_cap,
+                       unsigned long long *__restrict__ chunk_sums) {
     __shared__ RankShared sh;
     __shared__ __attribute__((aligned(16))) uint32_t sitems[2 * kBucketCap];
     uint32_t *skey = sitems;
@@ -815,13 +857,13 @@ __global__ void __launch_bounds__(kBigThreads)
         // ---- in LDS: items wave-striped, L per wave, as few rounds of 64 per wave as hold them
         const uint32_t L = (((size + kBigWaves - 1) / kBigWaves) + 63u) & ~63u;
         if (L <= 2 * 64)
-            bucket_in_lds<2>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max);
+            bucket_in_lds<2>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums);
         else if (L <= 4 * 64)
-            bucket_in_lds<4>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max);
+            bucket_in_lds<4>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums);
         else if (L <= 8 * 64)
-            bucket_in_lds<8>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max);
+            bucket_in_lds<8>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums);
         else
-            bucket_in_lds<kBucketRounds>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max);
+            bucket_in_lds<kBucketRounds>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums);
         return;
     }
     // ---- through global memory (a bucket that does not fit): LSD passes over the varying bytes, tile by tile
@@ -885,10 +927,17 @@ __global__ void __launch_bounds__(kBigThreads)
         uint32_t *tv = sv; sv = dv; dv = tv;
     }
     // the sorted values now sit in sv: they belong in vout, with their rectangles beside them
-    for (uint32_t i = threadIdx.x; i < size; i += kBigThreads) {
-        const uint32_t v = sv[i];
-        if (sv != vout + start) vout[start + i] = v;
-        rrect[start + i] = rect[v];
+    for (uint32_t i0 = 0; i0 < size; i0 += kBigThreads) {     // (each trip: 64 consecutive ranks per wave)
+        const uint32_t i = i0 + threadIdx.x;
+        ChunkTally tally(start + i0 + (uint32_t)w * 64u);
+        if (i < size) {
+            const uint32_t v = sv[i];
+            if (sv != vout + start) vout[start + i] = v;
+            const uint2 rc = reinterpret_cast<const uint2 *>(rect)[v];
+            reinterpret_cast<uint2 *>(rrect)[start + i] = rc;
+            tally.add(start + i, true, rc);
+        }
+        if (chunk_sums) tally.flush(chunk_sums);
     }
 }
 
@@ -900,7 +949,8 @@ __device__ __forceinline__ void small_sort_in_lds(const uint32_t *__restrict__ k
                                                   uint32_t *__restrict__ vout, const TileRect *__restrict__ rect,
                                                   TileRect *__restrict__ rrect, uint32_t *__restrict__ m_out,
                                                   uint32_t *__restrict__ culled_out, RankShared &sh, uint32_t *skey,
-                                                  uint32_t *sval, uint32_t *s_min, uint32_t *s_max, uint32_t *s_culled) {
+                                                  uint32_t *sval, uint32_t *s_min, uint32_t *s_max, uint32_t *s_culled,
+                                                  unsigned long long *__restrict__ chunk_sums) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t key[R], val[R];
     bool ok[R];
@@ -923,7 +973,7 @@ __device__ __forceinline__ void small_sort_in_lds(const uint32_t *__restrict__ k
     for (int r = 0; r < R; ++r) key[r] -= kmin;
     // one pass at least: the first pass is also what compacts
     const uint32_t m = lds_passes<R, true>(key, val, ok, L, 0, span ? 32 - __clz((int)span) : 1, sh, skey, sval);
-    store_ranked<R>(val, ok, L, 0u, vout, rect, rrect);
+    store_ranked<R>(val, ok, L, 0u, vout, rect, rrect, chunk_sums);
     if (threadIdx.x == 0) {
         *m_out = m;
         *culled_out = *s_culled;
@@ -933,7 +983,7 @@ __device__ __forceinline__ void small_sort_in_lds(const uint32_t *__restrict__ k
 __global__ void __launch_bounds__(kBigThreads)
     small_depth_sort_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ vout,
                             const TileRect *__restrict__ rect, TileRect *__restrict__ rrect, uint32_t *__restrict__ m_out,
-                            uint32_t *__restrict__ culled_out) {
+                            uint32_t *__restrict__ culled_out, unsigned long long *__restrict__ chunk_sums) {
     __shared__ RankShared sh;
     __shared__ uint32_t skey[kBucketCap];
     __shared__ uint32_t sval[kBucketCap];
@@ -943,17 +993,19 @@ __global__ void __launch_bounds__(kBigThreads)
         s_max = 0;
         s_culled = 0;
     }
+    // the chunk sums this kernel adds to at the end start from zero (n <= 16 384: at most 17 of them)
+    if (chunk_sums && threadIdx.x <= (n + (uint32_t)kEmitChunk - 1u) / (uint32_t)kEmitChunk) chunk_sums[threadIdx.x] = 0ull;
     __syncthreads();
     const uint32_t L = (((n + kBigWaves - 1) / kBigWaves) + 63u) & ~63u;
     if (L <= 2 * 64)
-        small_sort_in_lds<2>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled);
+        small_sort_in_lds<2>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled, chunk_sums);
     else if (L <= 4 * 64)
-        small_sort_in_lds<4>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled);
+        small_sort_in_lds<4>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled, chunk_sums);
     else if (L <= 8 * 64)
-        small_sort_in_lds<8>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled);
+        small_sort_in_lds<8>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled, chunk_sums);
     else
         small_sort_in_lds<kBucketRounds>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max,
-                                         &s_culled);
+                                         &s_culled, chunk_sums);
 }
 
 struct PassPlan {
@@ -1052,18 +1104,21 @@ bool depth_sort_is_sampled(int64_t n) {
 
 // Same contract as sort_depth_compact.  keys0 / keys1 / vals: n words each; on return vals_cur[0 .. *m_dev)
 // = Gaussian index of each depth rank, rrect[rank] = rect[index].  lds_cap: bucket size above which the
-// through-memory path is taken (tests shrink it).
+// through-memory path is taken (tests shrink it).  chunk_sums (or nullptr): ceil(n / 1024) + 1 words that receive
+// the tile count of every 1024 consecutive ranks -- what chunk_sums_kernel would compute from rrect.
 hipError_t sort_depth_sampled(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
-                              uint32_t lds_cap, hipStream_t s) {
+                              uint32_t lds_cap, uint64_t *chunk_sums, hipStream_t s) {
     if (n <= 0) return hipSuccess;
+    unsigned long long *cs = reinterpret_cast<unsigned long long *>(chunk_sums);
     if (n <= kBucketCap && lds_cap == 0) {   // everything fits one workgroup's LDS: one launch
-        small_depth_sort_kernel<<<1, kBigThreads, 0, s>>>(keys0, (uint32_t)n, vals_cur, rect, rrect, m_dev, culled_dev);
+        small_depth_sort_kernel<<<1, kBigThreads, 0, s>>>(keys0, (uint32_t)n, vals_cur, rect, rrect, m_dev, culled_dev, cs);
         return hipGetLastError();
     }
     const PassPlan p = plan_for(temp, n);
     uint32_t *splitters = p.totals + kBins;            // behind the row totals: 256 splitters
-    sample_rank_kernel<<<kSamples / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, splitters);
+    sample_rank_kernel<<<kSamples / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, splitters, cs,
+                                                                     (uint32_t)((n + kEmitChunk - 1) / kEmitChunk) + 1u);
     // partition: keys0 -> (keys1, vals_alt), values generated (FIRST)
     if (p.self_scan) {
         count_kernel<uint32_t, true, true, true><<<p.nblocks, kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u, p.table,
@@ -1079,7 +1134,7 @@ hipError_t sort_depth_sampled(void *temp, uint32_t *keys0, uint32_t *keys1, uint
     }
     if (lds_cap == 0 || lds_cap > (uint32_t)kBucketCap) lds_cap = kBucketCap;
     bucket_sort_kernel<<<kBins, kBigThreads, 0, s>>>(p.totals, p.table, p.self_scan ? p.nblocks : 0, keys1, vals_alt, keys0,
-                                                    vals_cur, rect, rrect, lds_cap);
+                                                    vals_cur, rect, rrect, lds_cap, cs);
     return hipGetLastError();
 }
 
