@@ -62,6 +62,25 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
     return start + i;
 }
 
+// Which tile does tile workgroup b composite?  All the tile workgroups of a frame of up to ~8 000 tiles are
+// resident at once (one wave each, 8 per SIMD), so a SIMD is busy for as long as the lists of ITS tiles take: with
+// a schedule (sched[k] = tile with the k-th longest list, tile_schedule_kernel) the tiles are handed out by list
+// length.  Workgroups b and b + 1024 land on the same SIMD (measured: XCD = b % 8, then round-robin over the XCD's
+// 128 SIMDs; workgroups ahead of the tiles in the grid come in multiples of 1024), so round r of 1024 workgroups
+// takes the r-th 1024 tiles of the falling-length order, alternately forwards and backwards: every SIMD gets one
+// tile of every length class and the sums even out (busiest SIMD / mean 1.11 -> 1.01 list entries at 1M Gaussians).
+// The price: neighbouring tiles no longer share an XCD's L2, the record gather misses more (610 MB instead of
+// ~200 MB per frame at 1M Gaussians, 2.3 TB/s) -- the kernel is VALU-bound and 33 us faster all the same.  (Tiles
+// dealt to the XCDs in two-column chunks and ranked inside each XCD: 460 MB, but 270 us instead of 262, and a
+// 16 us schedule kernel; better only on the clustered scene.)  Without a schedule: index order, a contiguous
+// eighth of the tiles per XCD.
+__device__ __forceinline__ uint32_t scheduled_tile(uint32_t b, uint32_t nt, const uint32_t *__restrict__ sched) {
+    if (!sched) return xcd_remap(b, nt);
+    const uint32_t round = b >> 10, slot = b & 1023u;
+    const uint32_t in_round = min(1024u, nt - (round << 10));
+    return sched[(round << 10) + ((round & 1u) ? in_round - 1u - slot : slot)];
+}
+
 // Pixels of the output buffer that no tile of the window covers are zeroed by extra workgroups of the
 // compositing launch itself (blockIdx >= number of tiles): no memset nodes on the frame path -- they cost
 // a 5 us dispatch each, and a hipGraph memset node replayed on another stream than the one it was
@@ -365,20 +384,7 @@ __global__ void __launch_bounds__(64)
         return;
     }
     const int lane = threadIdx.x;
-    // Which tile?  All the tile workgroups of a frame of up to ~8 000 tiles are resident at once (one wave
-    // each, 8 per SIMD), so a SIMD is busy for as long as the lists of ITS tiles take: the tiles are handed out
-    // by list length.  Workgroups b and b + 1024 land on the same SIMD (measured: XCD = b % 8, then round-robin
-    // over the XCD's 128 SIMDs; nhelpers is a multiple of 1024), so round r of 1024 workgroups takes the r-th
-    // 1024 tiles of the falling-length order, alternately forwards and backwards: every SIMD gets one tile of
-    // every length class and the sums even out (busiest SIMD / mean 1.11 -> 1.01 list entries at 1M Gaussians).
-    uint32_t t;
-    if (sched) {
-        const uint32_t nt = (uint32_t)g.count(), round = bid >> 10, slot = bid & 1023u;
-        const uint32_t in_round = min(1024u, nt - (round << 10));
-        t = sched[(round << 10) + ((round & 1u) ? in_round - 1u - slot : slot)];
-    } else {
-        t = xcd_remap(bid, (uint32_t)g.count());
-    }
+    const uint32_t t = scheduled_tile(bid, (uint32_t)g.count(), sched);
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     // WH3: lanes 4q..4q+3 cover one x (contiguous 192 B); HW3: lanes 16q..16q+15 cover one y-quad
     const bool y_contig = out.stride_y < out.stride_x;
@@ -654,14 +660,15 @@ __global__ void __launch_bounds__(64)
 // give bit-identical frames (tested).  Pixels outside the frame (partial edge tiles) start dead.
 __global__ void __launch_bounds__(64)
     blend_std16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
-                       const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, float bg0, float bg1, float bg2, ClearPlan cp) {
+                       const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, float bg0, float bg1, float bg2, ClearPlan cp,
+                       const uint32_t *__restrict__ sched) {
     __shared__ float4 sh[3][64];
     if (blockIdx.x >= (uint32_t)g.count()) {
         clear_block(blockIdx.x - (uint32_t)g.count(), cp, out.ptr);
         return;
     }
     const int lane = threadIdx.x;
-    const uint32_t t = xcd_remap(blockIdx.x, (uint32_t)g.count());
+    const uint32_t t = scheduled_tile(blockIdx.x, (uint32_t)g.count(), sched);
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     const bool y_contig = out.stride_y < out.stride_x;
     const int px = tx * 16 + (y_contig ? (lane >> 2) : (lane & 15));
@@ -757,7 +764,7 @@ bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int6
         const char *e = getenv("GSX_TILE_SCHEDULE");   // measurement knob: "0" never, "1" always
         return e ? (e[0] == '0' ? 0 : 1) : -1;
     }();
-    if (semantics != GSX_SEM_REF_CPU || grid.tile != 16 || generic || forced == 0) return false;
+    if ((semantics != GSX_SEM_REF_CPU && semantics != GSX_SEM_STD_3DGS) || grid.tile != 16 || generic || forced == 0) return false;
     return forced == 1 || n >= 300000;
 }
 
@@ -774,7 +781,7 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
     if (semantics == GSX_SEM_STD_3DGS) {
         if (grid.tile == 16 && !generic) {
             blend_std16_kernel<<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, background[0], background[1],
-                                                 background[2], cp);
+                                                 background[2], cp, sched);
             return hipGetLastError();
         }
         blend_rules_kernel<GSX_SEM_STD_3DGS><<<nb, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, background[0],
