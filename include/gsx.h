@@ -151,6 +151,15 @@ typedef struct GsxParams {
  * for tests that hold the two paths against each other. */
 #define GSX_FLAG_NO_LONG_TILE_SPLIT 16
 
+/* Tile 16, GSX_SEM_REF_CPU / GSX_SEM_STD_3DGS.  All the tile workgroups of a 1080p frame are resident at once, so
+ * a SIMD is busy for as long as the lists of its own tiles take; frames of >= 300 000 Gaussians therefore run one
+ * more small kernel that ranks the tiles by list length, and the compositing launch hands them out so that every
+ * SIMD gets its share of every length class.  Which workgroup composites which tile does
+ * not touch a pixel: the frame is the same bit for bit.  GSX_FLAG_TILE_SCHEDULE asks for the schedule whatever
+ * the size of the scene, GSX_FLAG_NO_TILE_SCHEDULE never builds it (tests hold the two against each other). */
+#define GSX_FLAG_TILE_SCHEDULE 32
+#define GSX_FLAG_NO_TILE_SCHEDULE 64
+
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
 enum {
     GSX_STAGE_PROJECT = 0,    /* projection, depth keys, record packing         */

@@ -29,6 +29,8 @@ GSX_FLAG_NO_SYNC = 2
 GSX_FLAG_GENERIC_KERNELS = 4
 GSX_FLAG_PUBLISHED_RECTS = 8
 GSX_FLAG_NO_LONG_TILE_SPLIT = 16
+GSX_FLAG_TILE_SCHEDULE = 32
+GSX_FLAG_NO_TILE_SCHEDULE = 64
 STAGE_NAMES = ("project", "depth_sort", "scan", "bin", "blend", "total")
 
 

@@ -127,7 +127,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
                                         (uint32_t *)(ws + c.tvals1), ranges, counters + kCtrPairs, lt, &sorted_vals, s));
             if (p.tile_counts) GSX_HIP(gsx::launch_tile_counts(ranges, p.grid.count(), p.tile_counts, s));
             uint32_t *sched = nullptr;
-            if (cap > 0 && gsx::blend_uses_schedule(p.grid, p.semantics, p.generic, n)) {
+            if (cap > 0 && gsx::blend_uses_schedule(p.grid, p.semantics, p.generic, n, p.schedule)) {
                 sched = (uint32_t *)(ws + c.sched);
                 GSX_HIP(gsx::launch_tile_schedule(ranges, p.grid.count(), sched, s));
             }

@@ -759,13 +759,15 @@ bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic) 
 // The schedule is one more kernel on the frame's critical path (5 .. 10 us): it pays when the compositing
 // kernel runs for 100+ us (1M Gaussians at 1080p: -33 us of compositing), not for the small scenes (100 000
 // Gaussians: -3 us).  D is not known on the host; the Gaussian count is.
-bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int64_t n) {
+bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int64_t n, int asked) {
     static const int forced = [] {
         const char *e = getenv("GSX_TILE_SCHEDULE");   // measurement knob: "0" never, "1" always
         return e ? (e[0] == '0' ? 0 : 1) : -1;
     }();
-    if ((semantics != GSX_SEM_REF_CPU && semantics != GSX_SEM_STD_3DGS) || grid.tile != 16 || generic || forced == 0) return false;
-    return forced == 1 || n >= 300000;
+    if ((semantics != GSX_SEM_REF_CPU && semantics != GSX_SEM_STD_3DGS) || grid.tile != 16 || generic) return false;
+    if (asked >= 0) return asked != 0;          // GSX_FLAG_TILE_SCHEDULE / GSX_FLAG_NO_TILE_SCHEDULE
+    if (forced >= 0) return forced != 0;
+    return n >= 300000;
 }
 
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,

@@ -152,7 +152,8 @@ hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, i
 // cp: what the launch zeroes besides compositing its tiles (extra workgroups of the same kernel).
 // lt: long tiles split over four waves (GSX_SEM_REF_CPU, tile 16 only; lt.max == 0 otherwise).
 // sched: launch_tile_schedule's order, or nullptr (tiles in index order); used by the tile-16 REF_CPU kernel.
-bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int64_t n);
+// asked: Plan.schedule (1 / 0 from the caller's flags, -1: by the size of the scene).
+bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int64_t n, int asked);
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
                         bool generic, const ClearPlan &cp, const LongTiles &lt, const uint32_t *sched, hipStream_t s);

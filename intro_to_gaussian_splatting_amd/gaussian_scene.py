@@ -248,7 +248,7 @@ class GaussianScene:
                          generic_kernels: bool = False, published_rects: bool = False,
                          camera_buffer: Optional[torch.Tensor] = None,
                          tile_counts: Optional[torch.Tensor] = None, split_long_tiles: bool = True,
-                         _private: Optional[dict] = None) -> torch.Tensor:
+                         tile_schedule: Optional[bool] = None, _private: Optional[dict] = None) -> torch.Tensor:
         """Full forward render in libgsx (gsx_render_forward).
 
         semantics: "ref_cpu" (the reference's ``render_image``), "ref_cuda" (its CUDA kernel's rules
@@ -287,6 +287,8 @@ class GaussianScene:
             params.flags |= _ffi.GSX_FLAG_GENERIC_KERNELS
         if not split_long_tiles:   # tests: every tile on one wave (same pixels as the four-wave path of long tiles)
             params.flags |= _ffi.GSX_FLAG_NO_LONG_TILE_SPLIT
+        if tile_schedule is not None:   # tiles handed out by list length (default: scenes of >= 300 000 Gaussians)
+            params.flags |= _ffi.GSX_FLAG_TILE_SCHEDULE if tile_schedule else _ffi.GSX_FLAG_NO_TILE_SCHEDULE
         if published_rects:     # std_3dgs: bin with the published 3-sigma squares (same pixels, longer lists)
             params.flags |= _ffi.GSX_FLAG_PUBLISHED_RECTS
         if camera_buffer is not None:   # GsxParams.camera_device: the kernels read the camera from this buffer
@@ -371,7 +373,7 @@ class GaussianScene:
                 image_idx=image_idx, tile_size=tile_size, layout=layout, tile_window=tile_window, out=out,
                 out_origin=out_origin, semantics=semantics, background=background,
                 generic_kernels=generic_kernels, published_rects=published_rects, camera_buffer=camera_buffer,
-                tile_counts=tile_counts, split_long_tiles=split_long_tiles)))
+                tile_counts=tile_counts, split_long_tiles=split_long_tiles, tile_schedule=tile_schedule)))
             if stats is not None:
                 stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
             return out

@@ -404,6 +404,39 @@ def test_long_tiles_on_four_waves_equal_the_single_wave_path(tmp_path):
     assert torch.equal(s2, scene2.render_image_hip(1, split_long_tiles=False))
 
 
+def test_tiles_handed_out_by_list_length_render_the_same_frame(tmp_path):
+    """GSX_FLAG_TILE_SCHEDULE: one more kernel ranks the tiles by list length and the compositing launch hands
+    them to the SIMDs in that order (default from 300 000 Gaussians up).  Which workgroup composites which tile
+    must not touch a pixel: both rule sets, both layouts, a tile window, a captured frame, a frame with long
+    tiles and an empty frame equal the unscheduled frame bit for bit -- i.e. the schedule is a permutation of
+    the tiles whatever their lengths (a tile missed or taken twice would show)."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    w, h = 640, 400
+    sc = make_scene(60_000, w, h, seed=11, cluster_fraction=0.5, cluster_area=0.05, sigma_ln=1.0, behind_fraction=0.1)
+    scene = _scene_from_arrays(tmp_path, sc)
+    for semantics in ("ref_cpu", "std_3dgs"):
+        for layout in ("wh3", "hw3"):
+            plain = scene.render_image_hip(1, layout=layout, semantics=semantics, tile_schedule=False)
+            ranked = scene.render_image_hip(1, layout=layout, semantics=semantics, tile_schedule=True)
+            assert plain.abs().sum() > 0 and torch.equal(plain, ranked), (semantics, layout)
+    plain = scene.render_image_hip(1, tile_schedule=False)
+    part = scene.render_image_hip(1, tile_window=(3, 29, 1, 17), tile_schedule=True)
+    assert torch.equal(part[48:464, 16:272], plain[48:464, 16:272])
+    one_wave = scene.render_image_hip(1, tile_schedule=True, split_long_tiles=False)
+    assert torch.equal(one_wave, plain)
+    # a window of a single tile, and tile counts that are no multiple of anything
+    tiny = scene.render_image_hip(1, tile_window=(20, 21, 12, 13), tile_schedule=True)
+    assert torch.equal(tiny[320:336, 192:208], plain[320:336, 192:208])
+    # nothing in view: every list is empty, the schedule is still a permutation and the frame is zero
+    (tmp_path / "behind").mkdir()
+    behind = make_scene(5_000, w, h, seed=12, behind_fraction=1.0)
+    st = {}
+    empty = _scene_from_arrays(tmp_path / "behind", behind).render_image_hip(1, tile_schedule=True, stats=st)
+    assert st["n_instances"] == 0 and float(empty.abs().sum()) == 0.0
+
+
 @pytest.mark.parametrize("n,mode,lds_cap,kind", [
     (16_384, 1, 0, "random"), (20_001, 1, 0, "random"), (100_003, 1, 0, "depth"), (131_072, 1, 0, "random"),
     (131_073, 1, 0, "depth"), (1_000_000, 1, 0, "depth"), (1_000_000, 0, 0, "depth"), (2_200_000, 1, 0, "random"),
