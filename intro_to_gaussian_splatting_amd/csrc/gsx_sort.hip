@@ -118,10 +118,11 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     const uint32_t t = threadIdx.x & 255u;
     const uint32_t chunk = blockIdx.x * (uint32_t)kLanes + (uint32_t)c;
     const uint32_t first = chunk * (uint32_t)kItems + t * (uint32_t)kRounds;
-    // the keys are requested first of all, before the element count is looked at (the grid covers the
-    // capacity `bound`) and before the splitters are put together: one trip to memory, not three in a row
+    // the keys are requested before the splitters are loaded -- but not before the element count is known: the
+    // grid covers the capacity `bound`, which may be many times the count
+    const uint32_t n = load_count(n_dev, bound);
     uint4 q[kVecs];
-    if (first + kRounds <= bound) {
+    if (first + kRounds <= n) {
         const uint4 *src = reinterpret_cast<const uint4 *>(keys + first);   // first is a multiple of kRounds
 #pragma unroll
         for (int v = 0; v < kVecs; ++v) q[v] = src[v];
@@ -135,7 +136,6 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     if (FIRST && threadIdx.x == 0) s_culled = 0;
     __syncthreads();
     uint32_t my_culled = 0;
-    const uint32_t n = load_count(n_dev, bound);
     if (first + kRounds <= n) {
 #pragma unroll
         for (int v = 0; v < kVecs; ++v) {
@@ -248,12 +248,14 @@ __global__ void __launch_bounds__(kThreads)
     __shared__ Key skey[kItems];
     __shared__ __attribute__((aligned(16))) uint32_t sval[kItems];   // 8 KB: also the 4 x 256 match words of the ranking
     static_assert(kItems * 4 == 4 * kBins * 8, "sval doubles as the per-wave match words");
+    // The grid covers the capacity `bound`; the element count comes first: a workgroup beyond it must not touch
+    // memory (requesting the keys before the count is known saved nothing measurable and cost 100 us on a frame
+    // whose capacity was 20x its pair count).
+    const uint32_t n = load_count(n_dev, bound);
     const uint32_t block_base = blockIdx.x * (uint32_t)kItems;
-    if (block_base >= bound) return;
+    if (block_base >= n) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     constexpr uint32_t nbins = 1u << BITS, mask = nbins - 1u;
-    // Everything the workgroup reads is requested before the element count is looked at (the grid covers the
-    // capacity `bound`; what lies beyond the count is masked below): one trip to memory, not two in a row.
     const uint32_t wave_base = block_base + (uint32_t)w * kWaveItems;
     Key key[kRounds];
     uint32_t val[kRounds];
@@ -261,10 +263,11 @@ __global__ void __launch_bounds__(kThreads)
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
         const uint32_t i = wave_base + (uint32_t)r * 64 + lane;
-        ok[r] = i < bound;
+        ok[r] = i < n;
         key[r] = ok[r] ? kin[i] : (Key)0;
         // FIRST: the value of an item is its position (the Gaussian index): nothing to read
         val[r] = (MODE & kModeFirst) ? i : (ok[r] ? vin[i] : 0u);
+        if (MODE & kModeFirst) ok[r] = ok[r] && (uint32_t)key[r] < kEmptyKey;
     }
     // this digit's row total and row prefix: needed after the ranking
     uint32_t t_pre = 0, before_pre = 0;
@@ -272,20 +275,12 @@ __global__ void __launch_bounds__(kThreads)
         t_pre = totals[threadIdx.x];
         before_pre = table[(size_t)threadIdx.x * nbp + blockIdx.x];
     }
-    const uint32_t n = load_count(n_dev, bound);
-    if (block_base >= n) return;
     for (int k = threadIdx.x; k < 4 * kBins; k += kThreads) (&cnt[0][0])[k] = 0;
     for (int k = threadIdx.x; k < kItems / 4; k += kThreads) reinterpret_cast<uint4 *>(sval)[k] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
     // ---- stable rank of every item among the same-digit items of its wave's consecutive slice
     const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
-        const uint32_t i = wave_base + (uint32_t)r * 64 + lane;
-        ok[r] = i < n;
-        if (MODE & kModeFirst) ok[r] = ok[r] && (uint32_t)key[r] < kEmptyKey;
-    }
     // The lanes of a wave that hold the same digit find each other through the LDS: every lane ORs its bit
     // into the wave's 64-bit word of the digit, reads the word back and clears it -- three DS operations that
     // one wave executes in issue order -- instead of BITS ballots at ~6 VALU instructions each.  The words
