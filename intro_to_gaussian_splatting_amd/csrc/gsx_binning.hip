@@ -14,14 +14,18 @@
 // path.  D never leaves the device: every kernel after the scan reads it from device memory and is
 // launched on a grid sized by the workspace capacity.
 //
-// Between the two sorts (round 2: two kernels, all reads coalesced, no per-rank offset array):
-//   chunk_sums   every workgroup adds up the tile counts of its 1024 consecutive depth ranks (from the
-//                rank-ordered rectangles) -> sums[chunk], 64 bit;
+// Between the two sorts (all reads coalesced, no per-rank offset array):
+//   chunk sums   the tile counts of every 1024 consecutive depth ranks (from the rank-ordered rectangles), 64
+//                bit: left behind by the last kernel of the sampled depth sort (gsx_sort.hip, up to 2^20
+//                Gaussians), by chunk_sums_kernel otherwise;
 //   emit         every workgroup (same chunking) adds up the sums before its chunk, scans its own 1024
-//                counts in LDS and writes its (tile id, Gaussian index) pairs PAIR by pair: thread p of
-//                the chunk's pair range finds its Gaussian by binary search in the LDS offsets, so
-//                consecutive lanes write consecutive addresses whatever the mix of footprints is (one
-//                frame-filling splat is spread over the whole workgroup by construction).
+//                counts in LDS and writes its (tile id, Gaussian index) pairs in RUNS: a thread takes one run
+//                of consecutive pairs, finds the Gaussian of the first one by binary search in the LDS offsets
+//                and walks from there (rows, columns, Gaussians), so stores are wide and contiguous whatever
+//                the mix of footprints is (one frame-filling splat is spread over the whole workgroup by
+//                construction).
+// After the second sort: tile_ranges_kernel ([first, last) of every tile's list, long tiles flagged) and, for
+// large scenes, tile_schedule_kernel (the tiles by falling list length, for the compositing launch).
 
 #include "gsx_internal.h"
 

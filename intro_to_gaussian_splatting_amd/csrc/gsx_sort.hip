@@ -15,8 +15,9 @@
 //            (round 1 stored 256 scattered 4-byte words per chunk: 9x write amplification at the memory side);
 //   scan     one workgroup per digit row turns its row into an exclusive prefix and records the
 //            row total; every thread loads its 16 consecutive counts up front (one memory round trip);
-//   scatter  each workgroup re-reads its items, ranks them STABLY inside the workgroup (wave-level
-//            match by ballots, per-wave running digit counters in LDS, waves and rounds in item
+//   scatter  each workgroup re-reads its items, ranks them STABLY inside the workgroup (the lanes of a
+//            wave that hold the same digit find each other through a 64-bit LDS word per digit, per-wave
+//            running digit counters in LDS, waves and rounds in item
 //            order), parks them in LDS in digit-major order, and streams them out: item j of the
 //            parked order goes to digit base (exclusive sum of the row totals, recomputed in LDS)
 //            + row prefix + (j - first j of its digit), so neighbouring lanes write neighbouring
@@ -1021,7 +1022,7 @@ PassPlan plan_for(void *temp, int64_t bound) {
 }
 
 // Bits per pass: the key bits spread evenly over ceil(key_bits / 8) passes (13 tile-id bits -> 7 + 6:
-// fewer ballots per item and half the digit rows of 8 + 5), at least 6.
+// half the digit rows of 8 + 5), at least 6.
 inline int pass_bits(int key_bits) {
     const int passes = (key_bits + 7) / 8;
     const int w = (key_bits + passes - 1) / passes;
