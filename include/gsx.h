@@ -165,7 +165,7 @@ enum {
     GSX_STAGE_PROJECT = 0,    /* projection, depth keys, record packing         */
     GSX_STAGE_DEPTH_SORT = 1, /* stable sort of the depth keys (drops Gaussians that reach no tile) */
     GSX_STAGE_SCAN = 2,       /* tile-count sums + (tile, Gaussian) pair emission */
-    GSX_STAGE_BIN = 3,        /* frame clear, tile sort, tile ranges            */
+    GSX_STAGE_BIN = 3,        /* tile sort, tile ranges (+ the compositing schedule) */
     GSX_STAGE_BLEND = 4,      /* the compositing kernel alone                   */
     GSX_STAGE_TOTAL = 5
 };

@@ -24,8 +24,9 @@
 //     is kept exact but off the common path: one v_min3 + v_min + v_cmp per record decides, for
 //     the whole wave, whether any of its 256 pixels stops at this record; only then are the
 //     per-pixel selects executed;
-//   - blockIdx -> tile mapping gives each XCD a contiguous stripe of tiles, so neighbouring
-//     tiles -- which share most of their Gaussians -- hit the same 4 MiB L2.
+//   - blockIdx -> tile: large scenes hand the tiles out by list length, so that every SIMD gets the same
+//     share of the work (scheduled_tile); otherwise each XCD gets a contiguous stripe of tiles, so
+//     neighbouring tiles -- which share most of their Gaussians -- hit the same 4 MiB L2.
 //
 // Arithmetic.  This translation unit is compiled with -ffp-contract=off and every fused
 // operation is an explicit fmaf, so the result does not depend on how the compiler would have
