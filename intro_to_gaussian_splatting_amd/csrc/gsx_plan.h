@@ -59,12 +59,13 @@ struct ClearPlan {
 };
 
 
-// Digit table [256][chunks rounded up to a multiple of 4] + 256 row totals + 256 splitters + 2048 samples
-// and their 2048 ranks (sample-partitioned depth sort).
-constexpr int kSortSamples = 2048;
+// Digit table [256][chunks rounded up to a multiple of 4] + 256 row totals + 256 splitters (sample-partitioned
+// depth sort) + 256 four-chunk totals for each of up to kSortQuadTotals count workgroups (passes of up to 512K
+// items, which run without a row-scan launch).
+constexpr int kSortSamples = 2048, kSortQuadTotals = 64;
 inline size_t radix_temp_bytes(int64_t max_items) {
     const size_t nblocks = (size_t)((max_items + kSortItems - 1) / kSortItems) + kSortQuad;
-    return ((size_t)kSortBins * (nblocks + kSortQuad) + 2 * kSortBins + 2 * kSortSamples) * sizeof(uint32_t);
+    return ((size_t)kSortBins * (nblocks + kSortQuad) + 2 * kSortBins + (size_t)kSortQuadTotals * kSortBins) * sizeof(uint32_t);
 }
 // Where the 64-bit chunk sums start inside `temp`: behind the radix table for max(n, cap) items.
 inline size_t binning_sums_offset(int64_t n, int64_t cap) {

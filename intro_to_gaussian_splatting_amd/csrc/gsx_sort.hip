@@ -52,6 +52,14 @@ static_assert(kItems == kSortItems, "gsx_plan.h sizes the digit table with this"
 // round 1, one frame in flight: 2 000 Gaussians 96 -> 85 us, 100 000 Gaussians 166 -> 161 us; beyond
 // ~100 chunks the per-workgroup table walk costs more than the launch it saves).
 constexpr int kSelfScanBlocks = 64;
+// Up to this many count workgroups (4 chunks each: 512K items) a pass has no row-scan launch either: the count
+// kernel also stores every workgroup's four-chunk totals and a scatter workgroup adds up the totals of the
+// workgroups before its own (coalesced, 8 loads in flight) plus at most three counts of its own quad.  Measured:
+// the scatter kernel gains 0.04 us per count workgroup (52 of them: 6.1 -> 8.2 us, 123: 14.5 -> 19.7 us) and the
+// launch it replaces costs 4.8 us, so the tile sort of a 100 000-Gaussian frame wins 2.7 us per pass and the
+// partition of 1M keys would win nothing.
+constexpr int kQuadScanQuads = kSortQuadTotals;
+constexpr int kScanRows = 0, kScanSelf = 1, kScanQuads = 2;   // who turns the counts into prefixes
 
 constexpr int kModePlain = 0, kModeFirst = 1, kModeFinal = 2;
 constexpr int kSamples = kSortSamples;   // sample keys of the sample-partitioned depth sort (8 per bucket)
@@ -111,7 +119,7 @@ template <typename Key, bool CHUNK_MAJOR, bool FIRST, bool SPLIT = false>
 __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     count_kernel(const Key *__restrict__ keys, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
                  uint32_t mask, uint32_t *__restrict__ table, int nbp, uint32_t *__restrict__ culled,
-                 const uint32_t *__restrict__ splitters = nullptr) {
+                 const uint32_t *__restrict__ splitters = nullptr, uint32_t *__restrict__ quad_totals = nullptr) {
     constexpr int kLanes = CHUNK_MAJOR ? 1 : kQuad;   // chunks per workgroup
     constexpr int kPerVec = 16 / sizeof(Key), kVecs = kRounds / kPerVec;   // 8 x u16 or 4 x u32 per 16 B
     static_assert(kRounds % kPerVec == 0, "a thread's items must fill whole 16-byte vectors");
@@ -171,8 +179,9 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     if (CHUNK_MAJOR) {
         table[(size_t)blockIdx.x * kBins + t] = h[0][t];
     } else if (threadIdx.x < kBins) {
-        reinterpret_cast<uint4 *>(table + (size_t)t * nbp)[blockIdx.x] =
-            make_uint4(h[0][t], h[kLanes > 1 ? 1 : 0][t], h[kLanes > 2 ? 2 : 0][t], h[kLanes > 3 ? 3 : 0][t]);
+        const uint4 c4 = make_uint4(h[0][t], h[kLanes > 1 ? 1 : 0][t], h[kLanes > 2 ? 2 : 0][t], h[kLanes > 3 ? 3 : 0][t]);
+        reinterpret_cast<uint4 *>(table + (size_t)t * nbp)[blockIdx.x] = c4;
+        if (quad_totals) quad_totals[(size_t)blockIdx.x * kBins + t] = c4.x + c4.y + c4.z + c4.w;   // kScanQuads
     }
     if (FIRST && threadIdx.x == 0 && s_culled) atomicAdd(culled, s_culled);
 }
@@ -232,13 +241,14 @@ __global__ void __launch_bounds__(kThreads) row_scan_kernel(uint32_t *__restrict
 // MODE: kModeFirst / kModeFinal, see the head of this file.  m_out (FIRST): number of items this pass
 // keeps, i.e. the element count of every later pass.  rect / rrect (FINAL): per-Gaussian tile
 // rectangles by index / by depth rank.
-template <typename Key, bool SELF_SCAN, int MODE, int BITS, bool SPLIT = false>
+template <typename Key, int SCAN, int MODE, int BITS, bool SPLIT = false>
 __global__ void __launch_bounds__(kThreads)
     scatter_kernel(const Key *__restrict__ kin, const uint32_t *__restrict__ vin, Key *__restrict__ kout,
                    uint32_t *__restrict__ vout, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
                    const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nbp,
                    uint32_t *__restrict__ m_out, const TileRect *__restrict__ rect, TileRect *__restrict__ rrect,
-                   const uint32_t *__restrict__ splitters = nullptr) {
+                   const uint32_t *__restrict__ splitters = nullptr, const uint32_t *__restrict__ quad_totals = nullptr) {
+    constexpr bool SELF_SCAN = SCAN == kScanSelf;
     constexpr int kWaveItems = kItems / 4;
     __shared__ uint32_t spl[SPLIT ? kBins : 1];
     __shared__ uint8_t sdig[SPLIT ? kItems : 1];     // SPLIT: the bucket of every parked item (not derivable by a shift)
@@ -272,9 +282,32 @@ __global__ void __launch_bounds__(kThreads)
     }
     // this digit's row total and row prefix: needed after the ranking
     uint32_t t_pre = 0, before_pre = 0;
-    if (!SELF_SCAN && (uint32_t)threadIdx.x < nbins) {
+    if (SCAN == kScanRows && (uint32_t)threadIdx.x < nbins) {
         t_pre = totals[threadIdx.x];
         before_pre = table[(size_t)threadIdx.x * nbp + blockIdx.x];
+    }
+    if (SCAN == kScanQuads && (uint32_t)threadIdx.x < nbins) {
+        // no row scan ran: this digit's total = the sum of all count workgroups' four-chunk totals, its prefix =
+        // the totals of the workgroups before this chunk's + the (raw) counts of the chunks before it in its quad
+        const int nquads = nbp / kQuad, quad = (int)(blockIdx.x / kQuad);
+        int q = 0;
+        for (; q + 8 <= nquads; q += 8) {      // 8 independent loads in flight (coalesced over the digits)
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = quad_totals[(size_t)(q + u) * kBins + threadIdx.x];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                before_pre += q + u < quad ? v[u] : 0u;
+                t_pre += v[u];
+            }
+        }
+        for (; q < nquads; ++q) {
+            const uint32_t v = quad_totals[(size_t)q * kBins + threadIdx.x];
+            before_pre += q < quad ? v : 0u;
+            t_pre += v;
+        }
+        for (uint32_t c = (uint32_t)quad * kQuad; c < blockIdx.x; ++c) before_pre += table[(size_t)threadIdx.x * nbp + c];
+        if (blockIdx.x == 0) const_cast<uint32_t *>(totals)[threadIdx.x] = t_pre;   // what bucket_sort_kernel reads
     }
     for (int k = threadIdx.x; k < 4 * kBins; k += kThreads) (&cnt[0][0])[k] = 0;
     for (int k = threadIdx.x; k < kItems / 4; k += kThreads) reinterpret_cast<uint4 *>(sval)[k] = make_uint4(0, 0, 0, 0);
@@ -1006,8 +1039,9 @@ __global__ void __launch_bounds__(kBigThreads)
 
 struct PassPlan {
     int nblocks, nbp, nquads;
-    bool self_scan;
-    uint32_t *table, *totals;
+    bool self_scan;           // scan == kScanSelf
+    int scan;                 // kScanSelf / kScanQuads / kScanRows, by size
+    uint32_t *table, *totals, *quad_totals;
 };
 
 PassPlan plan_for(void *temp, int64_t bound) {
@@ -1015,9 +1049,11 @@ PassPlan plan_for(void *temp, int64_t bound) {
     p.nblocks = (int)((bound + kItems - 1) / kItems);
     p.nquads = (p.nblocks + kQuad - 1) / kQuad;
     p.self_scan = p.nblocks <= kSelfScanBlocks;
+    p.scan = p.self_scan ? kScanSelf : (p.nquads <= kQuadScanQuads ? kScanQuads : kScanRows);
     p.nbp = p.self_scan ? p.nblocks : p.nquads * kQuad;
     p.table = (uint32_t *)temp;
     p.totals = p.table + (size_t)kBins * p.nquads * kQuad;
+    p.quad_totals = p.totals + 2 * kBins;      // behind the row totals and the 256 splitters
     return p;
 }
 
@@ -1038,15 +1074,21 @@ void launch_pass(const PassPlan &p, const Key *kc, const uint32_t *vc, Key *ka, 
     if (p.self_scan) {
         count_kernel<Key, true, first><<<p.nblocks, kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, mask, p.table,
                                                                        p.nbp, culled);
-        scatter_kernel<Key, true, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound, shift,
-                                                                              p.table, p.totals, p.nbp, m_out, rect, rrect);
+        scatter_kernel<Key, kScanSelf, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
+                                                                                   shift, p.table, p.totals, p.nbp, m_out, rect,
+                                                                                   rrect);
+    } else if (p.scan == kScanQuads) {
+        count_kernel<Key, false, first><<<p.nquads, kQuad * kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, mask,
+                                                                               p.table, p.nbp, culled, nullptr, p.quad_totals);
+        scatter_kernel<Key, kScanQuads, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(
+            kc, vc, ka, va, n_dev, (uint32_t)bound, shift, p.table, p.totals, p.nbp, m_out, rect, rrect, nullptr, p.quad_totals);
     } else {
         count_kernel<Key, false, first><<<p.nquads, kQuad * kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, mask,
                                                                                p.table, p.nbp, culled);
         row_scan_kernel<<<1u << BITS, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
-        scatter_kernel<Key, false, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
-                                                                               shift, p.table, p.totals, p.nbp, m_out, rect,
-                                                                               rrect);
+        scatter_kernel<Key, kScanRows, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
+                                                                                   shift, p.table, p.totals, p.nbp, m_out, rect,
+                                                                                   rrect);
     }
 }
 
@@ -1119,13 +1161,19 @@ hipError_t sort_depth_sampled(void *temp, uint32_t *keys0, uint32_t *keys1, uint
     if (p.self_scan) {
         count_kernel<uint32_t, true, true, true><<<p.nblocks, kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u, p.table,
                                                                                 p.nbp, culled_dev, splitters);
-        scatter_kernel<uint32_t, true, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
+        scatter_kernel<uint32_t, kScanSelf, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters);
+    } else if (p.scan == kScanQuads) {
+        count_kernel<uint32_t, false, true, true><<<p.nquads, kQuad * kThreads, 0, s>>>(
+            keys0, nullptr, (uint32_t)n, 0, 255u, p.table, p.nbp, culled_dev, splitters, p.quad_totals);
+        scatter_kernel<uint32_t, kScanQuads, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
+            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
+            p.quad_totals);
     } else {
         count_kernel<uint32_t, false, true, true><<<p.nquads, kQuad * kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u,
                                                                                         p.table, p.nbp, culled_dev, splitters);
         row_scan_kernel<<<kBins, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
-        scatter_kernel<uint32_t, false, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
+        scatter_kernel<uint32_t, kScanRows, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters);
     }
     if (lds_cap == 0 || lds_cap > (uint32_t)kBucketCap) lds_cap = kBucketCap;
