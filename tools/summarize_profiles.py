@@ -56,10 +56,10 @@ ALG = {   # algorithmic bytes per launch at C3
     "project_pack_kernel": (56 * N, 60 * N),
     "count_kernel<u32>": (4 * N, 0.5e6),
     "row_scan_kernel": (0.5e6, 0.5e6),
-    "scatter_kernel<u32,first>": (4 * N, 8 * N),
+    "scatter_kernel<u32,first>": (12 * N, 16 * N),     # keys + rectangles in; keys, values, rectangles out
     "scatter_kernel<u32>": (8 * N, 8 * N),
     "scatter_kernel<u32,final>": (16 * N, 12 * N),
-    "sample_rank_kernel": (8192, 16384),
+    "sample_rank_kernel": (128 * 2048 * 4, 1024),     # every one of its 128 workgroups reads the 2048 sample keys
     "count_kernel<u32,split>": (4 * N, 0.5e6),
     "bucket_sort_kernel": (16 * N, 12 * N),
     "chunk_sums_kernel": (8 * N, 0),
@@ -67,6 +67,7 @@ ALG = {   # algorithmic bytes per launch at C3
     "count_kernel<u16>": (2 * D, 1.2e6),
     "scatter_kernel<u16>": (6 * D, 6 * D),
     "tile_ranges_kernel": (2 * D, 64e3),
+    "tile_schedule_kernel": (64e3, 32e3),
     "blend_tile16_kernel": (40 * D, 12 * npix),
 }
 
@@ -74,10 +75,11 @@ ALG = {   # algorithmic bytes per launch at C3
 def k2(n):
     n = re.sub(r"\(anonymous namespace\)::|gsx::|void ", "", n)
     for key in ("blend_tile16_kernel", "project_pack_kernel", "emit_kernel", "tile_ranges_kernel", "chunk_sums_kernel",
-                "row_scan_kernel", "sample_rank_kernel", "bucket_sort_kernel", "small_depth_sort_kernel"):
+                "row_scan_kernel", "sample_rank_kernel", "bucket_sort_kernel", "small_depth_sort_kernel",
+                "tile_schedule_kernel"):
         if key in n:
             return key
-    m = re.match(r"(count|scatter)_kernel<(unsigned short|unsigned int), (?:true|false), (\w+)", n)
+    m = re.match(r"(count|scatter)_kernel<(unsigned short|unsigned int), (?:true|false|\d+), (\w+)", n)
     if m:
         kind, key, mode = m.group(1), "u16" if "short" in m.group(2) else "u32", m.group(3)
         if kind == "count" and n.rstrip(">").endswith("true") and key == "u32":
