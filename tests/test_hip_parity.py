@@ -770,7 +770,9 @@ def test_spherical_harmonics_kernel_and_trained_ply_pipeline(tmp_path):
 
 @pytest.mark.parametrize("n,bits,key16", [(1, 32, 0), (63, 32, 0), (8192, 32, 0), (8193, 32, 0), (100_003, 32, 0),
                                           (1_000_000, 32, 0), (70_001, 13, 1), (3_000_017, 16, 1), (500_000, 9, 1),
-                                          (40_000, 24, 0), (131_072, 32, 0), (131_073, 32, 0), (131_073, 11, 1)])
+                                          (40_000, 24, 0), (131_072, 32, 0), (131_073, 32, 0), (131_073, 11, 1),
+                                          (524_288, 32, 0), (524_289, 16, 1)])   # 64 / 65 count workgroups: last pass
+                                                                                # without / first with a row-scan launch
 def test_radix_sort_is_a_stable_sort(n, bits, key16):
     """gsx_sort.hip against torch's stable sort: same keys, same permutation (stability = the tie
     rule of the depth order and the reason the tile sort keeps depth order), incl. a device count."""
