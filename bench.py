@@ -389,10 +389,17 @@ def main() -> None:
 
     # setup, untimed: let clocks and caches settle (the first ~100 frames after start-up run 5-10 % slow)
     t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+    while True:
         for _ in range(8):
             single_frame()
         torch.cuda.synchronize()
+        done = (time.perf_counter() - t_settle) * 1e3 >= args.settle_ms
+        if world > 1:   # every frame is a collective: the ranks must agree on when to stop, not each ask its own clock
+            flag = torch.tensor([1 if done else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            done = bool(flag.item())
+        if done:
+            break
     scene.confirm_frames()
 
     # ---- the contract's region: W untimed steps, then EXACTLY K steps between fences, one frame in flight
