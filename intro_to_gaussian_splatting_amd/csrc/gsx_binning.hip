@@ -106,28 +106,42 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 // Large inputs only: sums[0 .. nchunks] <- exclusive prefix (entry nchunks = grand total), one workgroup.
+// Every thread owns a run of consecutive entries (all loaded before the first is needed), the runs' totals are
+// scanned with wave shuffles.
 __global__ void __launch_bounds__(kBlock) scan_sums_kernel(uint64_t *__restrict__ sums, int nchunks) {
-    __shared__ uint64_t part[kBlock];
+    __shared__ uint64_t wsum[kBlock / 64];
+    constexpr int kKeep = 32;                                   // entries a thread keeps in registers (8192 chunks = 8M Gaussians)
     const int per = (nchunks + kBlock - 1) / kBlock;
     const int i0 = threadIdx.x * per, i1 = min(nchunks, i0 + per);
-    uint64_t mine = 0;
-    for (int i = i0; i < i1; ++i) mine += sums[i];
-    part[threadIdx.x] = mine;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t v[kKeep], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k) {
+        v[k] = (k < per && i0 + k < i1) ? sums[i0 + k] : 0ull;
+        mine += v[k];
+    }
+    for (int i = i0 + kKeep; i < i1; ++i) mine += sums[i];      // (beyond 8M Gaussians: read again below)
+    uint64_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t y = (uint64_t)__shfl_up((long long)x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (int k = 0; k < kBlock; ++k) {
-            const uint64_t v = part[k];
-            part[k] = run;
-            run += v;
+    uint64_t run = x - mine;
+    for (int k = 0; k < w; ++k) run += wsum[k];
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k) {
+        if (k < per && i0 + k < i1) {
+            sums[i0 + k] = run;
+            run += v[k];
         }
     }
-    __syncthreads();
-    uint64_t run = part[threadIdx.x];
-    for (int i = i0; i < i1; ++i) {
-        const uint64_t v = sums[i];
+    for (int i = i0 + kKeep; i < i1; ++i) {
+        const uint64_t u = sums[i];
         sums[i] = run;
-        run += v;
+        run += u;
     }
     if (i0 < nchunks && i1 == nchunks) sums[nchunks] = run;   // exactly one thread owns the last entry
 }
