@@ -153,7 +153,7 @@ typedef struct GsxParams {
 
 /* Tile 16, GSX_SEM_REF_CPU / GSX_SEM_STD_3DGS.  All the tile workgroups of a 1080p frame are resident at once, so
  * a SIMD is busy for as long as the lists of its own tiles take; frames of >= 300 000 Gaussians therefore run one
- * more small kernel that ranks the tiles by list length, and the compositing launch hands them out so that every
+ * more small kernel that ranks the tiles by list length (windows of more than 2048 tiles), and the compositing launch hands them out so that every
  * SIMD gets its share of every length class.  Which workgroup composites which tile does
  * not touch a pixel: the frame is the same bit for bit.  GSX_FLAG_TILE_SCHEDULE asks for the schedule whatever
  * the size of the scene, GSX_FLAG_NO_TILE_SCHEDULE never builds it (tests hold the two against each other). */

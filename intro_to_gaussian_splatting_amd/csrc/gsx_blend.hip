@@ -363,7 +363,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
 //   GSX_LAYOUT_WH3  out[x][y][c]: the lane's 4 pixels are 48 contiguous bytes (3 x dwordx4);
 //   GSX_LAYOUT_HW3  out[y][x][c]: 4 stores of 12 B; the 16 lanes that share a y write 192
 //                   contiguous bytes per store instruction.
-// VARIANT 0: scalar-form composite<4>; VARIANT 1: packed form, two records per saturation test.
+// VARIANT 0: scalar-form composite<4>; VARIANT 1: packed form, four (then two) records per saturation test.
 template <int VARIANT>
 __global__ void __launch_bounds__(64)
     blend_tile16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
@@ -432,11 +432,49 @@ __global__ void __launch_bounds__(64)
                 c2a = v2f{c2[0], c2[1]}; c2b = v2f{c2[2], c2[3]};
             }
         } else {
-            // Common path: two records per trip, ONE wave-level saturation test, no per-pixel
+            // Common path: four (then two) records per trip, ONE wave-level saturation test, no per-pixel
             // selects.  The first time any pixel of the tile saturates the wave leaves this loop
             // (before committing the pair) and finishes the tile on the checked path below; a
             // saturated pixel has T = 0 and would trip the test on every record anyway.
             uint32_t k = 0;
+            if (!checked) {
+                // FOUR records per trip first (the two-record loop below takes what is left of the batch): twice
+                // the independent work between two saturation tests hides more of the wave's own LDS reads and
+                // exponentials -- 264 -> 254 us at 1M Gaussians, more where a SIMD holds fewer than 8 waves (a
+                // rank's strip) -- and still fits 64 VGPRs (six per trip: 74, no faster).  Same operations per pixel
+                // and record, same order: same bits.
+                constexpr int kTrip = 4;
+                for (; k + (kTrip - 1) < nb; k += kTrip) {
+                    float4 A[kTrip], B[kTrip];
+                    float cb[kTrip];
+#pragma unroll
+                    for (int u = 0; u < kTrip; ++u) {
+                        A[u] = sh[0][k + u];
+                        B[u] = sh[1][k + u];
+                        cb[u] = sh[2][k + u].x;
+                    }
+                    v2f ta_a[kTrip], ta_b[kTrip], ta = Ta, tb = Tb;
+                    float m = Ta.x;
+#pragma unroll
+                    for (int u = 0; u < kTrip; ++u) {
+                        v2f aa, ab;
+                        alphas(A[u], B[u].x, B[u].y, cx, cya, cyb, aa, ab);
+                        ta_a[u] = ta * aa;
+                        ta_b[u] = tb * ab;
+                        ta = ta - ta_a[u];
+                        tb = tb - ta_b[u];
+                        m = fminf(m, min4(ta, tb));
+                    }
+                    if (__builtin_expect(__any(m < kStopRefCpu), 0)) {
+                        checked = true;
+                        break;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kTrip; ++u) GSX_ACCUMULATE(ta_a[u], ta_b[u], B[u].z, B[u].w, cb[u]);
+                    Ta = ta;
+                    Tb = tb;
+                }
+            }
             if (!checked) {
                 for (; k + 1 < nb; k += 2) {
                     const float4 A0 = sh[0][k], B0 = sh[1][k], A1 = sh[0][k + 1], B1 = sh[1][k + 1];
@@ -803,7 +841,9 @@ bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int6
     if ((semantics != GSX_SEM_REF_CPU && semantics != GSX_SEM_STD_3DGS) || grid.tile != 16 || generic) return false;
     if (asked >= 0) return asked != 0;          // GSX_FLAG_TILE_SCHEDULE / GSX_FLAG_NO_TILE_SCHEDULE
     if (forced >= 0) return forced != 0;
-    return n >= 300000;
+    // a window of up to 2048 tiles (a rank's strip of a 1080p frame) puts at most two tiles on a SIMD: the
+    // kernel lasts as long as its longest tile whatever the hand-out
+    return n >= 300000 && grid.count() > 2048;
 }
 
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,

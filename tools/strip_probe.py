@@ -1,0 +1,27 @@
+import sys, os, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from intro_to_gaussian_splatting_amd import strips
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+arrays, scene = bench.build_scene(wl, "cuda")
+n, w, h, _ = bench.WORKLOADS[wl]
+ntx, nty = strips.tiles_along(w, 16), strips.tiles_along(h, 16)
+counts = torch.zeros(ntx * nty, dtype=torch.int32, device="cuda")
+scene.render_image_hip(1, tile_counts=counts)
+for world in (1, 2, 4, 8):
+    plan = strips.balanced_plan(strips.tile_row_costs(counts, ntx, nty, lead_is_x=True), world)
+    worst = None
+    for r in (0, world // 2, world - 1):
+        win = (plan[r][0], plan[r][1], 0, nty)
+        for _ in range(3):
+            scene.render_image_hip(1, tile_window=win)
+        acc = {}
+        reps = 10
+        for _ in range(reps):
+            st = {}
+            scene.render_image_hip(1, tile_window=win, stats=st, timing=True)
+            for k, v in st["stage_ms"].items():
+                acc[k] = acc.get(k, 0.0) + v / reps
+        if worst is None or acc["total"] > worst[1]["total"]:
+            worst = (r, acc)
+    print(wl, "world", world, "slowest of ranks probed:", worst[0], {k: round(v, 3) for k, v in worst[1].items()})
