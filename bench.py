@@ -1,8 +1,10 @@
 """Headline benchmark: Mpixels/s of one forward raster on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c1|notebook]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    (`python bench.py --gpus N` without a launcher starts the N ranks itself, as fresh child processes, before
+    anything touches a GPU, and relays rank 0's line; it never reports fewer GPUs than it was asked for.)
 
 A "step" is one whole forward render (projection -> depth sort -> tile binning -> compositing,
 Gaussian parameters already resident in HBM) of the named synthetic workload; the default is the
@@ -58,7 +60,16 @@ WORKLOADS = {
     # frame, log-normal footprints with sigma_ln = 1.0): what one-wave-per-tile compositing has to survive
     "c3_clustered": (1_000_000, 1920, 1080, "clustered: 1M Gaussians, half of them in 5 % of a 1920x1080 frame, "
                      "footprint sigma_ln 1.0"),
+    # not a BASELINE config: C3 with 20 % more Gaussians -- just past the 2^20 keys where round 2's depth sort fell
+    # back to four LSD passes (what a "~1M" trained .ply of 1.05M .. 1.2M Gaussians hits)
+    "c3_1m2": (1_200_000, 1920, 1080, "C3 variant: synthetic 1.2M Gaussians, 1920x1080"),
+    # the one GPU workload the reference publishes a number for: render_image_cuda on
+    # 52 363 constructor-default Gaussians (scale 0.001, identity rotation, opacity 0.9999) at Treehill's native
+    # size, timed as the reference times it (native render_image + synchronize; preprocess reported beside it)
+    "notebook": (52_363, 5068, 3328, "notebook: 52 363 constructor-default Gaussians, 5068x3328, render_image_cuda "
+                 "(splat/gaussian_scene.py:263-285)"),
 }
+REFERENCE_NOTEBOOK_S = 2.4787      # cuda_render_part_3.ipynb:218, NVIDIA sm_89, nvcc -O1: stated context, not a target
 GENERATOR_ARGS = {"c3_clustered": dict(cluster_fraction=0.5, cluster_area=0.05, sigma_ln=1.0)}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (unpacked VALU)
@@ -66,7 +77,7 @@ FP32_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 
 # blend_tile16_kernel: per trip (2 records x 4 pixels of a lane) 18 unpacked +
 # 32 packed (2 lane-ops each) + 8 v_exp_f32 = 90 lane-ops in 58 issue slots, i.e. 11.25 per pair.
 VALU_OPS_PER_PAIR = 11.25
-PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_c3.json")
+PMC_FILES = {w: os.path.join(ROOT, "profiles", "r3_pmc_%s.json" % w) for w in ("c2", "c3", "c4")}
 
 
 def build_scene_from_ply(ply_path: str, colmap_dir, image_id: int, width: int, height: int, device: str):
@@ -256,12 +267,154 @@ def cpu_baseline(sc, scene, gpu_frame: torch.Tensor, budget_s: float = 20.0, sem
 def pmc_record(workload: str, world: int):
     """PMC measurements of the compositing launch, taken with rocprofv3 in separate passes (FETCH_SIZE,
     WRITE_SIZE, SQ_*; MI355X_MICROARCH.md: FETCH_SIZE doubled on gfx950) and committed under profiles/;
-    recorded for C3 on 1 GPU.  Returns (HBM-side bytes per launch, VALU busy fraction) or (None, None)."""
-    if workload != "c3" or world != 1 or not os.path.exists(PMC_FILE):
-        return None, None
-    with open(PMC_FILE) as f:
+    recorded for C2, C3 and C4 on 1 GPU (tools/profile_round.sh).  Returns (HBM-side bytes per launch, VALU busy
+    fraction, file) or (None, None, None)."""
+    path = PMC_FILES.get(workload)
+    if world != 1 or path is None or not os.path.exists(path):
+        return None, None, None
+    with open(path) as f:
         d = json.load(f)
-    return d["blend_traffic_bytes_per_launch"]["total"], d.get("blend_valu", {}).get("valu_busy_frac")
+    return d["blend_traffic_bytes_per_launch"]["total"], d.get("blend_valu", {}).get("valu_busy_frac"), path
+
+
+def bench_notebook(args, device) -> None:
+    """The reference's own GPU workload (cuda_render_part_3.ipynb): 52 363 Gaussians as the
+    `Gaussians(points, colors)` constructor leaves them, Treehill's native frame, `render_image_cuda` -- and timed
+    the way the reference times it (splat/gaussian_scene.py:269-284): `preprocess` first, then the clock around the
+    native `render_image(H, W, tile, 8 tensors)` + one device synchronisation.  `preprocess()` is reported beside it.
+    The reference's 2.4787 s (NVIDIA sm_89, nvcc -O1) is stated context, not a target: another GPU, and a kernel
+    that walks all N Gaussians per pixel where this library bins them first."""
+    n, width, height, desc = WORKLOADS["notebook"]
+    sc = make_scene(n, width, height, seed=0)
+    with tempfile.TemporaryDirectory() as tmp:
+        write_colmap_text(tmp, sc)
+        g = Gaussians(torch.from_numpy(sc["points"]), torch.from_numpy(sc["colors_0_255"]), device=str(device))
+        scene = GaussianScene(tmp, g)
+    tile = 16
+    ext = scene.compile_cuda_ext()
+    call = lambda pre: ext.render_image(height, width, tile, pre.points.contiguous(), pre.colors.contiguous(),  # noqa: E731
+                                        pre.inverse_covariance_2d.contiguous(), pre.min_x.contiguous(),
+                                        pre.max_x.contiguous(), pre.min_y.contiguous(), pre.max_y.contiguous(),
+                                        pre.sigmoid_opacity.contiguous())
+    pre = scene.preprocess(1)
+    for _ in range(max(3, args.warmup)):
+        image = call(pre)
+        pre = scene.preprocess(1)
+    torch.cuda.synchronize()
+    t_pre, t_native, t_flow = [], [], []
+    for _ in range(max(args.steps, 5)):
+        t0 = time.perf_counter()
+        pre = scene.preprocess(1)                   # synchronises itself (it returns the visible count)
+        t1 = time.perf_counter()
+        image = call(pre)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        t_pre.append(t1 - t0)
+        t_native.append(t2 - t1)
+        t_flow.append(t2 - t0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        image = scene.render_image_cuda(1, tile_size=tile)     # the drop-in's method, whole flow, per call
+    ms_per_step = (time.perf_counter() - t0) / args.steps * 1e3
+    med = lambda v: float(np.median(np.asarray(v)))  # noqa: E731
+    native_ms, pre_ms, flow_ms = med(t_native) * 1e3, med(t_pre) * 1e3, med(t_flow) * 1e3
+    out = {
+        "metric": "Mpixels/sec forward raster (1M Gaussians, 1080p) + max |dpixel| vs CPU ref",
+        "value": round(width * height / (native_ms * 1e-3) / 1e6, 2), "unit": "Mpixels/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "n_gaussians": n, "width": width, "height": height, "tile": tile,
+                   "semantics": "ref_cuda", "layout": "hw3", "n_visible": int(pre.points.shape[0]),
+                   "timed": "value = W*H / median(native render_image + synchronize), the bracket of "
+                            "splat/gaussian_scene.py:269-284; ms_per_step = whole render_image_cuda() calls"},
+        "native_render_ms": round(native_ms, 4), "preprocess_ms": round(pre_ms, 4), "whole_flow_ms": round(flow_ms, 4),
+        "reference_published": {"seconds": REFERENCE_NOTEBOOK_S, "hardware": "NVIDIA sm_89, CUDA 12.1, nvcc -O1",
+                                "source": "cuda_render_part_3.ipynb:218", "same_bracket_ratio": round(
+                                    REFERENCE_NOTEBOOK_S / (native_ms * 1e-3), 1),
+                                "note": "stated context: other hardware, and the reference kernel visits every Gaussian "
+                                        "at every pixel (splat/c/render.cu:49-81) where libgsx bins them into tiles"},
+    }
+    if not args.no_cpu_baseline:
+        # the CUDA kernel's rules restated in C (oracle/raster_cpu.c:orc_render_cuda_semantics, parity unpinned: the
+        # reference kernel cannot run here) on a 640x640 window of the frame -- it walks all N per pixel like the
+        # kernel it restates -- compared on the window's interior (means are truncated toward zero: a splat
+        # that straddles the window's left / top edge would truncate differently in window coordinates)
+        from oracle import c_oracle, cpu_ref
+
+        x0, y0, side, margin = (width // 2 - 320) // 16 * 16, (height // 2 - 320) // 16 * 16, 640, 32
+        P = cpu_ref.Preprocessed
+        f = lambda t: t.cpu().numpy()  # noqa: E731
+        shift = np.array([x0, y0], np.float32)
+        pw = P(points=f(pre.points) - shift, colors=f(pre.colors), covariance_2d=f(pre.covariance_2d), depths=f(pre.depths),
+               inverse_covariance_2d=f(pre.inverse_covariance_2d), radius=f(pre.radius), points_xy=f(pre.points) - shift,
+               min_x=f(pre.min_x) - x0, min_y=f(pre.min_y) - y0, max_x=f(pre.max_x) - x0, max_y=f(pre.max_y) - y0,
+               sigmoid_opacity=f(pre.sigmoid_opacity), order=None)
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        ref = c_oracle.render_cuda_semantics(pw, side, side, nthreads=cores)
+        t_cpu = time.perf_counter() - t0
+        got = image[y0:y0 + side, x0:x0 + side].cpu().numpy()
+        inner = (slice(margin, side - margin),) * 2
+        err = float(np.abs(got[inner] - ref[inner]).max())
+        out["cpu_baseline"] = {"value": round(side * side / t_cpu / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+                               "cpu_model": _cpu_model(), "seconds": round(t_cpu, 3),
+                               "sample": "oracle/raster_cpu.c:orc_render_cuda_semantics (C restatement of splat/c/render.cu, "
+                                         "%d threads) on the %dx%d window at (%d,%d); stage 1 from the GPU" % (cores, side, side, x0, y0)}
+        out["max_abs_dpixel"] = err
+        out["parity_ok"] = bool(err <= 1e-4 and float(ref.max()) > 0.0)
+    print(json.dumps(out), flush=True)
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set)
+    before this process has touched a GPU, relay rank 0's JSON line, return the worst exit code.  Never os.exec*
+    (on this pool an exec from a process that has initialised the GPU takes the machine down), never a silent
+    fall-back to one GPU."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()           # counting devices does not initialise the GPU
+    if have < n:
+        print("bench.py: --gpus %d asked for, %d visible: refusing to report a %d-GPU number" % (n, have, n), file=sys.stderr)
+        return 3
+    with socket.socket() as sock:              # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    worst = 0
+    try:
+        while any(pr.poll() is None for pr in procs):
+            bad = [pr.returncode for pr in procs if pr.poll() not in (None, 0)]
+            if bad:             # a rank died: the others would wait in a collective for ever
+                worst = bad[0]
+                break
+            time.sleep(0.2)
+        worst = worst or next((pr.returncode for pr in procs if pr.poll() not in (None, 0)), 0)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()      # exactly the processes started above
+        for pr in procs:
+            try:
+                pr.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+    reader.join(timeout=20)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return worst
 
 
 def main() -> None:
@@ -290,15 +443,26 @@ def main() -> None:
     ap.add_argument("--no-graphs", action="store_true",
                     help="enqueue every frame as ~30 separate launches instead of replaying it as one hipGraph "
                          "(GaussianScene.capture_frame); 1 GPU only")
-    ap.add_argument("--no-balance", action="store_true",
-                    help="N > 1: equal strips instead of strips balanced by the per-tile-row pair counts of a planning frame")
+    ap.add_argument("--balance", action="store_true",
+                    help="N > 1: strips balanced by the per-tile-row pair counts of a planning frame, gathered point to "
+                         "point (default: equal strips and ONE dist.gather -- the plainer collective stays the default "
+                         "until a multi-GPU node has confirmed strips_equal_single_gpu for the balanced path)")
+    ap.add_argument("--test-lib", action="store_true",
+                    help="development: run on libgsx_test.so (same kernels + GSX_* measurement knobs from the environment)")
     ap.add_argument("--sync-frames", action="store_true",
                     help="read the instance count back inside every frame instead of speculating on it")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))       # nothing has touched a GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node == --gpus" % (args.gpus, world))
+    if args.test_lib:
+        from intro_to_gaussian_splatting_amd import _ffi
+        _ffi.use_test_library()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -306,7 +470,10 @@ def main() -> None:
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    if args.workload == "notebook":
+        if world != 1:
+            raise SystemExit("--workload notebook is the reference's single-GPU flow")
+        return bench_notebook(args, device)
 
     n, width, height, desc = WORKLOADS[args.workload]
     if args.ply:
@@ -322,7 +489,7 @@ def main() -> None:
     # N > 1: every rank renders the frame once (untimed), reads the per-tile list lengths the library reports
     # (GsxParams.tile_counts) and derives the same balanced strip plan from them -- no communication needed
     strip_plan = None
-    if world > 1 and not args.no_balance:
+    if world > 1 and args.balance:
         ntx, nty = strips.tiles_along(width, tile, sem), strips.tiles_along(height, tile, sem)
         counts = torch.zeros(max(1, ntx * nty), dtype=torch.int32, device=device)
         scene.render_image_hip(1, tile_size=tile, layout=layout, tile_counts=counts, semantics=sem)
@@ -535,7 +702,7 @@ def main() -> None:
         pairs = 256.0 * d
         valu = pairs * VALU_OPS_PER_PAIR / (blend_ms * 1e-3) / FP32_LANE_OPS_PER_S if blend_ms > 0 else 0.0
         ref_rules = sem == "ref_cpu"
-        pmc_traffic, pmc_valu = pmc_record(args.workload, world) if ref_rules else (None, None)
+        pmc_traffic, pmc_valu, pmc_file = pmc_record(args.workload, world) if ref_rules else (None, None, None)
         out = {
             "metric": "Mpixels/sec forward raster (1M Gaussians, 1080p) + max |dpixel| vs CPU ref",
             # W*H over the MEDIAN of hipEvent-bracketed single frames, one frame in flight
@@ -570,8 +737,8 @@ def main() -> None:
                          "valu_busy_pmc": pmc_valu,
                          "source": {"achieved": "live: hipEvent pair around the launch on its stream (GSX_FLAG_TIMING), this run",
                                     "traffic": None if pmc_traffic is None else "replayed from %s (rocprofv3 --pmc passes "
-                                    "of an earlier run of this command)" % os.path.relpath(PMC_FILE, ROOT),
-                                    "valu_busy_pmc": None if pmc_valu is None else os.path.relpath(PMC_FILE, ROOT)},
+                                    "of an earlier run of this command)" % os.path.relpath(pmc_file, ROOT),
+                                    "valu_busy_pmc": None if pmc_valu is None else os.path.relpath(pmc_file, ROOT)},
                          "note": "compositing under reference CPU semantics is VALU-bound (256 evaluations per "
                                  "36-B record); valu_frac = 256*D*%.2f lane-ops / t / (256 CU x 4 SIMD x 32 lanes x "
                                  "2.4 GHz); valu_busy_pmc = SQ_ACTIVE_INST_VALU share of kernel cycles; traffic = "
@@ -599,11 +766,16 @@ def main() -> None:
             out["max_abs_dpixel"] = err
             out["psnr_db"] = None if psnr in (None, float("inf")) else round(psnr, 2)
             if ref_rules:
+                # THE bar: the same instance count and every pixel within 1e-4 of the float32 restatement of the
+                # reference (pinned to the reference's own outputs, tests/test_oracle_golden.py).  Where the frame
+                # misses it, exact_arithmetic_check says which side is off -- reported apart, never folded into
+                # parity_ok (tests/test_hip_parity.py::test_clustered_1m_scene_against_port_and_exact_arithmetic
+                # states what is accepted on the heavy-tailed stress scene, and why).
+                out["parity_ok"] = bool(inst == d and err <= 1e-4)
                 ex = base.get("exact_arithmetic_check")
-                # within 1e-4 of the float32 restatement -- or, where that restatement is itself further than that from
-                # exact arithmetic (ill-conditioned footprints of the heavy-tailed stress scene), within 1e-5 of float64
-                out["parity_ok"] = bool(inst == d and (err <= 1e-4 or (ex is not None and ex["gpu_vs_float64"] <= 1e-5 and
-                                                                       err <= ex["cpu_float32_port_vs_float64"] + 1e-5)))
+                if ex is not None:
+                    out["closer_to_exact_than_reference"] = bool(ex["gpu_vs_float64"] <= 1e-5 and
+                                                                 ex["gpu_vs_float64"] <= ex["cpu_float32_port_vs_float64"])
             else:   # 1/255-threshold flips are counted apart (tests/test_hip_std3dgs.py states the bar)
                 # the default binning drops (Gaussian, tile) pairs that cannot reach alpha = 1/255: D <= published D
                 out["parity_ok"] = bool(err <= 1e-4 and (inst is None or d <= inst) and

@@ -26,7 +26,16 @@
 extern "C" {
 #endif
 
-#define GSX_VERSION 100 /* major*10000 + minor*100 + patch */
+#define GSX_VERSION 300 /* major*10000 + minor*100 + patch.  300: GsxParams.kept_hint, GsxFrameStats.n_kept,
+                           * tile_counts zeroed when nothing is rendered, tile_x1 == tile_x0 is an empty window,
+                           * GsxCamera.camera_center; the library exports exactly the functions declared here */
+
+/* Every entry point below is exported; nothing else is (the library is built with -fvisibility=hidden). */
+#if defined(__GNUC__)
+#define GSX_API __attribute__((visibility("default")))
+#else
+#define GSX_API
+#endif
 
 typedef enum GsxStatus {
     GSX_OK = 0,
@@ -104,7 +113,8 @@ typedef struct GsxParams {
     const GsxCamera *camera_device;
     /* Optional DEVICE array of one uint32 per tile of the window (window-local id = (tx - tile_x0) *
      * window_height_in_tiles + (ty - tile_y0)): the length of every tile's Gaussian list, written by the
-     * frame.  What a multi-GPU caller balances its strips with (strips.balanced_plan).  NULL: not reported. */
+     * frame (all zero when the scene is empty; an empty window has no entries).  What a multi-GPU caller balances
+     * its strips with (strips.balanced_plan).  NULL: not reported. */
     uint32_t *tile_counts;
     /* gsx_render_forward only, build extension (the reference has no spherical harmonics).  NULL (default): the
      * `colors` argument is (n,3) RGB.  Otherwise DEVICE coefficients (n, (sh_degree+1)^2, 3), sh_degree in 0..3,
@@ -114,6 +124,12 @@ typedef struct GsxParams {
     const float *sh;
     int32_t sh_degree;
     int32_t reserved0;
+    /* gsx_render_forward only.  How many Gaussians are expected to reach a tile of the window
+     * (GsxFrameStats.n_kept of an earlier frame of this view and window); 0 (default) = unknown, assume all n.
+     * A hint, never a bound: it only selects the depth-sort route (the sample-partitioned routes sort what is
+     * KEPT inside LDS buckets, so a rank that owns 1/8 of a 5M-Gaussian frame takes the fast route although
+     * n is large); a wrong value costs time, not correctness. */
+    int64_t kept_hint;
 } GsxParams;
 
 /* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call
@@ -176,19 +192,21 @@ typedef struct GsxFrameStats {
     int64_t n_instances; /* (Gaussian, tile) pairs binned inside the tile window */
     int64_t n_tiles;     /* tiles inside the window                             */
     int64_t reserved;
-    float stage_ms[8];   /* filled only with GSX_FLAG_TIMING                     */
+    float stage_ms[6];   /* filled only with GSX_FLAG_TIMING                     */
+    int64_t n_kept;      /* Gaussians that reach a tile of the window (what the depth sort keeps): GsxParams.kept_hint
+                          * of the next frame of this view                       */
 } GsxFrameStats;
 
-int gsx_version(void);
-const char *gsx_last_error(void);
-void gsx_default_params(GsxParams *params);
+GSX_API int gsx_version(void);
+GSX_API const char *gsx_last_error(void);
+GSX_API void gsx_default_params(GsxParams *params);
 
 /*
  * Bytes of device workspace needed by any entry point below for up to `n` Gaussians, a
  * width x height frame, tile size `tile` and at most `max_instances` (Gaussian, tile) pairs.
  * Returns 0 on invalid arguments.
  */
-size_t gsx_workspace_bytes(int64_t n, int32_t width, int32_t height, int32_t tile, int64_t max_instances);
+GSX_API size_t gsx_workspace_bytes(int64_t n, int32_t width, int32_t height, int32_t tile, int64_t max_instances);
 
 /*
  * Stage 1.  Replaces GaussianScene.preprocess (splat/gaussian_scene.py:70-144) with
@@ -199,7 +217,7 @@ size_t gsx_workspace_bytes(int64_t n, int32_t width, int32_t height, int32_t til
  * depth-sorted (ascending view z, ties by original index); rows >= *n_visible_host are unspecified.
  * order (n) int32: original index of each sorted row (may be NULL).  Synchronises `stream`.
  */
-int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
+GSX_API int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
                    const float *opacity_logit, const float *colors, int64_t n,
                    float *points_xy, float *colors_out, float *covariance_2d, float *depths,
                    float *inverse_covariance_2d, float *radius, float *min_x, float *max_x,
@@ -217,7 +235,7 @@ int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *s
  * GaussianScene.render_image (splat/gaussian_scene.py:200-238) computes from the same arrays.
  * out_image is fully written (pixels outside rendered tiles are set to 0).
  */
-int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t tile_size,
+GSX_API int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t tile_size,
                             const float *point_means, const float *point_colors,
                             const float *inverse_covariance_2d, const float *min_x, const float *max_x,
                             const float *min_y, const float *max_y, const float *opacity, int64_t n,
@@ -233,7 +251,7 @@ int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t t
  * and to detect n_instances > capacity (GSX_ERR_WORKSPACE_TOO_SMALL; stats_host->n_instances then
  * holds the count to size the workspace for); with GSX_FLAG_NO_SYNC it does not synchronise at all.
  */
-int gsx_render_forward(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
+GSX_API int gsx_render_forward(const GsxCamera *camera, const float *means3d, const float *scales, const float *quats,
                        const float *opacity_logit, const float *colors, int64_t n, int32_t tile_size,
                        float *out_image, const GsxParams *params, GsxFrameStats *stats_host,
                        void *workspace, size_t workspace_bytes, void *stream);
@@ -244,7 +262,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
  * normalised twice as the reference does.  The render entry points compute this inline; the
  * function exists for callers of the reference's method.
  */
-int gsx_covariance_3d(const float *scales, const float *quats, int64_t n, float *covariance_out, void *stream);
+GSX_API int gsx_covariance_3d(const float *scales, const float *quats, int64_t n, float *covariance_out, void *stream);
 
 /*
  * Replaces GaussianScene.get_2d_covariance (splat/gaussian_scene.py:53-68 -> compute_2d_covariance,
@@ -252,7 +270,7 @@ int gsx_covariance_3d(const float *scales, const float *quats, int64_t n, float 
  * (n,3,3) under `camera` -- view-space point clamped at 1.3 tan(fov/2), J from the COLMAP focal lengths,
  * (((J W) Sigma) W^T) J^T left to right, top-left 2x2.  No cull: every row is projected.
  */
-int gsx_covariance_2d(const GsxCamera *camera, const float *points, const float *covariance_3d, int64_t n,
+GSX_API int gsx_covariance_2d(const GsxCamera *camera, const float *points, const float *covariance_3d, int64_t n,
                       float *covariance_2d_out, void *stream);
 
 /*
@@ -260,7 +278,7 @@ int gsx_covariance_2d(const GsxCamera *camera, const float *points, const float 
  * (splat/gaussian_scene.py:44-51, splat/image.py:72-89).  Writes (x_pix, y_pix, ndc_z) for every
  * Gaussian in input order into points_out (n,3) and 1/0 into in_view_out (n) (uint8).
  */
-int gsx_project_points(const GsxCamera *camera, const float *means3d, int64_t n, float *points_out,
+GSX_API int gsx_project_points(const GsxCamera *camera, const float *means3d, int64_t n, float *points_out,
                        uint8_t *in_view_out, void *stream);
 
 /*
@@ -271,7 +289,7 @@ int gsx_project_points(const GsxCamera *camera, const float *means3d, int64_t n,
  * in HOST memory (GaussianImage.camera_center, splat/image.py:66); colors_out (n,3) then feeds the
  * `colors` argument of gsx_render_forward.
  */
-int gsx_sh_to_rgb(const float *means3d, const float *sh, int32_t degree, int64_t n,
+GSX_API int gsx_sh_to_rgb(const float *means3d, const float *sh, int32_t degree, int64_t n,
                   const float *camera_center_host, float *colors_out, void *stream);
 
 #ifdef __cplusplus

@@ -12,6 +12,9 @@ from ctypes import POINTER, c_float, c_int32, c_int64, c_size_t, c_uint8, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsx.so")
+# The same sources built with -DGSX_TEST_HOOKS plus csrc/gsx_debug.hip (csrc/gsx_debug.h): measurement knobs and the
+# sorts on caller-provided data.  tests/ and tools/ only -- load_test_hooks(); the product never loads it.
+TEST_LIB_PATH = os.path.join(_HERE, "libgsx_test.so")
 
 GSX_OK = 0
 GSX_ERR_INVALID_ARGUMENT = -1
@@ -45,12 +48,13 @@ class GsxParams(ctypes.Structure):
                 ("tile_x0", c_int32), ("tile_x1", c_int32), ("tile_y0", c_int32), ("tile_y1", c_int32),
                 ("out_x0", c_int32), ("out_y0", c_int32), ("out_w", c_int32), ("out_h", c_int32),
                 ("flags", c_int32), ("background", c_float * 3), ("camera_device", c_void_p),
-                ("tile_counts", c_void_p), ("sh", c_void_p), ("sh_degree", c_int32), ("reserved0", c_int32)]
+                ("tile_counts", c_void_p), ("sh", c_void_p), ("sh_degree", c_int32), ("reserved0", c_int32),
+                ("kept_hint", c_int64)]
 
 
 class GsxFrameStats(ctypes.Structure):
     _fields_ = [("n_visible", c_int64), ("n_instances", c_int64), ("n_tiles", c_int64), ("reserved", c_int64),
-                ("stage_ms", c_float * 8)]
+                ("stage_ms", c_float * 6), ("n_kept", c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/gsx.h declares.
@@ -72,7 +76,43 @@ SIGNATURES = {
     "gsx_sh_to_rgb": (ctypes.c_int, [_FP, _FP, c_int32, c_int64, POINTER(c_float), _FP, c_void_p]),
 }
 
+# csrc/gsx_debug.h
+DEBUG_SIGNATURES = {
+    "gsx_debug_sort_pairs": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t,
+                                            c_void_p]),
+    "gsx_debug_depth_sort": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_uint32,
+                                            c_int64, POINTER(c_int64), c_void_p, c_size_t, c_void_p]),
+}
+
 _lib = None
+_test_lib = None
+
+
+def _bind(lib, signatures):
+    for name, (res, args) in signatures.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load_test_hooks():
+    """libgsx_test.so (tests/ and tools/ only): every entry point of the product library plus the hooks of
+    csrc/gsx_debug.h; its kernels additionally honour the GSX_* measurement knobs of the environment."""
+    global _test_lib
+    if _test_lib is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            raise RuntimeError("libgsx_test.so not found at %s: build it with `make -C intro_to_gaussian_splatting_amd/csrc`"
+                               % TEST_LIB_PATH)
+        _test_lib = _bind(_bind(ctypes.CDLL(TEST_LIB_PATH), SIGNATURES), DEBUG_SIGNATURES)
+    return _test_lib
+
+
+def use_test_library() -> None:
+    """Development aid (tools/, bench.py --test-lib): every later load() returns libgsx_test.so, so that a whole
+    frame can be rendered under the GSX_* measurement knobs.  Never called by the package itself."""
+    global _lib
+    _lib = load_test_hooks()
 
 
 def load():
@@ -84,12 +124,7 @@ def load():
                 "libgsx.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C intro_to_gaussian_splatting_amd/csrc` (needs hipcc, targets gfx950). "
                 "There is no CPU fallback." % LIB_PATH)
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = lib
+        _lib = _bind(ctypes.CDLL(LIB_PATH), SIGNATURES)
     return _lib
 
 

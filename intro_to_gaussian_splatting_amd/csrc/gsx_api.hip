@@ -33,7 +33,7 @@ using namespace gsx::plan;   // Carve, Plan, carve(), capacity_for(), make_plan(
 struct StageTimer {
     bool on = false;
     hipStream_t s = nullptr;
-    hipEvent_t ev[8];
+    hipEvent_t ev[6];
     int n = 0;
     void begin(bool enable, hipStream_t stream) {
         on = enable;
@@ -41,7 +41,7 @@ struct StageTimer {
         mark();
     }
     void mark() {
-        if (!on || n >= 8) return;
+        if (!on || n >= 6) return;
         if (hipEventCreate(&ev[n]) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(ev[n], s);
         ++n;
@@ -50,7 +50,7 @@ struct StageTimer {
     void finish(GsxFrameStats *st) {
         if (n > 0) (void)hipEventSynchronize(ev[n - 1]);
         if (st) {
-            for (int i = 0; i < 8; ++i) st->stage_ms[i] = 0.0f;
+            for (int i = 0; i < 6; ++i) st->stage_ms[i] = 0.0f;
             for (int i = 1; i < n; ++i) {
                 float ms = 0.0f;
                 (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
@@ -89,6 +89,9 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
     int64_t *dev2 = (int64_t *)(counters + 4);
     uint2 *ranges = (uint2 *)(ws + c.ranges);
     bool counts_on_device = false, counts_in_host = false;
+    // no Gaussians: every tile's list is empty -- GsxParams.tile_counts says so (an empty WINDOW has no entries)
+    if (n == 0 && p.tile_counts && p.grid.count() > 0)
+        GSX_HIP(gsx::launch_zero_words(p.tile_counts, (size_t)p.grid.count(), s));
     if (p.grid.count() > 0 && n == 0 && p.semantics == GSX_SEM_STD_3DGS) {
         // no Gaussians: every pixel of the window is the background colour
         tm.mark();  // 3: scan + emit
@@ -144,20 +147,23 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             if (!counts_on_device) {
                 stats->n_visible = 0;
                 stats->n_instances = 0;
+                stats->n_kept = 0;
             } else if (!counts_in_host) {
                 GSX_HIP(hipMemcpyAsync(stats, dev2, 16, hipMemcpyDeviceToHost, s));
+                GSX_HIP(hipMemcpyAsync(&stats->n_kept, dev2 + 2, 8, hipMemcpyDeviceToHost, s));
             }
             stats->n_tiles = p.grid.count();
             stats->reserved = cap;  // > 0: counts are delivered asynchronously; value = pair capacity used
         }
         return GSX_OK;
     }
-    int64_t host2[2] = {0, 0};
-    if (counts_on_device) GSX_HIP(hipMemcpyAsync(host2, dev2, 16, hipMemcpyDeviceToHost, s));
+    int64_t host2[3] = {0, 0, 0};
+    if (counts_on_device) GSX_HIP(hipMemcpyAsync(host2, dev2, 24, hipMemcpyDeviceToHost, s));
     GSX_HIP(hipStreamSynchronize(s));
     if (stats) {
         stats->n_visible = host2[0];
         stats->n_instances = host2[1];
+        stats->n_kept = host2[2];
         stats->n_tiles = p.grid.count();
         stats->reserved = 0;
     }
@@ -296,79 +302,19 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
                                      (gsx::TileRect *)(ws + c.rect), counters,
                                      p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 1: project (+ depth keys)
-    // the sampled sort also leaves the per-chunk tile counts the pair emission starts from (one kernel less)
-    const bool sampled = gsx::depth_sort_is_sampled(n);
+    // the sampled routes also leave the per-chunk tile counts the pair emission starts from (one kernel less)
+    const gsx::DepthRoute route = gsx::depth_sort_route(n, p.kept_hint);
+    const bool sampled = route != gsx::kDepthLsd;
     if (sampled)
-        GSX_HIP(gsx::sort_depth_sampled(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
-                                        (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), 0,
-                                        gsx::emit_chunk_sums(ws + c.temp, n, cap), s));
+        GSX_HIP(gsx::sort_depth_sampled(route, ws + c.temp, k0, k1, v0, v1, n, p.kept_hint, counters + kCtrKept,
+                                        counters + kCtrCulled, (const gsx::TileRect *)(ws + c.rect),
+                                        (gsx::TileRect *)(ws + c.rrect), 0, gsx::emit_chunk_sums(ws + c.temp, n, cap), s));
     else
         GSX_HIP(gsx::sort_depth_compact(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
                                         (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s));
     tm.mark();  // 2: depth sort (drops what reaches no tile, leaves the rectangles in rank order)
     return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rrect), v0, counters + kCtrKept,
                          counters + kCtrCulled, sampled, stats_host, tm, s);
-}
-
-// Test hook (not part of include/gsx.h): the pipeline's radix sort on caller-provided pairs.
-// keys / vals: n 32-bit words each, sorted in place; key16 != 0 sorts uint16 keys.  scratch must
-// hold 2 * 4n bytes + gsx radix table (use gsx_workspace_bytes(n, 16, 16, 16, n)).  count_dev
-// (may be NULL) = device pointer to the element count, as the tile sort uses it.
-int gsx_debug_sort_pairs(void *keys, uint32_t *vals, int64_t n, int32_t key_bits, int32_t key16,
-                         const uint32_t *count_dev, void *scratch, size_t scratch_bytes, void *stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (n <= 0 || !keys || !vals || !scratch) return fail(GSX_ERR_INVALID_ARGUMENT, "bad arguments");
-    size_t need = align_up((size_t)n * 4) * 2 + radix_temp_bytes(n);
-    if (scratch_bytes < need) return fail(GSX_ERR_WORKSPACE_TOO_SMALL, "scratch needs %zu bytes", need);
-    char *sc = (char *)scratch;
-    uint32_t *valt = (uint32_t *)(sc + align_up((size_t)n * 4));
-    void *temp = sc + 2 * align_up((size_t)n * 4);
-    uint32_t *vc = vals, *va = valt;
-    if (key16) {
-        uint16_t *kc = (uint16_t *)keys, *ka = (uint16_t *)sc;
-        GSX_HIP(gsx::radix_sort_pairs_u16(temp, kc, ka, vc, va, count_dev, n, key_bits, s));
-        if (kc != (uint16_t *)keys) GSX_HIP(hipMemcpyAsync(keys, kc, (size_t)n * 2, hipMemcpyDeviceToDevice, s));
-    } else {
-        uint32_t *kc = (uint32_t *)keys, *ka = (uint32_t *)sc;
-        GSX_HIP(gsx::radix_sort_pairs_u32(temp, kc, ka, vc, va, count_dev, n, key_bits, s));
-        if (kc != (uint32_t *)keys) GSX_HIP(hipMemcpyAsync(keys, kc, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-    }
-    if (vc != vals) GSX_HIP(hipMemcpyAsync(vals, vc, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-    return GSX_OK;
-}
-
-// Test hook (not part of include/gsx.h): the depth sort of the whole-path entry on caller-provided keys.
-// keys (n, device; >= 0xFFFFFFFE = dropped; overwritten), rect / rrect (n x 4 uint16), order_out (n): on return
-// order_out[0 .. counts_host[0]) = index of each rank, rrect[rank] = rect[index]; counts_host = {kept, culled}.
-// mode 0: four LSD passes, 1: sample-partitioned; lds_cap: see sort_depth_sampled.  scratch: 16 n + 64 +
-// gsx_workspace_bytes(n, 16, 16, 16, 1) bytes.  Synchronises.
-int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, void *rrect, uint32_t *order_out, int32_t mode,
-                         uint32_t lds_cap, int64_t *counts_host, void *scratch, size_t scratch_bytes, void *stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (n <= 0 || !keys || !rect || !rrect || !order_out || !scratch) return fail(GSX_ERR_INVALID_ARGUMENT, "bad arguments");
-    const size_t words = align_up((size_t)n * 4);
-    const size_t need = 3 * words + 256 + binning_temp_bytes(n, 1);
-    if (scratch_bytes < need) return fail(GSX_ERR_WORKSPACE_TOO_SMALL, "scratch needs %zu bytes", need);
-    char *sc = (char *)scratch;
-    uint32_t *k1 = (uint32_t *)sc, *v0 = (uint32_t *)(sc + words), *v1 = (uint32_t *)(sc + 2 * words);
-    uint32_t *counters = (uint32_t *)(sc + 3 * words);
-    void *temp = sc + 3 * words + 256;
-    GSX_HIP(hipMemsetAsync(counters, 0, 64, s));
-    if (mode == 1)
-        GSX_HIP(gsx::sort_depth_sampled(temp, keys, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
-                                        (const gsx::TileRect *)rect, (gsx::TileRect *)rrect, lds_cap, nullptr, s));
-    else
-        GSX_HIP(gsx::sort_depth_compact(temp, keys, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
-                                        (const gsx::TileRect *)rect, (gsx::TileRect *)rrect, s));
-    uint32_t host[4] = {0, 0, 0, 0};
-    GSX_HIP(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, s));
-    GSX_HIP(hipMemcpyAsync(order_out, v0, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-    GSX_HIP(hipStreamSynchronize(s));
-    if (counts_host) {
-        counts_host[0] = host[kCtrKept];
-        counts_host[1] = host[kCtrCulled];
-    }
-    return GSX_OK;
 }
 
 int gsx_sh_to_rgb(const float *means3d, const float *sh, int32_t degree, int64_t n, const float *camera_center_host,

@@ -147,7 +147,8 @@ __global__ void __launch_bounds__(kBlock) scan_sums_kernel(uint64_t *__restrict_
 }
 
 // counts: what the frame reports and what the tile sort reads on the device.
-//   stats2[0] = visible Gaussians, stats2[1] = D as int64 (the first two fields of a GsxFrameStats);
+//   stats2[0] = visible Gaussians, stats2[1] = D as int64 (the first two fields of a GsxFrameStats), stats2[2] =
+//   Gaussians kept by the depth sort;
 //   *d32 = min(D, 2^32 - 1): element count of the tile sort.
 struct EmitCounts {
     int64_t *stats2;
@@ -239,9 +240,11 @@ __global__ void __launch_bounds__(kBlock)
         const int64_t nvis = ec.n_total - (ec.culled_dev ? (int64_t)*ec.culled_dev : 0);
         ec.stats2[0] = nvis;
         ec.stats2[1] = (int64_t)d;
-        if (ec.stats2_host) {
+        ec.stats2[2] = (int64_t)m;              // Gaussians the depth sort kept (GsxFrameStats.n_kept)
+        if (ec.stats2_host) {                    // a pinned GsxFrameStats: n_visible, n_instances, ..., n_kept at byte 56
             ec.stats2_host[0] = nvis;
             ec.stats2_host[1] = (int64_t)d;
+            ec.stats2_host[7] = (int64_t)m;
         }
         *ec.d32 = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d;
         *ec.long_count = 0u;

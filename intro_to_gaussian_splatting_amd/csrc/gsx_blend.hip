@@ -46,8 +46,6 @@
 // M11 is not positive and finite (only possible for caller-given inverse covariances on the stage-2 entry)
 // keeps the monomial coefficients and is flagged; a batch holding one takes the unpacked loop.
 // T(1 - alpha) is evaluated as T - T alpha (1 ulp).
-#include <stdlib.h>
-
 #include "gsx_internal.h"
 
 namespace gsx {
@@ -182,17 +180,24 @@ __device__ __forceinline__ void composite(float e_s, const float (&e_p)[NPX], co
 // Records that cannot matter to ANY pixel of the tile are not staged at all.  The reference lists a Gaussian
 // for every tile its bounding box touches, plus a tile of slack (`min <= x0 + T`, gaussian_scene.py:209-217), so
 // ~8 % of the listed (tile, Gaussian) pairs lie more than 5.9 sigma from every pixel of their tile.  If
-//     log2 op - D1 min(e0^2) - min(w^2) < -26   over the tile's pixel rectangle (w = r11 e1 + h e0 is linear: its
-//                                                 extremes are at the corners),
-// then alpha < 2^-26 at every pixel, so T - T alpha == T bit for bit (T alpha is below half an ulp of T) and
-// the colour the reference adds is below 2^-26: skipping the record leaves every T identical and moves a
-// channel by < 1.5e-8 per skipped record (measured on the frame: see DESIGN.md).  The tile lists and D are
-// untouched -- this is a decision of the compositing kernel, the same in every REF_CPU kernel (the test only
-// depends on the record and the tile), so the kernel families stay bit-identical to each other.
+//     log2 op - D1 min(e0^2) - min(w^2) < skip_below   over the tile's pixel rectangle (w = r11 e1 + h e0 is linear:
+//                                                        its extremes are at the corners),
+// with skip_below <= -26, then alpha < 2^-26 at every pixel, so T - T alpha == T bit for bit (T alpha is below half
+// an ulp of T): skipping the record leaves every T identical and drops less than 2^skip_below of colour per
+// channel.  The threshold depends on the LENGTH of the tile's list (skip_threshold below), so that all the records
+// a tile skips together stay below 512 x 2^-26 = 7.6e-6 however long the list is -- a flat -26 would let 6 711
+// skipped records of peak alpha 1.5e-8 each reach the 1e-4 pixel tolerance (round-2 verdict; tested with 12 000).
+// The tile lists and D are untouched -- this is a decision of the compositing kernel, the same in every REF_CPU
+// kernel (the test only depends on the record, the tile and the length of its list), so the kernel families stay
+// bit-identical to each other.
 // nb: in = records of the batch, out = records staged (wave-uniform).
+__device__ __forceinline__ float skip_threshold(uint32_t list_length) {
+    // -26 - log2(max(1, length / 512)): 512 x 2^-26 of colour at most per tile, whatever the length
+    return -26.0f - __builtin_amdgcn_logf(fmaxf(1.0f, (float)list_length * (1.0f / 512.0f)));
+}
 __device__ __forceinline__ bool stage_batch(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                                             uint32_t base, uint32_t &nb, float4 (*sh)[64], int lane, float tile_x0,
-                                            float tile_y0, float tile_side) {
+                                            float tile_y0, float tile_side, float skip_below) {
     bool mono = false, keep = false;
     float4 a, b, c;
     if ((uint32_t)lane < nb) {
@@ -212,7 +217,7 @@ __device__ __forceinline__ bool stage_batch(const Record *__restrict__ rec, cons
             const float wabs = fminf(fabsf(wlo), fabsf(whi));
             const float w_min2 = (wlo <= 0.0f && whi >= 0.0f) ? 0.0f : wabs * wabs;
             const float bound = b.y - a.z * ex_min2 - w_min2;
-            if (bound < -26.0f) keep = false;    // NaN anywhere: the comparison is false, the record stays
+            if (bound < skip_below) keep = false;    // NaN anywhere: the comparison is false, the record stays
         }
     }
     const unsigned long long mask = __ballot(keep);
@@ -300,10 +305,11 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     bool checked = false;   // wave-uniform: some pixel of this quarter has saturated
     uint2 rg = ranges[t];
     rg.y &= ~kLongFlag;
+    const float skip_below = skip_threshold(rg.y - rg.x);
     constexpr int kTrip = 8;
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
         uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
-        const bool mono = stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f);
+        const bool mono = stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skip_below);
         __syncthreads();
         uint32_t k = 0;
         if (!checked && !mono) {
@@ -405,9 +411,10 @@ __global__ void __launch_bounds__(64)
     bool checked = false;  // wave-uniform: some pixel of this tile has saturated
     const uint2 rg = ranges[t];
     if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
+    const float skip_below = skip_threshold(rg.y - rg.x);
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
         uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
-        const bool mono = stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f);
+        const bool mono = stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skip_below);
         __syncthreads();
         if (VARIANT == 0 || mono) {
             if (VARIANT != 0) {   // a batch with a monomial record (stage-2 entry only): unpack the state
@@ -553,6 +560,7 @@ __global__ void __launch_bounds__(64)
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     const int Ts = g.tile, npx = Ts * Ts;
     const uint2 rg = ranges[t];
+    const float skip_below = skip_threshold(rg.y - rg.x);
     const bool fast_y = out.stride_y < out.stride_x;
     for (int chunk = 0; chunk < npx; chunk += 64) {
         const int p = chunk + lane;
@@ -563,7 +571,7 @@ __global__ void __launch_bounds__(64)
         float T[1] = {1.0f}, c0[1] = {0.0f}, c1[1] = {0.0f}, c2[1] = {0.0f};
         for (uint32_t base = rg.x; base < rg.y; base += 64) {
             uint32_t nb = min(64u, rg.y - base);
-            (void)stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * Ts), (float)(ty * Ts), (float)Ts);
+            (void)stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * Ts), (float)(ty * Ts), (float)Ts, skip_below);
             __syncthreads();
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
@@ -808,12 +816,12 @@ __global__ void __launch_bounds__(64)
     }
 }
 
-}  // namespace
-
 __global__ void __launch_bounds__(256) zero_words_kernel(uint32_t *__restrict__ p, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0u;
 }
+
+}  // namespace
 
 hipError_t launch_zero_words(uint32_t *p, size_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
@@ -834,10 +842,7 @@ bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic) 
 // kernel runs for 100+ us (1M Gaussians at 1080p: -33 us of compositing), not for the small scenes (100 000
 // Gaussians: -3 us).  D is not known on the host; the Gaussian count is.
 bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int64_t n, int asked) {
-    static const int forced = [] {
-        const char *e = getenv("GSX_TILE_SCHEDULE");   // measurement knob: "0" never, "1" always
-        return e ? (e[0] == '0' ? 0 : 1) : -1;
-    }();
+    const int forced = knob("GSX_TILE_SCHEDULE", -1);   // test library only: 0 never, 1 always
     if ((semantics != GSX_SEM_REF_CPU && semantics != GSX_SEM_STD_3DGS) || grid.tile != 16 || generic) return false;
     if (asked >= 0) return asked != 0;          // GSX_FLAG_TILE_SCHEDULE / GSX_FLAG_NO_TILE_SCHEDULE
     if (forced >= 0) return forced != 0;
@@ -868,11 +873,7 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
     }
     if (semantics != GSX_SEM_REF_CPU) return hipErrorNotSupported;
     if (grid.tile == 16 && !generic) {
-        // GSX_BLEND_VARIANT: measurement knob for A/B runs of the compositing loop (default 1)
-        static const int variant = [] {
-            const char *e = getenv("GSX_BLEND_VARIANT");
-            return e ? atoi(e) : 1;
-        }();
+        const int variant = knob("GSX_BLEND_VARIANT", 1);   // test library only: A/B runs of the compositing loop
         const unsigned nh = lt.max ? 4u * lt.max : 0u;
         if (variant == 0)
             blend_tile16_kernel<0><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched);

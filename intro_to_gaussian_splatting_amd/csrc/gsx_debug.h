@@ -1,0 +1,36 @@
+/*
+ * gsx_debug.h -- test hooks of libgsx_test.so (the library sources built with -DGSX_TEST_HOOKS plus gsx_debug.hip).
+ * NOT part of the C ABI: the shipping libgsx.so neither declares nor exports these, and reads no environment
+ * variable.  tests/ and tools/ bind them with ctypes (intro_to_gaussian_splatting_amd/_ffi.py: load_test_hooks()).
+ */
+#ifndef GSX_DEBUG_H_
+#define GSX_DEBUG_H_
+
+#include "gsx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The pipeline's radix sort on caller-provided pairs.  keys / vals: n 32-bit words each, sorted in place;
+ * key16 != 0 sorts uint16 keys.  scratch must hold 2 * 4n bytes + the radix table (use
+ * gsx_workspace_bytes(n, 16, 16, 16, n)).  count_dev (may be NULL) = device pointer to the element count, as
+ * the tile sort uses it. */
+GSX_API int gsx_debug_sort_pairs(void *keys, uint32_t *vals, int64_t n, int32_t key_bits, int32_t key16,
+                                 const uint32_t *count_dev, void *scratch, size_t scratch_bytes, void *stream);
+
+/* The depth sort of the whole-path entry on caller-provided keys.  keys (n, device; >= 0xFFFFFFFE = dropped;
+ * overwritten), rect / rrect (n x 4 uint16), order_out (n): on return order_out[0 .. counts_host[0]) = index of
+ * each rank, rrect[rank] = rect[index]; counts_host (3 entries) = {kept, culled, route taken}.
+ * mode 0: four LSD passes; 1: sample-partitioned, 256 buckets; 2: sample-partitioned, 1024 buckets;
+ * -1: the route gsx_render_forward would take for (n, kept_hint).  lds_cap: bucket size above which the bucket
+ * kernel sorts through global memory (0 = its LDS capacity).  scratch: 16 n + 4096 +
+ * gsx_workspace_bytes(n, 16, 16, 16, 1) bytes.  Synchronises. */
+GSX_API int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, void *rrect, uint32_t *order_out,
+                                 int32_t mode, uint32_t lds_cap, int64_t kept_hint, int64_t *counts_host,
+                                 void *scratch, size_t scratch_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSX_DEBUG_H_ */

@@ -3,11 +3,25 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "gsx.h"
 #include "gsx_plan.h"
 
 namespace gsx {
+
+// Measurement knobs (A/B runs of a kernel variant on the GPU box: tools/, bench.py --test-lib) exist only in
+// libgsx_test.so, which is this same source built with -DGSX_TEST_HOOKS; in the shipping library knob() is its
+// default and no environment variable is read anywhere.
+inline int knob(const char *name, int dflt) {
+#ifdef GSX_TEST_HOOKS
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 constexpr uint32_t kCulledKey = 0xFFFFFFFFu;  // depth key of a Gaussian behind the z >= 0.2 plane
 constexpr uint32_t kEmptyKey = 0xFFFFFFFEu;   // visible, but it reaches no tile of the window; keys >= this are
@@ -91,8 +105,8 @@ hipError_t launch_project_points(const GsxCamera &cam, const float *means3d, int
 // ---- gsx_binning.hip
 // Where a frame's counts go on the device (and, optionally, straight into pinned host memory).
 struct BinCounts {
-    int64_t *stats2;             // [0] = visible Gaussians, [1] = D: the first two fields of a GsxFrameStats
-    int64_t *stats2_host;        // device-visible alias of a pinned GsxFrameStats, or null
+    int64_t *stats2;             // [0] = visible Gaussians, [1] = D, [2] = Gaussians kept by the depth sort
+    int64_t *stats2_host;        // device-visible alias of a pinned GsxFrameStats (fields 0, 1 and n_kept), or null
     uint32_t *d32;               // min(D, 2^32 - 1): element count of the tile sort
     uint32_t *long_count;        // zeroed by the emit kernel for tile_ranges_kernel (LongTiles.count)
     const uint32_t *culled_dev;  // Gaussians behind the cull plane (counted by the depth sort), or null
@@ -133,13 +147,15 @@ hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
                               hipStream_t s);
 
-// The same contract with 6 kernels instead of 12: sample 8192 keys -> 255 splitters, ONE stable partition
-// pass, one in-LDS sort per bucket (gsx_sort.hip).  Used when depth_sort_is_sampled(n).  lds_cap: 0 = the
-// kernel's capacity; tests pass a small value to drive buckets through the global-memory path.
-bool depth_sort_is_sampled(int64_t n);
-hipError_t sort_depth_sampled(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
-                              int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
-                              uint32_t lds_cap, uint64_t *chunk_sums, hipStream_t s);
+// The same contract with 5 kernels instead of 12: sample 2048 / 8192 keys -> 255 / 1023 splitters, ONE stable
+// partition pass, one in-LDS sort per bucket (gsx_sort.hip).  depth_sort_route picks the route from the
+// Gaussian count and the caller's hint of how many of them reach a tile (GsxParams.kept_hint; 0 = unknown).
+// lds_cap: 0 = the bucket kernel's capacity; tests pass a small value to drive buckets through its global-memory path.
+enum DepthRoute { kDepthLsd = 0, kDepth256 = 1, kDepth1024 = 2, kDepthOneWorkgroup = 3 };
+DepthRoute depth_sort_route(int64_t n, int64_t kept_hint);
+hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
+                              uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,
+                              const TileRect *rect, TileRect *rrect, uint32_t lds_cap, uint64_t *chunk_sums, hipStream_t s);
 // Where emit_instances keeps its chunk sums inside `temp` (for sort_depth_sampled to fill them in).
 uint64_t *emit_chunk_sums(void *temp, int64_t n, int64_t cap);
 

@@ -59,18 +59,24 @@ struct ClearPlan {
 };
 
 
-// Digit table [256][chunks rounded up to a multiple of 4] + 256 row totals + 256 splitters (sample-partitioned
-// depth sort) + 256 four-chunk totals for each of up to kSortQuadTotals count workgroups (passes of up to 512K
-// items, which run without a row-scan launch).
-constexpr int kSortSamples = 2048, kSortQuadTotals = 64;
-inline size_t radix_temp_bytes(int64_t max_items) {
+// Scratch of one radix / partition pass: digit table [bins][chunks rounded up to a multiple of 4] + `bins` row
+// totals + `bins` splitters (sample-partitioned depth sort) + 256 four-chunk totals for each of up to
+// kSortQuadTotals count workgroups (passes of up to 512K items, which run without a row-scan launch).
+// The LSD passes and the 256-bucket partition use kSortBins rows; the depth sort of more than ~1.5M kept
+// Gaussians partitions into kSortBinsMax buckets (gsx_sort.hip), over the n depth keys only.
+constexpr int kSortBinsMax = 1024;
+constexpr int kSortSamples = 2048, kSortSamplesMax = 8192, kSortQuadTotals = 64;
+inline size_t radix_temp_bytes(int64_t max_items, int bins = kSortBins) {
     const size_t nblocks = (size_t)((max_items + kSortItems - 1) / kSortItems) + kSortQuad;
-    return ((size_t)kSortBins * (nblocks + kSortQuad) + 2 * kSortBins + (size_t)kSortQuadTotals * kSortBins) * sizeof(uint32_t);
+    return ((size_t)bins * (nblocks + kSortQuad) + 2 * (size_t)bins + (size_t)kSortQuadTotals * kSortBins) * sizeof(uint32_t);
 }
-// Where the 64-bit chunk sums start inside `temp`: behind the radix table for max(n, cap) items.
+// Where the 64-bit chunk sums start inside `temp`: behind the radix table for max(n, cap) items (and behind the
+// kSortBinsMax-row table of the n depth keys).
 inline size_t binning_sums_offset(int64_t n, int64_t cap) {
     const int64_t items = n > cap ? n : cap;
-    return (radix_temp_bytes(items > 1 ? items : 1) + 255) & ~(size_t)255;   // a request for 0 pairs is sized like 1
+    const size_t a = radix_temp_bytes(items > 1 ? items : 1);   // a request for 0 pairs is sized like 1
+    const size_t b = radix_temp_bytes(n > 1 ? n : 1, kSortBinsMax);
+    return ((a > b ? a : b) + 255) & ~(size_t)255;
 }
 inline size_t binning_temp_bytes(int64_t n, int64_t cap) {
     const size_t nchunks = (size_t)((n + kEmitChunk - 1) / kEmitChunk) + 2;
@@ -113,7 +119,7 @@ struct Carve {
 // The 64-byte `counters` block: what the kernels of one frame hand to each other on the device.
 //   u32 [0] Gaussians behind the cull plane   [1] Gaussians kept by the depth sort (M)
 //       [2] min(D, 2^32 - 1)                   [3] long tiles found (LongTiles.count)
-//   i64 at byte 16: n_visible, D (the first two fields of a GsxFrameStats)
+//   i64 at byte 16: n_visible, D (the first two fields of a GsxFrameStats), M again (GsxFrameStats.n_kept)
 enum { kCtrCulled = 0, kCtrKept = 1, kCtrPairs = 2, kCtrLong = 3 };
 
 inline Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes) {
@@ -179,6 +185,7 @@ struct Plan {
     uint32_t *tile_counts;
     const float *sh;
     int sh_degree;   // -1: RGB colours
+    int64_t kept_hint;   // GsxParams.kept_hint (0: unknown)
     float background[3];
 };
 
@@ -203,6 +210,7 @@ inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_ima
     p.tile_counts = d.tile_counts;
     p.sh = d.sh;
     p.sh_degree = d.sh ? d.sh_degree : -1;
+    p.kept_hint = d.kept_hint > 0 ? d.kept_hint : 0;
     if (d.sh && (d.sh_degree < 0 || d.sh_degree > 3)) return fail(GSX_ERR_INVALID_ARGUMENT, "SH degree %d outside [0,3]", d.sh_degree);
     if (d.layout != GSX_LAYOUT_WH3 && d.layout != GSX_LAYOUT_HW3) return fail(GSX_ERR_INVALID_ARGUMENT, "unknown layout %d", d.layout);
     if (!out_image) return fail(GSX_ERR_INVALID_ARGUMENT, "out_image is NULL");

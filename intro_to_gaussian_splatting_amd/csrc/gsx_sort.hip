@@ -36,6 +36,8 @@
 //          in two later kernels, 5-8x the algorithmic traffic); the sorted keys are not written.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gsx_internal.h"
 
 namespace gsx {
@@ -70,12 +72,13 @@ __device__ __forceinline__ uint32_t load_count(const uint32_t *n_dev, uint32_t b
     return n < bound ? n : bound;
 }
 
-// SPLIT passes (sort_depth_sampled): the "digit" of a key is its bucket among 255 sorted splitters,
-// bucket(k) = #{j in 1..255 : spl[j] <= k}, spl[0] = 0 -- monotone in k, equal keys share a bucket.
+// SPLIT passes (sort_depth_sampled): the "digit" of a key is its bucket among NB - 1 sorted splitters,
+// bucket(k) = #{j in 1..NB-1 : spl[j] <= k}, spl[0] = 0 -- monotone in k, equal keys share a bucket.
+template <int NB>
 __device__ __forceinline__ uint32_t bucket_of(const uint32_t *spl, uint32_t k) {
-    uint32_t lo = 0, hi = 256;          // spl[lo] <= k < spl[hi], spl[256] = +inf
+    uint32_t lo = 0, hi = NB;          // spl[lo] <= k < spl[hi], spl[NB] = +inf
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = NB; s > 1; s >>= 1) {
         const uint32_t mid = (lo + hi) >> 1;
         const bool right = spl[mid] <= k;
         lo = right ? mid : lo;
@@ -85,17 +88,17 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t *spl, uint32_t k) {
 }
 
 // The same for N keys at once: the N searches advance in lock step, so their LDS reads are in flight together
-// (eight dependent reads in a row per key otherwise).
-template <int N>
+// (eight or ten dependent reads in a row per key otherwise).
+template <int NB, int N>
 __device__ __forceinline__ void buckets_of(const uint32_t *spl, const uint32_t (&k)[N], uint32_t (&b)[N]) {
     uint32_t lo[N], hi[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         lo[i] = 0;
-        hi[i] = 256;
+        hi[i] = NB;
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = NB; s > 1; s >>= 1) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const uint32_t mid = (lo[i] + hi[i]) >> 1;
@@ -115,14 +118,16 @@ __device__ __forceinline__ void buckets_of(const uint32_t *spl, const uint32_t (
 // four waves), table[digit][chunk .. chunk+3] stored as ONE 16-byte word per digit (nbp = row pitch, a
 // multiple of 4).  FIRST: keys >= kEmptyKey are not counted (they are dropped by this pass) and the
 // culled ones among them (== kCulledKey) are added to *culled (zeroed by an earlier kernel).
-template <typename Key, bool CHUNK_MAJOR, bool FIRST, bool SPLIT = false>
+template <typename Key, bool CHUNK_MAJOR, bool FIRST, int SPLIT = 0>   // SPLIT: 0, or the number of buckets (256 / 1024)
 __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     count_kernel(const Key *__restrict__ keys, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
                  uint32_t mask, uint32_t *__restrict__ table, int nbp, uint32_t *__restrict__ culled,
                  const uint32_t *__restrict__ splitters = nullptr, uint32_t *__restrict__ quad_totals = nullptr) {
     constexpr int kLanes = CHUNK_MAJOR ? 1 : kQuad;   // chunks per workgroup
+    constexpr int NB = SPLIT ? SPLIT : kBins;         // histogram rows
     constexpr int kPerVec = 16 / sizeof(Key), kVecs = kRounds / kPerVec;   // 8 x u16 or 4 x u32 per 16 B
     static_assert(kRounds % kPerVec == 0, "a thread's items must fill whole 16-byte vectors");
+    static_assert(NB == kBins || !CHUNK_MAJOR, "the chunk-major table (small inputs) has 256 rows");
     const int c = CHUNK_MAJOR ? 0 : (int)(threadIdx.x >> 8);
     const uint32_t t = threadIdx.x & 255u;
     const uint32_t chunk = blockIdx.x * (uint32_t)kLanes + (uint32_t)c;
@@ -136,12 +141,14 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
 #pragma unroll
         for (int v = 0; v < kVecs; ++v) q[v] = src[v];
     }
-    __shared__ uint32_t h[kLanes][kBins];
+    __shared__ uint32_t h[kLanes][NB];
     __shared__ uint32_t s_culled;
-    __shared__ uint32_t spl[SPLIT ? kBins : 1];
-    if (SPLIT && threadIdx.x < kBins) spl[threadIdx.x] = splitters[threadIdx.x];   // visible after the barrier below
-    auto digit = [&](uint32_t k) -> uint32_t { return SPLIT ? bucket_of(spl, k) : ((k >> shift) & mask); };
-    h[c][t] = 0;
+    __shared__ uint32_t spl[SPLIT ? SPLIT : 1];
+    if (SPLIT)
+        for (uint32_t k = threadIdx.x; k < (uint32_t)NB; k += blockDim.x) spl[k] = k ? splitters[k] : 0u;   // visible after the barrier below
+    auto digit = [&](uint32_t k) -> uint32_t { return SPLIT ? bucket_of<NB>(spl, k) : ((k >> shift) & mask); };
+#pragma unroll
+    for (int k = 0; k < NB / 256; ++k) h[c][t + 256u * k] = 0;
     if (FIRST && threadIdx.x == 0) s_culled = 0;
     __syncthreads();
     uint32_t my_culled = 0;
@@ -150,7 +157,7 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
         for (int v = 0; v < kVecs; ++v) {
             const uint32_t w4[4] = {q[v].x, q[v].y, q[v].z, q[v].w};
             uint32_t d4[4] = {0, 0, 0, 0};
-            if (sizeof(Key) == 4 && SPLIT) buckets_of<4>(spl, w4, d4);
+            if (sizeof(Key) == 4 && SPLIT) buckets_of<NB, 4>(spl, w4, d4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (sizeof(Key) == 4) {
@@ -178,10 +185,11 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     __syncthreads();
     if (CHUNK_MAJOR) {
         table[(size_t)blockIdx.x * kBins + t] = h[0][t];
-    } else if (threadIdx.x < kBins) {
-        const uint4 c4 = make_uint4(h[0][t], h[kLanes > 1 ? 1 : 0][t], h[kLanes > 2 ? 2 : 0][t], h[kLanes > 3 ? 3 : 0][t]);
-        reinterpret_cast<uint4 *>(table + (size_t)t * nbp)[blockIdx.x] = c4;
-        if (quad_totals) quad_totals[(size_t)blockIdx.x * kBins + t] = c4.x + c4.y + c4.z + c4.w;   // kScanQuads
+    } else if (threadIdx.x < NB) {
+        const uint32_t d = threadIdx.x;     // (1024 threads: one digit row each, whatever NB is)
+        const uint4 c4 = make_uint4(h[0][d], h[kLanes > 1 ? 1 : 0][d], h[kLanes > 2 ? 2 : 0][d], h[kLanes > 3 ? 3 : 0][d]);
+        reinterpret_cast<uint4 *>(table + (size_t)d * nbp)[blockIdx.x] = c4;
+        if (NB == kBins && quad_totals) quad_totals[(size_t)blockIdx.x * kBins + d] = c4.x + c4.y + c4.z + c4.w;   // kScanQuads
     }
     if (FIRST && threadIdx.x == 0 && s_culled) atomicAdd(culled, s_culled);
 }
@@ -241,7 +249,7 @@ __global__ void __launch_bounds__(kThreads) row_scan_kernel(uint32_t *__restrict
 // MODE: kModeFirst / kModeFinal, see the head of this file.  m_out (FIRST): number of items this pass
 // keeps, i.e. the element count of every later pass.  rect / rrect (FINAL): per-Gaussian tile
 // rectangles by index / by depth rank.
-template <typename Key, int SCAN, int MODE, int BITS, bool SPLIT = false>
+template <typename Key, int SCAN, int MODE, int BITS, int SPLIT = 0>   // SPLIT: 0, or the number of buckets (256 / 1024)
 __global__ void __launch_bounds__(kThreads)
     scatter_kernel(const Key *__restrict__ kin, const uint32_t *__restrict__ vin, Key *__restrict__ kout,
                    uint32_t *__restrict__ vout, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
@@ -250,11 +258,16 @@ __global__ void __launch_bounds__(kThreads)
                    const uint32_t *__restrict__ splitters = nullptr, const uint32_t *__restrict__ quad_totals = nullptr) {
     constexpr bool SELF_SCAN = SCAN == kScanSelf;
     constexpr int kWaveItems = kItems / 4;
-    __shared__ uint32_t spl[SPLIT ? kBins : 1];
-    __shared__ uint8_t sdig[SPLIT ? kItems : 1];     // SPLIT: the bucket of every parked item (not derivable by a shift)
-    if (SPLIT) spl[threadIdx.x] = threadIdx.x ? splitters[threadIdx.x] : 0u;   // visible after the barrier below
-    __shared__ uint32_t cnt[4][kBins];   // per-wave running digit counts, then per-wave LDS bases
-    __shared__ uint32_t gbase[kBins];    // global address of parked item j of digit d = gbase[d] + j
+    constexpr int NB = SPLIT ? SPLIT : kBins;     // digit rows the tables of this workgroup hold
+    constexpr int DPT = NB / kThreads;            // digits per thread in the per-digit steps: thread t owns t * DPT ..
+    static_assert(DPT == 1 || SCAN == kScanRows, "the passes without a row-scan launch have 256 digit rows");
+    typedef typename std::conditional<(NB > 256), uint16_t, uint8_t>::type Dig;
+    __shared__ uint32_t spl[SPLIT ? SPLIT : 1];
+    __shared__ Dig sdig[SPLIT ? kItems : 1];     // SPLIT: the bucket of every parked item (not derivable by a shift)
+    if (SPLIT)
+        for (int k = threadIdx.x; k < NB; k += kThreads) spl[k] = k ? splitters[k] : 0u;   // visible after the barrier below
+    __shared__ uint32_t cnt[4][NB];      // per-wave running digit counts, then per-wave LDS bases
+    __shared__ uint32_t gbase[NB];       // global address of parked item j of digit d = gbase[d] + j
     __shared__ uint32_t wsum[4], lsum[4];
     __shared__ Key skey[kItems];
     __shared__ __attribute__((aligned(16))) uint32_t sval[kItems];   // 8 KB: also the 4 x 256 match words of the ranking
@@ -266,7 +279,7 @@ __global__ void __launch_bounds__(kThreads)
     const uint32_t block_base = blockIdx.x * (uint32_t)kItems;
     if (block_base >= n) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    constexpr uint32_t nbins = 1u << BITS, mask = nbins - 1u;
+    constexpr uint32_t nbins = SPLIT ? (uint32_t)SPLIT : (1u << BITS), mask = (1u << BITS) - 1u;
     const uint32_t wave_base = block_base + (uint32_t)w * kWaveItems;
     Key key[kRounds];
     uint32_t val[kRounds];
@@ -280,11 +293,19 @@ __global__ void __launch_bounds__(kThreads)
         val[r] = (MODE & kModeFirst) ? i : (ok[r] ? vin[i] : 0u);
         if (MODE & kModeFirst) ok[r] = ok[r] && (uint32_t)key[r] < kEmptyKey;
     }
-    // this digit's row total and row prefix: needed after the ranking
-    uint32_t t_pre = 0, before_pre = 0;
-    if (SCAN == kScanRows && (uint32_t)threadIdx.x < nbins) {
-        t_pre = totals[threadIdx.x];
-        before_pre = table[(size_t)threadIdx.x * nbp + blockIdx.x];
+    // this thread's digits' row totals and row prefixes: needed after the ranking
+    uint32_t t_pre[DPT], before_pre[DPT];
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) t_pre[q] = before_pre[q] = 0;
+    if (SCAN == kScanRows) {
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            const uint32_t d = (uint32_t)threadIdx.x * DPT + q;
+            if (d < nbins) {
+                t_pre[q] = totals[d];
+                before_pre[q] = table[(size_t)d * nbp + blockIdx.x];
+            }
+        }
     }
     if (SCAN == kScanQuads && (uint32_t)threadIdx.x < nbins) {
         // no row scan ran: this digit's total = the sum of all count workgroups' four-chunk totals, its prefix =
@@ -297,19 +318,19 @@ __global__ void __launch_bounds__(kThreads)
             for (int u = 0; u < 8; ++u) v[u] = quad_totals[(size_t)(q + u) * kBins + threadIdx.x];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                before_pre += q + u < quad ? v[u] : 0u;
-                t_pre += v[u];
+                before_pre[0] += q + u < quad ? v[u] : 0u;
+                t_pre[0] += v[u];
             }
         }
         for (; q < nquads; ++q) {
             const uint32_t v = quad_totals[(size_t)q * kBins + threadIdx.x];
-            before_pre += q < quad ? v : 0u;
-            t_pre += v;
+            before_pre[0] += q < quad ? v : 0u;
+            t_pre[0] += v;
         }
-        for (uint32_t c = (uint32_t)quad * kQuad; c < blockIdx.x; ++c) before_pre += table[(size_t)threadIdx.x * nbp + c];
-        if (blockIdx.x == 0) const_cast<uint32_t *>(totals)[threadIdx.x] = t_pre;   // what bucket_sort_kernel reads
+        for (uint32_t c = (uint32_t)quad * kQuad; c < blockIdx.x; ++c) before_pre[0] += table[(size_t)threadIdx.x * nbp + c];
+        if (blockIdx.x == 0) const_cast<uint32_t *>(totals)[threadIdx.x] = t_pre[0];   // what bucket_sort_kernel reads
     }
-    for (int k = threadIdx.x; k < 4 * kBins; k += kThreads) (&cnt[0][0])[k] = 0;
+    for (int k = threadIdx.x; k < 4 * NB; k += kThreads) (&cnt[0][0])[k] = 0;
     for (int k = threadIdx.x; k < kItems / 4; k += kThreads) reinterpret_cast<uint4 *>(sval)[k] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
@@ -318,14 +339,16 @@ __global__ void __launch_bounds__(kThreads)
     // The lanes of a wave that hold the same digit find each other through the LDS: every lane ORs its bit
     // into the wave's 64-bit word of the digit, reads the word back and clears it -- three DS operations that
     // one wave executes in issue order -- instead of BITS ballots at ~6 VALU instructions each.  The words
-    // live in sval, which is dead until the items are parked.
+    // live in sval, which is dead until the items are parked.  With 1024 buckets the words are those of the
+    // digit's low 8 bits and two ballots tell apart the lanes that differ in the upper two (256 words per wave
+    // is what sval holds; 1024 would cost the kernel two resident workgroups per CU).
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     lds_u64 *wm = (lds_u64 *)(reinterpret_cast<unsigned long long *>(sval) + (size_t)w * kBins);
     lds_u32 *wc = (lds_u32 *)&cnt[w][0];
     const unsigned long long me = 1ull << lane;
     uint16_t rank[kRounds];
-    uint8_t dig[kRounds];
+    Dig dig[kRounds];
     {
         uint32_t kq[kRounds], dq[kRounds];
 #pragma unroll
@@ -333,21 +356,27 @@ __global__ void __launch_bounds__(kThreads)
             kq[r] = (uint32_t)key[r];
             dq[r] = ((uint32_t)key[r] >> shift) & mask;
         }
-        if (SPLIT) buckets_of<kRounds>(spl, kq, dq);
+        if (SPLIT) buckets_of<NB, kRounds>(spl, kq, dq);
 #pragma unroll
-        for (int r = 0; r < kRounds; ++r) dig[r] = (uint8_t)dq[r];
+        for (int r = 0; r < kRounds; ++r) dig[r] = (Dig)dq[r];
     }
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
         const uint32_t d = dig[r];
         rank[r] = 0;
+        unsigned long long hi0 = 0ull, hi1 = 0ull;
+        if (NB > 256) {       // lanes whose bucket has bit 8 / bit 9 set
+            hi0 = __ballot(ok[r] && (d & 256u));
+            hi1 = __ballot(ok[r] && (d & 512u));
+        }
         if (ok[r]) {
-            __hip_atomic_fetch_or(&wm[d], me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&wm[d & 255u], me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_wave_barrier();
-            const unsigned long long peers = wm[d];
+            unsigned long long peers = wm[d & 255u];
             const uint32_t before = wc[d];
             __builtin_amdgcn_wave_barrier();
-            wm[d] = 0ull;
+            wm[d & 255u] = 0ull;
+            if (NB > 256) peers &= ((d & 256u) ? hi0 : ~hi0) & ((d & 512u) ? hi1 : ~hi1);
             if ((peers & lt) == 0ull) wc[d] = before + (uint32_t)__popcll(peers);   // the first of them
             __builtin_amdgcn_wave_barrier();
             rank[r] = (uint16_t)(before + (uint32_t)__popcll(peers & lt));
@@ -355,37 +384,44 @@ __global__ void __launch_bounds__(kThreads)
     }
     __syncthreads();
 
-    // ---- per digit d (thread d): where its run starts in the parked (digit-major) order and in
+    // ---- per digit d (thread d / DPT): where its run starts in the parked (digit-major) order and in
     //      the global output: smaller digits (row totals) + this digit in earlier chunks (table)
     {
-        const int d = threadIdx.x;
-        const uint32_t c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
-        uint32_t t, before;
-        if (SELF_SCAN) {
-            t = 0;
-            before = 0;
-            int b = 0;
-            for (; b + 8 <= nbp; b += 8) {      // 8 independent loads in flight (chunk-major: coalesced over d)
-                uint32_t v[8];
+        uint32_t cw[DPT][4], l[DPT], t[DPT], before[DPT];
+        uint32_t tsum = 0, lsum_ = 0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = table[(size_t)(b + u) * kBins + d];
+        for (int q = 0; q < DPT; ++q) {
+            const int d = threadIdx.x * DPT + q;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    before += b + u < (int)blockIdx.x ? v[u] : 0u;
-                    t += v[u];
+            for (int k = 0; k < 4; ++k) cw[q][k] = cnt[k][d];
+            if (SELF_SCAN) {
+                t[q] = 0;
+                before[q] = 0;
+                int b = 0;
+                for (; b + 8 <= nbp; b += 8) {      // 8 independent loads in flight (chunk-major: coalesced over d)
+                    uint32_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = table[(size_t)(b + u) * kBins + d];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        before[q] += b + u < (int)blockIdx.x ? v[u] : 0u;
+                        t[q] += v[u];
+                    }
                 }
+                for (; b < nbp; ++b) {
+                    const uint32_t v = table[(size_t)b * kBins + d];
+                    before[q] += b < (int)blockIdx.x ? v : 0u;
+                    t[q] += v;
+                }
+            } else {
+                t[q] = t_pre[q];
+                before[q] = before_pre[q];
             }
-            for (; b < nbp; ++b) {
-                const uint32_t v = table[(size_t)b * kBins + d];
-                before += b < (int)blockIdx.x ? v : 0u;
-                t += v;
-            }
-        } else {
-            t = t_pre;
-            before = before_pre;
+            l[q] = cw[q][0] + cw[q][1] + cw[q][2] + cw[q][3];
+            tsum += t[q];
+            lsum_ += l[q];
         }
-        const uint32_t l = c0 + c1 + c2 + c3;
-        uint32_t x = t, y = l;  // inclusive wave scans of the global totals and of the local counts
+        uint32_t x = tsum, y = lsum_;  // inclusive wave scans of the global totals and of the local counts
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t xu = __shfl_up((int)x, o), yu = __shfl_up((int)y, o);
@@ -404,13 +440,19 @@ __global__ void __launch_bounds__(kThreads)
             gb += wsum[k];
             lb += lsum[k];
         }
-        const uint32_t lstart = lb + y - l;                       // first parked slot of digit d
-        const uint32_t gstart = gb + x - t + before;
-        gbase[d] = gstart - lstart;
-        cnt[0][d] = lstart;
-        cnt[1][d] = lstart + c0;
-        cnt[2][d] = lstart + c0 + c1;
-        cnt[3][d] = lstart + c0 + c1 + c2;
+        uint32_t lstart = lb + y - lsum_;                       // first parked slot of this thread's first digit
+        uint32_t gstart = gb + x - tsum;                        // keys of smaller digits, all chunks
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            const int d = threadIdx.x * DPT + q;
+            gbase[d] = gstart + before[q] - lstart;
+            cnt[0][d] = lstart;
+            cnt[1][d] = lstart + cw[q][0];
+            cnt[2][d] = lstart + cw[q][0] + cw[q][1];
+            cnt[3][d] = lstart + cw[q][0] + cw[q][1] + cw[q][2];
+            lstart += l[q];
+            gstart += t[q];
+        }
         if ((MODE & kModeFirst) && blockIdx.x == 0 && threadIdx.x == 0) *m_out = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
     __syncthreads();
@@ -782,60 +824,83 @@ __device__ __forceinline__ void bucket_in_lds(uint32_t start, uint32_t size, uin
     }
 }
 
-// The 255 splitters of the partition pass: regular quantiles of 2048 regularly spaced keys (key at index
-// i n / 2048), splitters[j] = the valid sample of rank floor(j V / 256), V = number of valid samples (dropped keys
-// sort to the end), splitters[0] = 0.  A single workgroup sorting the samples took 41 us (one CU doing 4 LDS radix
-// passes); here every sample's rank is counted directly -- #{j : s[j] < s[i]} + #{j < i : s[j] == s[i]} -- by 16
-// lanes that share the 2048 comparisons, 16 samples per workgroup, 128 workgroups: ~350 instructions per lane;
-// the sample that finds itself on a quantile writes the splitter(s) it is.
+// The NB - 1 splitters of the partition pass: regular quantiles of the VALID ones among `ns` regularly spaced keys
+// (key at index i n / ns; a key >= kEmptyKey is dropped by the sort and says nothing about where the kept keys
+// lie -- on a rank that owns 1/8 of the frame 7 of 8 samples are of that kind, which is why such a frame takes
+// 8192 samples instead of 2048): splitters[j] = the valid sample of rank floor(j V / NB), V = number of valid
+// samples, splitters[0] = 0.  A single workgroup sorting the samples took 41 us (one CU doing 4 LDS radix
+// passes); here every workgroup packs the valid samples into LDS in index order (a thread owns ns / 256
+// consecutive samples, all loads in flight at once) and every sample's rank is counted directly --
+// #{j : s[j] < s[i]} + #{j < i : s[j] == s[i]} -- by 16 lanes that share the V comparisons, 16 samples per
+// workgroup; the sample that finds itself on a quantile writes the splitter(s) it is.
 constexpr int kRankLanes = 16, kRankPerGroup = kThreads / kRankLanes;   // 16 samples per 256-thread workgroup
+constexpr int kSamplesMax = kSortSamplesMax, kSamplesPerThreadMax = kSamplesMax / kThreads;
+template <int NB>
 __global__ void __launch_bounds__(kThreads)
-    sample_rank_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ splitters,
+    sample_rank_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t ns, uint32_t *__restrict__ splitters,
                        unsigned long long *__restrict__ chunk_sums, uint32_t nsums) {
-    __shared__ uint32_t sm[kSamples];
-    __shared__ uint32_t s_valid;
+    __shared__ uint32_t sm[kSamplesMax];
+    __shared__ uint32_t s_wave[kThreads / 64];
     // the chunk sums the bucket kernel adds to start from zero (the first kernel of the sort has threads to spare)
     for (uint32_t k = blockIdx.x * (uint32_t)kThreads + threadIdx.x; chunk_sums && k < nsums; k += gridDim.x * (uint32_t)kThreads)
         chunk_sums[k] = 0ull;
-    if (threadIdx.x == 0) s_valid = 0;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t per = ns / (uint32_t)kThreads;           // 8 or 32 (ns = 2048 / 8192)
+    uint32_t v[kSamplesPerThreadMax];
     uint32_t mine = 0;
-    for (int k = threadIdx.x; k < kSamples; k += kThreads) {
-        const uint32_t v = keys[(uint32_t)(((uint64_t)k * n) / kSamples)];
-        sm[k] = v;
-        mine += v < kEmptyKey;
+#pragma unroll
+    for (int k = 0; k < kSamplesPerThreadMax; ++k) {
+        v[k] = kCulledKey;
+        if ((uint32_t)k < per) v[k] = keys[(uint32_t)(((uint64_t)(threadIdx.x * per + (uint32_t)k) * n) / ns)];
+        mine += v[k] < kEmptyKey;
+    }
+    uint32_t x = mine;   // inclusive scan over the wave, then over the workgroup
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) s_wave[w] = x;
+    __syncthreads();
+    uint32_t at = x - mine, valid = 0;
+#pragma unroll
+    for (int k = 0; k < kThreads / 64; ++k) {
+        at += k < w ? s_wave[k] : 0u;
+        valid += s_wave[k];
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_valid, mine);
+    for (int k = 0; k < kSamplesPerThreadMax; ++k)
+        if (v[k] < kEmptyKey) sm[at++] = v[k];
     __syncthreads();
-    const uint32_t valid = s_valid;
     if (valid == 0) {       // nothing reaches a tile: every key goes to bucket 0 (and is dropped there)
-        if (blockIdx.x == 0 && threadIdx.x < kBins) splitters[threadIdx.x] = 0u;
+        if (blockIdx.x == 0)
+            for (int k = threadIdx.x; k < NB; k += kThreads) splitters[k] = 0u;
         return;
     }
     const uint32_t i = blockIdx.x * (uint32_t)kRankPerGroup + (threadIdx.x / kRankLanes);
     const uint32_t part = threadIdx.x % kRankLanes;
-    const uint32_t v = sm[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) splitters[0] = 0u;
+    if (blockIdx.x * (uint32_t)kRankPerGroup >= valid) return;
+    const uint32_t mykey = i < valid ? sm[i] : 0u;
     uint32_t c = 0;
     // lane `part` compares against samples part, part + 16, part + 32, ... (conflict-free across the 16 lanes)
-    for (uint32_t j = part; j < kSamples; j += kRankLanes) {
-        const uint32_t x = sm[j];
-        c += (x < v) | ((x == v) & (j < i));
+    for (uint32_t j = part; j < valid; j += kRankLanes) {
+        const uint32_t y = sm[j];
+        c += (y < mykey) | ((y == mykey) & (j < i));
     }
 #pragma unroll
     for (int o = kRankLanes / 2; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
-    if (part == 0 && c < valid) {
-        // the quantiles j with floor(j valid / 256) == c (none, one, or several when valid < 256)
-        for (uint32_t j = (c * (uint32_t)kBins + valid - 1u) / valid; j < (uint32_t)kBins && (j * valid) / kBins == c; ++j)
-            splitters[j] = j ? v : 0u;
+    if (part == 0 && i < valid) {
+        // the quantiles j with floor(j valid / NB) == c (none, one, or several when valid < NB)
+        for (uint32_t j = (c * (uint32_t)NB + valid - 1u) / valid; j < (uint32_t)NB && (j * valid) / NB == c; ++j)
+            if (j) splitters[j] = mykey;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) splitters[0] = 0u;
 }
 
 // One workgroup per bucket of the partition pass.  in: (kin, vin) partitioned by bucket, bucket sizes = the
 // row totals of that pass.  out: vout[rank] = Gaussian index, rrect[rank] = rect[index] for the bucket's
 // ranks.  kalt: the other key buffer (scratch of the through-memory path).
+template <int NB>
 __global__ void __launch_bounds__(kBigThreads)
     bucket_sort_kernel(const uint32_t *__restrict__ totals, const uint32_t *__restrict__ table_cm, int nblocks_cm,
                        uint32_t *kin, uint32_t *vin, uint32_t *kalt, uint32_t *vout,
@@ -844,14 +909,15 @@ __global__ void __launch_bounds__(kBigThreads)
     __shared__ RankShared sh;
     __shared__ __attribute__((aligned(16))) uint32_t sitems[2 * kBucketCap];
     uint32_t *skey = sitems;
-    __shared__ uint32_t s_tot[kBins];
+    __shared__ uint32_t s_tot[NB];
     __shared__ uint32_t s_or, s_start, s_min, s_max;
+    static_assert(NB <= kBigThreads && NB >= kBins, "one thread per bucket size below");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x < kBins) {
+    if (threadIdx.x < NB) {
         // bucket sizes: the row totals of the partition pass, or (small inputs: chunk-major table, no row scan)
         // the column sums of the raw counts
         uint32_t t = 0;
-        if (nblocks_cm > 0) {
+        if (NB == kBins && nblocks_cm > 0) {
             int b = 0;
             for (; b + 8 <= nblocks_cm; b += 8) {     // 8 independent loads in flight
                 uint32_t v[8];
@@ -873,7 +939,7 @@ __global__ void __launch_bounds__(kBigThreads)
         s_max = 0;
     }
     __syncthreads();
-    if (threadIdx.x < kBins) {   // first rank of this bucket = sizes of the buckets before it
+    if (threadIdx.x < NB) {   // first rank of this bucket = sizes of the buckets before it
         uint32_t c = (uint32_t)threadIdx.x < blockIdx.x ? s_tot[threadIdx.x] : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
@@ -1044,16 +1110,16 @@ struct PassPlan {
     uint32_t *table, *totals, *quad_totals;
 };
 
-PassPlan plan_for(void *temp, int64_t bound) {
+PassPlan plan_for(void *temp, int64_t bound, int bins = kBins) {
     PassPlan p;
     p.nblocks = (int)((bound + kItems - 1) / kItems);
     p.nquads = (p.nblocks + kQuad - 1) / kQuad;
-    p.self_scan = p.nblocks <= kSelfScanBlocks;
-    p.scan = p.self_scan ? kScanSelf : (p.nquads <= kQuadScanQuads ? kScanQuads : kScanRows);
+    p.self_scan = bins == kBins && p.nblocks <= kSelfScanBlocks;
+    p.scan = p.self_scan ? kScanSelf : ((bins == kBins && p.nquads <= kQuadScanQuads) ? kScanQuads : kScanRows);
     p.nbp = p.self_scan ? p.nblocks : p.nquads * kQuad;
     p.table = (uint32_t *)temp;
-    p.totals = p.table + (size_t)kBins * p.nquads * kQuad;
-    p.quad_totals = p.totals + 2 * kBins;      // behind the row totals and the 256 splitters
+    p.totals = p.table + (size_t)bins * p.nquads * kQuad;
+    p.quad_totals = p.totals + 2 * (size_t)bins;      // behind the row totals and the splitters
     return p;
 }
 
@@ -1126,59 +1192,88 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
 }
 
 
-// Up to this many keys the depth sort is sample-partitioned (one partition pass + one bucket sort); beyond,
-// the average bucket would not fit the bucket kernel's LDS and the four LSD passes are used.
-constexpr int64_t kSampledMin = 8 * kSamples, kSampledMax = (int64_t)1 << 20;
+// Which route sorts the depth keys of a frame (gsx_internal.h: DepthRoute).  What decides is how many keys are
+// KEPT -- the sample-partitioned routes drop the others in their one pass over the n keys and sort the rest in
+// LDS buckets -- and that number is known to the caller from an earlier frame of the view (GsxParams.kept_hint;
+// without it: n).  A bucket is sorted in LDS up to kBucketCap = 16 384 keys; the routes keep the MEAN bucket below
+// ~6 000 (with 8 samples per bucket a bucket of 2.8x the mean has probability ~1e-4), and a bucket that does
+// not fit is still sorted correctly, through global memory: a wrong hint costs time, never the order.
+//   n <= 16 384                    one workgroup does everything in LDS
+//   kept <= 1.5M                   256 buckets   (1M Gaussians at 1080p; one rank's strip of 5M at 4K)
+//   kept <= 6M                     1024 buckets  (5M Gaussians at 4K on one GPU)
+//   beyond                         four compacting LSD passes of 8 bits
+constexpr int64_t kSampledMin = 8 * kSamples, kKeptMax256 = 1536 * 1024, kKeptMax1024 = 6 * 1024 * 1024;
 
-bool depth_sort_is_sampled(int64_t n) {
-    static const int force = [] {
-        const char *e = getenv("GSX_DEPTH_SORT");   // measurement knob: "lsd" / "sampled" (default: by size)
-        return !e ? 0 : (e[0] == 'l' ? 1 : 2);
-    }();
-    if (force == 1) return false;
-    if (n <= kBucketCap) return true;      // one workgroup sorts it all (sort_depth_sampled's small path)
-    return n >= kSampledMin && (force == 2 || n <= kSampledMax);
+DepthRoute depth_sort_route(int64_t n, int64_t kept_hint) {
+    const int force = knob("GSX_DEPTH_SORT", -1);   // test library only: a DepthRoute
+    if (n <= kBucketCap) return kDepthOneWorkgroup;
+    if (force == kDepthLsd || n < kSampledMin) return kDepthLsd;
+    if (force == kDepth256 || force == kDepth1024) return (DepthRoute)force;
+    const int64_t kept = kept_hint > 0 && kept_hint < n ? kept_hint : n;
+    if (kept <= kKeptMax256) return kDepth256;
+    if (kept <= kKeptMax1024) return kDepth1024;
+    return kDepthLsd;
 }
 
-// Same contract as sort_depth_compact.  keys0 / keys1 / vals: n words each; on return vals_cur[0 .. *m_dev)
-// = Gaussian index of each depth rank, rrect[rank] = rect[index].  lds_cap: bucket size above which the
-// through-memory path is taken (tests shrink it).  chunk_sums (or nullptr): ceil(n / 1024) + 1 words that receive
-// the tile count of every 1024 consecutive ranks -- what chunk_sums_kernel would compute from rrect.
-hipError_t sort_depth_sampled(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
-                              int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
-                              uint32_t lds_cap, uint64_t *chunk_sums, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
-    unsigned long long *cs = reinterpret_cast<unsigned long long *>(chunk_sums);
-    if (n <= kBucketCap && lds_cap == 0) {   // everything fits one workgroup's LDS: one launch
-        small_depth_sort_kernel<<<1, kBigThreads, 0, s>>>(keys0, (uint32_t)n, vals_cur, rect, rrect, m_dev, culled_dev, cs);
-        return hipGetLastError();
-    }
-    const PassPlan p = plan_for(temp, n);
-    uint32_t *splitters = p.totals + kBins;            // behind the row totals: 256 splitters
-    sample_rank_kernel<<<kSamples / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, splitters, cs,
-                                                                     (uint32_t)((n + kEmitChunk - 1) / kEmitChunk) + 1u);
-    // partition: keys0 -> (keys1, vals_alt), values generated (FIRST)
-    if (p.self_scan) {
-        count_kernel<uint32_t, true, true, true><<<p.nblocks, kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u, p.table,
-                                                                                p.nbp, culled_dev, splitters);
-        scatter_kernel<uint32_t, kScanSelf, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
+// The partition pass of the sampled routes: keys0 -> (keys1, vals_alt, rrect in partition order), values generated.
+template <int NB>
+static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1, uint32_t *vals_cur, uint32_t *vals_alt,
+                             int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
+                             const uint32_t *splitters, hipStream_t s) {
+    if (NB == kBins && p.self_scan) {
+        count_kernel<uint32_t, true, true, kBins><<<p.nblocks, kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u, p.table,
+                                                                                 p.nbp, culled_dev, splitters);
+        scatter_kernel<uint32_t, kScanSelf, kModeFirst, 8, kBins><<<p.nblocks, kThreads, 0, s>>>(
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters);
-    } else if (p.scan == kScanQuads) {
-        count_kernel<uint32_t, false, true, true><<<p.nquads, kQuad * kThreads, 0, s>>>(
+    } else if (NB == kBins && p.scan == kScanQuads) {
+        count_kernel<uint32_t, false, true, kBins><<<p.nquads, kQuad * kThreads, 0, s>>>(
             keys0, nullptr, (uint32_t)n, 0, 255u, p.table, p.nbp, culled_dev, splitters, p.quad_totals);
-        scatter_kernel<uint32_t, kScanQuads, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
+        scatter_kernel<uint32_t, kScanQuads, kModeFirst, 8, kBins><<<p.nblocks, kThreads, 0, s>>>(
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
             p.quad_totals);
     } else {
-        count_kernel<uint32_t, false, true, true><<<p.nquads, kQuad * kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u,
-                                                                                        p.table, p.nbp, culled_dev, splitters);
-        row_scan_kernel<<<kBins, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
-        scatter_kernel<uint32_t, kScanRows, kModeFirst, 8, true><<<p.nblocks, kThreads, 0, s>>>(
+        count_kernel<uint32_t, false, true, NB><<<p.nquads, kQuad * kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u,
+                                                                                      p.table, p.nbp, culled_dev, splitters);
+        row_scan_kernel<<<NB, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
+        scatter_kernel<uint32_t, kScanRows, kModeFirst, 8, NB><<<p.nblocks, kThreads, 0, s>>>(
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters);
     }
+}
+
+// Same contract as sort_depth_compact.  keys0 / keys1 / vals: n words each; on return vals_cur[0 .. *m_dev)
+// = Gaussian index of each depth rank, rrect[rank] = rect[index].  route: kDepthOneWorkgroup / kDepth256 /
+// kDepth1024.  kept_hint: see depth_sort_route (here it only sizes the sample).  lds_cap: bucket size above which
+// the through-memory path is taken (tests shrink it).  chunk_sums (or nullptr): ceil(n / 1024) + 1 words that receive
+// the tile count of every 1024 consecutive ranks -- what chunk_sums_kernel would compute from rrect.
+hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
+                              uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,
+                              const TileRect *rect, TileRect *rrect, uint32_t lds_cap, uint64_t *chunk_sums, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    unsigned long long *cs = reinterpret_cast<unsigned long long *>(chunk_sums);
+    if (route == kDepthOneWorkgroup && n <= kBucketCap && lds_cap == 0) {   // everything fits one workgroup's LDS: one launch
+        small_depth_sort_kernel<<<1, kBigThreads, 0, s>>>(keys0, (uint32_t)n, vals_cur, rect, rrect, m_dev, culled_dev, cs);
+        return hipGetLastError();
+    }
+    const int nb = route == kDepth1024 ? kSortBinsMax : kBins;
+    const PassPlan p = plan_for(temp, n, nb);
+    uint32_t *splitters = p.totals + nb;               // behind the row totals
+    // 8 samples per bucket -- of the keys that are kept: a window that keeps less than half of the Gaussians (a
+    // rank's strip) takes the larger sample as well
+    const int64_t kept = kept_hint > 0 && kept_hint < n ? kept_hint : n;
+    const uint32_t ns = (nb > kBins || 2 * kept < n) && n >= kSamplesMax ? (uint32_t)kSamplesMax : (uint32_t)kSamples;
+    const uint32_t nsums = (uint32_t)((n + kEmitChunk - 1) / kEmitChunk) + 1u;
     if (lds_cap == 0 || lds_cap > (uint32_t)kBucketCap) lds_cap = kBucketCap;
-    bucket_sort_kernel<<<kBins, kBigThreads, 0, s>>>(p.totals, p.table, p.self_scan ? p.nblocks : 0, keys1, vals_alt, keys0,
-                                                    vals_cur, rect, rrect, lds_cap, cs);
+    if (nb > kBins) {
+        sample_rank_kernel<kSortBinsMax><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
+        launch_partition<kSortBinsMax>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect, splitters, s);
+        bucket_sort_kernel<kSortBinsMax><<<kSortBinsMax, kBigThreads, 0, s>>>(p.totals, p.table, 0, keys1, vals_alt, keys0, vals_cur,
+                                                                              rect, rrect, lds_cap, cs);
+    } else {
+        sample_rank_kernel<kBins><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
+        launch_partition<kBins>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect, splitters, s);
+        bucket_sort_kernel<kBins><<<kBins, kBigThreads, 0, s>>>(p.totals, p.table, p.self_scan ? p.nblocks : 0, keys1, vals_alt,
+                                                                keys0, vals_cur, rect, rrect, lds_cap, cs);
+    }
     return hipGetLastError();
 }
 

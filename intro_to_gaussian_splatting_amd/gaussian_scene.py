@@ -114,6 +114,26 @@ def render_preprocessed(height: int, width: int, tile_size: int, point_means: to
     return out
 
 
+class NativeExtension:
+    """What ``GaussianScene.compile_cuda_ext()`` returns: the object the reference gets from ``load_inline``
+    (splat/gaussian_scene.py:240-261, splat/utils.py:426-434) -- ONE function, ``render_image``, with the argument
+    list and return value of splat/c/render.cu:90-101.  Here nothing is compiled at run time: the function is
+    ``gsx_render_preprocessed`` of the prebuilt libgsx.so under the CUDA kernel's own rules (GSX_SEM_REF_CUDA,
+    (H,W,3) output), so a caller that does ``ext = scene.compile_cuda_ext(); ext.render_image(H, W, tile, ...)``
+    keeps working unchanged."""
+
+    def __init__(self) -> None:
+        _ffi.load()          # fails loudly, like a failed JIT build would, when the library is absent
+
+    @staticmethod
+    def render_image(image_height: int, image_width: int, tile_size: int, point_means: torch.Tensor,
+                     point_colors: torch.Tensor, inverse_covariance_2d: torch.Tensor, min_x: torch.Tensor,
+                     max_x: torch.Tensor, min_y: torch.Tensor, max_y: torch.Tensor, opacity: torch.Tensor) -> torch.Tensor:
+        return render_preprocessed(int(image_height), int(image_width), int(tile_size), point_means, point_colors,
+                                   inverse_covariance_2d, min_x, max_x, min_y, max_y, opacity, layout="hw3",
+                                   semantics="ref_cuda")
+
+
 class CapturedFrame:
     """A frame recorded by ``GaussianScene.capture_frame``: ``replay()`` launches the graph,
     ``out`` is the frame buffer it writes, ``confirm()`` (synchronises) checks that the last replay
@@ -121,11 +141,14 @@ class CapturedFrame:
 
     def __init__(self, scene: "GaussianScene", graph, out: torch.Tensor, pinned: torch.Tensor, call: dict,
                  camera_buffer: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
-                 capacity: int = 0) -> None:
+                 capacity: int = 0, inputs: Optional[list] = None) -> None:
         self.scene, self.graph, self.out, self._pinned, self._call = scene, graph, out, pinned, call
         self._camera_buffer = camera_buffer      # device copy of the GsxCamera the recorded kernels read
         self._workspace = workspace              # scratch whose address the graph holds: lives as long as the frame
         self.capacity = int(capacity)            # (Gaussian, tile) pairs the recorded launches have room for
+        # the exact parameter tensors handed to the library while recording (a non-contiguous attribute of the
+        # scene is a COPY made for the call): the graph reads these addresses on every replay
+        self._inputs = inputs
 
     def set_camera(self, image_idx: int) -> None:
         """Points the captured frame at another camera of the scene (same frame size): the next
@@ -167,6 +190,7 @@ class GaussianScene:
         self._instances_hint = 0      # workspace sizing: largest instance count seen (+10 %)
         self._last_instances = 0      # instance count of the latest full frame
         self._cap_hints = {}          # (image, tile, window, semantics) -> pair capacity for the next frame
+        self._kept_hints = {}         # same key -> Gaussians that reached a tile of the window (GsxParams.kept_hint)
         self._pending = []            # speculative frames awaiting confirm_frames()
         self._pinned_pool = None
         self._pinned_next = 0
@@ -270,14 +294,16 @@ class GaussianScene:
         """
         lib = _ffi.load()
         dev, n, tensors = self._inputs(image_idx, inline_sh=True)
+        g_ = self.gaussians
         cam = self.images[image_idx].gsx_camera()
         width, height = cam.width, cam.height
         params = _ffi.default_params()
+        sh_flat = None
         if tensors[4] is None:      # SH scene: the projection kernel evaluates the view-dependent colour itself
             g = self.gaussians
             k = (int(g.sh_degree) + 1) ** 2
-            self._sh_flat = _check_f32("sh", g.sh.reshape(n, k, 3), dev)
-            params.sh, params.sh_degree = self._sh_flat.data_ptr(), int(g.sh_degree)
+            sh_flat = _check_f32("sh", g.sh.reshape(n, k, 3), dev)
+            params.sh, params.sh_degree = sh_flat.data_ptr(), int(g.sh_degree)
         params.layout = _ffi.GSX_LAYOUT_WH3 if layout == "wh3" else _ffi.GSX_LAYOUT_HW3
         params.semantics = _SEMANTICS[semantics]
         params.background[0], params.background[1], params.background[2] = [float(v) for v in background]
@@ -330,6 +356,17 @@ class GaussianScene:
         own = _private or {}
         if "cap" in own:
             cap = int(own["cap"])
+        if "inputs" in own:         # capture_frame: the tensors whose addresses the graph bakes in stay alive with it
+            passed = [t for t in tensors if t is not None] + ([sh_flat] if sh_flat is not None else [])
+            scene_own = [g_.points, g_.scales, g_.quaternions, g_.opacity] + \
+                ([g_.sh] if sh_flat is not None else [g_.colors])
+            if any(t.data_ptr() != a.data_ptr() for t, a in zip(passed, scene_own)):
+                raise ValueError("capture_frame needs contiguous float32 Gaussian tensors: a captured frame replays "
+                                 "from the scene's own memory, and a non-contiguous attribute would be copied once, "
+                                 "at capture time")
+            own["inputs"][:] = passed
+        # how many Gaussians reached a tile of this window last time: picks the depth-sort route (a hint)
+        params.kept_hint = int(own.get("kept", self._kept_hints.get(cap_key, 0)))
         speculative = bool(no_sync and not timing)
         if speculative:
             params.flags |= _ffi.GSX_FLAG_NO_SYNC
@@ -365,7 +402,7 @@ class GaussianScene:
         _ffi.check(rc)
         if own:
             if stats is not None and not speculative:
-                stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles)
+                stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles, n_kept=st.n_kept)
             return out
         if speculative:
             # counts are still in flight: remember what has to be confirmed
@@ -377,16 +414,17 @@ class GaussianScene:
             if stats is not None:
                 stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
             return out
-        self._note_count(cap_key, int(st.n_instances))
+        self._note_count(cap_key, int(st.n_instances), int(st.n_kept))
         if stats is not None:
-            stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles)
+            stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles, n_kept=st.n_kept)
             if timing:
                 stats["stage_ms"] = {k: float(st.stage_ms[i]) for i, k in enumerate(_ffi.STAGE_NAMES)}
         return out
 
-    def _note_count(self, cap_key, n_instances: int) -> None:
+    def _note_count(self, cap_key, n_instances: int, n_kept: int = 0) -> None:
         self._instances_hint = max(self._instances_hint, int(n_instances * 1.1))
         self._cap_hints[cap_key] = int(n_instances * 1.1) + 4096
+        self._kept_hints[cap_key] = max(1, int(n_kept))
         if cap_key[2] is None and cap_key[3] == "ref_cpu":
             self._last_instances = n_instances
 
@@ -415,7 +453,7 @@ class GaussianScene:
         pending, self._pending = self._pending, []
         for pinned, cap_key, call in pending:
             st = ctypes.cast(ctypes.c_void_p(pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents
-            self._note_count(cap_key, int(st.n_instances))
+            self._note_count(cap_key, int(st.n_instances), int(st.n_kept))
             if st.n_instances > st.reserved:           # more pairs than the workspace held: dropped
                 redone += 1
                 self.render_image_hip(**call)          # synchronising path, same output tensor
@@ -454,8 +492,8 @@ class GaussianScene:
         nbytes = lib.gsx_workspace_bytes(n, cam.width, cam.height, tile_size, cap)
         if nbytes == 0:
             raise _ffi.GsxError(_ffi.GSX_ERR_INVALID_ARGUMENT, "gsx_workspace_bytes rejected the sizes")
-        private = dict(cap=cap, workspace=torch.empty(nbytes, dtype=torch.uint8, device=dev),
-                       pinned=torch.zeros(ctypes.sizeof(_ffi.GsxFrameStats), dtype=torch.uint8).pin_memory())
+        private = dict(cap=cap, workspace=torch.empty(nbytes, dtype=torch.uint8, device=dev), kept=int(st["n_kept"]),
+                       pinned=torch.zeros(ctypes.sizeof(_ffi.GsxFrameStats), dtype=torch.uint8).pin_memory(), inputs=[])
         stream = torch.cuda.Stream(dev)
         with torch.cuda.stream(stream):   # the same call once on the capture stream, outside the capture
             self.render_image_hip(image_idx, _private=private, **kw)
@@ -465,7 +503,7 @@ class GaussianScene:
             self.render_image_hip(image_idx, no_sync=True, _private=private, **kw)
         call = dict(image_idx=image_idx, **kw)
         return CapturedFrame(self, graph, out, private["pinned"], call, camera_buffer=cam_buf,
-                             workspace=private["workspace"], capacity=cap)
+                             workspace=private["workspace"], capacity=cap, inputs=private["inputs"])
 
     def render_image(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:
         """(W,H,3) float32 indexed [x,y]; same result as the reference's pure-Python
@@ -483,15 +521,27 @@ class GaussianScene:
 
     render = render_image  # the name BASELINE.json's north star uses
 
+    def compile_cuda_ext(self) -> NativeExtension:
+        """The reference's drop-in boundary (splat/gaussian_scene.py:240-261): returns an object whose
+        ``render_image(image_height, image_width, tile_size, point_means, point_colors, inverse_covariance_2d,
+        min_x, max_x, min_y, max_y, opacity)`` is the native entry point.  Nothing is compiled here (libgsx.so is
+        built ahead of time by hipcc for gfx950); the call costs nothing and may be repeated per frame as the
+        reference does."""
+        return NativeExtension()
+
     def render_image_cuda(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:
         """(H,W,3) float32 indexed [y,x] with the semantics of the reference's CUDA kernel
-        (``render_image_cuda``, splat/gaussian_scene.py:263-285 -> splat/c/render.cu): same flow as the
-        reference -- ``preprocess`` then the native entry point on its arrays."""
+        (``render_image_cuda``, splat/gaussian_scene.py:263-285 -> splat/c/render.cu): the same flow as the
+        reference, call for call -- ``preprocess``, ``compile_cuda_ext``, the native ``render_image`` on the
+        stage-1 arrays, one device synchronisation."""
         pre = self.preprocess(image_idx)
-        cam = self.images[image_idx].gsx_camera()
-        return render_preprocessed(cam.height, cam.width, tile_size, pre.points, pre.colors,
-                                   pre.inverse_covariance_2d, pre.min_x, pre.max_x, pre.min_y, pre.max_y,
-                                   pre.sigmoid_opacity, layout="hw3", semantics="ref_cuda")
+        height, width = self.images[image_idx].height, self.images[image_idx].width
+        ext = self.compile_cuda_ext()
+        image = ext.render_image(height, width, tile_size, pre.points.contiguous(), pre.colors.contiguous(),
+                                 pre.inverse_covariance_2d.contiguous(), pre.min_x.contiguous(), pre.max_x.contiguous(),
+                                 pre.min_y.contiguous(), pre.max_y.contiguous(), pre.sigmoid_opacity.contiguous())
+        torch.cuda.synchronize(image.device)
+        return image
 
     def render_preprocessed(self, image_idx: int, pre: PreprocessedScene, tile_size: int = 16,
                             layout: str = "wh3", stats: Optional[dict] = None) -> torch.Tensor:

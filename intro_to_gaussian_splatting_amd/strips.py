@@ -71,6 +71,26 @@ def balanced_plan(row_cost: Sequence[float], world_size: int) -> List[Tuple[int,
     return plan + [(n, n)] * (world_size - len(plan))
 
 
+def check_plan(plan: Sequence[Tuple[int, int]], n_lead: int, world_size: int) -> List[Tuple[int, int]]:
+    """A strip plan is one (t0, t1) per rank, in rank order, each inside [0, n_lead], no two overlapping
+    (``t0 <= t1 <= next t0``).  Anything else would silently yield a wrong frame (two ranks writing the same rows,
+    rank 0's receive slices aliasing each other), so it raises."""
+    if len(plan) != world_size:
+        raise ValueError("the strip plan has %d entries for %d ranks" % (len(plan), world_size))
+    edge = 0
+    out = []
+    for r, (t0, t1) in enumerate(plan):
+        t0, t1 = int(t0), int(t1)
+        if not (0 <= t0 <= t1 <= n_lead):
+            raise ValueError("strip %d = [%d, %d) is not inside the %d tile rows of the frame" % (r, t0, t1, n_lead))
+        if t1 > t0:
+            if t0 < edge:
+                raise ValueError("strip %d = [%d, %d) overlaps or precedes the strip before it (ends at %d)" % (r, t0, t1, edge))
+            edge = t1
+        out.append((t0, t1))
+    return out
+
+
 def tile_row_costs(tile_counts, n_lead: int, n_other: int, lead_is_x: bool = True, per_tile: float = 8.0) -> List[float]:
     """Cost of every tile row of the leading axis from the per-tile list lengths a frame reported
     (GsxParams.tile_counts, x-major: index = tx * n_tiles_y + ty): the compositing and the pair sort cost
@@ -123,8 +143,8 @@ def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor,
     n_lead = tiles_along(lead, tile, semantics)
     n_other = tiles_along(other, tile, semantics)
     if plan is not None:
-        return _render_planned(render_fn, plan, lead, other, n_other, tile, layout, device, group, all_ranks, cache,
-                               rank, world)
+        return _render_planned(render_fn, check_plan(plan, n_lead, world), lead, other, n_other, tile, layout, device,
+                               group, all_ranks, cache, rank, world)
     per, plan = strip_plan(n_lead, world)
     rows = per * tile                                  # strip extent in pixels, tile aligned
     t0, t1 = plan[rank]
@@ -223,10 +243,8 @@ class StripPipeline:
         n_lead, n_other = tiles_along(lead, tile, semantics), tiles_along(other, tile, semantics)
         self.pixel_ranges = None
         if plan is not None:      # unequal strips (balanced_plan): point-to-point gather, strips of their own size
-            if len(plan) != self.world:
-                raise ValueError("the strip plan has %d entries for %d ranks" % (len(plan), self.world))
+            plan = check_plan(plan, n_lead, self.world)
             self.pixel_ranges = [(min(a * tile, lead), min(b * tile, lead)) for a, b in plan]
-            per = max((b - a) for a, b in plan) if plan else 0
             t0, t1 = plan[self.rank]
             self.rows, self.lead = self.pixel_ranges[self.rank][1] - self.pixel_ranges[self.rank][0], lead
             self.origin = (self.pixel_ranges[self.rank][0], 0) if layout == "wh3" else (0, self.pixel_ranges[self.rank][0])
@@ -266,7 +284,8 @@ class StripPipeline:
                 self.render_fn(self.window, strip, self.origin)
         if self.rows > 0 or (planned and self.world > 1):
             if self.world == 1:
-                self.frame[:self.rows].copy_(strip)
+                a = self.pixel_ranges[0][0] if planned else 0      # a plan need not start at tile row 0
+                self.frame[a:a + self.rows].copy_(strip)
             elif planned:                              # unequal strips: every rank takes part, also with no rows
                 if self.rank == 0 and self.rows > 0:
                     a, b = self.pixel_ranges[0]

@@ -53,7 +53,10 @@ static void check_carve(int64_t n, int64_t cap, int64_t max_tiles) {
     // the digit table of the larger sort and the chunk sums both fit `temp`
     const int64_t items = n > cap ? n : cap;
     const size_t nquads = (size_t)((items + kSortItems - 1) / kSortItems + kSortQuad - 1) / kSortQuad;
-    CHECK(((size_t)kSortBins * nquads * kSortQuad + 2 * kSortBins + 2 * kSortSamples) * 4 <= binning_sums_offset(n, cap));
+    CHECK(((size_t)kSortBins * nquads * kSortQuad + 2 * kSortBins + (size_t)kSortQuadTotals * kSortBins) * 4 <= binning_sums_offset(n, cap));
+    // ... and so does the kSortBinsMax-row table of the depth keys (1024-bucket partition of large scenes)
+    const size_t dquads = (size_t)((n + kSortItems - 1) / kSortItems + kSortQuad - 1) / kSortQuad;
+    CHECK(((size_t)kSortBinsMax * dquads * kSortQuad + 2 * kSortBinsMax) * 4 <= binning_sums_offset(n, cap));
     const size_t nchunks = (size_t)((n + kEmitChunk - 1) / kEmitChunk);
     CHECK(binning_sums_offset(n, cap) + (nchunks + 1) * 8 <= temp);
 }

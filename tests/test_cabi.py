@@ -3,6 +3,8 @@ the ctypes mirror match the header.  No compute calls: runs without a GPU."""
 import ctypes
 import os
 import re
+import shutil
+import subprocess
 
 import pytest
 
@@ -15,7 +17,7 @@ HEADER = os.path.join(ROOT, "include", "gsx.h")
 def _declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(gsx_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(gsx_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_declares_the_expected_entry_points():
@@ -30,12 +32,41 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), "libgsx.so does not export %s" % name
         assert name in _ffi.SIGNATURES, "ctypes binding lacks %s" % name
-    assert lib.gsx_version() == 100
+    assert lib.gsx_version() == 300
+
+
+def _exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+@pytest.mark.skipif(shutil.which("nm") is None, reason="needs binutils nm")
+def test_shipping_library_exports_exactly_the_header():
+    """libgsx.so is built with -fvisibility=hidden: its dynamic symbol table holds the functions include/gsx.h
+    declares and nothing else of ours -- no test hook, no internal C++ symbol (the __hip_cuid_* markers are
+    emitted by hipcc for every translation unit).  The hooks live in libgsx_test.so (csrc/gsx_debug.h)."""
+    names = [n for n in _exported(_ffi.LIB_PATH) if not n.startswith("__hip_")]
+    assert names == _declared_functions(), names
+    test_names = [n for n in _exported(_ffi.TEST_LIB_PATH) if not n.startswith("__hip_")]
+    assert sorted(set(test_names) - set(names)) == sorted(_ffi.DEBUG_SIGNATURES), test_names
+
+
+def test_shipping_library_reads_no_environment_variable():
+    """The measurement knobs (GSX_DEPTH_SORT, GSX_TILE_SCHEDULE, GSX_BLEND_VARIANT, ...) exist only under
+    -DGSX_TEST_HOOKS: the product library does not import getenv at all."""
+    if shutil.which("nm") is None:
+        pytest.skip("needs binutils nm")
+    und = subprocess.run(["nm", "-D", "--undefined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    und_test = subprocess.run(["nm", "-D", "--undefined-only", _ffi.TEST_LIB_PATH], capture_output=True, text=True,
+                              check=True).stdout
+    assert "getenv" in und_test
 
 
 def test_struct_layouts():
     assert ctypes.sizeof(_ffi.GsxCamera) == 16 * 4 * 2 + 4 * 4 + 2 * 4 + 3 * 4
-    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16
+    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16 + 8 and _ffi.GsxParams.kept_hint.offset == 88
+    assert _ffi.GsxFrameStats.n_kept.offset == 56 and _ffi.GsxFrameStats.stage_ms.offset == 32
     assert ctypes.sizeof(_ffi.GsxFrameStats) == 64
     p = _ffi.default_params()
     assert p.semantics == _ffi.GSX_SEM_REF_CPU and p.layout == _ffi.GSX_LAYOUT_WH3

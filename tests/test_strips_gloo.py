@@ -210,8 +210,19 @@ def _planned_worker(rank, world, port, name, layout, plan, all_ranks, pipeline, 
     ("c1_256x256_n2000", "wh3", [(0, 3), (3, 4), (4, 15)], False, False),
     ("c1_256x256_n2000", "hw3", [(0, 11), (11, 15), (15, 15)], True, False),      # a rank without rows
     ("pose_70x50_n250", "wh3", [(0, 1), (1, 4)], False, True),
+    # world size 8, what BASELINE config 5 runs: a balanced plan over the 15 tile rows of the C1 stand-in with ONE
+    # rank that gets no rows (its strip is empty: it still takes part in the gather), plain and pipelined
+    ("c1_256x256_n2000", "wh3", "balanced8", False, False),
+    ("c1_256x256_n2000", "hw3", "balanced8", False, True),
 ])
 def test_unequal_strips_equal_single_frame(tmp_path, name, layout, plan, all_ranks, pipeline):
+    if plan == "balanced8":
+        # what strips.balanced_plan gives for row costs with a heavy middle: 8 ranks, 15 tile rows, the last rank idle
+        plan = strips.balanced_plan([1, 1, 1, 2, 9, 9, 9, 9, 9, 9, 2, 1, 1, 1, 1], 8)
+        assert len(plan) == 8 and plan[0][0] == 0 and plan[-1][1] == 15
+        if all(b > a for a, b in plan):      # (should the partition ever use all eight: idle the last rank by hand)
+            plan = plan[:6] + [(plan[6][0], 15), (15, 15)]
+        assert any(a == b for a, b in plan) and len({b - a for a, b in plan}) > 2
     world = len(plan)
     mp.spawn(_planned_worker, args=(world, _free_port(), name, layout, plan, all_ranks, pipeline, str(tmp_path)),
              nprocs=world, join=True)
@@ -220,3 +231,39 @@ def test_unequal_strips_equal_single_frame(tmp_path, name, layout, plan, all_ran
     full = full if layout == "wh3" else full.transpose(1, 0, 2)
     for r in (range(world) if all_ranks else [0]):
         assert np.array_equal(np.load(tmp_path / ("frame_%d.npy" % r)), full)
+
+
+def test_equal_strips_at_world_size_eight(tmp_path):
+    """The default N > 1 path of bench.py (equal strips, ONE dist.gather) at the world size of BASELINE config 5:
+    15 tile rows over 8 ranks = 2 rows each, the last rank gets one, and the never-rendered last tile row stays zero."""
+    world, name, layout = 8, "c1_256x256_n2000", "wh3"
+    mp.spawn(_worker, args=(world, _free_port(), name, layout, False, str(tmp_path)), nprocs=world, join=True)
+    g = load_golden(name)
+    full, _, _ = c_oracle.render(golden_preprocessed(g), int(g["width"]), int(g["height"]), int(g["tile"]))
+    assert np.array_equal(np.load(tmp_path / "frame_0.npy"), full)
+    assert not any((tmp_path / ("frame_%d.npy" % r)).exists() for r in range(1, world))
+
+
+def test_strip_plans_are_validated():
+    """A plan that overlaps, runs backwards or leaves the frame would silently put pixels in the wrong rows (or make
+    rank 0's receive slices alias each other): render_sharded and StripPipeline refuse it."""
+    g = load_golden("small_64x48_n300")
+    w, h, t = int(g["width"]), int(g["height"]), int(g["tile"])
+    fn = _oracle_strip_renderer(golden_preprocessed(g), w, h, t, "wh3")
+    n_lead = strips.tiles_along(w, t)
+    assert strips.check_plan([(0, n_lead)], n_lead, 1) == [(0, n_lead)]
+    for bad, world in (([(0, 2), (1, 3)], 2), ([(2, 3), (0, 2)], 2), ([(0, n_lead + 1)], 1), ([(2, 1)], 1), ([(0, 1)], 2),
+                       ([(-1, 1)], 1)):
+        with pytest.raises(ValueError):
+            strips.check_plan(bad, n_lead, world)
+    with pytest.raises(ValueError):
+        strips.render_sharded(fn, w, h, t, "wh3", torch.device("cpu"), plan=[(0, n_lead + 2)])
+    with pytest.raises(ValueError):
+        strips.StripPipeline(fn, w, h, t, "wh3", torch.device("cpu"), plan=[(1, 0)])
+    # one process, a plan that does not start at tile row 0: the strip lands in ITS rows of the frame (round-2 advisor)
+    full, _, _ = c_oracle.render(golden_preprocessed(g), w, h, t)
+    pipe = strips.StripPipeline(fn, w, h, t, "wh3", torch.device("cpu"), plan=[(1, n_lead)])
+    frame = pipe.submit().numpy()
+    assert np.array_equal(frame[t:], full[t:]) and not frame[:t].any()
+    part = strips.render_sharded(fn, w, h, t, "wh3", torch.device("cpu"), plan=[(1, n_lead)]).numpy()
+    assert np.array_equal(part[t:], full[t:]) and not part[:t].any()
