@@ -80,6 +80,7 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     "gsx_debug_sort_pairs": (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_size_t,
                                             c_void_p]),
+    "gsx_debug_set_blend_probe": (ctypes.c_int, [c_void_p]),
     "gsx_debug_depth_sort": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_uint32,
                                             c_int64, POINTER(c_int64), c_void_p, c_size_t, c_void_p]),
 }
@@ -90,7 +91,11 @@ _test_lib = None
 
 def _bind(lib, signatures):
     for name, (res, args) in signatures.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None and "GSX_TEST_LIB_PATH" in os.environ:     # an older experiment build of the test library
+            continue
+        if fn is None:
+            raise AttributeError("%s is missing from %s" % (name, lib._name))
         fn.restype = res
         fn.argtypes = args
     return lib
@@ -104,7 +109,8 @@ def load_test_hooks():
         if not os.path.exists(TEST_LIB_PATH):
             raise RuntimeError("libgsx_test.so not found at %s: build it with `make -C intro_to_gaussian_splatting_amd/csrc`"
                                % TEST_LIB_PATH)
-        _test_lib = _bind(_bind(ctypes.CDLL(TEST_LIB_PATH), SIGNATURES), DEBUG_SIGNATURES)
+        # GSX_TEST_LIB_PATH: an experiment build of the test library (tools/: A/B of kernel variants on one GPU box)
+        _test_lib = _bind(_bind(ctypes.CDLL(os.environ.get("GSX_TEST_LIB_PATH", TEST_LIB_PATH)), SIGNATURES), DEBUG_SIGNATURES)
     return _test_lib
 
 

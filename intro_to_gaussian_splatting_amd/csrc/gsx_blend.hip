@@ -46,12 +46,34 @@
 // M11 is not positive and finite (only possible for caller-given inverse covariances on the stage-2 entry)
 // keeps the monomial coefficients and is flagged; a batch holding one takes the unpacked loop.
 // T(1 - alpha) is evaluated as T - T alpha (1 ulp).
+// Coordinates are TILE-RELATIVE (round 3): the lane that stages a record subtracts the tile's origin from the mean
+// once (x' = x - x0, y' = y - y0; pixel offsets px', py' = 0 .. tile-1 are exact) and forms c0 = fma(r11, y', h x'),
+// the value of w at the tile's origin.  Per lane then e0 = x' - px', c = fma(-h, px', c0) and per pixel
+// w = fma(-r11, py', c): the subtraction e1 = y' - py' and the product h e0 disappear from the loop (two packed and
+// one plain instruction per record and lane of the tile-16 kernel), and the chain of dependent operations in front
+// of v_exp_f32 is one shorter than before -- what a lone wave at the end of a heavy-tailed frame waits for.  The
+// cancellation inside w stays bounded by the splat's extent around the tile (hoisting against ABSOLUTE pixel
+// coordinates, r11 x 1000, would give back what completing the square won).
+#include <type_traits>
+
 #include "gsx_internal.h"
+
+#ifdef GSX_TEST_HOOKS
+// Test library only (gsx_debug.h: gsx_debug_set_blend_probe): when set, every workgroup of blend_tile16_kernel leaves
+// (cycles, tile, list length, records staged | flags << 24) there, indexed by blockIdx.x -- who is the frame waiting for?
+__device__ uint4 *g_blend_probe = nullptr;
+#endif
 
 namespace gsx {
 namespace {
 
 constexpr float kStopRefCpu = 0.000001f;  // gaussian_scene.py:153
+// A staged batch holds up to 64 records followed by kPad NULL records (log2 op = -inf: alpha = exp2(-inf) = 0 at every
+// pixel, colour 0), so that the compositing loops always take whole trips of 4 or 8 records with no per-record branch
+// (a branch between the records of a trip keeps the compiler from interleaving their dependent chains, and a wave
+// that has its SIMD to itself -- the long, saturated tiles of a heavy-tailed frame -- then pays every chain in full).
+// A null record changes nothing under either form of the rule: T alpha = 0, T - 0 = T, fma(0, 0, C) = C.
+constexpr int kPad = 8, kSlots = 64 + kPad;
 
 // Contiguous-chunk remap: hardware places block b on XCD b % 8; give XCD x the x-th eighth of
 // the tile list.  Bijective for every n_tiles.
@@ -104,42 +126,47 @@ __global__ void __launch_bounds__(64) clear_kernel(ClearPlan cp, float *__restri
     clear_block(blockIdx.x, cp, base);
 }
 
-struct Splat {  // one record, unpacked (wave-uniform values); mono: monomial coefficients in (d1, h, r11)
-    float mx, my, d1, h, r11, lop, cr, cg, cb;
+struct Splat {  // one staged record, unpacked (wave-uniform values); mono: monomial coefficients in (d1, h, r11)
+    float mx, c0, d1, h, r11, lop, cr, cg, cb, my;
     bool mono;
 };
 
-// Record: a = (x, y, D1, h)  b = (r11, log2 op, r, g)  c = (b, depth, monomial flag, -)
-__device__ __forceinline__ Splat read_splat(const float4 (*sh)[64], uint32_t k) {
+// Staged record (stage_batch): a = (x', c0, D1, h)  b = (r11, log2 op, r, g)  c = (b, y', monomial flag, -)
+__device__ __forceinline__ Splat read_splat(const float4 (*sh)[kSlots], uint32_t k) {
     const float4 A = sh[0][k], B = sh[1][k];
     const float2 C = *reinterpret_cast<const float2 *>(&sh[2][k]);
     const float flag = sh[2][k].z;
-    return Splat{A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, flag != 0.0f};
+    return Splat{A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, flag != 0.0f};
 }
 
-// Exponent of one pixel: e_s = mean_x - pixel_x (shared by the lane's pixels), e_p = mean_y - pixel_y.
-// The association is fixed; every REF_CPU kernel evaluates exactly this.
-__device__ __forceinline__ void exponent_x(const Splat &g, float e_s, float &s0, float &t0) {
+// Exponent of one pixel.  px, p = the pixel's offsets inside the tile (px shared by the lane's pixels); g.mx, g.my =
+// x', y' (tile-relative), g.c0 = r11 y' + h x'.  The association is fixed; every REF_CPU kernel evaluates exactly this.
+__device__ __forceinline__ void exponent_x(const Splat &g, float px, float &s0, float &t0) {
+    const float e_s = g.mx - px;
     if (g.mono) {   // monomial fallback: s0 = e_s^2 Q''00 + log2 op, t0 = e_s Qs
         s0 = __builtin_fmaf(e_s * e_s, g.d1, g.lop);
         t0 = e_s * g.h;
-    } else {
+    } else {        // t0 = c = w at the row of the tile's origin
         s0 = __builtin_fmaf(-(g.d1 * e_s), e_s, g.lop);
-        t0 = g.h * e_s;
+        t0 = __builtin_fmaf(-g.h, px, g.c0);
     }
 }
-__device__ __forceinline__ float exponent_y(const Splat &g, float e_p, float s0, float t0) {
-    if (g.mono) return __builtin_fmaf(e_p, __builtin_fmaf(e_p, g.r11, t0), s0);
-    const float w = __builtin_fmaf(g.r11, e_p, t0);
+__device__ __forceinline__ float exponent_y(const Splat &g, float p, float s0, float t0) {
+    if (g.mono) {
+        const float e_p = g.my - p;
+        return __builtin_fmaf(e_p, __builtin_fmaf(e_p, g.r11, t0), s0);
+    }
+    const float w = __builtin_fmaf(-g.r11, p, t0);
     return __builtin_fmaf(-w, w, s0);
 }
 
-// NPX pixels of one lane against one Gaussian.  The lane's pixels share x (e_s) and differ in y (e_p[j]).
+// NPX pixels of one lane against one Gaussian.  The lane's pixels share x (px = their x offset inside the tile) and
+// differ in y (e_p[j] = the pixel's y offset inside the tile).
 template <int NPX>
-__device__ __forceinline__ void composite(float e_s, const float (&e_p)[NPX], const Splat &g, float (&T)[NPX],
+__device__ __forceinline__ void composite(float px, const float (&e_p)[NPX], const Splat &g, float (&T)[NPX],
                                           float (&c0)[NPX], float (&c1)[NPX], float (&c2)[NPX]) {
     float s0, t0;
-    exponent_x(g, e_s, s0, t0);
+    exponent_x(g, px, s0, t0);
     float ta[NPX], test[NPX];
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
@@ -175,60 +202,105 @@ __device__ __forceinline__ void composite(float e_s, const float (&e_p)[NPX], co
     }
 }
 
-// Gathers one record per lane into LDS; returns (wave-uniform) whether the batch holds a monomial record.
+// Gathers one record per lane into LDS, the mean made tile-relative; returns (wave-uniform) what the batch holds:
+// kBatchRegular (every record has D1 >= 0, hence 0 <= alpha <= 1 and T never rises), kBatchWild (some D1 < 0: a 2D
+// covariance whose float32 determinant came out negative and was floored, utils.py:383 -- the reference's exp can
+// then exceed 1 -- thin footprints of a heavy-tailed scene have them in most batches) or kBatchMono (a record in
+// the monomial fallback: only caller-given inverse covariances on the stage-2 entry).
 //
 // Records that cannot matter to ANY pixel of the tile are not staged at all.  The reference lists a Gaussian
 // for every tile its bounding box touches, plus a tile of slack (`min <= x0 + T`, gaussian_scene.py:209-217), so
 // ~8 % of the listed (tile, Gaussian) pairs lie more than 5.9 sigma from every pixel of their tile.  If
-//     log2 op - D1 min(e0^2) - min(w^2) < skip_below   over the tile's pixel rectangle (w = r11 e1 + h e0 is linear:
-//                                                        its extremes are at the corners),
-// with skip_below <= -26, then alpha < 2^-26 at every pixel, so T - T alpha == T bit for bit (T alpha is below half
-// an ulp of T): skipping the record leaves every T identical and drops less than 2^skip_below of colour per
-// channel.  The threshold depends on the LENGTH of the tile's list (skip_threshold below), so that all the records
-// a tile skips together stay below 512 x 2^-26 = 7.6e-6 however long the list is -- a flat -26 would let 6 711
-// skipped records of peak alpha 1.5e-8 each reach the 1e-4 pixel tolerance (round-2 verdict; tested with 12 000).
-// The tile lists and D are untouched -- this is a decision of the compositing kernel, the same in every REF_CPU
-// kernel (the test only depends on the record, the tile and the length of its list), so the kernel families stay
-// bit-identical to each other.
+//     bound = log2 op - D1 min(e0^2) - min(w^2) < -26   over the tile's pixel rectangle (w = r11 e1 + h e0 is linear:
+//                                                         its extremes are at the corners),
+// then alpha < 2^-26 at every pixel, so T - T alpha == T bit for bit (T alpha is below half an ulp of T): skipping
+// the record leaves every T identical and drops less than 2^bound of colour per channel.  How much a tile drops
+// ALTOGETHER is accounted for, in scalar integer arithmetic: a skipped record is charged 2^-26, 2^-33 or 2^-40 --
+// the class its bound falls into (three ballots per batch) -- to `skipped`, the tile's running total in units of
+// 2^-40, and a batch skips only the classes that still fit kSkipBudget = 2^-17 = 7.6e-6 of colour per tile: all
+// three, else the two farther ones, else the farthest, else none.  (Round 2 had the flat -26 alone: 6 711 skipped
+// records of peak alpha 1.5e-8 each would have reached the 1e-4 pixel tolerance; tested with 16 384.  A threshold
+// falling with the list length -- the first fix -- cost the heavy-tailed scene 0.11 ms although its 12 000-entry
+// lists are mostly records 2^-100 away; summing the exact 2^bound over the wave -- the second -- cost the same in
+// cross-lane latency, the lists being mostly skipped records there.)  The tile lists and D are untouched -- this is
+// a decision of the compositing kernel, the same in every REF_CPU kernel (it depends only on the tile and its
+// list, walked 64 records at a time from the start), so the kernel families stay bit-identical to each other.
 // nb: in = records of the batch, out = records staged (wave-uniform).
-__device__ __forceinline__ float skip_threshold(uint32_t list_length) {
-    // -26 - log2(max(1, length / 512)): 512 x 2^-26 of colour at most per tile, whatever the length
-    return -26.0f - __builtin_amdgcn_logf(fmaxf(1.0f, (float)list_length * (1.0f / 512.0f)));
-}
-__device__ __forceinline__ bool stage_batch(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
-                                            uint32_t base, uint32_t &nb, float4 (*sh)[64], int lane, float tile_x0,
-                                            float tile_y0, float tile_side, float skip_below) {
-    bool mono = false, keep = false;
-    float4 a, b, c;
-    if ((uint32_t)lane < nb) {
-        const Record *q = rec + vals[base + lane];
-        a = q->a;
-        b = q->b;
-        c = q->c;
+constexpr uint32_t kSkipBudget = 1u << 23;   // 2^-17 of colour per tile and channel, in units of 2^-40 (colours are < 1)
+enum { kBatchRegular = 0, kBatchWild = 1, kBatchMono = 2 };
+// The second half of staging: `have` lanes hold a record (a, b, c) of the batch in registers.
+__device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool have, uint32_t &nb, float4 (*sh)[kSlots],
+                                             int lane, float tile_x0, float tile_y0, float tile_side, uint32_t &skipped,
+                                             uint32_t budget) {
+    bool irregular = false, keep = false, mono = false;
+    float bound = 0.0f;                 // < -26: a candidate, alpha < 2^bound on the whole tile
+    if (have) {
+        a.x -= tile_x0;                // tile-relative mean (see the head of this file)
+        a.y -= tile_y0;
         mono = c.z != 0.0f;
+        // irregular: the monomial fallback, or D1 < 0: alpha may exceed 1 there, T is no longer monotone, and the
+        // batch tests T after every record
+        irregular = mono || !(a.z >= 0.0f);
         keep = true;
-        if (!mono && a.z >= 0.0f) {     // (x, y, D1, h) (r11, log2 op, ..): completed square, D1 >= 0
-            const float ex0 = a.x - tile_x0, ex1 = a.x - (tile_x0 + tile_side - 1.0f);
-            const float ey0 = a.y - tile_y0, ey1 = a.y - (tile_y0 + tile_side - 1.0f);
+        if (!irregular) {               // (x', y', D1, h) (r11, log2 op, ..): completed square, D1 >= 0
+            const float ex0 = a.x, ex1 = a.x - (tile_side - 1.0f);
+            const float ey0 = a.y, ey1 = a.y - (tile_side - 1.0f);
             const float ex_min2 = ex0 * ex1 <= 0.0f ? 0.0f : fminf(ex0 * ex0, ex1 * ex1);
             const float w00 = __builtin_fmaf(b.x, ey0, a.w * ex0), w01 = __builtin_fmaf(b.x, ey1, a.w * ex0);
             const float w10 = __builtin_fmaf(b.x, ey0, a.w * ex1), w11 = __builtin_fmaf(b.x, ey1, a.w * ex1);
             const float wlo = fminf(fminf(w00, w01), fminf(w10, w11)), whi = fmaxf(fmaxf(w00, w01), fmaxf(w10, w11));
             const float wabs = fminf(fabsf(wlo), fabsf(whi));
             const float w_min2 = (wlo <= 0.0f && whi >= 0.0f) ? 0.0f : wabs * wabs;
-            const float bound = b.y - a.z * ex_min2 - w_min2;
-            if (bound < skip_below) keep = false;    // NaN anywhere: the comparison is false, the record stays
+            bound = b.y - a.z * ex_min2 - w_min2;      // NaN anywhere: every comparison below is false, the record stays
         }
+    }
+    // the three classes of this batch and what skipping them would add to the tile's total (units of 2^-40)
+    const unsigned long long far1 = __ballot(bound < -26.0f), far2 = __ballot(bound < -33.0f), far3 = __ballot(bound < -40.0f);
+    const uint32_t n3 = (uint32_t)__popcll(far3), n2 = (uint32_t)__popcll(far2) - n3, n1 = (uint32_t)__popcll(far1) - n2 - n3;
+    const uint32_t cost3 = n3, cost23 = cost3 + (n2 << 7), cost123 = cost23 + (n1 << 14);
+    if (skipped + cost123 <= budget) {              // (wave-uniform, scalar)
+        skipped += cost123;
+        keep = keep && !(bound < -26.0f);
+    } else if (skipped + cost23 <= budget) {
+        skipped += cost23;
+        keep = keep && !(bound < -33.0f);
+    } else if (skipped + cost3 <= budget) {
+        skipped += cost3;
+        keep = keep && !(bound < -40.0f);
     }
     const unsigned long long mask = __ballot(keep);
     if (keep) {
         const uint32_t slot = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        c.y = a.y;                                             // y' (the depth is not needed here)
+        if (!mono) a.y = __builtin_fmaf(b.x, a.y, a.w * a.x);  // c0 = w at the tile's origin
         sh[0][slot] = a;
         sh[1][slot] = b;
         sh[2][slot] = c;
     }
     nb = (uint32_t)__popcll(mask);
-    return __any(mono && keep) != 0;
+    if (lane < kPad) {                  // the null records behind the batch (see kPad)
+        sh[0][nb + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        sh[1][nb + lane] = make_float4(0.0f, -__builtin_inff(), 0.0f, 0.0f);
+        sh[2][nb + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    return __any(mono && keep) ? kBatchMono : (__any(irregular && keep) ? kBatchWild : kBatchRegular);
+}
+
+// Gather + staging of one batch.  idx: this lane's entry of the tile's list (vals[base + lane]) when the caller has
+// requested it ahead (a batch earlier: one of the two dependent trips to memory of a batch is then off its path).
+__device__ __forceinline__ int stage_batch(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
+                                           uint32_t base, uint32_t &nb, float4 (*sh)[kSlots], int lane, float tile_x0,
+                                           float tile_y0, float tile_side, uint32_t &skipped, uint32_t budget = kSkipBudget,
+                                           const uint32_t *idx = nullptr) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
+    const bool have = (uint32_t)lane < nb;
+    if (have) {
+        const Record *q = rec + (idx ? *idx : vals[base + lane]);
+        a = q->a;
+        b = q->b;
+        c = q->c;
+    }
+    return stage_records(a, b, c, have, nb, sh, lane, tile_x0, tile_y0, tile_side, skipped, budget);
 }
 
 // ---- packed-math form of the same arithmetic (two pixels per VGPR pair) ----------------------
@@ -244,16 +316,28 @@ __device__ __forceinline__ v2f pk_exp2(v2f p) { return v2f{__builtin_amdgcn_exp2
 __device__ __forceinline__ v2f splat2(float v) { return v2f{v, v}; }
 
 // alpha of one (completed-square) record at the lane's 4 pixels (pairs a = (y0,y1), b = (y2,y3)); independent
-// of T.  A = (x, y, D1, h), r11, lop = log2(opacity factor).  Same operations as exponent_x / exponent_y.
+// of T.  A = (x', c0, D1, h) as staged, r11, lop = log2(opacity factor); cx, cya, cyb = the pixels' offsets inside
+// the tile.  Same operations as exponent_x / exponent_y.
 __device__ __forceinline__ void alphas(float4 A, float r11, float lop, float cx, v2f cya, v2f cyb, v2f &al_a,
                                        v2f &al_b) {
     const float e_x = A.x - cx;
     const float s0 = __builtin_fmaf(-(A.z * e_x), e_x, lop);
-    const float t0 = A.w * e_x;
-    const v2f ea = splat2(A.y) - cya, eb = splat2(A.y) - cyb;
-    const v2f wa = pk_fma(splat2(r11), ea, splat2(t0)), wb = pk_fma(splat2(r11), eb, splat2(t0));
+    const float c = __builtin_fmaf(-A.w, cx, A.y);
+    const v2f wa = pk_fma(splat2(-r11), cya, splat2(c)), wb = pk_fma(splat2(-r11), cyb, splat2(c));
     al_a = pk_exp2(pk_fma(-wa, wa, splat2(s0)));
     al_b = pk_exp2(pk_fma(-wb, wb, splat2(s0)));
+}
+
+// The same for a record in the monomial fallback (flag set): the operations of exponent_x / exponent_y's mono branch,
+// packed.  A = (x', -, Q''00, Q''01 + Q''10), yp = y', q11 = Q''11.
+__device__ __forceinline__ void alphas_mono(float4 A, float yp, float q11, float lop, float cx, v2f cya, v2f cyb, v2f &al_a,
+                                            v2f &al_b) {
+    const float e_x = A.x - cx;
+    const float s0 = __builtin_fmaf(e_x * e_x, A.z, lop);
+    const float t0 = e_x * A.w;
+    const v2f ea = splat2(yp) - cya, eb = splat2(yp) - cyb;
+    al_a = pk_exp2(pk_fma(ea, pk_fma(ea, splat2(q11), splat2(t0)), splat2(s0)));
+    al_b = pk_exp2(pk_fma(eb, pk_fma(eb, splat2(q11), splat2(t0)), splat2(s0)));
 }
 
 #define GSX_ACCUMULATE(ta_a, ta_b, cr, cg, cb)          \
@@ -292,48 +376,106 @@ __device__ __forceinline__ float min4(v2f a, v2f b) { return fminf(fminf(a.x, a.
 __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                                                         const uint2 *__restrict__ ranges, const TileGrid &g,
                                                         const OutDesc &out, uint32_t t, int quarter,
-                                                        float4 (*sh)[64]) {
+                                                        float4 (*sh)[kSlots], uint32_t budget) {
     const int lane = threadIdx.x;
+#ifdef GSX_TEST_HOOKS
+    const unsigned long long probe_t0 = __builtin_readcyclecounter();
+    uint32_t probe_staged = 0, probe_checked_at = 0xFFFFFFu, probe_batch = 0;
+#endif
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     const bool y_contig = out.stride_y < out.stride_x;
     // WH3: a quarter = 4 columns of x, lanes run along y (192 contiguous bytes per column);
     // HW3: a quarter = 4 rows of y, lanes run along x
-    const int px = tx * 16 + (y_contig ? 4 * quarter + (lane >> 4) : (lane & 15));
-    const int py = ty * 16 + (y_contig ? (lane & 15) : 4 * quarter + (lane >> 4));
-    const float cx = (float)px, cy = (float)py;
+    const int lx = y_contig ? 4 * quarter + (lane >> 4) : (lane & 15);      // the pixel's offset inside the tile
+    const int ly = y_contig ? (lane & 15) : 4 * quarter + (lane >> 4);
+    const int px = tx * 16 + lx, py = ty * 16 + ly;
+    const float cx = (float)lx, cy = (float)ly;
     float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     bool checked = false;   // wave-uniform: some pixel of this quarter has saturated
     uint2 rg = ranges[t];
     rg.y &= ~kLongFlag;
-    const float skip_below = skip_threshold(rg.y - rg.x);
+    uint32_t skipped = 0;            // colour this tile has left out so far (stage_batch)
     constexpr int kTrip = 8;
+    // The gather runs AHEAD of the compositing: while batch i is composited, the records of batch i + 1 and the
+    // list entries of batch i + 2 are in flight.  A long tile's wave is nearly alone on its SIMD at the end of the
+    // frame, nothing hides its two dependent trips to memory per batch, and with most records of a heavy-tailed
+    // list not staged at all those trips ARE the tile's duration (188 batches x ~2.5 us on the clustered scene; the
+    // compiler overlapped them in one build and not in the next, depending on its register allocation -- round 3).
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb4 = na, nc = na;      // records of the next batch
+    uint32_t idx2 = 0;                                                      // list entry of the batch after it
+    if (rg.x + (uint32_t)lane < rg.y) {
+        const Record *q = rec + vals[rg.x + lane];
+        na = q->a; nb4 = q->b; nc = q->c;
+    }
+    if (rg.x + 64u + (uint32_t)lane < rg.y) idx2 = vals[rg.x + 64u + lane];
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
         uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
-        const bool mono = stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skip_below);
+        const float4 ra = na, rb = nb4, rc = nc;
+        if (base + 64u + (uint32_t)lane < rg.y) {
+            const Record *q = rec + idx2;
+            na = q->a; nb4 = q->b; nc = q->c;
+        }
+        if (base + 128u + (uint32_t)lane < rg.y) idx2 = vals[base + 128u + lane];
+        const int kind = stage_records(ra, rb, rc, (uint32_t)lane < nb, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f,
+                                       skipped, budget);
+#ifdef GSX_TEST_HOOKS
+        probe_staged += nb;
+        if (checked && probe_checked_at == 0xFFFFFFu) probe_checked_at = probe_batch;
+        ++probe_batch;
+#endif
         __syncthreads();
-        uint32_t k = 0;
-        if (!checked && !mono) {
-            for (; k + kTrip <= nb; k += kTrip) {
+        // Whole trips of eight records (the batch is padded with null records, see kPad).  The alphas of a trip
+        // are computed independently of each other and of T -- no branch between them --; then either the plain
+        // chain T -> T - T alpha with ONE wave-level saturation test per trip, or -- from the first trip in which any
+        // pixel of the quarter saturates, which is then done again -- the reference's exact rule per pixel and record
+        // with selects (a stopping pixel does not receive the record and stays at T = 0; T == 0 is tested on its
+        // own, see composite<>).  Where nothing stops the selects change nothing: same bits.  (Round 2 sent what was
+        // left of a batch, and every record of a saturated tile, through a one-record-at-a-time loop: on a
+        // heavy-tailed scene, where half the records of a long list are not staged and the dense tiles saturate early,
+        // that loop -- ~420 cycles per record for a wave alone on its SIMD -- was the frame's duration.)
+        if (kind == kBatchMono) {       // a record in the monomial fallback (stage-2 entry only): one at a time, exact rule
+            for (uint32_t k = 0; k < nb; ++k) {
+                const Splat s = read_splat(sh, k);
+                const float e_p[1] = {cy};
+                float T1[1] = {T}, a0[1] = {c0}, a1[1] = {c1}, a2[1] = {c2};
+                composite<1>(cx, e_p, s, T1, a0, a1, a2);
+                T = T1[0]; c0 = a0[0]; c1 = a1[0]; c2 = a2[0];
+            }
+        } else {
+            for (uint32_t k = 0; k < nb; k += kTrip) {
                 float alpha[kTrip];
 #pragma unroll
                 for (int u = 0; u < kTrip; ++u) {
                     const float4 A = sh[0][k + u];
                     const float2 Bq = *reinterpret_cast<const float2 *>(&sh[1][k + u]);   // (r11, log2 op)
-                    const float e_x = A.x - cx, e_y = A.y - cy;
+                    const float e_x = A.x - cx;
                     const float s0 = __builtin_fmaf(-(A.z * e_x), e_x, Bq.y);
-                    const float w = __builtin_fmaf(Bq.x, e_y, A.w * e_x);
+                    const float w = __builtin_fmaf(-Bq.x, cy, __builtin_fmaf(-A.w, cx, A.y));
                     alpha[u] = __builtin_amdgcn_exp2f(__builtin_fmaf(-w, w, s0));
                 }
-                float ta[kTrip], Tt = T, m = T;
+                float ta[kTrip], Tt = T;
+                if (!checked) {
+                    float m = T;
 #pragma unroll
-                for (int u = 0; u < kTrip; ++u) {
-                    ta[u] = Tt * alpha[u];
-                    Tt = Tt - ta[u];
-                    m = fminf(m, Tt);
+                    for (int u = 0; u < kTrip; ++u) {
+                        ta[u] = Tt * alpha[u];
+                        Tt = Tt - ta[u];
+                        m = fminf(m, Tt);       // (a wild batch -- alpha > 1 possible -- needs every T tested)
+                    }
+                    // (a NaN hides from fminf; `!(m >= ..)` sends such a trip to the exact rule as well)
+                    if (__builtin_expect(__any(!(m >= kStopRefCpu)), 0)) {
+                        checked = true;
+                        Tt = T;
+                    }
                 }
-                if (__builtin_expect(__any(m < kStopRefCpu), 0)) {
-                    checked = true;
-                    break;
+                if (checked) {
+#pragma unroll
+                    for (int u = 0; u < kTrip; ++u) {
+                        const float t_a = Tt * alpha[u], t = Tt - t_a;
+                        const bool stop = (Tt == 0.0f) | (t < kStopRefCpu);
+                        ta[u] = stop ? 0.0f : t_a;
+                        Tt = stop ? 0.0f : t;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < kTrip; ++u) {
@@ -346,16 +488,15 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
                 T = Tt;
             }
         }
-        for (; k < nb; ++k) {   // tail of the batch, or the checked path (exact stop rule, see composite<>)
-            const Splat s = read_splat(sh, k);
-            const float e_p[1] = {s.my - cy};
-            float T1[1] = {T}, a0[1] = {c0}, a1[1] = {c1}, a2[1] = {c2};
-            composite<1>(s.mx - cx, e_p, s, T1, a0, a1, a2);
-            T = T1[0]; c0 = a0[0]; c1 = a1[0]; c2 = a2[0];
-        }
         __syncthreads();
         if (__ballot(T > 0.0f) == 0ull) break;
     }
+#ifdef GSX_TEST_HOOKS
+    if (g_blend_probe && lane == 0)
+        g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t | 0x40000000u, rg.y - rg.x,
+                                               probe_staged | (checked ? 0x80000000u : 0u));
+    if (g_blend_probe && lane == 1) g_blend_probe[gridDim.x + blockIdx.x] = make_uint4(probe_checked_at, 0, 0, 0);
+#endif
     float *o = out.ptr + (int64_t)(px - out.x0) * out.stride_x + (int64_t)(py - out.y0) * out.stride_y;
     o[0] = c0;
     o[1] = c1;
@@ -369,20 +510,21 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
 //   GSX_LAYOUT_WH3  out[x][y][c]: the lane's 4 pixels are 48 contiguous bytes (3 x dwordx4);
 //   GSX_LAYOUT_HW3  out[y][x][c]: 4 stores of 12 B; the 16 lanes that share a y write 192
 //                   contiguous bytes per store instruction.
-// VARIANT 0: scalar-form composite<4>; VARIANT 1: packed form, four (then two) records per saturation test.
+// VARIANT 0: scalar-form composite<4>; VARIANT 1: packed form, four (then two) records per saturation test;
+// VARIANT 2 (test library only): six per test.
 template <int VARIANT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))   // 64 VGPRs: every lost wave costs
     blend_tile16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                         const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
-                        uint32_t nhelpers, const uint32_t *__restrict__ sched) {
-    __shared__ float4 sh[3][64];
+                        uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget) {
+    __shared__ float4 sh[3][kSlots];
     // block order: [helpers of long tiles (dispatched first: they have the most to do)] [tiles] [clears]
     if (blockIdx.x < nhelpers) {
         // 32 consecutive blocks serve 8 long tiles; the 4 quarters of a tile share b % 8, i.e. an XCD
         const uint32_t b = blockIdx.x, slot = (b >> 5) * 8u + (b & 7u);
         const int quarter = (int)((b >> 3) & 3u);
         if (slot >= min(*lt.count, lt.max)) return;
-        blend_long_tile_quarter(rec, vals, ranges, g, out, lt.list[slot], quarter, sh);
+        blend_long_tile_quarter(rec, vals, ranges, g, out, lt.list[slot], quarter, sh, budget);
         return;
     }
     const uint32_t bid = blockIdx.x - nhelpers;
@@ -392,15 +534,20 @@ __global__ void __launch_bounds__(64)
     }
     const int lane = threadIdx.x;
     const uint32_t t = scheduled_tile(bid, (uint32_t)g.count(), sched);
+#ifdef GSX_TEST_HOOKS
+    const unsigned long long probe_t0 = __builtin_readcyclecounter();
+    uint32_t probe_staged = 0, probe_checked_at = 0xFFFFFFu;
+#endif
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     // WH3: lanes 4q..4q+3 cover one x (contiguous 192 B); HW3: lanes 16q..16q+15 cover one y-quad
     const bool y_contig = out.stride_y < out.stride_x;
-    const int px = tx * 16 + (y_contig ? (lane >> 2) : (lane & 15));
-    const int py0 = ty * 16 + 4 * (y_contig ? (lane & 3) : (lane >> 4));
-    const float cx = (float)px;  // pixel coordinates as floats (exact)
+    const int lx = y_contig ? (lane >> 2) : (lane & 15);            // the lane's pixels: offsets inside the tile
+    const int ly0 = 4 * (y_contig ? (lane & 3) : (lane >> 4));
+    const int px = tx * 16 + lx, py0 = ty * 16 + ly0;
+    const float cx = (float)lx;  // pixel offsets as floats (exact)
     float cy[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cy[j] = (float)(py0 + j);
+    for (int j = 0; j < 4; ++j) cy[j] = (float)(ly0 + j);
     const v2f cya = v2f{cy[0], cy[1]}, cyb = v2f{cy[2], cy[3]};
 
     float T[4] = {1.0f, 1.0f, 1.0f, 1.0f};
@@ -409,108 +556,100 @@ __global__ void __launch_bounds__(64)
     v2f c0a = splat2(0.0f), c1a = c0a, c2a = c0a, c0b = c0a, c1b = c0a, c2b = c0a;
 
     bool checked = false;  // wave-uniform: some pixel of this tile has saturated
-    const uint2 rg = ranges[t];
+    bool restart_scalar = false;     // wave-uniform: a monomial record turned up, the tile starts over on the scalar form
+    uint2 rg = ranges[t];            // the same in every lane: kept in scalar registers
+    rg.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.x);
+    rg.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.y);
     if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
-    const float skip_below = skip_threshold(rg.y - rg.x);
+    uint32_t skipped = 0;            // colour this tile has left out so far (stage_batch)
+    // the list entries of the next batch are requested while this one is composited (one register): one of the two
+    // dependent trips to memory per batch leaves the path of a wave that has its SIMD to itself
+    uint32_t idx = rg.x + (uint32_t)lane < rg.y ? vals[rg.x + lane] : 0u;
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
         uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
-        const bool mono = stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skip_below);
+        const uint32_t idx_now = idx;
+        if (base + 64u + (uint32_t)lane < rg.y) idx = vals[base + 64u + lane];
+        const int kind = stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skipped, budget,
+                                     &idx_now);
+        const bool wild = kind != kBatchRegular;     // wave-uniform
+#ifdef GSX_TEST_HOOKS
+        probe_staged += nb;
+        if (checked && probe_checked_at == 0xFFFFFFu) probe_checked_at = (base - rg.x) >> 6;
+#endif
         __syncthreads();
-        if (VARIANT == 0 || mono) {
-            if (VARIANT != 0) {   // a batch with a monomial record (stage-2 entry only): unpack the state
-                T[0] = Ta.x; T[1] = Ta.y; T[2] = Tb.x; T[3] = Tb.y;
-                c0[0] = c0a.x; c0[1] = c0a.y; c0[2] = c0b.x; c0[3] = c0b.y;
-                c1[0] = c1a.x; c1[1] = c1a.y; c1[2] = c1b.x; c1[3] = c1b.y;
-                c2[0] = c2a.x; c2[1] = c2a.y; c2[2] = c2b.x; c2[3] = c2b.y;
-            }
+        if (VARIANT == 0) {
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
-                // e = mean - pixel, the pixel coordinate formed first, as the reference does
-                const float e_x = s.mx - cx;
-                float e_y[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e_y[j] = s.my - cy[j];
-                composite<4>(e_x, e_y, s, T, c0, c1, c2);
+                composite<4>(cx, cy, s, T, c0, c1, c2);
             }
-            if (VARIANT != 0) {
-                Ta = v2f{T[0], T[1]}; Tb = v2f{T[2], T[3]};
-                c0a = v2f{c0[0], c0[1]}; c0b = v2f{c0[2], c0[3]};
-                c1a = v2f{c1[0], c1[1]}; c1b = v2f{c1[2], c1[3]};
-                c2a = v2f{c2[0], c2[1]}; c2b = v2f{c2[2], c2[3]};
-            }
+        } else if (kind == kBatchMono) {
+            // A record in the monomial fallback (caller-given inverse covariances on the stage-2 entry; a degenerate
+            // footprint): the packed loops cannot evaluate it, and written on the packed state that rare path cost
+            // the kernel 14 registers.  The tile starts over on the scalar form instead (below): the packed state is
+            // dead from here, so the two forms do not add up in the register file.
+            restart_scalar = true;
+            break;
         } else {
-            // Common path: four (then two) records per trip, ONE wave-level saturation test, no per-pixel
-            // selects.  The first time any pixel of the tile saturates the wave leaves this loop
-            // (before committing the pair) and finishes the tile on the checked path below; a
-            // saturated pixel has T = 0 and would trip the test on every record anyway.
+            // Common path: whole trips of four records (the batch is padded with null records, see kPad), ONE
+            // wave-level saturation test per trip, no per-pixel selects: twice the independent work of two records
+            // between two tests hides more of the wave's own LDS reads and exponentials -- 264 -> 254 us at 1M
+            // Gaussians in round 2, more where a SIMD holds fewer than 8 waves (a rank's strip).  From the first
+            // trip in which any pixel of the tile saturates -- that trip is done again -- the reference's exact rule
+            // per pixel and record (checked_pair) on trips of two; a saturated pixel has T = 0, adds 0 and stays 0.
+            // Same operations per pixel and record in both forms, same order: same bits.
+            constexpr int kTrip = VARIANT == 2 ? 6 : 4;
             uint32_t k = 0;
-            if (!checked) {
-                // FOUR records per trip first (the two-record loop below takes what is left of the batch): twice
-                // the independent work between two saturation tests hides more of the wave's own LDS reads and
-                // exponentials -- 264 -> 254 us at 1M Gaussians, more where a SIMD holds fewer than 8 waves (a
-                // rank's strip) -- and still fits 64 VGPRs (six per trip: 74, no faster).  Same operations per pixel
-                // and record, same order: same bits.
-                constexpr int kTrip = 4;
-                for (; k + (kTrip - 1) < nb; k += kTrip) {
-                    float4 A[kTrip], B[kTrip];
-                    float cb[kTrip];
+            // one trip of N records from k; false: some pixel saturates inside it (nothing is committed)
+            auto trip = [&](auto n_tag) -> bool {
+                constexpr int N = decltype(n_tag)::value;
+                // geometry now, colour after the test: what stays live across the saturation test is T alpha of
+                // the trip (16 registers), not its records (36) -- the colours are read again from LDS (uniform
+                // address: one broadcast read), which keeps the kernel at 64 VGPRs without spills
+                v2f ta_a[N], ta_b[N], ta = Ta, tb = Tb;
 #pragma unroll
-                    for (int u = 0; u < kTrip; ++u) {
-                        A[u] = sh[0][k + u];
-                        B[u] = sh[1][k + u];
-                        cb[u] = sh[2][k + u].x;
-                    }
-                    v2f ta_a[kTrip], ta_b[kTrip], ta = Ta, tb = Tb;
-                    float m = Ta.x;
-#pragma unroll
-                    for (int u = 0; u < kTrip; ++u) {
-                        v2f aa, ab;
-                        alphas(A[u], B[u].x, B[u].y, cx, cya, cyb, aa, ab);
-                        ta_a[u] = ta * aa;
-                        ta_b[u] = tb * ab;
-                        ta = ta - ta_a[u];
-                        tb = tb - ta_b[u];
-                        m = fminf(m, min4(ta, tb));
-                    }
-                    if (__builtin_expect(__any(m < kStopRefCpu), 0)) {
-                        checked = true;
-                        break;
-                    }
-#pragma unroll
-                    for (int u = 0; u < kTrip; ++u) GSX_ACCUMULATE(ta_a[u], ta_b[u], B[u].z, B[u].w, cb[u]);
-                    Ta = ta;
-                    Tb = tb;
+                for (int u = 0; u < N; ++u) {
+                    const float4 A = sh[0][k + u];
+                    const float2 Bq = *reinterpret_cast<const float2 *>(&sh[1][k + u]);   // (r11, log2 op)
+                    v2f aa, ab;
+                    alphas(A, Bq.x, Bq.y, cx, cya, cyb, aa, ab);
+                    ta_a[u] = ta * aa;
+                    ta_b[u] = tb * ab;
+                    ta = ta - ta_a[u];
+                    tb = tb - ta_b[u];
                 }
-            }
-            if (!checked) {
-                for (; k + 1 < nb; k += 2) {
-                    const float4 A0 = sh[0][k], B0 = sh[1][k], A1 = sh[0][k + 1], B1 = sh[1][k + 1];
-                    const float cb0 = sh[2][k].x, cb1 = sh[2][k + 1].x;
-                    v2f aa0, ab0, aa1, ab1;
-                    alphas(A0, B0.x, B0.y, cx, cya, cyb, aa0, ab0);
-                    alphas(A1, B1.x, B1.y, cx, cya, cyb, aa1, ab1);
-                    const v2f ta0a = Ta * aa0, ta0b = Tb * ab0;
-                    const v2f t1a = Ta - ta0a, t1b = Tb - ta0b;
-                    const v2f ta1a = t1a * aa1, ta1b = t1b * ab1;
-                    const v2f t2a = t1a - ta1a, t2b = t1b - ta1b;
-                    if (__builtin_expect(__any(fminf(min4(t1a, t1b), min4(t2a, t2b)) < kStopRefCpu), 0)) {
-                        checked = true;
-                        break;
-                    }
-                    GSX_ACCUMULATE(ta0a, ta0b, B0.z, B0.w, cb0);
-                    GSX_ACCUMULATE(ta1a, ta1b, B1.z, B1.w, cb1);
-                    Ta = t2a;
-                    Tb = t2b;
+                // a regular batch has 0 <= alpha <= 1 (D1 >= 0, log2 op <= 0): T never rises inside the trip, its
+                // last value is its smallest -- ONE test per trip (round 2 folded a min per record).  (A NaN hides
+                // from fminf; `!(m >= ..)` sends such a trip to the exact rule as well.)
+                if (__builtin_expect(__any(!(min4(ta, tb) >= kStopRefCpu)), 0)) return false;
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    const float2 rg_ = *reinterpret_cast<const float2 *>(&sh[1][k + u].z);    // (r, g)
+                    const float cb = sh[2][k + u].x;
+                    GSX_ACCUMULATE(ta_a[u], ta_b[u], rg_.x, rg_.y, cb);
                 }
+                Ta = ta;
+                Tb = tb;
+                k += N;
+                return true;
+            };
+            // (a wild batch -- alpha > 1 possible, T may rise again inside a trip -- goes straight to the exact rule
+            // below, for this batch only: that rule is valid for any batch, it just costs a few selects per record)
+            if (!wild) {
+                while (!checked && k + kTrip <= nb) checked = !trip(std::integral_constant<int, kTrip>());
+                while (!checked && k < nb) checked = !trip(std::integral_constant<int, 2>());   // what is left: trips of two (+ a null record)
             }
-            for (; k < nb; ++k) {  // tail record of the batch, or the checked path
-                const float4 A0 = sh[0][k], B0 = sh[1][k];
-                const float cb0 = sh[2][k].x;
-                v2f aa0, ab0, ta0a, ta0b;
+            for (; k < nb; k += 2) {       // the exact rule, two records per trip (their alphas are independent)
+                const float4 A0 = sh[0][k], B0 = sh[1][k], A1 = sh[0][k + 1], B1 = sh[1][k + 1];
+                const float cb0 = sh[2][k].x, cb1 = sh[2][k + 1].x;
+                v2f aa0, ab0, aa1, ab1, ta0a, ta0b, ta1a, ta1b;
                 alphas(A0, B0.x, B0.y, cx, cya, cyb, aa0, ab0);
+                alphas(A1, B1.x, B1.y, cx, cya, cyb, aa1, ab1);
                 checked_pair(aa0, Ta, ta0a);
                 checked_pair(ab0, Tb, ta0b);
                 GSX_ACCUMULATE(ta0a, ta0b, B0.z, B0.w, cb0);
+                checked_pair(aa1, Ta, ta1a);
+                checked_pair(ab1, Tb, ta1b);
+                GSX_ACCUMULATE(ta1a, ta1b, B1.z, B1.w, cb1);
             }
         }
         __syncthreads();
@@ -521,12 +660,38 @@ __global__ void __launch_bounds__(64)
             live = (Ta.x > 0.0f) | (Ta.y > 0.0f) | (Tb.x > 0.0f) | (Tb.y > 0.0f);
         if (__ballot(live) == 0ull) break;
     }
-    if (VARIANT != 0) {
+    if (VARIANT != 0 && restart_scalar) {
+        // the whole tile again, one record at a time on the scalar form (composite<4>: same bits as the packed loops)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            T[j] = 1.0f;
+            c0[j] = c1[j] = c2[j] = 0.0f;
+        }
+        skipped = 0;
+        for (uint32_t base = rg.x; base < rg.y; base += 64) {
+            uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
+            (void)stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skipped, budget);
+            __syncthreads();
+            for (uint32_t k = 0; k < nb; ++k) {
+                const Splat s = read_splat(sh, k);
+                composite<4>(cx, cy, s, T, c0, c1, c2);
+            }
+            __syncthreads();
+            if (__ballot((T[0] > 0.0f) | (T[1] > 0.0f) | (T[2] > 0.0f) | (T[3] > 0.0f)) == 0ull) break;
+        }
+    } else if (VARIANT != 0) {
         c0[0] = c0a.x; c0[1] = c0a.y; c0[2] = c0b.x; c0[3] = c0b.y;
         c1[0] = c1a.x; c1[1] = c1a.y; c1[2] = c1b.x; c1[3] = c1b.y;
         c2[0] = c2a.x; c2[1] = c2a.y; c2[2] = c2b.x; c2[3] = c2b.y;
     }
 
+#ifdef GSX_TEST_HOOKS
+    if (g_blend_probe && lane == 0)
+        g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t, rg.y - rg.x,
+                                               probe_staged | (checked ? 0x80000000u : 0u));
+    if (g_blend_probe && lane == 1) g_blend_probe[gridDim.x + blockIdx.x] = make_uint4(probe_checked_at, 0, 0, 0);
+#endif
     float *o = out.ptr + (int64_t)(px - out.x0) * out.stride_x + (int64_t)(py0 - out.y0) * out.stride_y;
     if (y_contig && (reinterpret_cast<uintptr_t>(o) & 15u) == 0) {
         float4 *o4 = reinterpret_cast<float4 *>(o);
@@ -550,7 +715,7 @@ __global__ void __launch_bounds__(64)
 __global__ void __launch_bounds__(64)
     blend_generic_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                          const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp) {
-    __shared__ float4 sh[3][64];
+    __shared__ float4 sh[3][kSlots];
     if (blockIdx.x >= (uint32_t)g.count()) {
         clear_block(blockIdx.x - (uint32_t)g.count(), cp, out.ptr);
         return;
@@ -560,23 +725,24 @@ __global__ void __launch_bounds__(64)
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     const int Ts = g.tile, npx = Ts * Ts;
     const uint2 rg = ranges[t];
-    const float skip_below = skip_threshold(rg.y - rg.x);
     const bool fast_y = out.stride_y < out.stride_x;
     for (int chunk = 0; chunk < npx; chunk += 64) {
+        uint32_t skipped = 0;        // colour the tile leaves out (stage_batch): every sweep over the list decides alike
         const int p = chunk + lane;
         const bool valid = p < npx;
         const int pf = p % Ts, ps = p / Ts;
-        const int px = tx * Ts + (fast_y ? ps : pf), py = ty * Ts + (fast_y ? pf : ps);
-        const float fx = (float)px, fy = (float)py;
+        const int lx = fast_y ? ps : pf, ly = fast_y ? pf : ps;      // the pixel's offset inside the tile
+        const int px = tx * Ts + lx, py = ty * Ts + ly;
+        const float fx = (float)lx, fy = (float)ly;
         float T[1] = {1.0f}, c0[1] = {0.0f}, c1[1] = {0.0f}, c2[1] = {0.0f};
         for (uint32_t base = rg.x; base < rg.y; base += 64) {
             uint32_t nb = min(64u, rg.y - base);
-            (void)stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * Ts), (float)(ty * Ts), (float)Ts, skip_below);
+            (void)stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * Ts), (float)(ty * Ts), (float)Ts, skipped);
             __syncthreads();
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
-                const float e_p[1] = {s.my - fy};
-                composite<1>(s.mx - fx, e_p, s, T, c0, c1, c2);
+                const float e_p[1] = {fy};
+                composite<1>(fx, e_p, s, T, c0, c1, c2);
             }
             __syncthreads();
             if (__ballot(valid && T[0] > 0.0f) == 0ull) break;
@@ -705,7 +871,7 @@ __global__ void __launch_bounds__(64)
 // assignment of blend_tile16_kernel), so a record read from LDS and the x-only terms of the exponent
 // serve 4 evaluations.  Same per-pixel arithmetic as blend_rules_kernel<GSX_SEM_STD_3DGS> -- the two
 // give bit-identical frames (tested).  Pixels outside the frame (partial edge tiles) start dead.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     blend_std16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                        const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, float bg0, float bg1, float bg2, ClearPlan cp,
                        const uint32_t *__restrict__ sched) {
@@ -835,7 +1001,15 @@ hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifdef GSX_TEST_HOOKS
+hipError_t set_blend_probe(void *device_buffer) {
+    uint4 *p = (uint4 *)device_buffer;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_blend_probe), &p, sizeof p);
+}
+#endif
+
 bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic) {
+    if (knob("GSX_LONG_SPLIT", 1) == 0) return false;     // test library only
     return semantics == GSX_SEM_REF_CPU && grid.tile == 16 && !generic;
 }
 // The schedule is one more kernel on the frame's critical path (5 .. 10 us): it pays when the compositing
@@ -875,10 +1049,16 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
     if (grid.tile == 16 && !generic) {
         const int variant = knob("GSX_BLEND_VARIANT", 1);   // test library only: A/B runs of the compositing loop
         const unsigned nh = lt.max ? 4u * lt.max : 0u;
+        // test library only: GSX_SKIP_BUDGET_LOG2 = -9 hardly ever refuses a skip (round 2's behaviour); default 2^-17
+        const uint32_t budget = 1u << (40 + knob("GSX_SKIP_BUDGET_LOG2", -17));
         if (variant == 0)
-            blend_tile16_kernel<0><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched);
+            blend_tile16_kernel<0><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget);
+        else if (variant == 2)
+            blend_tile16_kernel<2><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget);
+        else if (variant == 3)
+            blend_tile16_kernel<3><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget);
         else
-            blend_tile16_kernel<1><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched);
+            blend_tile16_kernel<1><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget);
     } else {
         blend_generic_kernel<<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp);
     }

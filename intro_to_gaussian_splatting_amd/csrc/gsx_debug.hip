@@ -12,7 +12,13 @@ using namespace gsx::plan;
         if ((expr) != hipSuccess) return GSX_ERR_HIP; \
     } while (0)
 
+namespace gsx { hipError_t set_blend_probe(void *device_buffer); }
+
 extern "C" {
+
+int gsx_debug_set_blend_probe(void *device_buffer) {
+    return gsx::set_blend_probe(device_buffer) == hipSuccess ? GSX_OK : GSX_ERR_HIP;
+}
 
 int gsx_debug_sort_pairs(void *keys, uint32_t *vals, int64_t n, int32_t key_bits, int32_t key16,
                          const uint32_t *count_dev, void *scratch, size_t scratch_bytes, void *stream) {
