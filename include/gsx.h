@@ -130,6 +130,16 @@ typedef struct GsxParams {
      * KEPT inside LDS buckets, so a rank that owns 1/8 of a 5M-Gaussian frame takes the fast route although
      * n is large); a wrong value costs time, not correctness. */
     int64_t kept_hint;
+    /* gsx_render_forward only.  NULL (default) or a DEVICE buffer of gsx_hints_bytes() bytes that the caller keeps
+     * for ONE view (camera, window, tile size) from frame to frame, zero-filled before its first use.  Two things a
+     * frame computes for its own use are correct whatever their values -- the splitters of the depth sort and the
+     * order in which tiles are handed to the SIMDs -- so with GSX_FLAG_HINTS_VALID a frame takes both from what the
+     * PREVIOUS frame of this view left in the buffer instead of computing them on its own critical path (two
+     * dependent kernels, ~20 us of a 0.42 ms frame), and every frame given the buffer leaves fresh ones for the next
+     * (computed by spare workgroups of launches that run anyway).  Stale hints (the camera moved) cost time -- unevenly
+     * filled sort buckets -- never a pixel: the frame is the same bit for bit (tested).  Frames in flight on different
+     * streams need a buffer each. */
+    void *hints;
 } GsxParams;
 
 /* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call
@@ -176,6 +186,10 @@ typedef struct GsxParams {
 #define GSX_FLAG_TILE_SCHEDULE 32
 #define GSX_FLAG_NO_TILE_SCHEDULE 64
 
+/* GsxParams.hints holds what an earlier frame of the same view (same buffer, same n, same window and tile size) left
+ * there: use it.  Without the flag a frame given a hints buffer only fills it. */
+#define GSX_FLAG_HINTS_VALID 128
+
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
 enum {
     GSX_STAGE_PROJECT = 0,    /* projection, depth keys, record packing         */
@@ -207,6 +221,9 @@ GSX_API void gsx_default_params(GsxParams *params);
  * Returns 0 on invalid arguments.
  */
 GSX_API size_t gsx_workspace_bytes(int64_t n, int32_t width, int32_t height, int32_t tile, int64_t max_instances);
+
+/* Bytes of a GsxParams.hints buffer for frames of width x height at tile size `tile` (0 on invalid arguments). */
+GSX_API size_t gsx_hints_bytes(int32_t width, int32_t height, int32_t tile);
 
 /*
  * Stage 1.  Replaces GaussianScene.preprocess (splat/gaussian_scene.py:70-144) with

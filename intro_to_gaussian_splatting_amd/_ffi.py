@@ -34,6 +34,7 @@ GSX_FLAG_PUBLISHED_RECTS = 8
 GSX_FLAG_NO_LONG_TILE_SPLIT = 16
 GSX_FLAG_TILE_SCHEDULE = 32
 GSX_FLAG_NO_TILE_SCHEDULE = 64
+GSX_FLAG_HINTS_VALID = 128
 STAGE_NAMES = ("project", "depth_sort", "scan", "bin", "blend", "total")
 
 
@@ -49,7 +50,7 @@ class GsxParams(ctypes.Structure):
                 ("out_x0", c_int32), ("out_y0", c_int32), ("out_w", c_int32), ("out_h", c_int32),
                 ("flags", c_int32), ("background", c_float * 3), ("camera_device", c_void_p),
                 ("tile_counts", c_void_p), ("sh", c_void_p), ("sh_degree", c_int32), ("reserved0", c_int32),
-                ("kept_hint", c_int64)]
+                ("kept_hint", c_int64), ("hints", c_void_p)]
 
 
 class GsxFrameStats(ctypes.Structure):
@@ -64,6 +65,7 @@ SIGNATURES = {
     "gsx_last_error": (ctypes.c_char_p, []),
     "gsx_default_params": (None, [POINTER(GsxParams)]),
     "gsx_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int64]),
+    "gsx_hints_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "gsx_preprocess": (ctypes.c_int, [POINTER(GsxCamera)] + [_FP] * 5 + [c_int64] + [_FP] * 11 +
                        [c_void_p, POINTER(c_int64), POINTER(GsxParams), c_void_p, c_size_t, c_void_p]),
     "gsx_render_preprocessed": (ctypes.c_int, [c_int32, c_int32, c_int32] + [_FP] * 8 + [c_int64, _FP,

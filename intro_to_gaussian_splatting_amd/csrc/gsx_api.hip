@@ -81,9 +81,15 @@ int make_plan_or_fail(int32_t width, int32_t height, int32_t tile, float *out_im
 // it from device memory and their grids are sized by the workspace capacity.  The normal call
 // synchronises ONCE, after the last launch, to report the counts and to detect D > capacity;
 // GSX_FLAG_NO_SYNC skips even that (the counts then arrive in pinned memory on their own).
+// fh: the frame's use of GsxParams.hints (FrameHints below; all null / false without a hints buffer).
+struct FrameHints {
+    gsx::BlendHints blend = gsx::BlendHints{nullptr, nullptr, nullptr, nullptr, 0u};
+    const uint32_t *sched = nullptr;   // hints.sched, put together from the previous frame's list lengths, or null
+};
+
 int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t cap, const gsx::TileRect *rrect,
                   const uint32_t *order, const uint32_t *m_dev, const uint32_t *culled_dev, bool sums_ready,
-                  GsxFrameStats *stats, StageTimer &tm, hipStream_t s) {
+                  GsxFrameStats *stats, StageTimer &tm, hipStream_t s, const FrameHints &fh = FrameHints()) {
     uint32_t *counters = (uint32_t *)(ws + c.counters);
     void *temp = ws + c.temp;
     int64_t *dev2 = (int64_t *)(counters + 4);
@@ -98,7 +104,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
         GSX_HIP(gsx::launch_zero_words((uint32_t *)ranges, (size_t)p.grid.count() * 2, s));
         GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), nullptr, (const uint32_t *)(ws + c.tvals0), ranges,
                                   p.grid, p.out, p.semantics, p.background, p.generic, make_clear_plan(p, false),
-                                  gsx::LongTiles{nullptr, nullptr, 0u}, nullptr, s));
+                                  gsx::LongTiles{nullptr, nullptr, 0u}, nullptr, gsx::BlendHints{nullptr, nullptr, nullptr, nullptr, 0u}, s));
     } else if (n == 0) {
         tm.mark();
         GSX_HIP(gsx::launch_clear(make_clear_plan(p, true), p.out.ptr, s));
@@ -129,15 +135,17 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             GSX_HIP(gsx::sort_instances(temp, cap, p.grid, ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0),
                                         (uint32_t *)(ws + c.tvals1), ranges, counters + kCtrPairs, lt, &sorted_vals, s));
             if (p.tile_counts) GSX_HIP(gsx::launch_tile_counts(ranges, p.grid.count(), p.tile_counts, s));
-            uint32_t *sched = nullptr;
-            if (cap > 0 && gsx::blend_uses_schedule(p.grid, p.semantics, p.generic, n, p.schedule)) {
+            const uint32_t *sched = fh.sched;      // handed over by the previous frame (GsxParams.hints): no kernel
+            if (!sched && cap > 0 && gsx::blend_uses_schedule(p.grid, p.semantics, p.generic, n, p.schedule)) {
                 sched = (uint32_t *)(ws + c.sched);
-                GSX_HIP(gsx::launch_tile_schedule(ranges, p.grid.count(), sched, s));
+                GSX_HIP(gsx::launch_tile_schedule(ranges, p.grid.count(), (uint32_t *)(ws + c.sched), s));
             }
             tm.mark();  // 4: tile sort (+ the compositing schedule)
+            gsx::BlendHints bh = fh.blend;
+            bh.check_sched = fh.sched ? 1u : 0u;
             GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
                                       ranges, p.grid, p.out, p.semantics, p.background, p.generic,
-                                      make_clear_plan(p, false), lt, sched, s));
+                                      make_clear_plan(p, false), lt, sched, bh, s));
             tm.mark();  // 5: blend
         }
     }
@@ -194,6 +202,11 @@ const char *gsx_last_error(void) { return g_error; }
 
 void gsx_default_params(GsxParams *params) {
     if (params) default_params(params);
+}
+
+size_t gsx_hints_bytes(int32_t width, int32_t height, int32_t tile) {
+    if (width <= 0 || height <= 0 || tile <= 0) return 0;
+    return gsx::hints_layout(max_tiles_of(width, height, tile)).total;
 }
 
 size_t gsx_workspace_bytes(int64_t n, int32_t width, int32_t height, int32_t tile, int64_t max_instances) {
@@ -305,16 +318,38 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     // the sampled routes also leave the per-chunk tile counts the pair emission starts from (one kernel less)
     const gsx::DepthRoute route = gsx::depth_sort_route(n, p.kept_hint);
     const bool sampled = route != gsx::kDepthLsd;
+    // GsxParams.hints: what the previous frame of this view left (splitters, tile-list lengths) and what this one
+    // leaves.  Only where every producer and consumer exists: the 256-bucket depth sort with a row-scan-free or
+    // row-scan partition (not the one-workgroup sort of tiny scenes) and the tile-16 REF_CPU compositing kernel.
+    FrameHints fh;
+    gsx::SortHints sh{nullptr, nullptr, nullptr, false, nullptr, nullptr, 0u};
+    if (p.hints && route == gsx::kDepth256 && n >= gsx::kSortSamples && p.grid.count() > 0 &&
+        gsx::blend_splits_long_tiles(p.grid, p.semantics, p.generic)) {
+        const gsx::HintsLayout hl = gsx::hints_layout(max_tiles_of(camera->width, camera->height, tile_size));
+        uint32_t *hdr = (uint32_t *)p.hints;
+        sh.header = hdr;
+        sh.splitters = (const uint32_t *)(p.hints + hl.splitters);
+        sh.samples = (uint32_t *)(p.hints + hl.samples);
+        sh.use = p.hints_valid;
+        fh.blend = gsx::BlendHints{hdr, sh.samples, (uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.lens), 0u};
+        // the schedule costs nothing here: every window of more than two tiles per SIMD gets one, unless told not to
+        if (p.hints_valid && p.schedule != 0 && p.grid.count() > 2048 && gsx::depth_partition_has_spare_workgroup(n)) {
+            sh.lens = (const uint32_t *)(p.hints + hl.lens);
+            sh.sched = (uint32_t *)(p.hints + hl.sched);
+            sh.ntiles = (uint32_t)p.grid.count();
+            fh.sched = sh.sched;
+        }
+    }
     if (sampled)
         GSX_HIP(gsx::sort_depth_sampled(route, ws + c.temp, k0, k1, v0, v1, n, p.kept_hint, counters + kCtrKept,
                                         counters + kCtrCulled, (const gsx::TileRect *)(ws + c.rect),
-                                        (gsx::TileRect *)(ws + c.rrect), 0, gsx::emit_chunk_sums(ws + c.temp, n, cap), s));
+                                        (gsx::TileRect *)(ws + c.rrect), 0, gsx::emit_chunk_sums(ws + c.temp, n, cap), sh, s));
     else
         GSX_HIP(gsx::sort_depth_compact(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
                                         (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s));
     tm.mark();  // 2: depth sort (drops what reaches no tile, leaves the rectangles in rank order)
     return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rrect), v0, counters + kCtrKept,
-                         counters + kCtrCulled, sampled, stats_host, tm, s);
+                         counters + kCtrCulled, sampled, stats_host, tm, s, fh);
 }
 
 int gsx_sh_to_rgb(const float *means3d, const float *sh, int32_t degree, int64_t n, const float *camera_center_host,

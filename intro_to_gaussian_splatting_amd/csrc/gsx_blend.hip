@@ -95,8 +95,10 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 // dealt to the XCDs in two-column chunks and ranked inside each XCD: 460 MB, but 270 us instead of 262, and a
 // 16 us schedule kernel; better only on the clustered scene.)  Without a schedule: index order, a contiguous
 // eighth of the tiles per XCD.
-__device__ __forceinline__ uint32_t scheduled_tile(uint32_t b, uint32_t nt, const uint32_t *__restrict__ sched) {
-    if (!sched) return xcd_remap(b, nt);
+__device__ __forceinline__ uint32_t scheduled_tile(uint32_t b, uint32_t nt, const uint32_t *__restrict__ sched,
+                                                   const uint32_t *__restrict__ hint_header = nullptr) {
+    // (a schedule handed over through GsxParams.hints counts only if its header says it is for this many tiles)
+    if (!sched || (hint_header && hint_header[kHintSched] != nt)) return xcd_remap(b, nt);
     const uint32_t round = b >> 10, slot = b & 1023u;
     const uint32_t in_round = min(1024u, nt - (round << 10));
     return sched[(round << 10) + ((round & 1u) ? in_round - 1u - slot : slot)];
@@ -366,6 +368,48 @@ __device__ __forceinline__ void checked_pair(v2f alpha, v2f &T, v2f &ta) {
 
 __device__ __forceinline__ float min4(v2f a, v2f b) { return fminf(fminf(a.x, a.y), fminf(b.x, b.y)); }
 
+// ---- spare workgroups of the compositing launch: the next frame's depth-sort splitters (GsxParams.hints) ----------
+// kSortSamples regularly spaced kept depth keys of this frame (left by the partition's count kernel; invalid entries
+// >= kEmptyKey) -> splitters[j] = the valid sample of rank floor(j V / 256), j = 1 .. 255.  kRankGroups single-wave
+// workgroups; every sample's rank is counted directly -- #{s_j < s_i} + #{j < i : s_j == s_i} -- from the 8 KB table
+// in the cache: no LDS, ~2 000 VALU instructions per lane, lost inside the compositing launch.  That launch is the
+// frame's last: every reader of the current splitters has finished (stream order), so they are overwritten in place.
+constexpr uint32_t kRankLanes = 4, kRankPerGroup = 64 / kRankLanes, kRankGroups = kSortSamples / kRankPerGroup;
+__device__ __forceinline__ void rank_samples(uint32_t group, int lane, const BlendHints &h) {
+    // 128 single-wave workgroups, 16 samples each, 4 lanes per sample that share the 2048 comparisons (a wave per 64
+    // samples, 2048 comparisons per lane, took ~70 us -- longer than the compositing of a 100 000-Gaussian frame)
+    const uint32_t *__restrict__ sm = h.samples;
+    const uint32_t i = group * kRankPerGroup + ((uint32_t)lane / kRankLanes), part = (uint32_t)lane % kRankLanes;
+    const uint32_t v = sm[i];
+    uint32_t c = 0, valid = 0;
+    for (uint32_t j0 = 0; j0 < (uint32_t)kSortSamples; j0 += 8 * kRankLanes) {
+        uint32_t x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = sm[j0 + (uint32_t)e * kRankLanes + part];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t j = j0 + (uint32_t)e * kRankLanes + part;
+            const bool ok = x[e] < kEmptyKey;
+            valid += ok ? 1u : 0u;
+            c += (ok && ((x[e] < v) | ((x[e] == v) & (j < i)))) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int o = kRankLanes / 2; o > 0; o >>= 1) {
+        c += (uint32_t)__shfl_xor((int)c, o);
+        valid += (uint32_t)__shfl_xor((int)valid, o);
+    }
+    if (group == 0 && lane == 0) {
+        h.splitters[0] = 0u;
+        h.header[kHintSplitters] = valid ? (uint32_t)kSortBins : 0u;   // nothing kept: the next frame takes its stand-in splitters
+    }
+    if (part == 0 && v < kEmptyKey && valid) {
+        // the quantiles j with floor(j valid / 256) == c (none, one, or several when valid < 256)
+        for (uint32_t j = (c * (uint32_t)kSortBins + valid - 1u) / valid; j < (uint32_t)kSortBins && (j * valid) / kSortBins == c; ++j)
+            if (j) h.splitters[j] = v;
+    }
+}
+
 // ---- long tiles: a quarter of the tile per wave, one pixel per lane, eight records per trip ----------
 // Same per-(pixel, record) arithmetic as the kernels above (bit-identical frames, tested): what changes is
 // the shape of the loop.  A lone wave spends ~430 cycles per record in the two-records-per-trip loop (LDS
@@ -516,24 +560,50 @@ template <int VARIANT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))   // 64 VGPRs: every lost wave costs
     blend_tile16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                         const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
-                        uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget) {
+                        uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints) {
     __shared__ float4 sh[3][kSlots];
-    // block order: [helpers of long tiles (dispatched first: they have the most to do)] [tiles] [clears]
-    if (blockIdx.x < nhelpers) {
+    // block order: [spare workgroups: the next frame's splitters] [helpers of long tiles (dispatched first: they have
+    // the most to do)] [tiles] [clears]
+    const uint32_t nrank = hints.samples ? kRankGroups : 0u;
+    if (blockIdx.x < nrank) {
+        rank_samples(blockIdx.x, (int)threadIdx.x, hints);
+        return;
+    }
+    const uint32_t block = blockIdx.x - nrank;
+    if (quarters) {
+        // A window of few tiles (a rank's strip): EVERY tile on four waves, a quarter of its pixels each.  One wave per
+        // tile would leave the SIMDs with one to four waves, and a wave with few neighbours needs up to 3.3x its own
+        // issue time per trip (tools/occupancy_probe.py); the quarter form -- one pixel per lane, eight independent
+        // alphas per trip, the gather running ahead -- is built for exactly that situation.  Same arithmetic, same
+        // pixels.  32 consecutive blocks serve 8 tiles; the 4 quarters of a tile share b % 8, i.e. an XCD, and XCD x
+        // gets the x-th eighth of the window's tiles (neighbouring tiles share most of their Gaussians).
+        const uint32_t b = block, nt = (uint32_t)g.count(), groups = (nt + 7u) >> 3;
+        if (b >= groups * 32u) {
+            clear_block(b - groups * 32u, cp, out.ptr);
+            return;
+        }
+        const uint32_t u = ((b >> 5) << 3) | (b & 7u);          // (XCD = b & 7, index inside it = b >> 5)
+        const uint32_t per = nt >> 3, extra = nt & 7u, xcd = b & 7u, i = b >> 5;
+        if (i >= per + (xcd < extra ? 1u : 0u)) return;
+        (void)u;
+        blend_long_tile_quarter(rec, vals, ranges, g, out, xcd_remap((i << 3) | xcd, nt), (int)((b >> 3) & 3u), sh, budget);
+        return;
+    }
+    if (block < nhelpers) {
         // 32 consecutive blocks serve 8 long tiles; the 4 quarters of a tile share b % 8, i.e. an XCD
-        const uint32_t b = blockIdx.x, slot = (b >> 5) * 8u + (b & 7u);
+        const uint32_t b = block, slot = (b >> 5) * 8u + (b & 7u);
         const int quarter = (int)((b >> 3) & 3u);
         if (slot >= min(*lt.count, lt.max)) return;
         blend_long_tile_quarter(rec, vals, ranges, g, out, lt.list[slot], quarter, sh, budget);
         return;
     }
-    const uint32_t bid = blockIdx.x - nhelpers;
+    const uint32_t bid = block - nhelpers;
     if (bid >= (uint32_t)g.count()) {
         clear_block(bid - (uint32_t)g.count(), cp, out.ptr);
         return;
     }
     const int lane = threadIdx.x;
-    const uint32_t t = scheduled_tile(bid, (uint32_t)g.count(), sched);
+    const uint32_t t = scheduled_tile(bid, (uint32_t)g.count(), sched, hints.check_sched ? hints.header : nullptr);
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
     uint32_t probe_staged = 0, probe_checked_at = 0xFFFFFFu;
@@ -560,6 +630,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     uint2 rg = ranges[t];            // the same in every lane: kept in scalar registers
     rg.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.x);
     rg.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.y);
+    if (hints.lens && lane == 0) {  // what the next frame's schedule is made from (GsxParams.hints; long tiles count as empty)
+        hints.lens[t] = (rg.y & kLongFlag) ? 0u : rg.y - rg.x;
+        if (bid == 0) hints.header[kHintLens] = (uint32_t)g.count();
+    }
     if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
     uint32_t skipped = 0;            // colour this tile has left out so far (stage_batch)
     // the list entries of the next batch are requested while this one is composited (one register): one of the two
@@ -1001,6 +1075,14 @@ hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Up to this many tiles in the window every tile is composited by four waves (blend_tile16_kernel, `quarters`).
+// Measured (round 3, tools/strip_probe.py with GSX_QUARTERS_BELOW): it does NOT pay -- a 1/8 strip of the 5M / 4K frame
+// composites in 0.192 ms on one wave per tile and in 0.314 ms on four, 1M / 1080p: 0.073 vs 0.090 ms; the quarter form
+// issues 14 operations per pixel and record where the 4-pixel form shares the x terms (11.25) and stages every
+// record four times.  The mode stays in the kernel (default off) as the strongest test of the quarter path: a frame
+// rendered with it must equal the normal frame bit for bit.
+constexpr int kQuartersBelow = 0;
+
 #ifdef GSX_TEST_HOOKS
 hipError_t set_blend_probe(void *device_buffer) {
     uint4 *p = (uint4 *)device_buffer;
@@ -1018,6 +1100,8 @@ bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic) 
 bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int64_t n, int asked) {
     const int forced = knob("GSX_TILE_SCHEDULE", -1);   // test library only: 0 never, 1 always
     if ((semantics != GSX_SEM_REF_CPU && semantics != GSX_SEM_STD_3DGS) || grid.tile != 16 || generic) return false;
+    // a window whose tiles all go on four waves (launch_blend) is not handed out by list length
+    if (semantics == GSX_SEM_REF_CPU && grid.count() <= (int64_t)knob("GSX_QUARTERS_BELOW", kQuartersBelow)) return false;
     if (asked >= 0) return asked != 0;          // GSX_FLAG_TILE_SCHEDULE / GSX_FLAG_NO_TILE_SCHEDULE
     if (forced >= 0) return forced != 0;
     // a window of up to 2048 tiles (a rank's strip of a 1080p frame) puts at most two tiles on a SIMD: the
@@ -1027,7 +1111,8 @@ bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int6
 
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
-                        bool generic, const ClearPlan &cp, const LongTiles &lt, const uint32_t *sched, hipStream_t s) {
+                        bool generic, const ClearPlan &cp, const LongTiles &lt, const uint32_t *sched,
+                        const BlendHints &hints, hipStream_t s) {
     const int64_t nt = grid.count();
     if (nt <= 0) return launch_clear(cp, out.ptr, s);
     const unsigned nb = (unsigned)nt + (unsigned)(cp.n > 0 ? cp.first[cp.n] : 0);
@@ -1048,17 +1133,27 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
     if (semantics != GSX_SEM_REF_CPU) return hipErrorNotSupported;
     if (grid.tile == 16 && !generic) {
         const int variant = knob("GSX_BLEND_VARIANT", 1);   // test library only: A/B runs of the compositing loop
-        const unsigned nh = lt.max ? 4u * lt.max : 0u;
         // test library only: GSX_SKIP_BUDGET_LOG2 = -9 hardly ever refuses a skip (round 2's behaviour); default 2^-17
         const uint32_t budget = 1u << (40 + knob("GSX_SKIP_BUDGET_LOG2", -17));
+        // a window of up to kQuartersBelow tiles puts every tile on four waves (see the kernel)
+        const bool quarters = nt <= (int64_t)knob("GSX_QUARTERS_BELOW", kQuartersBelow);
+        unsigned nh = lt.max ? 4u * lt.max : 0u, grid_blocks = nb + nh;
+        if (quarters) {
+            nh = 0;
+            grid_blocks = (unsigned)((nt + 7) / 8) * 32u + (unsigned)(cp.n > 0 ? cp.first[cp.n] : 0);
+        }
+        BlendHints bh = hints;
+        if (quarters) bh.lens = nullptr;
+        grid_blocks += bh.samples ? kRankGroups : 0u;
+        const uint32_t q = quarters ? 1u : 0u;
         if (variant == 0)
-            blend_tile16_kernel<0><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget);
+            blend_tile16_kernel<0><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh);
         else if (variant == 2)
-            blend_tile16_kernel<2><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget);
+            blend_tile16_kernel<2><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh);
         else if (variant == 3)
-            blend_tile16_kernel<3><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget);
+            blend_tile16_kernel<3><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh);
         else
-            blend_tile16_kernel<1><<<nb + nh, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget);
+            blend_tile16_kernel<1><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh);
     } else {
         blend_generic_kernel<<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp);
     }

@@ -62,7 +62,7 @@ int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, void *rrec
     if (route != gsx::kDepthLsd)
         GSX_DBG_HIP(gsx::sort_depth_sampled(route, temp, keys, k1, v0, v1, n, kept_hint, counters + kCtrKept,
                                             counters + kCtrCulled, (const gsx::TileRect *)rect, (gsx::TileRect *)rrect, lds_cap,
-                                            nullptr, s));
+                                            nullptr, gsx::SortHints{nullptr, nullptr, nullptr, false}, s));
     else
         GSX_DBG_HIP(gsx::sort_depth_compact(temp, keys, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
                                             (const gsx::TileRect *)rect, (gsx::TileRect *)rrect, s));

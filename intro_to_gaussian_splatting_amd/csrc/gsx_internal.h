@@ -153,9 +153,34 @@ hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint
 // lds_cap: 0 = the bucket kernel's capacity; tests pass a small value to drive buckets through its global-memory path.
 enum DepthRoute { kDepthLsd = 0, kDepth256 = 1, kDepth1024 = 2, kDepthOneWorkgroup = 3 };
 DepthRoute depth_sort_route(int64_t n, int64_t kept_hint);
+// The depth sort's share of GsxParams.hints (gsx_plan.h: hints_layout); header == nullptr: no hints buffer.
+struct SortHints {
+    uint32_t *header;           // kHintSplitters says whether `splitters` are there, kHintLens / kHintSched how many tiles
+    const uint32_t *splitters;  // 256 words left by the previous frame
+    uint32_t *samples;          // kSortSamples words this frame's count kernel fills for the next frame
+    bool use;                   // GSX_FLAG_HINTS_VALID: partition with `splitters`, no sample kernel
+    // the compositing schedule of THIS frame from the tile-list lengths the previous frame left (a spare workgroup
+    // of the partition's count launch; sched == nullptr: not wanted)
+    const uint32_t *lens;
+    uint32_t *sched;
+    uint32_t ntiles;
+};
+// The compositing launch's share: spare workgroups rank the samples into the next frame's splitters, every tile
+// workgroup leaves the length of its list.  header == nullptr: no hints buffer.
+struct BlendHints {
+    uint32_t *header;
+    const uint32_t *samples;    // kSortSamples words of this frame's count kernel, or nullptr (nothing to rank)
+    uint32_t *splitters;
+    uint32_t *lens;
+    uint32_t check_sched;       // != 0: `sched` is hints.sched -- trust it only if header[kHintSched] == number of tiles
+};
 hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
                               uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,
-                              const TileRect *rect, TileRect *rrect, uint32_t lds_cap, uint64_t *chunk_sums, hipStream_t s);
+                              const TileRect *rect, TileRect *rrect, uint32_t lds_cap, uint64_t *chunk_sums,
+                              const SortHints &hints, hipStream_t s);
+// Does the 256-bucket partition of n keys launch the four-chunk count kernel (whose spare workgroup can build the
+// compositing schedule)?  Not for the small inputs whose pass has no row-scan launch and a chunk-major table.
+bool depth_partition_has_spare_workgroup(int64_t n);
 // Where emit_instances keeps its chunk sums inside `temp` (for sort_depth_sampled to fill them in).
 uint64_t *emit_chunk_sums(void *temp, int64_t n, int64_t cap);
 
@@ -172,7 +197,8 @@ hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, i
 bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int64_t n, int asked);
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
-                        bool generic, const ClearPlan &cp, const LongTiles &lt, const uint32_t *sched, hipStream_t s);
+                        bool generic, const ClearPlan &cp, const LongTiles &lt, const uint32_t *sched,
+                        const BlendHints &hints, hipStream_t s);
 bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic);
 hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s);   // the zero fill alone
 hipError_t launch_zero_words(uint32_t *p, size_t n, hipStream_t s);

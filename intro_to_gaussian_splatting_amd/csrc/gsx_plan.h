@@ -87,6 +87,29 @@ inline int clear_blocks_for(int64_t rows, int64_t fw) {
     return (int)((floats + kClearFloats - 1) / kClearFloats);
 }
 
+// ---- GsxParams.hints: what one frame leaves for the next frame of the same view (device memory, caller-owned)
+//   header (64 words)  [kHintSplitters] 256 when `splitters` holds 255 sorted splitters (+ splitters[0] = 0), else 0
+//                      [kHintSamples]   number of entries of `samples` the last depth sort filled (2048) or 0
+//                      [kHintLens]      number of tiles `lens` was written for, [kHintSched] the same for `sched`
+//   splitters[256]     depth-sort splitters of the last frame (written by spare workgroups of its compositing launch)
+//   samples[2048]      regularly spaced KEPT depth keys of the last frame (written by its partition count kernel)
+//   lens[max_tiles]    list length of every tile of the window (written by the compositing launch; long tiles: 0)
+//   sched[max_tiles]   the tiles by falling list length (written by a spare workgroup of the projection launch)
+enum { kHintSplitters = 0, kHintSamples = 1, kHintLens = 2, kHintSched = 3, kHintHeaderWords = 64 };
+struct HintsLayout {
+    size_t splitters, samples, lens, sched, total;   // byte offsets
+};
+inline HintsLayout hints_layout(int64_t max_tiles) {
+    HintsLayout h;
+    const size_t t = (size_t)(max_tiles > 0 ? max_tiles : 1);
+    h.splitters = kHintHeaderWords * 4;
+    h.samples = h.splitters + (size_t)kSortBins * 4;
+    h.lens = h.samples + (size_t)kSortSamples * 4;
+    h.sched = h.lens + ((t * 4 + 255) & ~(size_t)255);
+    h.total = h.sched + ((t * 4 + 255) & ~(size_t)255);
+    return h;
+}
+
 namespace plan {
 
 constexpr size_t kAlign = 256;
@@ -186,6 +209,8 @@ struct Plan {
     const float *sh;
     int sh_degree;   // -1: RGB colours
     int64_t kept_hint;   // GsxParams.kept_hint (0: unknown)
+    char *hints;         // GsxParams.hints (or null)
+    bool hints_valid;    // GSX_FLAG_HINTS_VALID
     float background[3];
 };
 
@@ -211,6 +236,10 @@ inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_ima
     p.sh = d.sh;
     p.sh_degree = d.sh ? d.sh_degree : -1;
     p.kept_hint = d.kept_hint > 0 ? d.kept_hint : 0;
+    p.hints = (char *)d.hints;
+    p.hints_valid = d.hints != nullptr && (d.flags & GSX_FLAG_HINTS_VALID) != 0;
+    if (d.hints && (reinterpret_cast<uintptr_t>(d.hints) & 255u) != 0)
+        return fail(GSX_ERR_INVALID_ARGUMENT, "hints must be 256-byte aligned");
     if (d.sh && (d.sh_degree < 0 || d.sh_degree > 3)) return fail(GSX_ERR_INVALID_ARGUMENT, "SH degree %d outside [0,3]", d.sh_degree);
     if (d.layout != GSX_LAYOUT_WH3 && d.layout != GSX_LAYOUT_HW3) return fail(GSX_ERR_INVALID_ARGUMENT, "unknown layout %d", d.layout);
     if (!out_image) return fail(GSX_ERR_INVALID_ARGUMENT, "out_image is NULL");

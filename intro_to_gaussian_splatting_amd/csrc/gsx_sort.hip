@@ -111,6 +111,83 @@ __device__ __forceinline__ void buckets_of(const uint32_t *spl, const uint32_t (
     for (int i = 0; i < N; ++i) b[i] = lo[i];
 }
 
+// Splitters handed over by the previous frame (GsxParams.hints): used when their header word says they are there;
+// otherwise 255 splitters evenly spaced over the depth codes of 0.2 .. 1000 (roughly log-uniform in depth: a
+// stand-in that keeps the buckets usable for ordinary scenes -- any monotone set is CORRECT, the bucket kernel sorts
+// what it is given).  hdr == nullptr: `splitters` were computed by this frame's own sample kernel.
+__device__ __forceinline__ uint32_t splitter_at(const uint32_t *__restrict__ splitters, const uint32_t *__restrict__ hdr, uint32_t k) {
+    if (k == 0) return 0u;
+    if (hdr && hdr[kHintSplitters] != (uint32_t)kBins) {
+        const uint32_t lo = 0x3E4CCCCDu, hi = 0x447A0000u;      // 0.2f, 1000.0f
+        return lo + (uint32_t)(((uint64_t)(hi - lo) * k) >> 8);
+    }
+    return splitters[k];
+}
+
+// The compositing schedule from the tile-list lengths of the PREVIOUS frame (GsxParams.hints): sched[k] = the tile
+// with the k-th longest list, 1024 length classes between the shortest and the longest (what tile_schedule_kernel
+// computes from this frame's ranges, gsx_binning.hip -- here one spare 1024-thread workgroup of the partition's
+// count launch does it while that kernel runs anyway).  hist: 1024 words of LDS.  Tiles in any order inside a
+// class.  header[kHintSched] = nt when done (0 when the lengths on file are for another tile count).
+struct SchedJob {
+    const uint32_t *lens;
+    uint32_t *sched, *header;
+    uint32_t nt;
+};
+__device__ __forceinline__ void schedule_from_lengths(const SchedJob &job, uint32_t *hist) {
+    __shared__ uint32_t s_lo, s_hi, s_wsum[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t nt = job.nt;
+    if (job.header[kHintLens] != nt) {          // nothing usable on file: the compositing launch falls back to index order
+        if (threadIdx.x == 0) job.header[kHintSched] = 0u;
+        return;
+    }
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    for (uint32_t t = threadIdx.x; t < nt; t += blockDim.x) {
+        const uint32_t l = job.lens[t];
+        mn = min(mn, l);
+        mx = max(mx, l);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    }
+    hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        s_lo = 0xFFFFFFFFu;
+        s_hi = 0u;
+    }
+    __syncthreads();
+    if (lane == 0 && mn <= mx) {
+        atomicMin(&s_lo, mn);
+        atomicMax(&s_hi, mx);
+    }
+    __syncthreads();
+    const uint32_t shortest = s_lo;
+    const float per_entry = 1023.0f / (float)max(s_hi - shortest, 1u);
+    auto cls = [&](uint32_t l) -> uint32_t {   // class 0 = the longest lists
+        return 1023u - min((uint32_t)((float)(l - shortest) * per_entry), 1023u);
+    };
+    for (uint32_t t = threadIdx.x; t < nt; t += blockDim.x) atomicAdd(&hist[cls(job.lens[t])], 1u);
+    __syncthreads();
+    const uint32_t mine = hist[threadIdx.x];
+    uint32_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) s_wsum[w] = x;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int k = 0; k < w; ++k) before += s_wsum[k];
+    hist[threadIdx.x] = before + x - mine;   // first slot of this class
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < nt; t += blockDim.x) job.sched[atomicAdd(&hist[cls(job.lens[t])], 1u)] = t;
+    if (threadIdx.x == 0) job.header[kHintSched] = nt;
+}
+
 // Each thread owns kRounds CONSECUTIVE items of one chunk (one or two 16-byte loads) -- the histogram does
 // not care about order, so the count kernel reads wide; the scatter kernel needs the wave-striped order.
 // CHUNK_MAJOR (small inputs): 256 threads, one chunk, table[chunk][digit] (what the self-scanning scatter
@@ -122,7 +199,10 @@ template <typename Key, bool CHUNK_MAJOR, bool FIRST, int SPLIT = 0>   // SPLIT:
 __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     count_kernel(const Key *__restrict__ keys, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
                  uint32_t mask, uint32_t *__restrict__ table, int nbp, uint32_t *__restrict__ culled,
-                 const uint32_t *__restrict__ splitters = nullptr, uint32_t *__restrict__ quad_totals = nullptr) {
+                 const uint32_t *__restrict__ splitters = nullptr, uint32_t *__restrict__ quad_totals = nullptr,
+                 const uint32_t *__restrict__ hint_hdr = nullptr, uint32_t *__restrict__ samples_out = nullptr,
+                 uint32_t sample_step = 0, unsigned long long *__restrict__ zero_sums = nullptr, uint32_t nsums = 0,
+                 SchedJob sched_job = SchedJob{nullptr, nullptr, nullptr, 0u}) {
     constexpr int kLanes = CHUNK_MAJOR ? 1 : kQuad;   // chunks per workgroup
     constexpr int NB = SPLIT ? SPLIT : kBins;         // histogram rows
     constexpr int kPerVec = 16 / sizeof(Key), kVecs = kRounds / kPerVec;   // 8 x u16 or 4 x u32 per 16 B
@@ -144,8 +224,35 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     __shared__ uint32_t h[kLanes][NB];
     __shared__ uint32_t s_culled;
     __shared__ uint32_t spl[SPLIT ? SPLIT : 1];
+
     if (SPLIT)
-        for (uint32_t k = threadIdx.x; k < (uint32_t)NB; k += blockDim.x) spl[k] = k ? splitters[k] : 0u;   // visible after the barrier below
+        for (uint32_t k = threadIdx.x; k < (uint32_t)NB; k += blockDim.x) spl[k] = splitter_at(splitters, hint_hdr, k);   // visible after the barrier below
+    if (FIRST && SPLIT && zero_sums)   // (no sample kernel ran: the chunk sums the bucket kernel adds to start from zero here)
+        for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nsums; k += gridDim.x * blockDim.x) zero_sums[k] = 0ull;
+    if (FIRST && SPLIT && samples_out && sample_step) {
+        // What the NEXT frame's splitters are made from (GsxParams.hints): kSamples regularly spaced keys, kept ones
+        // where possible -- the thread whose 8 keys hold position k * step hands over the first of them, from that
+        // position on, that the sort keeps (a rank's strip keeps 1 key in 8: a plain regular sample would be 7/8 void)
+        const uint32_t k = (first + sample_step - 1u) / sample_step, pos = k * sample_step;
+        if (k < (uint32_t)kSamples && pos < first + (uint32_t)kRounds) {
+            uint32_t pick = kCulledKey;
+            if (first + kRounds <= n) {
+                const uint32_t w8[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[kVecs > 1 ? 1 : 0].x, q[kVecs > 1 ? 1 : 0].y,
+                                        q[kVecs > 1 ? 1 : 0].z, q[kVecs > 1 ? 1 : 0].w};
+#pragma unroll
+                for (int e = kRounds - 1; e >= 0; --e)
+                    if ((uint32_t)e >= pos - first && w8[e] < kEmptyKey) pick = w8[e];
+            } else {
+                for (int e = kRounds - 1; e >= 0; --e)
+                    if (first + e < n && (uint32_t)e >= pos - first && (uint32_t)keys[first + e] < kEmptyKey) pick = (uint32_t)keys[first + e];
+            }
+            samples_out[k] = pick;
+        }
+    }
+    if (FIRST && SPLIT == kBins && !CHUNK_MAJOR && sched_job.sched && blockIdx.x == gridDim.x - 1) {
+        schedule_from_lengths(sched_job, &h[0][0]);     // the launch's spare workgroup (h = 1024 words of LDS)
+        return;
+    }
     auto digit = [&](uint32_t k) -> uint32_t { return SPLIT ? bucket_of<NB>(spl, k) : ((k >> shift) & mask); };
 #pragma unroll
     for (int k = 0; k < NB / 256; ++k) h[c][t + 256u * k] = 0;
@@ -255,7 +362,8 @@ __global__ void __launch_bounds__(kThreads)
                    uint32_t *__restrict__ vout, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
                    const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nbp,
                    uint32_t *__restrict__ m_out, const TileRect *__restrict__ rect, TileRect *__restrict__ rrect,
-                   const uint32_t *__restrict__ splitters = nullptr, const uint32_t *__restrict__ quad_totals = nullptr) {
+                   const uint32_t *__restrict__ splitters = nullptr, const uint32_t *__restrict__ quad_totals = nullptr,
+                   const uint32_t *__restrict__ hint_hdr = nullptr) {
     constexpr bool SELF_SCAN = SCAN == kScanSelf;
     constexpr int kWaveItems = kItems / 4;
     constexpr int NB = SPLIT ? SPLIT : kBins;     // digit rows the tables of this workgroup hold
@@ -265,7 +373,7 @@ __global__ void __launch_bounds__(kThreads)
     __shared__ uint32_t spl[SPLIT ? SPLIT : 1];
     __shared__ Dig sdig[SPLIT ? kItems : 1];     // SPLIT: the bucket of every parked item (not derivable by a shift)
     if (SPLIT)
-        for (int k = threadIdx.x; k < NB; k += kThreads) spl[k] = k ? splitters[k] : 0u;   // visible after the barrier below
+        for (int k = threadIdx.x; k < NB; k += kThreads) spl[k] = splitter_at(splitters, hint_hdr, (uint32_t)k);   // visible after the barrier below
     __shared__ uint32_t cnt[4][NB];      // per-wave running digit counts, then per-wave LDS bases
     __shared__ uint32_t gbase[NB];       // global address of parked item j of digit d = gbase[d] + j
     __shared__ uint32_t wsum[4], lsum[4];
@@ -1204,6 +1312,8 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
 //   beyond                         four compacting LSD passes of 8 bits
 constexpr int64_t kSampledMin = 8 * kSamples, kKeptMax256 = 1536 * 1024, kKeptMax1024 = 6 * 1024 * 1024;
 
+bool depth_partition_has_spare_workgroup(int64_t n) { return (n + kItems - 1) / kItems > kSelfScanBlocks; }
+
 DepthRoute depth_sort_route(int64_t n, int64_t kept_hint) {
     const int force = knob("GSX_DEPTH_SORT", -1);   // test library only: a DepthRoute
     if (n <= kBucketCap) return kDepthOneWorkgroup;
@@ -1219,24 +1329,31 @@ DepthRoute depth_sort_route(int64_t n, int64_t kept_hint) {
 template <int NB>
 static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1, uint32_t *vals_cur, uint32_t *vals_alt,
                              int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
-                             const uint32_t *splitters, hipStream_t s) {
+                             const uint32_t *splitters, const uint32_t *hdr, uint32_t *samples_out, uint32_t step,
+                             unsigned long long *zero_sums, uint32_t nsums, const SchedJob &job, hipStream_t s) {
+    const unsigned spare = (NB == kBins && job.sched) ? 1u : 0u;    // one more count workgroup: the compositing schedule
     if (NB == kBins && p.self_scan) {
         count_kernel<uint32_t, true, true, kBins><<<p.nblocks, kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u, p.table,
-                                                                                 p.nbp, culled_dev, splitters);
+                                                                                 p.nbp, culled_dev, splitters, nullptr, hdr,
+                                                                                 samples_out, step, zero_sums, nsums);
         scatter_kernel<uint32_t, kScanSelf, kModeFirst, 8, kBins><<<p.nblocks, kThreads, 0, s>>>(
-            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters);
+            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
+            nullptr, hdr);
     } else if (NB == kBins && p.scan == kScanQuads) {
-        count_kernel<uint32_t, false, true, kBins><<<p.nquads, kQuad * kThreads, 0, s>>>(
-            keys0, nullptr, (uint32_t)n, 0, 255u, p.table, p.nbp, culled_dev, splitters, p.quad_totals);
+        count_kernel<uint32_t, false, true, kBins><<<p.nquads + spare, kQuad * kThreads, 0, s>>>(
+            keys0, nullptr, (uint32_t)n, 0, 255u, p.table, p.nbp, culled_dev, splitters, p.quad_totals, hdr, samples_out, step,
+            zero_sums, nsums, job);
         scatter_kernel<uint32_t, kScanQuads, kModeFirst, 8, kBins><<<p.nblocks, kThreads, 0, s>>>(
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
-            p.quad_totals);
+            p.quad_totals, hdr);
     } else {
-        count_kernel<uint32_t, false, true, NB><<<p.nquads, kQuad * kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u,
-                                                                                      p.table, p.nbp, culled_dev, splitters);
+        count_kernel<uint32_t, false, true, NB><<<p.nquads + spare, kQuad * kThreads, 0, s>>>(
+            keys0, nullptr, (uint32_t)n, 0, 255u, p.table, p.nbp, culled_dev, splitters, nullptr, NB == kBins ? hdr : nullptr,
+            NB == kBins ? samples_out : nullptr, step, zero_sums, nsums, NB == kBins ? job : SchedJob{nullptr, nullptr, nullptr, 0u});
         row_scan_kernel<<<NB, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
         scatter_kernel<uint32_t, kScanRows, kModeFirst, 8, NB><<<p.nblocks, kThreads, 0, s>>>(
-            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters);
+            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
+            nullptr, NB == kBins ? hdr : nullptr);
     }
 }
 
@@ -1247,7 +1364,8 @@ static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1
 // the tile count of every 1024 consecutive ranks -- what chunk_sums_kernel would compute from rrect.
 hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
                               uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,
-                              const TileRect *rect, TileRect *rrect, uint32_t lds_cap, uint64_t *chunk_sums, hipStream_t s) {
+                              const TileRect *rect, TileRect *rrect, uint32_t lds_cap, uint64_t *chunk_sums,
+                              const SortHints &hints, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     unsigned long long *cs = reinterpret_cast<unsigned long long *>(chunk_sums);
     if (route == kDepthOneWorkgroup && n <= kBucketCap && lds_cap == 0) {   // everything fits one workgroup's LDS: one launch
@@ -1263,14 +1381,25 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
     const uint32_t ns = (nb > kBins || 2 * kept < n) && n >= kSamplesMax ? (uint32_t)kSamplesMax : (uint32_t)kSamples;
     const uint32_t nsums = (uint32_t)((n + kEmitChunk - 1) / kEmitChunk) + 1u;
     if (lds_cap == 0 || lds_cap > (uint32_t)kBucketCap) lds_cap = kBucketCap;
+    // GsxParams.hints (256-bucket route): the count kernel leaves a sample of the kept keys for the next frame's
+    // splitters, and with GSX_FLAG_HINTS_VALID the splitters of THIS frame are the ones the previous frame left --
+    // no sample kernel on the frame's critical path
+    const bool hinted = nb == kBins && hints.header != nullptr;
+    uint32_t *samples_out = hinted ? hints.samples : nullptr;
+    const uint32_t step = hinted && n >= kSamples ? (uint32_t)(n / kSamples) : 0u;
     if (nb > kBins) {
         sample_rank_kernel<kSortBinsMax><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
-        launch_partition<kSortBinsMax>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect, splitters, s);
+        launch_partition<kSortBinsMax>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect, splitters, nullptr,
+                                       nullptr, 0u, nullptr, 0u, SchedJob{nullptr, nullptr, nullptr, 0u}, s);
         bucket_sort_kernel<kSortBinsMax><<<kSortBinsMax, kBigThreads, 0, s>>>(p.totals, p.table, 0, keys1, vals_alt, keys0, vals_cur,
                                                                               rect, rrect, lds_cap, cs);
     } else {
-        sample_rank_kernel<kBins><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
-        launch_partition<kBins>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect, splitters, s);
+        const bool use = hinted && hints.use;
+        if (!use) sample_rank_kernel<kBins><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
+        launch_partition<kBins>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect,
+                                use ? hints.splitters : splitters, use ? hints.header : nullptr, samples_out, step,
+                                use ? cs : nullptr, nsums,
+                                SchedJob{hints.lens, (use && !p.self_scan) ? hints.sched : nullptr, hints.header, hints.ntiles}, s);
         bucket_sort_kernel<kBins><<<kBins, kBigThreads, 0, s>>>(p.totals, p.table, p.self_scan ? p.nblocks : 0, keys1, vals_alt,
                                                                 keys0, vals_cur, rect, rrect, lds_cap, cs);
     }

@@ -191,6 +191,7 @@ class GaussianScene:
         self._last_instances = 0      # instance count of the latest full frame
         self._cap_hints = {}          # (image, tile, window, semantics) -> pair capacity for the next frame
         self._kept_hints = {}         # same key -> Gaussians that reached a tile of the window (GsxParams.kept_hint)
+        self._hints = {}              # (same key, stream) -> [GsxParams.hints buffer, filled?]
         self._pending = []            # speculative frames awaiting confirm_frames()
         self._pinned_pool = None
         self._pinned_next = 0
@@ -272,7 +273,8 @@ class GaussianScene:
                          generic_kernels: bool = False, published_rects: bool = False,
                          camera_buffer: Optional[torch.Tensor] = None,
                          tile_counts: Optional[torch.Tensor] = None, split_long_tiles: bool = True,
-                         tile_schedule: Optional[bool] = None, _private: Optional[dict] = None) -> torch.Tensor:
+                         tile_schedule: Optional[bool] = None, use_hints: bool = True,
+                         _private: Optional[dict] = None) -> torch.Tensor:
         """Full forward render in libgsx (gsx_render_forward).
 
         semantics: "ref_cpu" (the reference's ``render_image``), "ref_cuda" (its CUDA kernel's rules
@@ -287,6 +289,11 @@ class GaussianScene:
         then waits for the frame.
         ``tile_counts`` (int32 / uint32 device tensor, one entry per tile of the window, x-major) receives
         the length of every tile's Gaussian list (GsxParams.tile_counts; ``strips.balanced_plan``).
+        ``use_hints`` (default): every (camera, tile size, window, rule set, stream) of this scene keeps a small
+        device buffer (GsxParams.hints) in which a frame leaves the depth-sort splitters and the tile-list lengths
+        for the NEXT frame of that view, which then skips the two kernels that would compute them on its own critical
+        path; stale hints (the Gaussians or the camera changed) cost time, never a pixel.  ``use_hints=False``
+        renders every frame from scratch (tests hold the two against each other).
         ``no_sync`` (GSX_FLAG_NO_SYNC) enqueues the frame without waiting for the device at all: the
         counts arrive later in pinned memory and ``confirm_frames()`` must be called (it
         synchronises) before the images are trusted -- it re-renders, on the normal path, any frame
@@ -367,6 +374,20 @@ class GaussianScene:
             own["inputs"][:] = passed
         # how many Gaussians reached a tile of this window last time: picks the depth-sort route (a hint)
         params.kept_hint = int(own.get("kept", self._kept_hints.get(cap_key, 0)))
+        # GsxParams.hints: one buffer per view and stream (a captured frame owns its own), valid once a frame has filled it
+        hint_slot = None
+        if use_hints:
+            if "hints" in own:
+                hint_slot = own["hints"]
+            else:
+                hkey = (cap_key, torch.cuda.current_stream(dev).cuda_stream)
+                hint_slot = self._hints.get(hkey)
+                hbytes = lib.gsx_hints_bytes(width, height, tile_size)
+                if hint_slot is None or hint_slot[0].numel() != hbytes or hint_slot[0].device != dev:
+                    hint_slot = self._hints[hkey] = [torch.zeros(hbytes, dtype=torch.uint8, device=dev), False]
+            params.hints = hint_slot[0].data_ptr()
+            if hint_slot[1]:
+                params.flags |= _ffi.GSX_FLAG_HINTS_VALID
         speculative = bool(no_sync and not timing)
         if speculative:
             params.flags |= _ffi.GSX_FLAG_NO_SYNC
@@ -400,6 +421,8 @@ class GaussianScene:
                     break
                 cap = int(st.n_instances * 1.25) + 4096
         _ffi.check(rc)
+        if hint_slot is not None:
+            hint_slot[1] = True         # (stream order: the next frame on this stream finds what this one left)
         if own:
             if stats is not None and not speculative:
                 stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles, n_kept=st.n_kept)
@@ -410,7 +433,8 @@ class GaussianScene:
                 image_idx=image_idx, tile_size=tile_size, layout=layout, tile_window=tile_window, out=out,
                 out_origin=out_origin, semantics=semantics, background=background,
                 generic_kernels=generic_kernels, published_rects=published_rects, camera_buffer=camera_buffer,
-                tile_counts=tile_counts, split_long_tiles=split_long_tiles, tile_schedule=tile_schedule)))
+                tile_counts=tile_counts, split_long_tiles=split_long_tiles, tile_schedule=tile_schedule,
+                use_hints=use_hints)))
             if stats is not None:
                 stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
             return out
@@ -493,7 +517,9 @@ class GaussianScene:
         if nbytes == 0:
             raise _ffi.GsxError(_ffi.GSX_ERR_INVALID_ARGUMENT, "gsx_workspace_bytes rejected the sizes")
         private = dict(cap=cap, workspace=torch.empty(nbytes, dtype=torch.uint8, device=dev), kept=int(st["n_kept"]),
-                       pinned=torch.zeros(ctypes.sizeof(_ffi.GsxFrameStats), dtype=torch.uint8).pin_memory(), inputs=[])
+                       pinned=torch.zeros(ctypes.sizeof(_ffi.GsxFrameStats), dtype=torch.uint8).pin_memory(), inputs=[],
+                       hints=[torch.zeros(lib.gsx_hints_bytes(cam.width, cam.height, tile_size), dtype=torch.uint8,
+                                          device=dev), False])
         stream = torch.cuda.Stream(dev)
         with torch.cuda.stream(stream):   # the same call once on the capture stream, outside the capture
             self.render_image_hip(image_idx, _private=private, **kw)
@@ -502,8 +528,10 @@ class GaussianScene:
         with torch.cuda.graph(graph, stream=stream):
             self.render_image_hip(image_idx, no_sync=True, _private=private, **kw)
         call = dict(image_idx=image_idx, **kw)
-        return CapturedFrame(self, graph, out, private["pinned"], call, camera_buffer=cam_buf,
-                             workspace=private["workspace"], capacity=cap, inputs=private["inputs"])
+        frame = CapturedFrame(self, graph, out, private["pinned"], call, camera_buffer=cam_buf,
+                              workspace=private["workspace"], capacity=cap, inputs=private["inputs"])
+        frame._hints = private["hints"][0]     # the recorded kernels read and refresh this buffer on every replay
+        return frame
 
     def render_image(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:
         """(W,H,3) float32 indexed [x,y]; same result as the reference's pure-Python

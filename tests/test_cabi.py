@@ -65,7 +65,8 @@ def test_shipping_library_reads_no_environment_variable():
 
 def test_struct_layouts():
     assert ctypes.sizeof(_ffi.GsxCamera) == 16 * 4 * 2 + 4 * 4 + 2 * 4 + 3 * 4
-    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16 + 8 and _ffi.GsxParams.kept_hint.offset == 88
+    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16 + 8 + 8 and _ffi.GsxParams.kept_hint.offset == 88
+    assert _ffi.GsxParams.hints.offset == 96
     assert _ffi.GsxFrameStats.n_kept.offset == 56 and _ffi.GsxFrameStats.stage_ms.offset == 32
     assert ctypes.sizeof(_ffi.GsxFrameStats) == 64
     p = _ffi.default_params()
@@ -80,6 +81,9 @@ def test_argument_errors_do_not_need_a_gpu():
     # pure host arithmetic (no library primitive with device queries is left on the path)
     small, big = lib.gsx_workspace_bytes(1000, 256, 256, 16, 8000), lib.gsx_workspace_bytes(1_000_000, 1920, 1080, 16, 5_000_000)
     assert 0 < small < big and big % 256 == 0
+    assert lib.gsx_hints_bytes(0, 64, 16) == 0
+    # header + 256 splitters + 2048 samples + two words per tile (120 x 68 tiles at 1080p, each array rounded up to 256 bytes)
+    assert lib.gsx_hints_bytes(1920, 1080, 16) == 256 + 1024 + 8192 + 2 * 32768
     assert big >= 1_000_000 * (16 + 48 + 8 + 8 + 16) + 5_000_000 * 16
     rc = lib.gsx_project_points(None, None, 0, None, None, None)
     assert rc == _ffi.GSX_ERR_INVALID_ARGUMENT

@@ -1270,3 +1270,68 @@ def test_captured_frame_follows_a_moving_camera(tmp_path):
         sh_frame.set_camera(i)
         sh_frame.replay()
         assert torch.equal(sh_frame.confirm(), sh_refs[i]), i
+
+
+def test_hinted_frames_equal_frames_rendered_from_scratch(tmp_path):
+    """GsxParams.hints (round 3): a frame takes the depth-sort splitters and the tile hand-out order from what the
+    PREVIOUS frame of the view left in a small device buffer instead of computing them on its own critical path.
+    Both are correct whatever their values -- equal depth keys share a bucket and every step is stable, the schedule
+    is a permutation of the tiles -- so the hinted frame must equal the frame rendered from scratch BIT FOR BIT and
+    report the same counts: for fresh hints, for stale ones (the camera changed between the frames; the scene was
+    replaced by another), for a buffer that was never filled (zeroed: the stand-in splitters, index order), on a
+    tile window, and inside a captured frame replayed while the camera moves."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene, write_colmap_text
+
+    w, h, n = 1280, 720, 400_000
+    sc = make_scene(n, w, h, seed=21)
+    write_colmap_text(str(tmp_path), sc)
+    # a second camera for the same scene: slightly rotated and moved back
+    with open(tmp_path / "images.txt", "a") as fid:
+        q = np.array([0.95, -0.25, 0.15, 0.05]); q = q / np.linalg.norm(q)
+        fid.write("2 %r %r %r %r 0.1 0.8 4.2 1 other.jpg\n1.0 2.0 -1\n" % tuple(float(v) for v in q))
+    g = Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"], sc["opacity"], device="cuda:0")
+    scene = GaussianScene(str(tmp_path), g)
+    ref = {}
+    for cam in (1, 2):
+        st = {}
+        ref[cam] = (scene.render_image_hip(cam, use_hints=False, stats=st).clone(), st["n_instances"], st["n_visible"])
+        assert st["n_instances"] > 5 * 3520                     # (far more than two tiles per SIMD's worth of lists)
+    for rep in range(3):                                         # frame 0 fills the buffer, frames 1, 2 use it
+        st = {}
+        img = scene.render_image_hip(1, stats=st)
+        assert torch.equal(img, ref[1][0]) and (st["n_instances"], st["n_visible"]) == ref[1][1:], rep
+    # stale hints: the buffer of camera 1's view, used for camera 2's frame (same frame size) -- and back
+    key1 = [k for k in scene._hints if k[0][0] == 1][0]
+    slot = scene._hints[key1]
+    assert slot[1] is True
+    hdr = slot[0][:16].view(torch.int32).cpu().numpy()
+    assert hdr[0] == 256 and hdr[2] == hdr[3] > 2048, hdr       # splitters, list lengths and a schedule are on file
+    scene._hints[(key1[0][:0] + (2,) + key1[0][1:], key1[1])] = slot
+    for rep in range(2):
+        img2 = scene.render_image_hip(2)
+        assert torch.equal(img2, ref[2][0]), rep
+    assert torch.equal(scene.render_image_hip(1), ref[1][0])     # camera 1 again, with what camera 2's frames left
+    # a buffer nobody filled, declared valid: zeros -> stand-in splitters, no schedule; still the same frame
+    slot[0].zero_()
+    assert torch.equal(scene.render_image_hip(1), ref[1][0])
+    # another scene through the same buffer (fewer, larger splats): its hints are stale in every respect
+    sc2 = make_scene(150_000, w, h, seed=22, sigma_scale=2.0)
+    g2 = Gaussians.from_arrays(sc2["points"], sc2["colors_0_255"], sc2["scales"], sc2["quaternions"], sc2["opacity"], device="cuda:0")
+    scene2 = GaussianScene(str(tmp_path), g2)
+    fresh2 = scene2.render_image_hip(1, use_hints=False).clone()
+    scene2._hints[key1] = slot
+    assert torch.equal(scene2.render_image_hip(1), fresh2) and torch.equal(scene2.render_image_hip(1), fresh2)
+    # a tile window keeps hints of its own
+    win = (10, 50, 3, 40)
+    a = scene.render_image_hip(1, tile_window=win, use_hints=False).clone()
+    for rep in range(3):
+        assert torch.equal(scene.render_image_hip(1, tile_window=win), a)
+    # a captured frame: its graph reads and refreshes its own hints on every replay, also while the camera moves
+    frame = scene.capture_frame(1, movable_camera=True)
+    for cam in (1, 2, 2, 1, 1):
+        frame.set_camera(cam)
+        frame.out.fill_(5.0)
+        frame.replay()
+        assert torch.equal(frame.confirm(), ref[cam][0]), cam

@@ -3,15 +3,17 @@ probed), on ONE GPU:   python tools/strip_probe.py [workload]
 What a rank of an N-GPU run would spend per frame before the gather (timing mode: separate launches)."""
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from intro_to_gaussian_splatting_amd import _ffi, strips
+if os.environ.get("GSX_USE_TEST_LIB"):      # measurement knobs (GSX_*) from the environment
+    _ffi.use_test_library()
 import bench
-from intro_to_gaussian_splatting_amd import strips
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 arrays, scene = bench.build_scene(wl, "cuda")
 n, w, h, _ = bench.WORKLOADS[wl]
 ntx, nty = strips.tiles_along(w, 16), strips.tiles_along(h, 16)
 counts = torch.zeros(ntx * nty, dtype=torch.int32, device="cuda")
 scene.render_image_hip(1, tile_counts=counts)
-for world in (1, 2, 4, 8):
+for world in [int(v) for v in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
     plan = strips.balanced_plan(strips.tile_row_costs(counts, ntx, nty, lead_is_x=True), world)
     worst = None
     for r in (0, world // 2, world - 1):
