@@ -241,16 +241,29 @@ int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *s
     uint32_t *k0 = (uint32_t *)(ws + c.keys0), *k1 = (uint32_t *)(ws + c.keys1);
     uint32_t *v0 = (uint32_t *)(ws + c.vals0), *v1 = (uint32_t *)(ws + c.vals1);
     uint32_t *counters = (uint32_t *)(ws + c.counters);
-    GSX_HIP(hipMemsetAsync(counters, 0, 64, s));
-    GSX_HIP(gsx::launch_depth_keys(*camera, means3d, n, k0, v0, s));
-    GSX_HIP(gsx::radix_sort_pairs_u32(ws + c.temp, k0, k1, v0, v1, nullptr, n, 32, s));
-    GSX_HIP(gsx::launch_count_visible(k0, n, counters, s));
+    // Three steps.  (1) Original order, coalesced: depth key + the projected quantities of every visible Gaussian in
+    // its record slot (the kernel also zeroes the sort's counters).  (2) The SAME compacting depth sort as the
+    // whole-path entry: it drops -- and counts -- the culled Gaussians in its first step and leaves the index of every
+    // depth rank (the rectangles it carries along are not needed here: it moves whatever the workspace holds).
+    // (3) Rank order: one 48-byte gather per rank, the derived fields, eleven coalesced output arrays.  Round 2 ran a
+    // memset node, a key kernel, a 12-launch LSD sort over all n keys, a counting kernel and a projection that
+    // gathered the five input arrays by rank.
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
+    gsx::Record *stage = (gsx::Record *)(ws + c.rec);
+    GSX_HIP(gsx::launch_project_stage(*camera, in, n, k0, stage, counters, s));
+    const gsx::DepthRoute route = gsx::depth_sort_route(n, 0);
+    if (route != gsx::kDepthLsd)
+        GSX_HIP(gsx::sort_depth_sampled(route, ws + c.temp, k0, k1, v0, v1, n, 0, counters + kCtrKept, counters + kCtrCulled,
+                                        (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), 0, nullptr,
+                                        gsx::SortHints{nullptr, nullptr, nullptr, false, nullptr, nullptr, 0u}, s));
+    else
+        GSX_HIP(gsx::sort_depth_compact(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
+                                        (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s));
     gsx::StageOneOut out{points_xy, colors_out, covariance_2d, depths, inverse_covariance_2d, radius,
                          min_x, max_x, min_y, max_y, sigmoid_opacity, order};
-    GSX_HIP(gsx::launch_project_full(*camera, in, k0, v0, n, out, s));
+    GSX_HIP(gsx::launch_project_full(stage, v0, counters + kCtrKept, n, out, s));
     uint32_t nv = 0;
-    GSX_HIP(hipMemcpyAsync(&nv, counters, 4, hipMemcpyDeviceToHost, s));
+    GSX_HIP(hipMemcpyAsync(&nv, counters + kCtrKept, 4, hipMemcpyDeviceToHost, s));
     GSX_HIP(hipStreamSynchronize(s));
     if (n_visible_host) *n_visible_host = nv;
     return GSX_OK;

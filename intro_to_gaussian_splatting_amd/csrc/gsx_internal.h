@@ -77,9 +77,10 @@ struct PreprocessedIn {  // argument list of splat/c/render.cu:90-101
 };
 
 // ---- gsx_project.hip (compiled with -ffp-contract=off)
-hipError_t launch_depth_keys(const GsxCamera &cam, const float *means3d, int64_t n, uint32_t *keys,
-                             uint32_t *vals, hipStream_t s);
-hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t *n_visible, hipStream_t s);
+// gsx_preprocess, first kernel: depth keys in original order (kCulledKey behind the cull plane), the 11 floats of
+// every visible Gaussian that the rank-ordered output kernel gathers (in its record slot), the sort's counters zeroed.
+hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int64_t n, uint32_t *keys, Record *stage,
+                                uint32_t *counters, hipStream_t s);
 // Original order: depth keys (kCulledKey behind the cull plane, kEmptyKey when no tile of the window is
 // reached), records / rects indexed by the ORIGINAL Gaussian index (only written for the Gaussians that
 // reach a tile; the depth sort generates the identity values itself).
@@ -92,8 +93,9 @@ hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                const TileGrid &grid, int semantics, bool tight_rects, int sh_degree, uint32_t *keys,
                                Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s);
-hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
-                               const uint32_t *sorted_idx, int64_t n, const StageOneOut &out, hipStream_t s);
+// gsx_preprocess, last kernel: all PreprocessedScene fields in depth order; order[r] = Gaussian of rank r, r < *m_dev.
+hipError_t launch_project_full(const Record *stage, const uint32_t *order, const uint32_t *m_dev, int64_t n,
+                               const StageOneOut &out, hipStream_t s);
 hipError_t launch_pack_preprocessed(const PreprocessedIn &in, int64_t n, const TileGrid &grid, int semantics,
                                     Record *rec, TileRect *rect, float4 *bbox, hipStream_t s);
 hipError_t launch_covariance3d(const float *scales, const float *quats, int64_t n, float *out, hipStream_t s);

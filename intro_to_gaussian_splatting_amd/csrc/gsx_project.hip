@@ -111,23 +111,10 @@ __device__ __forceinline__ void ewa_covariance(const GsxCamera &cam, float fx, f
     o.cd = C[1][1] * j11 + C[1][2] * j12;
 }
 
-// Everything of stage 1 for one visible Gaussian.
-__device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1, float p2, float tz,
-                                        float s0, float s1, float s2, float qw, float qx, float qy, float qz,
-                                        Projected &o) {
-    const float *F = cam.full_proj;
-    float S[3][3];
-    covariance3d(s0, s1, s2, qw, qx, qy, qz, S);
-
-    // pixel position
-    float cw = row4(p0, p1, p2, F, 3);
-    float ndcx = row4(p0, p1, p2, F, 0) / cw;
-    float ndcy = row4(p0, p1, p2, F, 1) / cw;
-    o.x = (ndcx + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
-    o.y = (ndcy + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
-
-    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o);
-
+// What stage 1 derives from the pixel position and the 2D covariance alone (o.x, o.y, o.ca .. o.cd, tz): inverse
+// with the determinant floored at 1e-3, radius with the discriminant floored at 0.1, bounding box.  One sequence
+// of float32 operations, used by every caller: the same inputs give the same bits.
+__device__ __forceinline__ void finish_projection(float tz, Projected &o) {
     float det = o.ca * o.cd - o.cb * o.cc;
     det = fmaxf(det, 1e-3f);
     o.q00 = o.cd / det;
@@ -146,6 +133,25 @@ __device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1
     o.max_x = ceilf(o.x + o.radius);
     o.min_y = floorf(o.y - o.radius);
     o.max_y = ceilf(o.y + o.radius);
+}
+
+// Everything of stage 1 for one visible Gaussian.
+__device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1, float p2, float tz,
+                                        float s0, float s1, float s2, float qw, float qx, float qy, float qz,
+                                        Projected &o) {
+    const float *F = cam.full_proj;
+    float S[3][3];
+    covariance3d(s0, s1, s2, qw, qx, qy, qz, S);
+
+    // pixel position
+    float cw = row4(p0, p1, p2, F, 3);
+    float ndcx = row4(p0, p1, p2, F, 0) / cw;
+    float ndcy = row4(p0, p1, p2, F, 1) / cw;
+    o.x = (ndcx + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
+    o.y = (ndcy + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
+
+    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o);
+    finish_projection(tz, o);
 }
 
 // GSX_SEM_STD_3DGS stage 1 (published 3DGS forward pass; see include/gsx.h).  Returns false when
@@ -283,25 +289,34 @@ __device__ __forceinline__ uint32_t tile_rect(float mnx, float mxx, float mny, f
 
 // ------------------------------------------------------------------------------------ kernels
 
-// One thread per Gaussian: view depth -> sortable key (stage-1 API path).  z >= 0.2 > 0, so the
-// IEEE bits of z are monotone in z; culled Gaussians get the largest key and sort to the end.
-__global__ void __launch_bounds__(kBlock) depth_keys_kernel(GsxCamera cam, const float *__restrict__ means3d,
-                                                            int64_t n, uint32_t *__restrict__ keys,
-                                                            uint32_t *__restrict__ vals) {
-    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    float tz = row4(means3d[3 * i], means3d[3 * i + 1], means3d[3 * i + 2], cam.world2view, 2);
-    keys[i] = tz >= 0.2f ? __float_as_uint(tz) : kCulledKey;
-    vals[i] = (uint32_t)i;
-}
-
-// The number of visible Gaussians is where the culled keys start in the sorted key array: one
-// writer, no atomics (a shared counter costs ~12 ns per wave-level atomic, 180 us at N = 1M).
+// gsx_preprocess, first kernel: one thread per Gaussian in ORIGINAL order (coalesced reads of the five parameter
+// arrays): the depth key for the sort (z >= 0.2 > 0: the IEEE bits of z are monotone in z; kCulledKey behind the cull
+// plane -- dropped and counted by the sort's first step) and, for a visible Gaussian, what the rank-ordered output
+// kernel cannot cheaply recompute -- pixel position, colour, 2D covariance, depth, sigmoid(opacity): 11 floats in the
+// Gaussian's 48-byte record slot.  (Round 3: gathering the five input arrays by depth rank instead -- five random
+// 64-byte sectors per Gaussian -- took 124 us at 1M.)  Also zeroes the sort's device counters (no memset node).
 __global__ void __launch_bounds__(kBlock)
-    count_visible_kernel(const uint32_t *__restrict__ sorted_keys, int64_t n, uint32_t *__restrict__ n_visible) {
-    int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r >= n) return;
-    if (sorted_keys[r] != kCulledKey && (r == n - 1 || sorted_keys[r + 1] == kCulledKey)) *n_visible = (uint32_t)(r + 1);
+    project_stage_kernel(GsxCamera cam, GaussiansIn in, int64_t n, uint32_t *__restrict__ keys, Record *__restrict__ stage,
+                         uint32_t *__restrict__ counters) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < 4) counters[i] = 0u;
+    if (i >= n) return;
+    const float *p = in.means3d + 3 * i;
+    const float p0 = p[0], p1 = p[1], p2 = p[2];
+    const float tz = row4(p0, p1, p2, cam.world2view, 2);
+    if (!(tz >= 0.2f)) {                                          // utils.py:293-310
+        keys[i] = kCulledKey;
+        return;
+    }
+    keys[i] = __float_as_uint(tz);
+    const float *s = in.scales + 3 * i, *q = in.quats + 4 * i, *c = in.colors + 3 * i;
+    Projected o;
+    project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
+    Record r;
+    r.a = make_float4(o.x, o.y, c[0], c[1]);
+    r.b = make_float4(c[2], tz, sigmoidf(in.opacity_logit[i]), o.ca);
+    r.c = make_float4(o.cb, o.cc, o.cd, 0.0f);
+    stage[i] = r;
 }
 
 // Opacity factor and conic as the compositing kernel consumes them.
@@ -526,29 +541,32 @@ __global__ void __launch_bounds__(kBlock)
     rect[g] = tr;
 }
 
-// Same projection, all PreprocessedScene fields (the reference's stage-1 API surface).
+// gsx_preprocess, last kernel: all PreprocessedScene fields (the reference's stage-1 API surface) in depth order, one
+// thread per rank: order[r] = Gaussian of rank r (the compacting depth sort's output), *m_dev = number of ranks =
+// visible Gaussians.  ONE 48-byte gather per rank (project_stage_kernel's slot); inverse covariance, radius and
+// bounding box are derived here by the same operations as everywhere else (finish_projection).
 __global__ void __launch_bounds__(kBlock)
-    project_full_kernel(GsxCamera cam, GaussiansIn in, const uint32_t *__restrict__ sorted_keys,
-                        const uint32_t *__restrict__ sorted_idx, int64_t n, StageOneOut out) {
+    project_full_kernel(const Record *__restrict__ stage, const uint32_t *__restrict__ order,
+                        const uint32_t *__restrict__ m_dev, int64_t n, StageOneOut out) {
     int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r >= n) return;
-    uint32_t key = sorted_keys[r];
-    if (key == kCulledKey) return;
-    int64_t g = sorted_idx[r];
-    const float *p = in.means3d + 3 * g, *s = in.scales + 3 * g, *q = in.quats + 4 * g, *c = in.colors + 3 * g;
+    if (r >= n || r >= (int64_t)*m_dev) return;
+    const uint32_t g = order[r];
+    const Record q = stage[g];
     Projected o;
-    project(cam, p[0], p[1], p[2], __uint_as_float(key), s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
+    o.x = q.a.x; o.y = q.a.y;
+    o.ca = q.b.w; o.cb = q.c.x; o.cc = q.c.y; o.cd = q.c.z;
+    finish_projection(q.b.y, o);
     out.points_xy[2 * r] = o.x;
     out.points_xy[2 * r + 1] = o.y;
-    out.colors[3 * r] = c[0];
-    out.colors[3 * r + 1] = c[1];
-    out.colors[3 * r + 2] = c[2];
+    out.colors[3 * r] = q.a.z;
+    out.colors[3 * r + 1] = q.a.w;
+    out.colors[3 * r + 2] = q.b.x;
     out.cov2d[4 * r] = o.ca; out.cov2d[4 * r + 1] = o.cb; out.cov2d[4 * r + 2] = o.cc; out.cov2d[4 * r + 3] = o.cd;
     out.depths[r] = o.depth;
     out.inv_cov[4 * r] = o.q00; out.inv_cov[4 * r + 1] = o.q01; out.inv_cov[4 * r + 2] = o.q10; out.inv_cov[4 * r + 3] = o.q11;
     out.radius[r] = o.radius;
     out.min_x[r] = o.min_x; out.max_x[r] = o.max_x; out.min_y[r] = o.min_y; out.max_y[r] = o.max_y;
-    out.sig_op[r] = sigmoidf(in.opacity_logit[g]);
+    out.sig_op[r] = q.b.z;
     if (out.order) out.order[r] = (int32_t)g;
 }
 
@@ -638,16 +656,10 @@ hipError_t launch_covariance3d(const float *scales, const float *quats, int64_t 
     return hipGetLastError();
 }
 
-hipError_t launch_depth_keys(const GsxCamera &cam, const float *means3d, int64_t n, uint32_t *keys,
-                             uint32_t *vals, hipStream_t s) {
+hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int64_t n, uint32_t *keys, Record *stage,
+                                uint32_t *counters, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    depth_keys_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, means3d, n, keys, vals);
-    return hipGetLastError();
-}
-
-hipError_t launch_count_visible(const uint32_t *sorted_keys, int64_t n, uint32_t *n_visible, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    count_visible_kernel<<<blocks_for(n), kBlock, 0, s>>>(sorted_keys, n, n_visible);
+    project_stage_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, n, keys, stage, counters);
     return hipGetLastError();
 }
 
@@ -684,10 +696,10 @@ hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device
     return hipGetLastError();
 }
 
-hipError_t launch_project_full(const GsxCamera &cam, const GaussiansIn &in, const uint32_t *sorted_keys,
-                               const uint32_t *sorted_idx, int64_t n, const StageOneOut &out, hipStream_t s) {
+hipError_t launch_project_full(const Record *stage, const uint32_t *order, const uint32_t *m_dev, int64_t n,
+                               const StageOneOut &out, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    project_full_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, sorted_keys, sorted_idx, n, out);
+    project_full_kernel<<<blocks_for(n), kBlock, 0, s>>>(stage, order, m_dev, n, out);
     return hipGetLastError();
 }
 

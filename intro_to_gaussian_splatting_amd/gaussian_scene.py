@@ -244,10 +244,21 @@ class GaussianScene:
         lib = _ffi.load()
         dev, n, tensors = self._inputs(image_idx)
         cam = self.images[image_idx].gsx_camera()
-        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)  # noqa: E731
+        # one allocation for the eleven float outputs (21 floats per Gaussian) and the order, carved into views
+        flat = torch.empty(max(n, 1) * 22, dtype=torch.float32, device=dev)
+        off = [0]
+
+        def f(*shape):
+            cnt = 1
+            for v in shape:
+                cnt *= v
+            view = flat[off[0]:off[0] + cnt].view(*shape)
+            off[0] += cnt
+            return view
+
         xy, col, c2, dep, inv, rad = f(n, 2), f(n, 3), f(n, 2, 2), f(n), f(n, 2, 2), f(n)
         mnx, mxx, mny, mxy, sop = f(n), f(n), f(n), f(n), f(n, 1)
-        order = torch.empty(n, dtype=torch.int32, device=dev)
+        order = f(n).view(torch.int32)
         nvis = ctypes.c_int64(0)
         with torch.cuda.device(dev):
             nbytes = lib.gsx_workspace_bytes(n, cam.width, cam.height, 16, 1)
