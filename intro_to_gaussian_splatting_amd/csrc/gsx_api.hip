@@ -142,7 +142,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             }
             tm.mark();  // 4: tile sort (+ the compositing schedule)
             gsx::BlendHints bh = fh.blend;
-            bh.check_sched = fh.sched ? 1u : 0u;
+            bh.xcd_sched = fh.sched ? 1u : 0u;
             GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
                                       ranges, p.grid, p.out, p.semantics, p.background, p.generic,
                                       make_clear_plan(p, false), lt, sched, bh, s));
@@ -206,7 +206,7 @@ void gsx_default_params(GsxParams *params) {
 
 size_t gsx_hints_bytes(int32_t width, int32_t height, int32_t tile) {
     if (width <= 0 || height <= 0 || tile <= 0) return 0;
-    return gsx::hints_layout(max_tiles_of(width, height, tile)).total;
+    return gsx::hints_layout(max_tiles_of(width, height, tile), max_axis_tiles_of(width, height, tile)).total;
 }
 
 size_t gsx_workspace_bytes(int64_t n, int32_t width, int32_t height, int32_t tile, int64_t max_instances) {
@@ -255,7 +255,7 @@ int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *s
     if (route != gsx::kDepthLsd)
         GSX_HIP(gsx::sort_depth_sampled(route, ws + c.temp, k0, k1, v0, v1, n, 0, counters + kCtrKept, counters + kCtrCulled,
                                         (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), 0, nullptr,
-                                        gsx::SortHints{nullptr, nullptr, nullptr, false, nullptr, nullptr, 0u}, s));
+                                        gsx::SortHints{nullptr, nullptr, nullptr, false}, s));
     else
         GSX_HIP(gsx::sort_depth_compact(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
                                         (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s));
@@ -324,35 +324,36 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     tm.begin(p.timing, s);
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, p.sh ? p.sh : colors};
     uint32_t *counters = (uint32_t *)(ws + c.counters);
-    GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, p.sh_degree, k0, (gsx::Record *)(ws + c.rec),
-                                     (gsx::TileRect *)(ws + c.rect), counters,
-                                     p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
-    tm.mark();  // 1: project (+ depth keys)
-    // the sampled routes also leave the per-chunk tile counts the pair emission starts from (one kernel less)
+    // GsxParams.hints: what the previous frame of this view left (splitters, tile-list lengths) and what this one
+    // leaves.  Only where every producer and consumer exists: the tile-16 REF_CPU compositing kernel (lengths,
+    // ranked samples), the 256-bucket depth sort (splitters; the LSD passes of larger scenes only take the schedule).
     const gsx::DepthRoute route = gsx::depth_sort_route(n, p.kept_hint);
     const bool sampled = route != gsx::kDepthLsd;
-    // GsxParams.hints: what the previous frame of this view left (splitters, tile-list lengths) and what this one
-    // leaves.  Only where every producer and consumer exists: the 256-bucket depth sort with a row-scan-free or
-    // row-scan partition (not the one-workgroup sort of tiny scenes) and the tile-16 REF_CPU compositing kernel.
     FrameHints fh;
-    gsx::SortHints sh{nullptr, nullptr, nullptr, false, nullptr, nullptr, 0u};
-    if (p.hints && route == gsx::kDepth256 && n >= gsx::kSortSamples && p.grid.count() > 0 &&
+    gsx::SortHints sh{nullptr, nullptr, nullptr, false};
+    gsx::ScheduleHint sched_hint{nullptr, nullptr, nullptr, 0u};
+    if (p.hints && (route == gsx::kDepth256 || route == gsx::kDepthLsd) && n >= gsx::kSortSamples && p.grid.count() > 0 &&
         gsx::blend_splits_long_tiles(p.grid, p.semantics, p.generic)) {
-        const gsx::HintsLayout hl = gsx::hints_layout(max_tiles_of(camera->width, camera->height, tile_size));
+        const gsx::HintsLayout hl = gsx::hints_layout(max_tiles_of(camera->width, camera->height, tile_size),
+                                                      max_axis_tiles_of(camera->width, camera->height, tile_size));
         uint32_t *hdr = (uint32_t *)p.hints;
-        sh.header = hdr;
-        sh.splitters = (const uint32_t *)(p.hints + hl.splitters);
-        sh.samples = (uint32_t *)(p.hints + hl.samples);
-        sh.use = p.hints_valid;
+        if (route == gsx::kDepth256) {
+            sh = gsx::SortHints{hdr, (const uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.samples), p.hints_valid};
+        }
         fh.blend = gsx::BlendHints{hdr, sh.samples, (uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.lens), 0u};
-        // the schedule costs nothing here: every window of more than two tiles per SIMD gets one, unless told not to
-        if (p.hints_valid && p.schedule != 0 && p.grid.count() > 2048 && gsx::depth_partition_has_spare_workgroup(n)) {
-            sh.lens = (const uint32_t *)(p.hints + hl.lens);
-            sh.sched = (uint32_t *)(p.hints + hl.sched);
-            sh.ntiles = (uint32_t)p.grid.count();
-            fh.sched = sh.sched;
+        // the schedule costs nothing here (a spare workgroup of the projection launch): every window of more than two
+        // tiles per SIMD gets one, unless told not to
+        if (p.hints_valid && p.schedule != 0 && p.grid.count() > 2048) {
+            sched_hint = gsx::ScheduleHint{(const uint32_t *)(p.hints + hl.lens), (uint32_t *)(p.hints + hl.sched), hdr,
+                                           (uint32_t)p.grid.count(), (uint32_t)p.grid.nwy()};
+            fh.sched = sched_hint.sched;
         }
     }
+    GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, p.sh_degree, k0, (gsx::Record *)(ws + c.rec),
+                                     (gsx::TileRect *)(ws + c.rect), counters,
+                                     p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, sched_hint, s));
+    tm.mark();  // 1: project (+ depth keys)
+    // the sampled routes also leave the per-chunk tile counts the pair emission starts from (one kernel less)
     if (sampled)
         GSX_HIP(gsx::sort_depth_sampled(route, ws + c.temp, k0, k1, v0, v1, n, p.kept_hint, counters + kCtrKept,
                                         counters + kCtrCulled, (const gsx::TileRect *)(ws + c.rect),

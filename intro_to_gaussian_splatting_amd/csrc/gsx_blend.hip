@@ -57,6 +57,7 @@
 #include <type_traits>
 
 #include "gsx_internal.h"
+#include "gsx_schedule_device.h"
 
 #ifdef GSX_TEST_HOOKS
 // Test library only (gsx_debug.h: gsx_debug_set_blend_probe): when set, every workgroup of blend_tile16_kernel leaves
@@ -95,13 +96,26 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
 // dealt to the XCDs in two-column chunks and ranked inside each XCD: 460 MB, but 270 us instead of 262, and a
 // 16 us schedule kernel; better only on the clustered scene.)  Without a schedule: index order, a contiguous
 // eighth of the tiles per XCD.
-__device__ __forceinline__ uint32_t scheduled_tile(uint32_t b, uint32_t nt, const uint32_t *__restrict__ sched,
-                                                   const uint32_t *__restrict__ hint_header = nullptr) {
-    // (a schedule handed over through GsxParams.hints counts only if its header says it is for this many tiles)
-    if (!sched || (hint_header && hint_header[kHintSched] != nt)) return xcd_remap(b, nt);
+__device__ __forceinline__ uint32_t scheduled_tile(uint32_t b, uint32_t nt, const uint32_t *__restrict__ sched) {
+    if (!sched) return xcd_remap(b, nt);
     const uint32_t round = b >> 10, slot = b & 1023u;
     const uint32_t in_round = min(1024u, nt - (round << 10));
     return sched[(round << 10) + ((round & 1u) ? in_round - 1u - slot : slot)];
+}
+
+// The same with the schedule handed over through GsxParams.hints (gsx_schedule_device.h): XCD x = b % 8 composites ITS
+// tiles -- the chunks of two tile columns dealt to it -- by falling list length, round by round over its 128 SIMDs
+// (workgroups b and b + 1024 share a SIMD), alternately forwards and backwards.  The launch carries 8 x cap tile
+// workgroups; one beyond its XCD's tile count has nothing to do (returns nt).  A schedule for another window (header
+// word) is ignored: tiles in index order, workgroups beyond nt idle.
+__device__ __forceinline__ uint32_t xcd_scheduled_tile(uint32_t b, uint32_t nt, uint32_t cap, const uint32_t *__restrict__ sched,
+                                                       const uint32_t *__restrict__ header) {
+    if (header[kHintSched] != nt) return b < nt ? xcd_remap(b, nt) : nt;
+    const uint32_t x = b & 7u, i = b >> 3, mine = header[kHintXcdTiles + x];
+    if (i >= mine) return nt;
+    const uint32_t round = i >> 7, slot = i & 127u;
+    const uint32_t in_round = min(128u, mine - (round << 7));
+    return sched[(size_t)x * cap + (round << 7) + ((round & 1u) ? in_round - 1u - slot : slot)];
 }
 
 // Pixels of the output buffer that no tile of the window covers are zeroed by extra workgroups of the
@@ -560,7 +574,8 @@ template <int VARIANT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))   // 64 VGPRs: every lost wave costs
     blend_tile16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                         const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
-                        uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints) {
+                        uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints,
+                        uint32_t tile_blocks, uint32_t sched_cap_) {
     __shared__ float4 sh[3][kSlots];
     // block order: [spare workgroups: the next frame's splitters] [helpers of long tiles (dispatched first: they have
     // the most to do)] [tiles] [clears]
@@ -598,12 +613,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         return;
     }
     const uint32_t bid = block - nhelpers;
-    if (bid >= (uint32_t)g.count()) {
-        clear_block(bid - (uint32_t)g.count(), cp, out.ptr);
+    if (bid >= tile_blocks) {       // (tile_blocks = number of tiles, or 8 x cap with the per-XCD schedule)
+        clear_block(bid - tile_blocks, cp, out.ptr);
         return;
     }
     const int lane = threadIdx.x;
-    const uint32_t t = scheduled_tile(bid, (uint32_t)g.count(), sched, hints.check_sched ? hints.header : nullptr);
+    const uint32_t t = hints.xcd_sched ? xcd_scheduled_tile(bid, (uint32_t)g.count(), sched_cap_, sched, hints.header)
+                                       : scheduled_tile(bid, (uint32_t)g.count(), sched);
+    if (t >= (uint32_t)g.count()) return;
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
     uint32_t probe_staged = 0, probe_checked_at = 0xFFFFFFu;
@@ -632,7 +649,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     rg.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.y);
     if (hints.lens && lane == 0) {  // what the next frame's schedule is made from (GsxParams.hints; long tiles count as empty)
         hints.lens[t] = (rg.y & kLongFlag) ? 0u : rg.y - rg.x;
-        if (bid == 0) hints.header[kHintLens] = (uint32_t)g.count();
+        if (t == 0) hints.header[kHintLens] = (uint32_t)g.count();
     }
     if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
     uint32_t skipped = 0;            // colour this tile has left out so far (stage_batch)
@@ -1137,23 +1154,27 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
         const uint32_t budget = 1u << (40 + knob("GSX_SKIP_BUDGET_LOG2", -17));
         // a window of up to kQuartersBelow tiles puts every tile on four waves (see the kernel)
         const bool quarters = nt <= (int64_t)knob("GSX_QUARTERS_BELOW", kQuartersBelow);
-        unsigned nh = lt.max ? 4u * lt.max : 0u, grid_blocks = nb + nh;
-        if (quarters) {
-            nh = 0;
-            grid_blocks = (unsigned)((nt + 7) / 8) * 32u + (unsigned)(cp.n > 0 ? cp.first[cp.n] : 0);
-        }
         BlendHints bh = hints;
         if (quarters) bh.lens = nullptr;
+        // tile workgroups: one per tile, or -- per-XCD schedule from GsxParams.hints -- 8 x cap (gsx_schedule_device.h)
+        const uint32_t cap = bh.xcd_sched ? sched_cap((uint32_t)nt, (uint32_t)grid.nwy()) : 0u;
+        const unsigned tile_blocks = bh.xcd_sched ? kSchedXcds * cap : (unsigned)nt;
+        const unsigned clear_blocks = (unsigned)(cp.n > 0 ? cp.first[cp.n] : 0);
+        unsigned nh = lt.max ? 4u * lt.max : 0u, grid_blocks = tile_blocks + clear_blocks + nh;
+        if (quarters) {
+            nh = 0;
+            grid_blocks = (unsigned)((nt + 7) / 8) * 32u + clear_blocks;
+        }
         grid_blocks += bh.samples ? kRankGroups : 0u;
         const uint32_t q = quarters ? 1u : 0u;
         if (variant == 0)
-            blend_tile16_kernel<0><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh);
+            blend_tile16_kernel<0><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap);
         else if (variant == 2)
-            blend_tile16_kernel<2><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh);
+            blend_tile16_kernel<2><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap);
         else if (variant == 3)
-            blend_tile16_kernel<3><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh);
+            blend_tile16_kernel<3><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap);
         else
-            blend_tile16_kernel<1><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh);
+            blend_tile16_kernel<1><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap);
     } else {
         blend_generic_kernel<<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp);
     }

@@ -76,6 +76,14 @@ struct PreprocessedIn {  // argument list of splat/c/render.cu:90-101
     const float *means, *colors, *inv_cov, *min_x, *max_x, *min_y, *max_y, *opacity;
 };
 
+// The projection launch's share: one spare workgroup puts the compositing schedule of THIS frame together from the
+// tile-list lengths the previous frame left (gsx_schedule_device.h; sched == nullptr: not wanted).
+struct ScheduleHint {
+    const uint32_t *lens;
+    uint32_t *sched, *header;
+    uint32_t ntiles, nwy;       // tiles of the window, and along its y axis (tile ids are column-major)
+};
+
 // ---- gsx_project.hip (compiled with -ffp-contract=off)
 // gsx_preprocess, first kernel: depth keys in original order (kCulledKey behind the cull plane), the 11 floats of
 // every visible Gaussian that the rank-ordered output kernel gathers (in its record slot), the sort's counters zeroed.
@@ -92,7 +100,8 @@ hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int
 // counters: 4 words this kernel zeroes for the depth sort (culled count, kept count, ...).
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                const TileGrid &grid, int semantics, bool tight_rects, int sh_degree, uint32_t *keys,
-                               Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s);
+                               Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, const ScheduleHint &sched,
+                               hipStream_t s);
 // gsx_preprocess, last kernel: all PreprocessedScene fields in depth order; order[r] = Gaussian of rank r, r < *m_dev.
 hipError_t launch_project_full(const Record *stage, const uint32_t *order, const uint32_t *m_dev, int64_t n,
                                const StageOneOut &out, hipStream_t s);
@@ -161,12 +170,8 @@ struct SortHints {
     const uint32_t *splitters;  // 256 words left by the previous frame
     uint32_t *samples;          // kSortSamples words this frame's count kernel fills for the next frame
     bool use;                   // GSX_FLAG_HINTS_VALID: partition with `splitters`, no sample kernel
-    // the compositing schedule of THIS frame from the tile-list lengths the previous frame left (a spare workgroup
-    // of the partition's count launch; sched == nullptr: not wanted)
-    const uint32_t *lens;
-    uint32_t *sched;
-    uint32_t ntiles;
 };
+
 // The compositing launch's share: spare workgroups rank the samples into the next frame's splitters, every tile
 // workgroup leaves the length of its list.  header == nullptr: no hints buffer.
 struct BlendHints {
@@ -174,15 +179,13 @@ struct BlendHints {
     const uint32_t *samples;    // kSortSamples words of this frame's count kernel, or nullptr (nothing to rank)
     uint32_t *splitters;
     uint32_t *lens;
-    uint32_t check_sched;       // != 0: `sched` is hints.sched -- trust it only if header[kHintSched] == number of tiles
+    uint32_t xcd_sched;         // != 0: `sched` is hints.sched, the per-XCD schedule (gsx_schedule_device.h) -- trusted
+                                // only if header[kHintSched] == number of tiles; 0: tile_schedule_kernel's whole-frame order
 };
 hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
                               uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,
                               const TileRect *rect, TileRect *rrect, uint32_t lds_cap, uint64_t *chunk_sums,
                               const SortHints &hints, hipStream_t s);
-// Does the 256-bucket partition of n keys launch the four-chunk count kernel (whose spare workgroup can build the
-// compositing schedule)?  Not for the small inputs whose pass has no row-scan launch and a chunk-major table.
-bool depth_partition_has_spare_workgroup(int64_t n);
 // Where emit_instances keeps its chunk sums inside `temp` (for sort_depth_sampled to fill them in).
 uint64_t *emit_chunk_sums(void *temp, int64_t n, int64_t cap);
 

@@ -94,19 +94,21 @@ inline int clear_blocks_for(int64_t rows, int64_t fw) {
 //   splitters[256]     depth-sort splitters of the last frame (written by spare workgroups of its compositing launch)
 //   samples[2048]      regularly spaced KEPT depth keys of the last frame (written by its partition count kernel)
 //   lens[max_tiles]    list length of every tile of the window (written by the compositing launch; long tiles: 0)
-//   sched[max_tiles]   the tiles by falling list length (written by a spare workgroup of the projection launch)
-enum { kHintSplitters = 0, kHintSamples = 1, kHintLens = 2, kHintSched = 3, kHintHeaderWords = 64 };
+//   sched[..]          per XCD, its tiles by falling list length (eight spare workgroups of the projection launch,
+//                      gsx_schedule_device.h; header[kHintXcdTiles + x] = how many tiles XCD x has)
+enum { kHintSplitters = 0, kHintSamples = 1, kHintLens = 2, kHintSched = 3, kHintXcdTiles = 8 /* .. 15 */, kHintHeaderWords = 64 };
 struct HintsLayout {
     size_t splitters, samples, lens, sched, total;   // byte offsets
 };
-inline HintsLayout hints_layout(int64_t max_tiles) {
+// max_tiles: tiles of the frame; max_axis: tiles along its longer axis (a window is at most that high).
+inline HintsLayout hints_layout(int64_t max_tiles, int64_t max_axis) {
     HintsLayout h;
-    const size_t t = (size_t)(max_tiles > 0 ? max_tiles : 1);
+    const size_t t = (size_t)(max_tiles > 0 ? max_tiles : 1), a = (size_t)(max_axis > 0 ? max_axis : 1);
     h.splitters = kHintHeaderWords * 4;
     h.samples = h.splitters + (size_t)kSortBins * 4;
     h.lens = h.samples + (size_t)kSortSamples * 4;
     h.sched = h.lens + ((t * 4 + 255) & ~(size_t)255);
-    h.total = h.sched + ((t * 4 + 255) & ~(size_t)255);
+    h.total = h.sched + (((t + 16 * a) * 4 + 255) & ~(size_t)255);   // 8 x sched_cap(nt, nwy) <= nt + 16 nwy entries
     return h;
 }
 
@@ -172,6 +174,10 @@ inline Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes)
 
 inline int64_t max_tiles_of(int32_t width, int32_t height, int32_t tile) {
     return (int64_t)((width + tile - 1) / tile) * ((height + tile - 1) / tile);
+}
+inline int64_t max_axis_tiles_of(int32_t width, int32_t height, int32_t tile) {
+    const int64_t a = (width + tile - 1) / tile, b = (height + tile - 1) / tile;
+    return a > b ? a : b;
 }
 
 // Largest pair capacity whose carve fits `bytes` (the size of a carve grows monotonically with the capacity:

@@ -17,6 +17,7 @@
 //   splat/utils.py:409-423          r = ceil(3 sqrt(lambda_max)), discriminant floored at 0.1
 //   splat/gaussian_scene.py:209-217 tile membership test (min <= x0 + T and max >= x0)
 #include "gsx_internal.h"
+#include "gsx_schedule_device.h"
 #include "gsx_sh_device.h"
 
 namespace gsx {
@@ -380,11 +381,19 @@ __global__ void __launch_bounds__(kBlock)
                         TileGrid grid, int semantics, bool tight,
                         uint32_t *__restrict__ keys, Record *__restrict__ rec,
                         TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox,
-                        bool sh_vec) {
+                        bool sh_vec, SchedJob sched_job) {
+    // the launch's eight spare workgroups -- blocks 0 .. 7, dispatched FIRST and long done when the Gaussians' blocks
+    // are: the compositing schedule of this frame, one XCD's share each, from the list lengths the previous frame left
+    // (GsxParams.hints, gsx_schedule_device.h)
+    if (sched_job.sched && blockIdx.x < kSchedXcds) {
+        schedule_from_lengths(sched_job, blockIdx.x);
+        return;
+    }
+    const int64_t blk = (int64_t)blockIdx.x - (sched_job.sched ? (int64_t)kSchedXcds : 0);
     constexpr int DEG = SHDEG >= 0 ? SHDEG : 0;
     using L = sh::Layout<DEG>;
     __shared__ float sh_lds[SHDEG >= 0 ? L::kRows * L::STRIDE : 1];
-    int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int64_t g = blk * kBlock + threadIdx.x;
     if (g < 4) counters[g] = 0u;   // the depth sort's culled / kept counts start from zero (no memset node)
     float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     if (SHDEG >= 0) {
@@ -396,7 +405,7 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
         for (int part = 0; part < L::kParts; ++part) {
             if (part) __syncthreads();
-            sh::stage<DEG, L::kRows>(in.colors, n, (int64_t)blockIdx.x * kBlock + part * L::kRows, sh_lds, vec);
+            sh::stage<DEG, L::kRows>(in.colors, n, blk * kBlock + part * L::kRows, sh_lds, vec);
             const int row = (int)threadIdx.x - part * L::kRows;
             if (row >= 0 && row < L::kRows && g < n) {
                 const float *pp = in.means3d + 3 * g;
@@ -471,7 +480,7 @@ __global__ void __launch_bounds__(kBlock)
     __syncthreads();
     if (threadIdx.x >= total) return;
     const uint32_t src = s_list[threadIdx.x];
-    g = (int64_t)blockIdx.x * kBlock + src;
+    g = blk * kBlock + src;
     if (SHDEG >= 0) {
         cr = s_col[3 * src];
         cg = s_col[3 * src + 1];
@@ -666,13 +675,15 @@ hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int
 template <int SHDEG>
 static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                     const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys, Record *rec,
-                                    TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s) {
+                                    TileRect *rect, uint32_t *counters, float4 *bbox, const ScheduleHint &sh, hipStream_t s) {
+    const SchedJob job{sh.lens, sh.sched, sh.header, sh.ntiles, sh.nwy, sched_cap(sh.ntiles, sh.nwy)};
+    const unsigned spare = sh.sched ? kSchedXcds : 0u;
     const bool vec = (reinterpret_cast<uintptr_t>(in.colors) & 15u) == 0;
     // a strict part of the frame (a rank's strip, a tile window): most Gaussians miss it -> two-phase kernel
     const bool windowed = grid.wx0 > 0 || grid.wy0 > 0 || grid.wx1 < grid.ntx || grid.wy1 < grid.nty;
 #define GSX_LAUNCH_PP(DC, WIN)                                                                                          \
-    project_pack_kernel<DC, SHDEG, WIN><<<blocks_for(n), kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics,      \
-                                                                         tight_rects, keys, rec, rect, counters, bbox, vec)
+    project_pack_kernel<DC, SHDEG, WIN><<<blocks_for(n) + spare, kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics, \
+                                                                         tight_rects, keys, rec, rect, counters, bbox, vec, job)
     if (cam_device) {
         if (windowed) GSX_LAUNCH_PP(true, true); else GSX_LAUNCH_PP(true, false);
     } else {
@@ -684,14 +695,15 @@ static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_d
 // sh_degree < 0: in.colors is (n,3) RGB; 0..3: in.colors is (n, (degree+1)^2, 3) spherical harmonics.
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                const TileGrid &grid, int semantics, bool tight_rects, int sh_degree, uint32_t *keys,
-                               Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, hipStream_t s) {
+                               Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, const ScheduleHint &sched,
+                               hipStream_t s) {
     if (n == 0) return hipSuccess;
     switch (sh_degree) {
-        case 0: launch_project_pack_deg<0>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, s); break;
-        case 1: launch_project_pack_deg<1>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, s); break;
-        case 2: launch_project_pack_deg<2>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, s); break;
-        case 3: launch_project_pack_deg<3>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, s); break;
-        default: launch_project_pack_deg<-1>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, s); break;
+        case 0: launch_project_pack_deg<0>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, sched, s); break;
+        case 1: launch_project_pack_deg<1>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, sched, s); break;
+        case 2: launch_project_pack_deg<2>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, sched, s); break;
+        case 3: launch_project_pack_deg<3>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, sched, s); break;
+        default: launch_project_pack_deg<-1>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, sched, s); break;
     }
     return hipGetLastError();
 }

@@ -1,0 +1,144 @@
+// The compositing schedule from the tile-list lengths of the PREVIOUS frame (GsxParams.hints), put together by eight
+// spare workgroups of the projection launch (the frame's first kernel and, of those in front of the compositing
+// launch, its longest: 25 us at 1M Gaussians, 116 us at 5M) -- one per XCD:
+//   * the window's tiles are dealt to the XCDs in chunks of ~32 consecutive tile ids (ids are column-major: half a
+//     tile column at 1080p; chunk c goes to XCD c % 8, see sched_cut): vertical neighbours, which share most of their
+//     Gaussians, stay in one 4 MiB L2, and every XCD gets its share of a dense region;
+//   * inside an XCD the tiles are ranked by list length (256 classes between its shortest and its longest list) and
+//     the compositing launch hands them to the XCD's 128 SIMDs round by round, alternately forwards and backwards
+//     (blend_tile16_kernel), so that every SIMD gets one tile of every length class.
+// Round 2 ranked the tiles over the whole frame (tile_schedule_kernel: one workgroup, 10 us at 1080p, 22 us at 4K, on
+// the frame's critical path; 3.3x the algorithmic record traffic because neighbours no longer shared an L2); its own
+// measurements had the two-column variant at 270 vs 262 us on the uniform scene and 454 vs 488 us on the heavy-tailed
+// one, with a quarter less traffic -- with the schedule off the critical path the choice is this one.  (One workgroup
+// ranking the whole frame behind the projection was tried first in round 3: 256 threads need 29 us for 8 000 tiles and
+// 190 us for 32 000 -- longer than the kernel that was to hide it; an XCD's share is an eighth of that.)
+//
+// Layout: sched[x * cap + k] = the tile with the k-th longest list of XCD x, k < header[kHintXcdTiles + x]; cap =
+// sched_cap(nt, nwy).  header[kHintSched] = nt when the schedule is there, 0 when the lengths on file are for another
+// window (the compositing launch then takes the tiles in index order).
+#pragma once
+
+#include "gsx_internal.h"
+
+namespace gsx {
+
+struct SchedJob {
+    const uint32_t *lens;       // list length of every tile of the window, left by the previous frame's compositing launch
+    uint32_t *sched, *header;
+    uint32_t nt, nwy, cap;
+};
+
+constexpr uint32_t kSchedXcds = 8;
+
+// The window's nt tiles are cut into 8 k chunks of consecutive ids, k = max(1, nt / 256) per XCD, whose sizes differ
+// by at most one (the first `rem` chunks hold s + 1 tiles, the others s), and chunk c goes to XCD c % 8: every XCD's
+// share of the TILES is within k tiles of an eighth, its share of the list entries as even as ~30 chunks spread over
+// the frame make it.  (Chunks of two whole tile columns -- 59.5 of them at 1080p -- gave four XCDs 8 chunks and four
+// 7, and the compositing launch waited 18 us for the first four: round 3, measured.)
+struct SchedCut {
+    uint32_t k, s, rem;        // chunks per XCD, size of the small chunks, number of chunks of size s + 1
+};
+__host__ __device__ inline SchedCut sched_cut(uint32_t nt) {
+    SchedCut c;
+    c.k = nt / (kSchedXcds * 32u) ? nt / (kSchedXcds * 32u) : 1u;
+    c.s = nt / (kSchedXcds * c.k);
+    c.rem = nt - c.s * kSchedXcds * c.k;
+    return c;
+}
+__host__ __device__ inline uint32_t sched_cap(uint32_t nt, uint32_t /*nwy*/) {
+    const SchedCut c = sched_cut(nt);
+    return (c.s + 1u) * c.k;
+}
+// chunks of XCD x that hold s + 1 tiles (they come first among its chunks x, x + 8, ...)
+__host__ __device__ inline uint32_t sched_big_chunks(const SchedCut &c, uint32_t x) {
+    return c.rem > x ? (c.rem - x + kSchedXcds - 1u) / kSchedXcds : 0u;
+}
+__host__ __device__ inline uint32_t sched_count(uint32_t nt, uint32_t /*nwy*/, uint32_t x) {
+    const SchedCut c = sched_cut(nt);
+    const uint32_t n1 = sched_big_chunks(c, x);
+    return n1 * (c.s + 1u) + (c.k - n1) * c.s;
+}
+// the j-th tile of XCD x
+__host__ __device__ inline uint32_t sched_tile_of(uint32_t j, uint32_t x, const SchedCut &c) {
+    const uint32_t n1 = sched_big_chunks(c, x), big = n1 * (c.s + 1u);
+    uint32_t q, r;
+    if (j < big) {
+        q = j / (c.s + 1u);
+        r = j % (c.s + 1u);
+    } else {
+        q = n1 + (j - big) / c.s;     // (c.s > 0 here: j >= big means a small chunk holds tile j)
+        r = (j - big) % c.s;
+    }
+    const uint32_t ch = x + kSchedXcds * q;
+    return ch * c.s + (ch < c.rem ? ch : c.rem) + r;
+}
+
+// All 256 threads of spare workgroup x (0 .. 7) call this.
+__device__ __forceinline__ void schedule_from_lengths(const SchedJob &job, uint32_t x) {
+    constexpr uint32_t kClasses = 256;
+    __shared__ uint32_t hist[kClasses];
+    __shared__ uint32_t s_lo, s_hi, s_wsum[4];
+    const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const uint32_t nt = job.nt;
+    const SchedCut cut = sched_cut(nt);
+    if (job.header[kHintLens] != nt) {          // nothing usable on file: the compositing launch falls back to index order
+        if (x == 0 && tid == 0) job.header[kHintSched] = 0u;
+        return;
+    }
+    const uint32_t mine_n = sched_count(nt, job.nwy, x);
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    for (uint32_t j = tid; j < mine_n; j += nthreads) {
+        const uint32_t l = job.lens[sched_tile_of(j, x, cut)];
+        mn = min(mn, l);
+        mx = max(mx, l);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    }
+    if (tid < kClasses) hist[tid] = 0;
+    if (tid == 0) {
+        s_lo = 0xFFFFFFFFu;
+        s_hi = 0u;
+    }
+    __syncthreads();
+    if (lane == 0 && mn <= mx) {
+        atomicMin(&s_lo, mn);
+        atomicMax(&s_hi, mx);
+    }
+    __syncthreads();
+    const uint32_t shortest = s_lo;
+    const float per_entry = (float)(kClasses - 1) / (float)max(s_hi - shortest, 1u);
+    auto cls = [&](uint32_t l) -> uint32_t {   // class 0 = the longest lists
+        return (kClasses - 1u) - min((uint32_t)((float)(l - shortest) * per_entry), kClasses - 1u);
+    };
+    for (uint32_t j = tid; j < mine_n; j += nthreads) atomicAdd(&hist[cls(job.lens[sched_tile_of(j, x, cut)])], 1u);
+    __syncthreads();
+    const uint32_t mine = tid < kClasses ? hist[tid] : 0u;     // (256 threads: one class each)
+    uint32_t v = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)v, o);
+        if (lane >= o) v += y;
+    }
+    if (lane == 63) s_wsum[w] = v;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int k = 0; k < w; ++k) before += s_wsum[k];
+    if (tid < kClasses) hist[tid] = before + v - mine;   // first slot of this class
+    __syncthreads();
+    uint32_t *out = job.sched + (size_t)x * job.cap;
+    for (uint32_t j = tid; j < mine_n; j += nthreads) {
+        const uint32_t t = sched_tile_of(j, x, cut);
+        out[atomicAdd(&hist[cls(job.lens[t])], 1u)] = t;
+    }
+    if (tid == 0) {
+        job.header[kHintXcdTiles + x] = mine_n;
+        if (x == 0) job.header[kHintSched] = nt;
+    }
+}
+
+}  // namespace gsx

@@ -124,70 +124,6 @@ __device__ __forceinline__ uint32_t splitter_at(const uint32_t *__restrict__ spl
     return splitters[k];
 }
 
-// The compositing schedule from the tile-list lengths of the PREVIOUS frame (GsxParams.hints): sched[k] = the tile
-// with the k-th longest list, 1024 length classes between the shortest and the longest (what tile_schedule_kernel
-// computes from this frame's ranges, gsx_binning.hip -- here one spare 1024-thread workgroup of the partition's
-// count launch does it while that kernel runs anyway).  hist: 1024 words of LDS.  Tiles in any order inside a
-// class.  header[kHintSched] = nt when done (0 when the lengths on file are for another tile count).
-struct SchedJob {
-    const uint32_t *lens;
-    uint32_t *sched, *header;
-    uint32_t nt;
-};
-__device__ __forceinline__ void schedule_from_lengths(const SchedJob &job, uint32_t *hist) {
-    __shared__ uint32_t s_lo, s_hi, s_wsum[16];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t nt = job.nt;
-    if (job.header[kHintLens] != nt) {          // nothing usable on file: the compositing launch falls back to index order
-        if (threadIdx.x == 0) job.header[kHintSched] = 0u;
-        return;
-    }
-    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-    for (uint32_t t = threadIdx.x; t < nt; t += blockDim.x) {
-        const uint32_t l = job.lens[t];
-        mn = min(mn, l);
-        mx = max(mx, l);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
-        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
-    }
-    hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) {
-        s_lo = 0xFFFFFFFFu;
-        s_hi = 0u;
-    }
-    __syncthreads();
-    if (lane == 0 && mn <= mx) {
-        atomicMin(&s_lo, mn);
-        atomicMax(&s_hi, mx);
-    }
-    __syncthreads();
-    const uint32_t shortest = s_lo;
-    const float per_entry = 1023.0f / (float)max(s_hi - shortest, 1u);
-    auto cls = [&](uint32_t l) -> uint32_t {   // class 0 = the longest lists
-        return 1023u - min((uint32_t)((float)(l - shortest) * per_entry), 1023u);
-    };
-    for (uint32_t t = threadIdx.x; t < nt; t += blockDim.x) atomicAdd(&hist[cls(job.lens[t])], 1u);
-    __syncthreads();
-    const uint32_t mine = hist[threadIdx.x];
-    uint32_t x = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)x, o);
-        if (lane >= o) x += y;
-    }
-    if (lane == 63) s_wsum[w] = x;
-    __syncthreads();
-    uint32_t before = 0;
-    for (int k = 0; k < w; ++k) before += s_wsum[k];
-    hist[threadIdx.x] = before + x - mine;   // first slot of this class
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < nt; t += blockDim.x) job.sched[atomicAdd(&hist[cls(job.lens[t])], 1u)] = t;
-    if (threadIdx.x == 0) job.header[kHintSched] = nt;
-}
-
 // Each thread owns kRounds CONSECUTIVE items of one chunk (one or two 16-byte loads) -- the histogram does
 // not care about order, so the count kernel reads wide; the scatter kernel needs the wave-striped order.
 // CHUNK_MAJOR (small inputs): 256 threads, one chunk, table[chunk][digit] (what the self-scanning scatter
@@ -201,8 +137,7 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
                  uint32_t mask, uint32_t *__restrict__ table, int nbp, uint32_t *__restrict__ culled,
                  const uint32_t *__restrict__ splitters = nullptr, uint32_t *__restrict__ quad_totals = nullptr,
                  const uint32_t *__restrict__ hint_hdr = nullptr, uint32_t *__restrict__ samples_out = nullptr,
-                 uint32_t sample_step = 0, unsigned long long *__restrict__ zero_sums = nullptr, uint32_t nsums = 0,
-                 SchedJob sched_job = SchedJob{nullptr, nullptr, nullptr, 0u}) {
+                 uint32_t sample_step = 0, unsigned long long *__restrict__ zero_sums = nullptr, uint32_t nsums = 0) {
     constexpr int kLanes = CHUNK_MAJOR ? 1 : kQuad;   // chunks per workgroup
     constexpr int NB = SPLIT ? SPLIT : kBins;         // histogram rows
     constexpr int kPerVec = 16 / sizeof(Key), kVecs = kRounds / kPerVec;   // 8 x u16 or 4 x u32 per 16 B
@@ -248,10 +183,6 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
             }
             samples_out[k] = pick;
         }
-    }
-    if (FIRST && SPLIT == kBins && !CHUNK_MAJOR && sched_job.sched && blockIdx.x == gridDim.x - 1) {
-        schedule_from_lengths(sched_job, &h[0][0]);     // the launch's spare workgroup (h = 1024 words of LDS)
-        return;
     }
     auto digit = [&](uint32_t k) -> uint32_t { return SPLIT ? bucket_of<NB>(spl, k) : ((k >> shift) & mask); };
 #pragma unroll
@@ -1301,18 +1232,22 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
 
 
 // Which route sorts the depth keys of a frame (gsx_internal.h: DepthRoute).  What decides is how many keys are
-// KEPT -- the sample-partitioned routes drop the others in their one pass over the n keys and sort the rest in
+// KEPT -- the sample-partitioned route drops the others in its one pass over the n keys and sorts the rest in
 // LDS buckets -- and that number is known to the caller from an earlier frame of the view (GsxParams.kept_hint;
-// without it: n).  A bucket is sorted in LDS up to kBucketCap = 16 384 keys; the routes keep the MEAN bucket below
+// without it: n).  A bucket is sorted in LDS up to kBucketCap = 16 384 keys; the route keeps the MEAN bucket below
 // ~6 000 (with 8 samples per bucket a bucket of 2.8x the mean has probability ~1e-4), and a bucket that does
 // not fit is still sorted correctly, through global memory: a wrong hint costs time, never the order.
 //   n <= 16 384                    one workgroup does everything in LDS
 //   kept <= 1.5M                   256 buckets   (1M Gaussians at 1080p; one rank's strip of 5M at 4K)
-//   kept <= 6M                     1024 buckets  (5M Gaussians at 4K on one GPU)
 //   beyond                         four compacting LSD passes of 8 bits
-constexpr int64_t kSampledMin = 8 * kSamples, kKeptMax256 = 1536 * 1024, kKeptMax1024 = 6 * 1024 * 1024;
-
-bool depth_partition_has_spare_workgroup(int64_t n) { return (n + kItems - 1) / kItems > kSelfScanBlocks; }
+// Measured, depth sort alone (tools/sort_probe.py under rocprofv3, round 3):  1.5M keys: 256 buckets 83 us (72 with
+// the previous frame's splitters), LSD 107;  2.2M: LSD 137, 1024 buckets 179;  5M: LSD 260, 1024 buckets 284;  5M
+// of which 1/8 kept (a rank's strip): 256 buckets 94 (70 hinted).  The 1024-bucket variant (8192 samples, 1023
+// splitters, hybrid LDS-word / ballot matching) was built for 1.5M .. 6M kept keys and LOSES to the LSD passes at
+// every size: a 2048-key chunk holds two keys per bucket, so its scatter writes 8-byte runs (125 us at 5M against
+// 31 us for a plain 8-bit pass), and ranking 8192 samples costs 40 us.  It stays selectable for the tests (the
+// partition machinery is the same templates), no frame takes it.
+constexpr int64_t kSampledMin = 8 * kSamples, kKeptMax256 = 1536 * 1024;
 
 DepthRoute depth_sort_route(int64_t n, int64_t kept_hint) {
     const int force = knob("GSX_DEPTH_SORT", -1);   // test library only: a DepthRoute
@@ -1320,9 +1255,7 @@ DepthRoute depth_sort_route(int64_t n, int64_t kept_hint) {
     if (force == kDepthLsd || n < kSampledMin) return kDepthLsd;
     if (force == kDepth256 || force == kDepth1024) return (DepthRoute)force;
     const int64_t kept = kept_hint > 0 && kept_hint < n ? kept_hint : n;
-    if (kept <= kKeptMax256) return kDepth256;
-    if (kept <= kKeptMax1024) return kDepth1024;
-    return kDepthLsd;
+    return kept <= kKeptMax256 ? kDepth256 : kDepthLsd;
 }
 
 // The partition pass of the sampled routes: keys0 -> (keys1, vals_alt, rrect in partition order), values generated.
@@ -1330,8 +1263,7 @@ template <int NB>
 static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1, uint32_t *vals_cur, uint32_t *vals_alt,
                              int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
                              const uint32_t *splitters, const uint32_t *hdr, uint32_t *samples_out, uint32_t step,
-                             unsigned long long *zero_sums, uint32_t nsums, const SchedJob &job, hipStream_t s) {
-    const unsigned spare = (NB == kBins && job.sched) ? 1u : 0u;    // one more count workgroup: the compositing schedule
+                             unsigned long long *zero_sums, uint32_t nsums, hipStream_t s) {
     if (NB == kBins && p.self_scan) {
         count_kernel<uint32_t, true, true, kBins><<<p.nblocks, kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u, p.table,
                                                                                  p.nbp, culled_dev, splitters, nullptr, hdr,
@@ -1340,16 +1272,16 @@ static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
             nullptr, hdr);
     } else if (NB == kBins && p.scan == kScanQuads) {
-        count_kernel<uint32_t, false, true, kBins><<<p.nquads + spare, kQuad * kThreads, 0, s>>>(
+        count_kernel<uint32_t, false, true, kBins><<<p.nquads, kQuad * kThreads, 0, s>>>(
             keys0, nullptr, (uint32_t)n, 0, 255u, p.table, p.nbp, culled_dev, splitters, p.quad_totals, hdr, samples_out, step,
-            zero_sums, nsums, job);
+            zero_sums, nsums);
         scatter_kernel<uint32_t, kScanQuads, kModeFirst, 8, kBins><<<p.nblocks, kThreads, 0, s>>>(
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
             p.quad_totals, hdr);
     } else {
-        count_kernel<uint32_t, false, true, NB><<<p.nquads + spare, kQuad * kThreads, 0, s>>>(
+        count_kernel<uint32_t, false, true, NB><<<p.nquads, kQuad * kThreads, 0, s>>>(
             keys0, nullptr, (uint32_t)n, 0, 255u, p.table, p.nbp, culled_dev, splitters, nullptr, NB == kBins ? hdr : nullptr,
-            NB == kBins ? samples_out : nullptr, step, zero_sums, nsums, NB == kBins ? job : SchedJob{nullptr, nullptr, nullptr, 0u});
+            NB == kBins ? samples_out : nullptr, step, zero_sums, nsums);
         row_scan_kernel<<<NB, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
         scatter_kernel<uint32_t, kScanRows, kModeFirst, 8, NB><<<p.nblocks, kThreads, 0, s>>>(
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
@@ -1390,7 +1322,7 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
     if (nb > kBins) {
         sample_rank_kernel<kSortBinsMax><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
         launch_partition<kSortBinsMax>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect, splitters, nullptr,
-                                       nullptr, 0u, nullptr, 0u, SchedJob{nullptr, nullptr, nullptr, 0u}, s);
+                                       nullptr, 0u, nullptr, 0u, s);
         bucket_sort_kernel<kSortBinsMax><<<kSortBinsMax, kBigThreads, 0, s>>>(p.totals, p.table, 0, keys1, vals_alt, keys0, vals_cur,
                                                                               rect, rrect, lds_cap, cs);
     } else {
@@ -1398,8 +1330,7 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
         if (!use) sample_rank_kernel<kBins><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
         launch_partition<kBins>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect,
                                 use ? hints.splitters : splitters, use ? hints.header : nullptr, samples_out, step,
-                                use ? cs : nullptr, nsums,
-                                SchedJob{hints.lens, (use && !p.self_scan) ? hints.sched : nullptr, hints.header, hints.ntiles}, s);
+                                use ? cs : nullptr, nsums, s);
         bucket_sort_kernel<kBins><<<kBins, kBigThreads, 0, s>>>(p.totals, p.table, p.self_scan ? p.nblocks : 0, keys1, vals_alt,
                                                                 keys0, vals_cur, rect, rrect, lds_cap, cs);
     }

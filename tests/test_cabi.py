@@ -82,8 +82,8 @@ def test_argument_errors_do_not_need_a_gpu():
     small, big = lib.gsx_workspace_bytes(1000, 256, 256, 16, 8000), lib.gsx_workspace_bytes(1_000_000, 1920, 1080, 16, 5_000_000)
     assert 0 < small < big and big % 256 == 0
     assert lib.gsx_hints_bytes(0, 64, 16) == 0
-    # header + 256 splitters + 2048 samples + two words per tile (120 x 68 tiles at 1080p, each array rounded up to 256 bytes)
-    assert lib.gsx_hints_bytes(1920, 1080, 16) == 256 + 1024 + 8192 + 2 * 32768
+    # header + 256 splitters + 2048 samples + list lengths (120 x 68 tiles at 1080p) + per-XCD schedule (tiles + 16 x 120)
+    assert lib.gsx_hints_bytes(1920, 1080, 16) == 256 + 1024 + 8192 + 32768 + 40448
     assert big >= 1_000_000 * (16 + 48 + 8 + 8 + 16) + 5_000_000 * 16
     rc = lib.gsx_project_points(None, None, 0, None, None, None)
     assert rc == _ffi.GSX_ERR_INVALID_ARGUMENT
