@@ -447,6 +447,10 @@ def main() -> None:
                     help="N > 1: strips balanced by the per-tile-row pair counts of a planning frame, gathered point to "
                          "point (default: equal strips and ONE dist.gather -- the plainer collective stays the default "
                          "until a multi-GPU node has confirmed strips_equal_single_gpu for the balanced path)")
+    ap.add_argument("--strip-of", type=int, default=0,
+                    help="profiling aid, 1 GPU: render only the strip that rank N/2 of an N-rank run would own (equal "
+                         "strips of tile columns) -- what one rank of BASELINE config 5 spends per frame before the gather; "
+                         "separate launches (no graph), the line says so in config.workload")
     ap.add_argument("--test-lib", action="store_true",
                     help="development: run on libgsx_test.so (same kernels + GSX_* measurement knobs from the environment)")
     ap.add_argument("--sync-frames", action="store_true",
@@ -485,6 +489,16 @@ def main() -> None:
     else:
         sc, scene = build_scene(args.workload, str(device))
     tile, layout, sem = 16, "wh3", args.semantics
+    strip_window = strip_out = None
+    if args.strip_of > 1:
+        if world != 1:
+            raise SystemExit("--strip-of is a one-GPU profiling aid")
+        n_lead, n_other = strips.tiles_along(width, tile, sem), strips.tiles_along(height, tile, sem)
+        t0_, t1_ = strips.strip_plan(n_lead, args.strip_of)[1][args.strip_of // 2]
+        strip_window = (t0_, t1_, 0, n_other)
+        strip_out = torch.empty(((t1_ - t0_) * tile, height, 3), dtype=torch.float32, device=device)
+        desc += " -- strip %d of %d (tile columns [%d,%d)), one GPU" % (args.strip_of // 2, args.strip_of, t0_, t1_)
+        args.no_graphs, args.no_cpu_baseline, args.streams = True, True, 1
 
     # N > 1: every rank renders the frame once (untimed), reads the per-tile list lengths the library reports
     # (GsxParams.tile_counts) and derives the same balanced strip plan from them -- no communication needed
@@ -541,6 +555,9 @@ def main() -> None:
 
     def single_frame():
         """ONE frame, nothing else in flight: what SURVEY.md 8(d) times."""
+        if strip_window is not None:
+            return scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=strip_window, out=strip_out,
+                                          out_origin=(strip_window[0] * tile, 0), no_sync=not args.sync_frames, semantics=sem)
         if world > 1:
             return strips.render_sharded(render_strip, width, height, tile, layout, device, cache=strip_cache,
                                          semantics=sem, plan=strip_plan)
@@ -610,7 +627,8 @@ def main() -> None:
         median_ms = float(t.item())
     else:
         median_ms = float(np.median(frame_ms))
-    mpix = width * height / (median_ms * 1e-3) / 1e6
+    frame_pixels = width * height if strip_window is None else (strip_window[1] - strip_window[0]) * tile * height
+    mpix = frame_pixels / (median_ms * 1e-3) / 1e6
 
     # ---- for reference: several frames in flight (whole-job throughput of a stream of frames)
     inflight_ms = None
@@ -658,7 +676,7 @@ def main() -> None:
     stage = {}
     stats = {}
     reps = max(3, min(args.steps, 10))
-    window = None
+    window = strip_window
     if world > 1:
         plan = strip_plan or strips.strip_plan(strips.tiles_along(width, tile, sem), world)[1]
         window = (plan[rank][0], plan[rank][1], 0, strips.tiles_along(height, tile, sem))
@@ -671,7 +689,7 @@ def main() -> None:
 
     # how long the tile lists are (GsxParams.tile_counts): the compositing kernel lasts as long as its longest
     tile_list = None
-    if world == 1:
+    if world == 1 and strip_window is None:
         ntx_, nty_ = strips.tiles_along(width, tile, sem), strips.tiles_along(height, tile, sem)
         if ntx_ * nty_ > 0:
             tc = torch.zeros(ntx_ * nty_, dtype=torch.int32, device=device)
@@ -717,7 +735,7 @@ def main() -> None:
             # whole-job rate with several frames in flight on separate HIP streams (not the contract's number)
             "value_frames_in_flight": None if inflight_ms is None else round(width * height / (inflight_ms * 1e-3) / 1e6, 2),
             "config": {"workload": desc, "n_gaussians": n, "width": width, "height": height, "tile": tile,
-                       "semantics": sem, "layout": layout, "n_visible": nvis, "tile_instances": d,
+                       "semantics": sem, "layout": layout, "n_visible": nvis, "n_kept": int(stats.get("n_kept") or 0), "tile_instances": d,
                        "frames_in_flight": 1,
                        "launch": "one hipGraph replay per frame" if one is not None else "separate kernel launches",
                        "ms_per_frame_in_flight": None if inflight_ms is None else round(inflight_ms, 4),

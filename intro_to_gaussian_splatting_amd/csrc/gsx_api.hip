@@ -123,7 +123,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             }
         }
         GSX_HIP(gsx::emit_instances(temp, rrect, order, m_dev, n, cap, p.grid, ws + c.tkeys0, (uint32_t *)(ws + c.tvals0),
-                                    ranges, bc, sums_ready, s));
+                                    ranges, bc, sums_ready, p.kept_hint, s));
         counts_on_device = true;
         tm.mark();  // 3: scan + emit
         if (p.grid.count() == 0) {
@@ -337,9 +337,10 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
         const gsx::HintsLayout hl = gsx::hints_layout(max_tiles_of(camera->width, camera->height, tile_size),
                                                       max_axis_tiles_of(camera->width, camera->height, tile_size));
         uint32_t *hdr = (uint32_t *)p.hints;
-        if (route == gsx::kDepth256) {
-            sh = gsx::SortHints{hdr, (const uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.samples), p.hints_valid};
-        }
+        // (the LSD passes of larger scenes have no use for splitters, but they leave the sample all the same: the next
+        // frame of the view may take the 256-bucket route -- a rank's strip does once its kept count is known)
+        sh = gsx::SortHints{hdr, (const uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.samples),
+                            p.hints_valid && route == gsx::kDepth256};
         fh.blend = gsx::BlendHints{hdr, sh.samples, (uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.lens), 0u};
         // the schedule costs nothing here (a spare workgroup of the projection launch): every window of more than two
         // tiles per SIMD gets one, unless told not to
@@ -360,7 +361,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
                                         (gsx::TileRect *)(ws + c.rrect), 0, gsx::emit_chunk_sums(ws + c.temp, n, cap), sh, s));
     else
         GSX_HIP(gsx::sort_depth_compact(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
-                                        (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s));
+                                        (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s, sh.samples));
     tm.mark();  // 2: depth sort (drops what reaches no tile, leaves the rectangles in rank order)
     return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rrect), v0, counters + kCtrKept,
                          counters + kCtrCulled, sampled, stats_host, tm, s, fh);

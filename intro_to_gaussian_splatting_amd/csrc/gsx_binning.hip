@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(kBlock)
     emit_kernel(const TileRect *__restrict__ rrect, const uint32_t *__restrict__ order,
                 const uint32_t *__restrict__ m_dev, uint32_t bound, const uint64_t *__restrict__ sums, int nchunks,
                 TileGrid g, uint32_t limit, Key *__restrict__ keys, uint32_t *__restrict__ vals,
-                uint2 *__restrict__ ranges, EmitCounts ec) {
+                uint2 *__restrict__ ranges, EmitCounts ec, uint32_t eager) {
     __shared__ uint64_t wsum[4];
     __shared__ uint32_t offs[kChunk + 1];
     __shared__ __attribute__((aligned(16))) EmitSlot slot[kChunk + 2];
@@ -187,12 +187,20 @@ __global__ void __launch_bounds__(kBlock)
     //      before this chunk, its rectangles and indices (bounded by the host-known `bound`; what lies beyond
     //      the kept count is masked afterwards): one trip to memory instead of three dependent ones.  With one
     //      workgroup per 1024 ranks and all of them resident the kernel's duration IS that chain.
+    // A workgroup whose ranks lie below `eager` -- the number of kept Gaussians the caller expects (GsxParams.kept_hint,
+    // with a margin; without a hint: all n) -- requests its rectangles and indices before it knows the kept count; one
+    // beyond reads the count first and, nearly always, finds it has nothing to fetch: on a rank that owns 1/8 of the
+    // frame the eager form read 60 MB of rectangles and indices where 7.7 MB are in use (round 3, PMC).
     TileRect r[kPerThread];
     uint32_t gidx[kPerThread];
-    load_rects(rrect, first, bound, r);
+    const bool early = blockIdx.x * (uint32_t)kChunk < eager;
+    uint32_t m = 0;
+    if (!early) m = load_count(m_dev, bound);
+    const uint32_t fetch_bound = early ? bound : m;
+    load_rects(rrect, first, fetch_bound, r);
 #pragma unroll
-    for (int k = 0; k < kPerThread; ++k) gidx[k] = first + k < bound ? (order ? order[first + k] : first + k) : 0u;
-    const uint32_t m = load_count(m_dev, bound);
+    for (int k = 0; k < kPerThread; ++k) gidx[k] = first + k < fetch_bound ? (order ? order[first + k] : first + k) : 0u;
+    if (early) m = load_count(m_dev, bound);
     uint64_t base;
     const bool last = (int)blockIdx.x == nchunks - 1;
     if (PREFIXED) {
@@ -518,7 +526,7 @@ static uint64_t *sums_of(void *temp, int64_t n, int64_t cap) {
 template <typename Key>
 hipError_t emit_impl(void *temp, const TileRect *rrect, const uint32_t *order, const uint32_t *m_dev, int64_t n,
                      int64_t cap, const TileGrid &grid, void *keys0, uint32_t *vals0, uint2 *ranges, const BinCounts &bc,
-                     bool sums_ready, hipStream_t s) {
+                     bool sums_ready, uint32_t eager, hipStream_t s) {
     const int64_t nt = grid.count();
     const int nchunks = (int)((n + kChunk - 1) / kChunk);
     uint64_t *sums = sums_of(temp, n, cap);
@@ -528,11 +536,11 @@ hipError_t emit_impl(void *temp, const TileRect *rrect, const uint32_t *order, c
     const unsigned egrid = (unsigned)nchunks > tiles_grid ? (unsigned)nchunks : tiles_grid;
     if (nchunks <= kSelfScanChunks) {
         emit_kernel<Key, false><<<egrid, kBlock, 0, s>>>(rrect, order, m_dev, (uint32_t)n, sums, nchunks, grid,
-                                                         (uint32_t)cap, (Key *)keys0, vals0, ranges, ec);
+                                                         (uint32_t)cap, (Key *)keys0, vals0, ranges, ec, eager);
     } else {
         scan_sums_kernel<<<1, kBlock, 0, s>>>(sums, nchunks);
         emit_kernel<Key, true><<<egrid, kBlock, 0, s>>>(rrect, order, m_dev, (uint32_t)n, sums, nchunks, grid,
-                                                        (uint32_t)cap, (Key *)keys0, vals0, ranges, ec);
+                                                        (uint32_t)cap, (Key *)keys0, vals0, ranges, ec, eager);
     }
     return hipGetLastError();
 }
@@ -557,11 +565,14 @@ hipError_t sort_impl(void *temp, int64_t cap, void *keys0, void *keys1, uint32_t
 
 hipError_t emit_instances(void *temp, const TileRect *rrect, const uint32_t *order, const uint32_t *m_dev, int64_t n,
                           int64_t cap, const TileGrid &grid, void *keys0, uint32_t *vals0, uint2 *ranges,
-                          const BinCounts &bc, bool sums_ready, hipStream_t s) {
+                          const BinCounts &bc, bool sums_ready, int64_t kept_hint, hipStream_t s) {
     if (n <= 0) return hipErrorInvalidValue;   // callers handle the empty scene themselves
+    // ranks expected to exist: the hint with 2 % + a chunk of margin (a larger count is still handled, one trip later)
+    const int64_t expect = kept_hint > 0 && kept_hint < n ? kept_hint + kept_hint / 50 + kChunk : n;
+    const uint32_t eager = (uint32_t)(expect < n ? expect : n);
     if (grid.count() <= 65536)
-        return emit_impl<uint16_t>(temp, rrect, order, m_dev, n, cap, grid, keys0, vals0, ranges, bc, sums_ready, s);
-    return emit_impl<uint32_t>(temp, rrect, order, m_dev, n, cap, grid, keys0, vals0, ranges, bc, sums_ready, s);
+        return emit_impl<uint16_t>(temp, rrect, order, m_dev, n, cap, grid, keys0, vals0, ranges, bc, sums_ready, eager, s);
+    return emit_impl<uint32_t>(temp, rrect, order, m_dev, n, cap, grid, keys0, vals0, ranges, bc, sums_ready, eager, s);
 }
 
 uint64_t *emit_chunk_sums(void *temp, int64_t n, int64_t cap) { return sums_of(temp, n, cap); }

@@ -130,7 +130,7 @@ struct BinCounts {
 // holds the chunk sums (the sampled depth sort left them there).
 hipError_t emit_instances(void *temp, const TileRect *rrect, const uint32_t *order, const uint32_t *m_dev, int64_t n,
                           int64_t cap, const TileGrid &grid, void *keys0, uint32_t *vals0, uint2 *ranges,
-                          const BinCounts &bc, bool sums_ready, hipStream_t s);
+                          const BinCounts &bc, bool sums_ready, int64_t kept_hint, hipStream_t s);
 // Stable sort of the emitted pairs by tile id and ranges[t] = [first, last) for every tile of the
 // window; *sorted_vals points at the sorted Gaussian indices.  The pair count is read from *d32.
 hipError_t sort_instances(void *temp, int64_t cap, const TileGrid &grid, void *keys0, void *keys1, uint32_t *vals0,
@@ -156,7 +156,7 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
 // first pass are the item positions themselves (vals_cur need not be initialised).
 hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
-                              hipStream_t s);
+                              hipStream_t s, uint32_t *samples_out = nullptr);
 
 // The same contract with 5 kernels instead of 12: sample 2048 / 8192 keys -> 255 / 1023 splitters, ONE stable
 // partition pass, one in-LDS sort per bucket (gsx_sort.hip).  depth_sort_route picks the route from the

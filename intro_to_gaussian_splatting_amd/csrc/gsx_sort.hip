@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
         for (uint32_t k = threadIdx.x; k < (uint32_t)NB; k += blockDim.x) spl[k] = splitter_at(splitters, hint_hdr, k);   // visible after the barrier below
     if (FIRST && SPLIT && zero_sums)   // (no sample kernel ran: the chunk sums the bucket kernel adds to start from zero here)
         for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nsums; k += gridDim.x * blockDim.x) zero_sums[k] = 0ull;
-    if (FIRST && SPLIT && samples_out && sample_step) {
+    if (FIRST && sizeof(Key) == 4 && samples_out && sample_step) {
         // What the NEXT frame's splitters are made from (GsxParams.hints): kSamples regularly spaced keys, kept ones
         // where possible -- the thread whose 8 keys hold position k * step hands over the first of them, from that
         // position on, that the sort keeps (a rank's strip keeps 1 key in 8: a plain regular sample would be 7/8 void)
@@ -1173,23 +1173,26 @@ inline int pass_bits(int key_bits) {
 template <typename Key, int MODE, int BITS>
 void launch_pass(const PassPlan &p, const Key *kc, const uint32_t *vc, Key *ka, uint32_t *va, const uint32_t *n_dev,
                  int64_t bound, int shift, uint32_t *m_out, uint32_t *culled, const TileRect *rect, TileRect *rrect,
-                 hipStream_t s) {
+                 hipStream_t s, uint32_t *samples_out = nullptr, uint32_t sample_step = 0) {
     constexpr uint32_t mask = (1u << BITS) - 1u;
     constexpr bool first = (MODE & kModeFirst) != 0;
     if (p.self_scan) {
         count_kernel<Key, true, first><<<p.nblocks, kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, mask, p.table,
-                                                                       p.nbp, culled);
+                                                                       p.nbp, culled, nullptr, nullptr, nullptr, samples_out,
+                                                                       sample_step);
         scatter_kernel<Key, kScanSelf, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
                                                                                    shift, p.table, p.totals, p.nbp, m_out, rect,
                                                                                    rrect);
     } else if (p.scan == kScanQuads) {
         count_kernel<Key, false, first><<<p.nquads, kQuad * kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, mask,
-                                                                               p.table, p.nbp, culled, nullptr, p.quad_totals);
+                                                                               p.table, p.nbp, culled, nullptr, p.quad_totals,
+                                                                               nullptr, samples_out, sample_step);
         scatter_kernel<Key, kScanQuads, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(
             kc, vc, ka, va, n_dev, (uint32_t)bound, shift, p.table, p.totals, p.nbp, m_out, rect, rrect, nullptr, p.quad_totals);
     } else {
         count_kernel<Key, false, first><<<p.nquads, kQuad * kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, mask,
-                                                                               p.table, p.nbp, culled);
+                                                                               p.table, p.nbp, culled, nullptr, nullptr, nullptr,
+                                                                               samples_out, sample_step);
         row_scan_kernel<<<1u << BITS, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
         scatter_kernel<Key, kScanRows, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
                                                                                    shift, p.table, p.totals, p.nbp, m_out, rect,
@@ -1343,7 +1346,7 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
 // On return vals_cur[0 .. *m_dev) = Gaussian index of each depth rank.
 hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
-                              hipStream_t s) {
+                              hipStream_t s, uint32_t *samples_out) {
     if (n <= 0) return hipSuccess;
     const PassPlan p = plan_for(temp, n);
     uint32_t *kc = keys0, *ka = keys1;
@@ -1351,7 +1354,10 @@ hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint
         uint32_t *tk = kc; kc = ka; ka = tk;
         uint32_t *tv = vals_cur; vals_cur = vals_alt; vals_alt = tv;
     };
-    launch_pass<uint32_t, kModeFirst, 8>(p, kc, vals_cur, ka, vals_alt, nullptr, n, 0, m_dev, culled_dev, nullptr, nullptr, s);
+    // (samples_out: GsxParams.hints -- pass 0's count kernel leaves the sample of kept keys a later frame's splitters
+    // are ranked from, should that frame take the 256-bucket route: a rank's strip does, once its kept count is known)
+    launch_pass<uint32_t, kModeFirst, 8>(p, kc, vals_cur, ka, vals_alt, nullptr, n, 0, m_dev, culled_dev, nullptr, nullptr, s,
+                                         samples_out, samples_out && n >= kSamples ? (uint32_t)(n / kSamples) : 0u);
     flip();
     for (int shift = 8; shift < 24; shift += 8) {
         launch_pass<uint32_t, kModePlain, 8>(p, kc, vals_cur, ka, vals_alt, m_dev, n, shift, nullptr, nullptr, nullptr, nullptr, s);

@@ -335,9 +335,14 @@ def test_4k_5m_stress_properties(tmp_path):
     frame[ntx * 16:].zero_()
     per_rank = []
     for t0, t1 in plan:
-        st = {}
-        scene.render_image_hip(1, tile_window=(t0, t1, 0, nty), out=frame[t0 * 16:t1 * 16], out_origin=(t0 * 16, 0),
-                               stats=st, timing=True)
+        # twice: the second frame of a window is what a rank renders frame after frame -- pair capacity sized by the
+        # count, depth-sort route picked from the kept count (GsxParams.kept_hint), splitters and schedule from the
+        # hints the first one left
+        for rep in range(2):
+            st = {}
+            scene.render_image_hip(1, tile_window=(t0, t1, 0, nty), out=frame[t0 * 16:t1 * 16], out_origin=(t0 * 16, 0),
+                                   stats=st, timing=True)
+        assert st["n_kept"] < 0.2 * 5_000_000                 # an eighth of the frame keeps about an eighth of the Gaussians
         per_rank.append((st["n_instances"], st["stage_ms"]))
     assert torch.equal(frame, a)
     assert sum(p[0] for p in per_rank) >= inst               # a Gaussian on a strip border is binned by both ranks
@@ -352,6 +357,10 @@ def test_4k_5m_stress_properties(tmp_path):
     print("C4 full frame stage ms: %s" % {k: round(v, 3) for k, v in full_ms.items()})
     print("C4 1/8 strip stage ms:  %s" % {k: round(v, 3) for k, v in strip_ms.items()})
     assert strip_ms["depth_sort"] + strip_ms["scan"] <= 0.5 * (full_ms["depth_sort"] + full_ms["scan"])
+    # round-3 bar (VERDICT r2, next #1b): a rank's strip in <= 0.40 ms where the frame takes ~2 ms -- measured as the
+    # median of event-bracketed frames by `bench.py --workload c4 --strip-of 8` (0.386 ms); the per-stage times printed
+    # here are taken with a host synchronisation per stage mark and add up to more
+    assert strip_ms["total"] <= 0.30 * full_ms["total"]
 
 
 def test_long_tiles_on_four_waves_equal_the_single_wave_path(tmp_path):
