@@ -572,6 +572,9 @@ def main() -> None:
         torch.cuda.synchronize()
 
     # setup, untimed: let clocks and caches settle (the first ~100 frames after start-up run 5-10 % slow)
+    single_frame()              # the first frame learns the counts every later one is sized and routed by
+    torch.cuda.synchronize()
+    scene.confirm_frames()
     t_settle = time.perf_counter()
     while True:
         for _ in range(8):

@@ -143,6 +143,16 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             tm.mark();  // 4: tile sort (+ the compositing schedule)
             gsx::BlendHints bh = fh.blend;
             bh.xcd_sched = fh.sched ? 1u : 0u;
+            // The 128 spare workgroups hold 16 wave slots of every XCD for ~15 us.  In front of the tiles that is free
+            // -- unless the window's tiles fill the chip's 8 192 wave slots just about once (1080p: 7 973 tiles): then
+            // some tiles find no slot until the spare workgroups are done.  Behind the tiles they are dispatched as
+            // slots free up -- late, so only a frame whose compositing lasts several times their 15 us takes them
+            // there (pairs per tile, from the pair capacity = last frame's count).  Measured under rocprofv3, same box:
+            // uniform 1M / 1080p 239 us either way, heavy-tailed 1M / 1080p 382 -> 368 us; a 100k frame (36 us of
+            // compositing) loses 10 us with them last.
+            const int64_t ntl = p.grid.count();
+            bh.rank_last = (fh.sched && ntl > 7400 && ntl <= 8192 && (int64_t)cap >= 128 * ntl) ? 1u : 0u;
+            if (gsx::knob("GSX_RANK_LAST", -1) >= 0) bh.rank_last = (uint32_t)gsx::knob("GSX_RANK_LAST", -1);   // test library only
             GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
                                       ranges, p.grid, p.out, p.semantics, p.background, p.generic,
                                       make_clear_plan(p, false), lt, sched, bh, s));

@@ -63,6 +63,7 @@
 // Test library only (gsx_debug.h: gsx_debug_set_blend_probe): when set, every workgroup of blend_tile16_kernel leaves
 // (cycles, tile, list length, records staged | flags << 24) there, indexed by blockIdx.x -- who is the frame waiting for?
 __device__ uint4 *g_blend_probe = nullptr;
+constexpr uint32_t kProbeSecond = 1u << 17;     // a second record per workgroup starts here (the buffer holds 2^18 records)
 #endif
 
 namespace gsx {
@@ -553,7 +554,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     if (g_blend_probe && lane == 0)
         g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t | 0x40000000u, rg.y - rg.x,
                                                probe_staged | (checked ? 0x80000000u : 0u));
-    if (g_blend_probe && lane == 1) g_blend_probe[gridDim.x + blockIdx.x] = make_uint4(probe_checked_at, 0, 0, 0);
+    if (g_blend_probe && lane == 1) g_blend_probe[kProbeSecond + blockIdx.x] = make_uint4(probe_checked_at, 0, 0, 0);
 #endif
     float *o = out.ptr + (int64_t)(px - out.x0) * out.stride_x + (int64_t)(py - out.y0) * out.stride_y;
     o[0] = c0;
@@ -579,12 +580,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     __shared__ float4 sh[3][kSlots];
     // block order: [spare workgroups: the next frame's splitters] [helpers of long tiles (dispatched first: they have
     // the most to do)] [tiles] [clears]
+    // (hints.rank_last -- gsx_api.hip: a window whose tiles just about fill the chip once -- : the spare workgroups come
+    // last in the grid instead)
     const uint32_t nrank = hints.samples ? kRankGroups : 0u;
-    if (blockIdx.x < nrank) {
-        rank_samples(blockIdx.x, (int)threadIdx.x, hints);
+    const uint32_t rank0 = hints.rank_last ? gridDim.x - nrank : 0u;
+    if (blockIdx.x - rank0 < nrank) {
+        rank_samples(blockIdx.x - rank0, (int)threadIdx.x, hints);
         return;
     }
-    const uint32_t block = blockIdx.x - nrank;
+    const uint32_t block = hints.rank_last ? blockIdx.x : blockIdx.x - nrank;
     if (quarters) {
         // A window of few tiles (a rank's strip): EVERY tile on four waves, a quarter of its pixels each.  One wave per
         // tile would leave the SIMDs with one to four waves, and a wave with few neighbours needs up to 3.3x its own
@@ -623,6 +627,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if (t >= (uint32_t)g.count()) return;
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
+    const uint32_t probe_w0 = (uint32_t)wall_clock64();
     uint32_t probe_staged = 0, probe_checked_at = 0xFFFFFFu;
 #endif
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
@@ -781,7 +786,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if (g_blend_probe && lane == 0)
         g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t, rg.y - rg.x,
                                                probe_staged | (checked ? 0x80000000u : 0u));
-    if (g_blend_probe && lane == 1) g_blend_probe[gridDim.x + blockIdx.x] = make_uint4(probe_checked_at, 0, 0, 0);
+    // (where and when: HW_ID = register 4, XCC_ID = register 20; wall_clock64 ticks at 100 MHz on every XCD alike)
+    if (g_blend_probe && lane == 1)
+        g_blend_probe[kProbeSecond + blockIdx.x] =
+            make_uint4(probe_checked_at, (uint32_t)wall_clock64(),
+                       (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16),
+                       probe_w0);
 #endif
     float *o = out.ptr + (int64_t)(px - out.x0) * out.stride_x + (int64_t)(py0 - out.y0) * out.stride_y;
     if (y_contig && (reinterpret_cast<uintptr_t>(o) & 15u) == 0) {

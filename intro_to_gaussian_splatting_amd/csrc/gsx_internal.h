@@ -181,6 +181,7 @@ struct BlendHints {
     uint32_t *lens;
     uint32_t xcd_sched;         // != 0: `sched` is hints.sched, the per-XCD schedule (gsx_schedule_device.h) -- trusted
                                 // only if header[kHintSched] == number of tiles; 0: tile_schedule_kernel's whole-frame order
+    uint32_t rank_last = 0;     // the spare workgroups that rank the samples come last in the grid instead of first
 };
 hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
                               uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,

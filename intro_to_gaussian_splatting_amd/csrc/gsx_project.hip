@@ -396,8 +396,9 @@ __global__ void __launch_bounds__(kBlock)
     int64_t g = blk * kBlock + threadIdx.x;
     if (g < 4) counters[g] = 0u;   // the depth sort's culled / kept counts start from zero (no memset node)
     float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    if (SHDEG >= 0) {
-        // colour of every Gaussian of the workgroup first (all threads take part in the staging rounds)
+    if (SHDEG >= 0 && !WINDOWED) {
+        // colour of every Gaussian of the workgroup first (all threads take part in the staging rounds); a windowed
+        // call evaluates the colours of the survivors of its window test only, after the compaction below
         const float *cc = DEVICE_CAMERA ? cam_dev->camera_center : cam_arg.camera_center;
         const float c0 = cc[0], c1 = cc[1], c2 = cc[2];
         // a part's coefficient block starts 16-byte aligned only if the whole array is and kRows * W * 4 is a multiple of 16
@@ -424,7 +425,6 @@ __global__ void __launch_bounds__(kBlock)
     // the Gaussians end here, having cost 24 B of reads and one key.  A whole-frame call skips the phase
     // (measured: +8 us at 1M Gaussians when nearly everything survives anyway).
     __shared__ uint16_t s_list[WINDOWED ? kBlock : 1];
-    __shared__ float s_col[(WINDOWED && SHDEG >= 0) ? kBlock * 3 : 1];
     __shared__ uint32_t s_wcnt[kBlock / 64];
     if (WINDOWED) {
     bool survives = false;
@@ -461,11 +461,6 @@ __global__ void __launch_bounds__(kBlock)
             }
         }
     }
-    if (SHDEG >= 0) {
-        s_col[3 * threadIdx.x] = cr;
-        s_col[3 * threadIdx.x + 1] = cg;
-        s_col[3 * threadIdx.x + 2] = cb;
-    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // (indentation: still inside `if (WINDOWED)`)
     const unsigned long long mask = __ballot(survives);
     if (lane == 0) s_wcnt[w] = (uint32_t)__popcll(mask);
@@ -478,14 +473,23 @@ __global__ void __launch_bounds__(kBlock)
     }
     if (survives) s_list[before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
     __syncthreads();
-    if (threadIdx.x >= total) return;
-    const uint32_t src = s_list[threadIdx.x];
+    const uint32_t src = threadIdx.x < total ? s_list[threadIdx.x] : 0u;
     g = blk * kBlock + src;
     if (SHDEG >= 0) {
-        cr = s_col[3 * src];
-        cg = s_col[3 * src + 1];
-        cb = s_col[3 * src + 2];
+        // the survivors' coefficient rows through LDS (a row per Gaussian, read by consecutive lanes), kRows at a time
+        const float *cc = DEVICE_CAMERA ? cam_dev->camera_center : cam_arg.camera_center;
+        const float c0 = cc[0], c1 = cc[1], c2 = cc[2];
+        for (int first = 0; first < (int)total; first += L::kRows) {
+            if (first) __syncthreads();
+            sh::stage_rows<DEG, L::kRows>(in.colors, blk * kBlock, s_list, (int)total, first, sh_lds, sh_vec);
+            const int row = (int)threadIdx.x - first;
+            if (row >= 0 && row < L::kRows && threadIdx.x < total) {
+                const float *pp = in.means3d + 3 * g;
+                sh::eval<DEG>(sh_lds + row * L::STRIDE, pp[0] - c0, pp[1] - c1, pp[2] - c2, cr, cg, cb);
+            }
+        }
     }
+    if (threadIdx.x >= total) return;
     } else if (g >= n) {
         return;
     }

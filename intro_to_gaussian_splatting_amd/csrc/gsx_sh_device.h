@@ -59,6 +59,32 @@ __device__ __forceinline__ void stage(const float *__restrict__ sh, int64_t n, i
     __syncthreads();
 }
 
+// The same for a LIST of Gaussians (the windowed projection: the survivors of its window test, a small share of the
+// workgroup's 256): rows[first .. first + ROWS) of the list -- indices relative to g0 -- are staged, each row's 3 K
+// floats read by consecutive lanes; nothing is read for a Gaussian that is not on the list.  count: list length.
+// Every thread of the workgroup must call this (it ends with a barrier).
+template <int DEG, int ROWS>
+__device__ __forceinline__ void stage_rows(const float *__restrict__ sh, int64_t g0, const uint16_t *rows, int count,
+                                           int first, float *lds, bool vec) {
+    constexpr int W = Layout<DEG>::W, STRIDE = Layout<DEG>::STRIDE;
+    const int have = count - first < ROWS ? count - first : ROWS;
+    if (W % 4 == 0 && vec) {
+        constexpr int Q = W % 4 == 0 ? W / 4 : 1;           // 16-byte words per row
+        for (int v = threadIdx.x; v < have * Q; v += kBlock) {
+            const int r = v / Q, q = v % Q;
+            const float4 f = *reinterpret_cast<const float4 *>(sh + (size_t)(g0 + rows[first + r]) * W + 4 * q);
+            float *d = lds + r * STRIDE + 4 * q;
+            d[0] = f.x; d[1] = f.y; d[2] = f.z; d[3] = f.w;
+        }
+    } else {
+        for (int v = threadIdx.x; v < have * W; v += kBlock) {
+            const int r = v / W, c = v % W;
+            lds[r * STRIDE + c] = sh[(size_t)(g0 + rows[first + r]) * W + c];
+        }
+    }
+    __syncthreads();
+}
+
 // colour = max(0, 0.5 + sum_k Y_k(d) sh[k]), d = normalize(mean - camera centre); c = this thread's LDS row.
 template <int DEG>
 __device__ __forceinline__ void eval(const float *c, float dx, float dy, float dz, float &r_out, float &g_out, float &b_out) {

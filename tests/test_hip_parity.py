@@ -886,6 +886,11 @@ def test_spherical_harmonics_kernel_and_trained_ply_pipeline(tmp_path):
                                        g.quaternions.cpu().numpy(), g.opacity.cpu().numpy(), device="cuda:0")
         g_cols.colors = scene._colors(1).clone()
         assert torch.equal(GaussianScene(str(tmp_path), g_cols).render_image_hip(1).cpu(), img)
+        # a tile window (a rank's strip) evaluates the colours of the Gaussians that survive its window test only,
+        # from rows staged by list instead of by block: same pixels
+        for x0, x1, y0, y1 in ((3, 9, 0, 15), (0, 15, 6, 7), (14, 15, 14, 15)):
+            part = scene.render_image_hip(1, tile_window=(x0, x1, y0, y1)).cpu()
+            assert torch.equal(part[x0 * 16:x1 * 16, y0 * 16:y1 * 16], img[x0 * 16:x1 * 16, y0 * 16:y1 * 16]), (deg, x0)
         # the same frame through the pinned RGB path with those colours (colors = rgb/256 convention)
         g_rgb = Gaussians.from_arrays(sc["points"], ref * 256.0, np.exp(np.log(sc["scales"])), sc["quaternions"],
                                       sc["opacity"], device="cuda:0")

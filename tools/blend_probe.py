@@ -14,9 +14,8 @@ sc, scene = bench.build_scene(wl, "cuda")
 lib = _ffi.load()
 for _ in range(3):
     scene.render_image_hip(1)
-grid = 3 * 8192 + 65536
+grid = 1 << 17                # gsx_blend.hip: kProbeSecond
 buf = torch.zeros((2 * grid, 4), dtype=torch.int32, device="cuda")
-# the probe's second half starts at gridDim.x, which we do not know here: find it from the data afterwards
 lib.gsx_debug_set_blend_probe(buf.data_ptr())
 st = {}
 scene.render_image_hip(1, stats=st, timing=True)
