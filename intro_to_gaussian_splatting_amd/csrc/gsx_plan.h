@@ -67,7 +67,7 @@ struct ClearPlan {
 constexpr int kSortBinsMax = 1024;
 constexpr int kSortSamples = 2048, kSortSamplesMax = 8192, kSortQuadTotals = 64;
 inline size_t radix_temp_bytes(int64_t max_items, int bins = kSortBins) {
-    const size_t nblocks = (size_t)((max_items + kSortItems - 1) / kSortItems) + kSortQuad;
+    const size_t nblocks = (size_t)((max_items + kSortItems - 1) / kSortItems) + 9 * kSortQuad;   // (the count grid: whole quads, 8 at a time)
     return ((size_t)bins * (nblocks + kSortQuad) + 2 * (size_t)bins + (size_t)kSortQuadTotals * kSortBins) * sizeof(uint32_t);
 }
 // Where the 64-bit chunk sums start inside `temp`: behind the radix table for max(n, cap) items (and behind the

@@ -62,6 +62,7 @@ constexpr int kSelfScanBlocks = 64;
 // partition of 1M keys would win nothing.
 constexpr int kQuadScanQuads = kSortQuadTotals;
 constexpr int kScanRows = 0, kScanSelf = 1, kScanQuads = 2;   // who turns the counts into prefixes
+constexpr bool kXcdChunks = true;      // scatter_kernel: an XCD's workgroups take consecutive chunks (see there)
 
 constexpr int kModePlain = 0, kModeFirst = 1, kModeFinal = 2;
 constexpr int kSamples = kSortSamples;   // sample keys of the sample-partitioned depth sort (8 per bucket)
@@ -145,11 +146,20 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     static_assert(NB == kBins || !CHUNK_MAJOR, "the chunk-major table (small inputs) has 256 rows");
     const int c = CHUNK_MAJOR ? 0 : (int)(threadIdx.x >> 8);
     const uint32_t t = threadIdx.x & 255u;
-    const uint32_t chunk = blockIdx.x * (uint32_t)kLanes + (uint32_t)c;
-    const uint32_t first = chunk * (uint32_t)kItems + t * (uint32_t)kRounds;
     // the keys are requested before the splitters are loaded -- but not before the element count is known: the
     // grid covers the capacity `bound`, which may be many times the count
     const uint32_t n = load_count(n_dev, bound);
+    // With a row-scan launch behind it (large inputs) XCD x -- blockIdx % 8 == x -- counts the x-th eighth of the quads
+    // that hold items: the 16 bytes a workgroup leaves in every digit row then meet the 16 bytes of its neighbours in
+    // ONE L2 and leave it as a whole sector (see scatter_kernel; the quads behind them hold nothing and keep their
+    // own number).  The grid is a multiple of 8 workgroups (plan_for).
+    uint32_t quad = blockIdx.x;
+    if (!CHUNK_MAJOR && !quad_totals && kXcdChunks) {
+        const uint32_t quads = (n + (uint32_t)(kItems * kQuad) - 1u) / (uint32_t)(kItems * kQuad), per = (quads + 7u) >> 3;
+        if ((blockIdx.x >> 3) < per) quad = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    }
+    const uint32_t chunk = quad * (uint32_t)kLanes + (uint32_t)c;
+    const uint32_t first = chunk * (uint32_t)kItems + t * (uint32_t)kRounds;
     uint4 q[kVecs];
     if (first + kRounds <= n) {
         const uint4 *src = reinterpret_cast<const uint4 *>(keys + first);   // first is a multiple of kRounds
@@ -226,7 +236,7 @@ __global__ void __launch_bounds__(CHUNK_MAJOR ? kThreads : kQuad * kThreads)
     } else if (threadIdx.x < NB) {
         const uint32_t d = threadIdx.x;     // (1024 threads: one digit row each, whatever NB is)
         const uint4 c4 = make_uint4(h[0][d], h[kLanes > 1 ? 1 : 0][d], h[kLanes > 2 ? 2 : 0][d], h[kLanes > 3 ? 3 : 0][d]);
-        reinterpret_cast<uint4 *>(table + (size_t)d * nbp)[blockIdx.x] = c4;
+        reinterpret_cast<uint4 *>(table + (size_t)d * nbp)[quad] = c4;
         if (NB == kBins && quad_totals) quad_totals[(size_t)blockIdx.x * kBins + d] = c4.x + c4.y + c4.z + c4.w;   // kScanQuads
     }
     if (FIRST && threadIdx.x == 0 && s_culled) atomicAdd(culled, s_culled);
@@ -315,7 +325,21 @@ __global__ void __launch_bounds__(kThreads)
     // memory (requesting the keys before the count is known saved nothing measurable and cost 100 us on a frame
     // whose capacity was 20x its pair count).
     const uint32_t n = load_count(n_dev, bound);
-    const uint32_t block_base = blockIdx.x * (uint32_t)kItems;
+    // Which chunk is this workgroup's?  With a row-scan launch behind it (large inputs): XCD x -- the workgroups with
+    // blockIdx % 8 == x -- takes the x-th eighth of the chunks that hold items, so that the workgroups resident on one
+    // XCD at a time work on CONSECUTIVE chunks.  A chunk leaves a run of ~8 items per digit (16 B of keys, 32 B of
+    // values), and the runs of consecutive chunks are neighbours in memory: written from one XCD they meet in its L2
+    // and leave it as whole 64-byte sectors; dealt round robin over the eight L2s (chunk = blockIdx) every run reached
+    // HBM as a partial sector of its own -- 2.0x the algorithmic bytes written, and as much again read for the
+    // read-modify-write, in the 4K frame's tile sort (PMC, round 3).
+    uint32_t chunk_id = blockIdx.x;
+    if (SCAN == kScanRows && kXcdChunks) {
+        const uint32_t chunks = (n + (uint32_t)kItems - 1u) / (uint32_t)kItems, per = (chunks + 7u) >> 3;
+        const uint32_t x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        if (i >= per) return;
+        chunk_id = x * per + i;
+    }
+    const uint32_t block_base = chunk_id * (uint32_t)kItems;
     if (block_base >= n) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     constexpr uint32_t nbins = SPLIT ? (uint32_t)SPLIT : (1u << BITS), mask = (1u << BITS) - 1u;
@@ -342,14 +366,14 @@ __global__ void __launch_bounds__(kThreads)
             const uint32_t d = (uint32_t)threadIdx.x * DPT + q;
             if (d < nbins) {
                 t_pre[q] = totals[d];
-                before_pre[q] = table[(size_t)d * nbp + blockIdx.x];
+                before_pre[q] = table[(size_t)d * nbp + chunk_id];
             }
         }
     }
     if (SCAN == kScanQuads && (uint32_t)threadIdx.x < nbins) {
         // no row scan ran: this digit's total = the sum of all count workgroups' four-chunk totals, its prefix =
         // the totals of the workgroups before this chunk's + the (raw) counts of the chunks before it in its quad
-        const int nquads = nbp / kQuad, quad = (int)(blockIdx.x / kQuad);
+        const int nquads = nbp / kQuad, quad = (int)(chunk_id / kQuad);
         int q = 0;
         for (; q + 8 <= nquads; q += 8) {      // 8 independent loads in flight (coalesced over the digits)
             uint32_t v[8];
@@ -366,8 +390,8 @@ __global__ void __launch_bounds__(kThreads)
             before_pre[0] += q < quad ? v : 0u;
             t_pre[0] += v;
         }
-        for (uint32_t c = (uint32_t)quad * kQuad; c < blockIdx.x; ++c) before_pre[0] += table[(size_t)threadIdx.x * nbp + c];
-        if (blockIdx.x == 0) const_cast<uint32_t *>(totals)[threadIdx.x] = t_pre[0];   // what bucket_sort_kernel reads
+        for (uint32_t c = (uint32_t)quad * kQuad; c < chunk_id; ++c) before_pre[0] += table[(size_t)threadIdx.x * nbp + c];
+        if (chunk_id == 0) const_cast<uint32_t *>(totals)[threadIdx.x] = t_pre[0];   // what bucket_sort_kernel reads
     }
     for (int k = threadIdx.x; k < 4 * NB; k += kThreads) (&cnt[0][0])[k] = 0;
     for (int k = threadIdx.x; k < kItems / 4; k += kThreads) reinterpret_cast<uint4 *>(sval)[k] = make_uint4(0, 0, 0, 0);
@@ -443,13 +467,13 @@ __global__ void __launch_bounds__(kThreads)
                     for (int u = 0; u < 8; ++u) v[u] = table[(size_t)(b + u) * kBins + d];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        before[q] += b + u < (int)blockIdx.x ? v[u] : 0u;
+                        before[q] += b + u < (int)chunk_id ? v[u] : 0u;
                         t[q] += v[u];
                     }
                 }
                 for (; b < nbp; ++b) {
                     const uint32_t v = table[(size_t)b * kBins + d];
-                    before[q] += b < (int)blockIdx.x ? v : 0u;
+                    before[q] += b < (int)chunk_id ? v : 0u;
                     t[q] += v;
                 }
             } else {
@@ -492,7 +516,7 @@ __global__ void __launch_bounds__(kThreads)
             lstart += l[q];
             gstart += t[q];
         }
-        if ((MODE & kModeFirst) && blockIdx.x == 0 && threadIdx.x == 0) *m_out = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if ((MODE & kModeFirst) && chunk_id == 0 && threadIdx.x == 0) *m_out = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
     __syncthreads();
     const uint32_t live = lsum[0] + lsum[1] + lsum[2] + lsum[3];   // items of this chunk that the pass keeps
@@ -1155,6 +1179,7 @@ PassPlan plan_for(void *temp, int64_t bound, int bins = kBins) {
     p.nquads = (p.nblocks + kQuad - 1) / kQuad;
     p.self_scan = bins == kBins && p.nblocks <= kSelfScanBlocks;
     p.scan = p.self_scan ? kScanSelf : ((bins == kBins && p.nquads <= kQuadScanQuads) ? kScanQuads : kScanRows);
+    if (p.scan == kScanRows) p.nquads = (p.nquads + 7) & ~7;    // whole groups of 8 workgroups: one per XCD (count_kernel, scatter_kernel)
     p.nbp = p.self_scan ? p.nblocks : p.nquads * kQuad;
     p.table = (uint32_t *)temp;
     p.totals = p.table + (size_t)bins * p.nquads * kQuad;
@@ -1194,7 +1219,8 @@ void launch_pass(const PassPlan &p, const Key *kc, const uint32_t *vc, Key *ka, 
                                                                                p.table, p.nbp, culled, nullptr, nullptr, nullptr,
                                                                                samples_out, sample_step);
         row_scan_kernel<<<1u << BITS, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
-        scatter_kernel<Key, kScanRows, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
+        scatter_kernel<Key, kScanRows, MODE, BITS><<<(p.nblocks + 7) & ~7, kThreads, 0, s>>>(     // (whole groups of 8: see chunk_id)
+            kc, vc, ka, va, n_dev, (uint32_t)bound,
                                                                                    shift, p.table, p.totals, p.nbp, m_out, rect,
                                                                                    rrect);
     }
@@ -1286,7 +1312,7 @@ static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1
             keys0, nullptr, (uint32_t)n, 0, 255u, p.table, p.nbp, culled_dev, splitters, nullptr, NB == kBins ? hdr : nullptr,
             NB == kBins ? samples_out : nullptr, step, zero_sums, nsums);
         row_scan_kernel<<<NB, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
-        scatter_kernel<uint32_t, kScanRows, kModeFirst, 8, NB><<<p.nblocks, kThreads, 0, s>>>(
+        scatter_kernel<uint32_t, kScanRows, kModeFirst, 8, NB><<<(p.nblocks + 7) & ~7, kThreads, 0, s>>>(
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
             nullptr, NB == kBins ? hdr : nullptr);
     }
