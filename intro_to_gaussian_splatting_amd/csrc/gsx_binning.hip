@@ -258,12 +258,17 @@ __global__ void __launch_bounds__(kBlock)
         *ec.long_count = 0u;
     }
 
-    // ---- the chunk's pairs: every thread takes ONE run of consecutive pairs (8 L of them, L the same for the
-    //      whole workgroup), finds the Gaussian of its first pair by binary search (largest rank with offs <= p)
-    //      and then walks -- next row of the rectangle, next column, next Gaussian (one 16-byte LDS word, fetched
-    //      one Gaussian ahead) -- at ~8 instructions per pair.  (A search and an integer division per pair, as in
-    //      the first version of this kernel, were ~100.)  Runs are aligned in the GLOBAL pair index, so every 8
-    //      keys and 8 values are whole 16-byte words: wide stores, every byte written once.
+    // ---- the chunk's pairs, in groups of 8 consecutive pairs aligned in the GLOBAL pair index (8 keys and 8 values
+    //      are whole 16-byte words: wide stores, every byte written once).  A thread takes groups t, t + 256, ...: for
+    //      each it finds the Gaussian of the first pair by binary search (largest rank with offs <= p) and walks --
+    //      next row of the rectangle, next column, next Gaussian (one 16-byte LDS word, fetched one Gaussian ahead)
+    //      -- at ~8 instructions per pair.  (A search and an integer division per pair, as in the first version of
+    //      this kernel, were ~100.)  Neighbouring lanes hold neighbouring groups, so ONE store instruction of a wave
+    //      covers 1 KB of keys / 2 x 1 KB of values without a gap.  Round 2 gave every thread one run of 8 L
+    //      consecutive pairs (one search instead of L): a store instruction then wrote 16 of every 16 L bytes, the rest
+    //      of each sector followed an iteration of the walk later -- too late to be merged on the way out: 39.0 MB
+    //      reached HBM for 25.3 (1M Gaussians, PMC WRITE_SIZE), 195 MB for 128 at 5M, where the kernel is
+    //      bandwidth-bound.  Now 24.9 and 125 MB; 17.7 -> 15.0 us and 65.8 -> 41.4 us (same box, rocprofv3).
     if (base >= (uint64_t)limit) return;   // speculative mode: the pair count exceeded the caller's hint
     const uint64_t room = (uint64_t)limit - base;
     const uint32_t npairs = (uint32_t)(chunk_total < room ? chunk_total : room);
@@ -271,79 +276,80 @@ __global__ void __launch_bounds__(kBlock)
     const uint32_t out0 = (uint32_t)base, out1 = out0 + npairs;      // limit < 2^32: no wrap
     const uint32_t nwy = (uint32_t)g.nwy();
     const uint32_t q_first = out0 & ~7u;
-    const uint32_t run_len = 8u * (((out1 - q_first + (uint32_t)kBlock - 1u) / (uint32_t)kBlock + 7u) / 8u);
-    const uint32_t qb = q_first + threadIdx.x * run_len;
-    if (qb >= out1) return;
-    const uint32_t qa = max(qb, out0), qe = min(qb + run_len, out1);   // this thread's pairs: global [qa, qe)
-    uint32_t p = qa - out0;
-    uint32_t lo = 0, hi = kChunk;            // invariant: offs[lo] <= p < offs[hi]
-#pragma unroll
-    for (int s_ = 0; s_ < 10; ++s_) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const bool right = offs[mid] <= p;
-        lo = right ? mid : lo;
-        hi = right ? hi : mid;
-    }
+    const uint32_t groups = (out1 - q_first + 7u) >> 3;
     const uint4 *slots = reinterpret_cast<const uint4 *>(slot);
-    uint4 cur = slots[lo], ahead = slots[lo + 1];     // (xs, ys, index, end)
-    uint32_t x0 = cur.x & 0xFFFFu, y0 = cur.y & 0xFFFFu, y1 = cur.y >> 16;
-    uint32_t tx, ty;
-    {
-        const uint32_t k = p - offs[lo], h = y1 - y0 + 1u;
-        tx = x0 + k / h;
-        ty = y0 + k % h;
-    }
-    uint32_t key = (tx - (uint32_t)g.wx0) * nwy + (ty - (uint32_t)g.wy0);
-    for (uint32_t q8 = qb; q8 < qe; q8 += 8u) {
-        uint32_t kk[8], vv[8];
+    for (uint32_t gi = threadIdx.x; gi < groups; gi += (uint32_t)kBlock) {
+        const uint32_t qb = q_first + gi * 8u;
+        const uint32_t qa = max(qb, out0), qe = min(qb + 8u, out1);   // this group's pairs: global [qa, qe)
+        uint32_t p = qa - out0;
+        uint32_t lo = 0, hi = kChunk;            // invariant: offs[lo] <= p < offs[hi]
 #pragma unroll
-        for (uint32_t i = 0; i < 8u; ++i) {
-            const uint32_t q = q8 + i;
-            kk[i] = key;
-            vv[i] = cur.z;
-            if (q >= qa && q + 1u < qe) {        // step to pair p + 1 (there is one)
-                ++p;
-                if (p >= cur.w) {                // the next Gaussian that has tiles
-                    do {
-                        cur = ahead;
-                        ++lo;
-                        ahead = slots[lo + 1];
-                    } while (p >= cur.w);
-                    x0 = cur.x & 0xFFFFu;
-                    y0 = cur.y & 0xFFFFu;
-                    y1 = cur.y >> 16;
-                    tx = x0;
-                    ty = y0;
-                    key = (tx - (uint32_t)g.wx0) * nwy + (ty - (uint32_t)g.wy0);
-                } else if (ty == y1) {           // next column of the rectangle
-                    ty = y0;
-                    ++tx;
-                    key += nwy - (y1 - y0);
-                } else {
-                    ++ty;
-                    ++key;
-                }
-            }
+        for (int s_ = 0; s_ < 10; ++s_) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool right = offs[mid] <= p;
+            lo = right ? mid : lo;
+            hi = right ? hi : mid;
         }
-        if (q8 >= qa && q8 + 8u <= qe) {
-            if (sizeof(Key) == 2) {
-                *reinterpret_cast<uint4 *>(keys + q8) =
-                    make_uint4(kk[0] | (kk[1] << 16), kk[2] | (kk[3] << 16), kk[4] | (kk[5] << 16), kk[6] | (kk[7] << 16));
-            } else {
-                uint4 *dk = reinterpret_cast<uint4 *>(keys + q8);
-                dk[0] = make_uint4(kk[0], kk[1], kk[2], kk[3]);
-                dk[1] = make_uint4(kk[4], kk[5], kk[6], kk[7]);
-            }
-            uint4 *dv = reinterpret_cast<uint4 *>(vals + q8);
-            dv[0] = make_uint4(vv[0], vv[1], vv[2], vv[3]);
-            dv[1] = make_uint4(vv[4], vv[5], vv[6], vv[7]);
-        } else {                                  // the ragged first / last 8 of the chunk
+        uint4 cur = slots[lo], ahead = slots[lo + 1];     // (xs, ys, index, end)
+        uint32_t x0 = cur.x & 0xFFFFu, y0 = cur.y & 0xFFFFu, y1 = cur.y >> 16;
+        uint32_t tx, ty;
+        {
+            const uint32_t k = p - offs[lo], h = y1 - y0 + 1u;
+            tx = x0 + k / h;
+            ty = y0 + k % h;
+        }
+        uint32_t key = (tx - (uint32_t)g.wx0) * nwy + (ty - (uint32_t)g.wy0);
+        for (uint32_t q8 = qb; q8 < qe; q8 += 8u) {
+            uint32_t kk[8], vv[8];
 #pragma unroll
             for (uint32_t i = 0; i < 8u; ++i) {
                 const uint32_t q = q8 + i;
-                if (q >= qa && q < qe) {
-                    keys[q] = (Key)kk[i];
-                    vals[q] = vv[i];
+                kk[i] = key;
+                vv[i] = cur.z;
+                if (q >= qa && q + 1u < qe) {        // step to pair p + 1 (there is one)
+                    ++p;
+                    if (p >= cur.w) {                // the next Gaussian that has tiles
+                        do {
+                            cur = ahead;
+                            ++lo;
+                            ahead = slots[lo + 1];
+                        } while (p >= cur.w);
+                        x0 = cur.x & 0xFFFFu;
+                        y0 = cur.y & 0xFFFFu;
+                        y1 = cur.y >> 16;
+                        tx = x0;
+                        ty = y0;
+                        key = (tx - (uint32_t)g.wx0) * nwy + (ty - (uint32_t)g.wy0);
+                    } else if (ty == y1) {           // next column of the rectangle
+                        ty = y0;
+                        ++tx;
+                        key += nwy - (y1 - y0);
+                    } else {
+                        ++ty;
+                        ++key;
+                    }
+                }
+            }
+            if (q8 >= qa && q8 + 8u <= qe) {
+                if (sizeof(Key) == 2) {
+                    *reinterpret_cast<uint4 *>(keys + q8) =
+                        make_uint4(kk[0] | (kk[1] << 16), kk[2] | (kk[3] << 16), kk[4] | (kk[5] << 16), kk[6] | (kk[7] << 16));
+                } else {
+                    uint4 *dk = reinterpret_cast<uint4 *>(keys + q8);
+                    dk[0] = make_uint4(kk[0], kk[1], kk[2], kk[3]);
+                    dk[1] = make_uint4(kk[4], kk[5], kk[6], kk[7]);
+                }
+                uint4 *dv = reinterpret_cast<uint4 *>(vals + q8);
+                dv[0] = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+                dv[1] = make_uint4(vv[4], vv[5], vv[6], vv[7]);
+            } else {                                  // the ragged first / last 8 of the chunk
+#pragma unroll
+                for (uint32_t i = 0; i < 8u; ++i) {
+                    const uint32_t q = q8 + i;
+                    if (q >= qa && q < qe) {
+                        keys[q] = (Key)kk[i];
+                        vals[q] = vv[i];
+                    }
                 }
             }
         }
