@@ -1276,6 +1276,12 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
 // every size: a 2048-key chunk holds two keys per bucket, so its scatter writes 8-byte runs (125 us at 5M against
 // 31 us for a plain 8-bit pass), and ranking 8192 samples costs 40 us.  It stays selectable for the tests (the
 // partition machinery is the same templates), no frame takes it.
+// Re-measured after the XCD-contiguous chunk mapping (which makes short runs much cheaper: scatter_kernel), kept =
+// 0.95 n: 5M: LSD 220 (102 of them the last pass' rectangle gather), 1024 buckets 238 (scatter 80, bucket sort 77,
+// count 35, sample 39), 512 buckets 293 (buckets of 9 300 keys overflow the LDS too often: bucket sort 166);  3M: LSD
+// 148, 512 buckets 161;  2.2M: LSD 124, 512 buckets 135, 1024 buckets 158.  Without their 40 us sample kernel --
+// i.e. with splitters handed over by the previous frame, which today exists for 256 buckets only -- 512 buckets would
+// win by ~25 us between 1.5M and 3.5M kept keys and 1024 buckets by ~20 us at 5M: not built.
 constexpr int64_t kSampledMin = 8 * kSamples, kKeptMax256 = 1536 * 1024;
 
 DepthRoute depth_sort_route(int64_t n, int64_t kept_hint) {
