@@ -1,5 +1,5 @@
-"""Per-stage HIP-event times of one rank's strip for 1, 2, 4, 8 ranks (balanced plan, the slowest of three ranks
-probed), on ONE GPU:   python tools/strip_probe.py [workload]
+"""Per-stage HIP-event times of one rank's strip for 1, 2, 4, 8 ranks (equal strips, or PLAN=balanced; the slowest of
+three ranks probed), on ONE GPU:   python tools/strip_probe.py [workload]
 What a rank of an N-GPU run would spend per frame before the gather (timing mode: separate launches)."""
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,6 +15,8 @@ counts = torch.zeros(ntx * nty, dtype=torch.int32, device="cuda")
 scene.render_image_hip(1, tile_counts=counts)
 for world in [int(v) for v in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
     plan = strips.balanced_plan(strips.tile_row_costs(counts, ntx, nty, lead_is_x=True), world)
+    if os.environ.get("PLAN", "equal") == "equal":       # bench.py's default; PLAN=balanced: --balance
+        plan = strips.strip_plan(ntx, world)[1]
     worst = None
     for r in (0, world // 2, world - 1):
         win = (plan[r][0], plan[r][1], 0, nty)
