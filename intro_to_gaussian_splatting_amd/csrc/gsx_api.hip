@@ -369,9 +369,15 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
         GSX_HIP(gsx::sort_depth_sampled(route, ws + c.temp, k0, k1, v0, v1, n, p.kept_hint, counters + kCtrKept,
                                         counters + kCtrCulled, (const gsx::TileRect *)(ws + c.rect),
                                         (gsx::TileRect *)(ws + c.rrect), 0, gsx::emit_chunk_sums(ws + c.temp, n, cap), sh, s));
-    else
+    else {
+        // the LSD passes carry the rectangles along, packed into 4 bytes, when tile coordinates fit 8 bits; the two
+        // arrays they travel in are the pair lists' value arrays, which nothing uses before the emission
+        const bool carry = p.grid.ntx <= 256 && p.grid.nty <= 256 && cap >= n && gsx::knob("GSX_LSD_CARRY", 1) != 0;
         GSX_HIP(gsx::sort_depth_compact(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
-                                        (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s, sh.samples));
+                                        (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s, sh.samples,
+                                        carry ? (uint32_t *)(ws + c.tvals0) : nullptr,
+                                        carry ? (uint32_t *)(ws + c.tvals1) : nullptr));
+    }
     tm.mark();  // 2: depth sort (drops what reaches no tile, leaves the rectangles in rank order)
     return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rrect), v0, counters + kCtrKept,
                          counters + kCtrCulled, sampled, stats_host, tm, s, fh);

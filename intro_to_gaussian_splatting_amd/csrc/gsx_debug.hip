@@ -49,7 +49,7 @@ int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, void *rrec
     hipStream_t s = (hipStream_t)stream;
     if (n <= 0 || !keys || !rect || !rrect || !order_out || !scratch) return GSX_ERR_INVALID_ARGUMENT;
     const size_t words = align_up((size_t)n * 4);
-    const size_t need = 3 * words + 256 + binning_temp_bytes(n, 1);
+    const size_t need = 3 * words + 256 + binning_temp_bytes(n, 1) + (mode == 4 ? 2 * words : 0);
     if (scratch_bytes < need) return GSX_ERR_WORKSPACE_TOO_SMALL;
     char *sc = (char *)scratch;
     uint32_t *k1 = (uint32_t *)sc, *v0 = (uint32_t *)(sc + words), *v1 = (uint32_t *)(sc + 2 * words);
@@ -57,7 +57,10 @@ int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, void *rrec
     void *temp = sc + 3 * words + 256;
     GSX_DBG_HIP(hipMemsetAsync(counters, 0, 64, s));
     gsx::DepthRoute route = mode < 0 ? gsx::depth_sort_route(n, kept_hint)
-                                     : (mode == 0 ? gsx::kDepthLsd : (mode == 2 ? gsx::kDepth1024 : gsx::kDepth256));
+                                     : (mode == 0 || mode == 4 ? gsx::kDepthLsd : (mode == 2 ? gsx::kDepth1024 : gsx::kDepth256));
+    // mode 4: the LSD passes with the rectangles carried along (coordinates below 256), in two more arrays at the end
+    uint32_t *carry0 = mode == 4 ? (uint32_t *)(sc + need - 2 * words) : nullptr;
+    uint32_t *carry1 = mode == 4 ? (uint32_t *)(sc + need - words) : nullptr;
     if (mode > 0 && n <= 16384 && lds_cap == 0) route = gsx::kDepthOneWorkgroup;
     if (route != gsx::kDepthLsd)
         GSX_DBG_HIP(gsx::sort_depth_sampled(route, temp, keys, k1, v0, v1, n, kept_hint, counters + kCtrKept,
@@ -65,7 +68,7 @@ int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, void *rrec
                                             nullptr, gsx::SortHints{nullptr, nullptr, nullptr, false}, s));
     else
         GSX_DBG_HIP(gsx::sort_depth_compact(temp, keys, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
-                                            (const gsx::TileRect *)rect, (gsx::TileRect *)rrect, s));
+                                            (const gsx::TileRect *)rect, (gsx::TileRect *)rrect, s, nullptr, carry0, carry1));
     uint32_t host[4] = {0, 0, 0, 0};
     GSX_DBG_HIP(hipMemcpyAsync(host, counters, 16, hipMemcpyDeviceToHost, s));
     GSX_DBG_HIP(hipMemcpyAsync(order_out, v0, (size_t)n * 4, hipMemcpyDeviceToDevice, s));

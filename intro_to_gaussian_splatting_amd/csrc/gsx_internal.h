@@ -156,7 +156,8 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
 // first pass are the item positions themselves (vals_cur need not be initialised).
 hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
-                              hipStream_t s, uint32_t *samples_out = nullptr);
+                              hipStream_t s, uint32_t *samples_out = nullptr, uint32_t *carry0 = nullptr,
+                              uint32_t *carry1 = nullptr);
 
 // The same contract with 5 kernels instead of 12: sample 2048 / 8192 keys -> 255 / 1023 splitters, ONE stable
 // partition pass, one in-LDS sort per bucket (gsx_sort.hip).  depth_sort_route picks the route from the

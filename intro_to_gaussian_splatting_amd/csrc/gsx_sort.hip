@@ -297,14 +297,20 @@ __global__ void __launch_bounds__(kThreads) row_scan_kernel(uint32_t *__restrict
 // MODE: kModeFirst / kModeFinal, see the head of this file.  m_out (FIRST): number of items this pass
 // keeps, i.e. the element count of every later pass.  rect / rrect (FINAL): per-Gaussian tile
 // rectangles by index / by depth rank.
-template <typename Key, int SCAN, int MODE, int BITS, int SPLIT = 0>   // SPLIT: 0, or the number of buckets (256 / 1024)
+// CARRY (the LSD depth sort of a large scene, tile grids of up to 256 x 256): every item carries its tile rectangle
+// along, packed into 4 bytes -- read in index order by the FIRST pass (cin unused), moved cin -> cout by the
+// passes between, unpacked into rrect by the FINAL pass -- instead of the FINAL pass gathering rect[index] by
+// Gaussian index: at 5M keys that gather read 128 bytes of a 40 MB table per key, 640 MB, and made the last pass 102 us
+// of the sort's 220; carried, the rectangles cost 160 MB over the four passes.
+template <typename Key, int SCAN, int MODE, int BITS, int SPLIT = 0, bool CARRY = false>   // SPLIT: 0, or the number of buckets (256 / 1024)
 __global__ void __launch_bounds__(kThreads)
     scatter_kernel(const Key *__restrict__ kin, const uint32_t *__restrict__ vin, Key *__restrict__ kout,
                    uint32_t *__restrict__ vout, const uint32_t *__restrict__ n_dev, uint32_t bound, int shift,
                    const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals, int nbp,
                    uint32_t *__restrict__ m_out, const TileRect *__restrict__ rect, TileRect *__restrict__ rrect,
                    const uint32_t *__restrict__ splitters = nullptr, const uint32_t *__restrict__ quad_totals = nullptr,
-                   const uint32_t *__restrict__ hint_hdr = nullptr) {
+                   const uint32_t *__restrict__ hint_hdr = nullptr, const uint32_t *__restrict__ cin = nullptr,
+                   uint32_t *__restrict__ cout = nullptr) {
     constexpr bool SELF_SCAN = SCAN == kScanSelf;
     constexpr int kWaveItems = kItems / 4;
     constexpr int NB = SPLIT ? SPLIT : kBins;     // digit rows the tables of this workgroup hold
@@ -320,6 +326,8 @@ __global__ void __launch_bounds__(kThreads)
     __shared__ uint32_t wsum[4], lsum[4];
     __shared__ Key skey[kItems];
     __shared__ __attribute__((aligned(16))) uint32_t sval[kItems];   // 8 KB: also the 4 x 256 match words of the ranking
+    __shared__ uint32_t scarry[CARRY ? kItems : 1];
+    static_assert(!CARRY || (SCAN == kScanRows && !SPLIT && sizeof(Key) == 4), "the carried rectangle belongs to the LSD depth sort");
     static_assert(kItems * 4 == 4 * kBins * 8, "sval doubles as the per-wave match words");
     // The grid covers the capacity `bound`; the element count comes first: a workgroup beyond it must not touch
     // memory (requesting the keys before the count is known saved nothing measurable and cost 100 us on a frame
@@ -346,6 +354,7 @@ __global__ void __launch_bounds__(kThreads)
     const uint32_t wave_base = block_base + (uint32_t)w * kWaveItems;
     Key key[kRounds];
     uint32_t val[kRounds];
+    uint32_t carry[CARRY ? kRounds : 1];
     bool ok[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
@@ -354,6 +363,17 @@ __global__ void __launch_bounds__(kThreads)
         key[r] = ok[r] ? kin[i] : (Key)0;
         // FIRST: the value of an item is its position (the Gaussian index): nothing to read
         val[r] = (MODE & kModeFirst) ? i : (ok[r] ? vin[i] : 0u);
+        if (CARRY) {
+            carry[r] = 0u;
+            if (ok[r]) {
+                if (MODE & kModeFirst) {
+                    const TileRect t = rect[i];       // (index order: coalesced)
+                    carry[r] = (uint32_t)t.x0 | ((uint32_t)t.x1 << 8) | ((uint32_t)t.y0 << 16) | ((uint32_t)t.y1 << 24);
+                } else {
+                    carry[r] = cin[i];
+                }
+            }
+        }
         if (MODE & kModeFirst) ok[r] = ok[r] && (uint32_t)key[r] < kEmptyKey;
     }
     // this thread's digits' row totals and row prefixes: needed after the ranking
@@ -529,13 +549,14 @@ __global__ void __launch_bounds__(kThreads)
             const uint32_t pos = cnt[w][d] + rank[r];
             skey[pos] = key[r];
             sval[pos] = val[r];
+            if (CARRY) scarry[pos] = carry[r];
             if (SPLIT) sdig[pos] = dig[r];
         }
     }
     __syncthreads();
 
     // ---- stream out: consecutive j of one digit -> consecutive addresses
-    constexpr bool with_rect = (MODE & kModeFinal) || SPLIT;
+    constexpr bool with_rect = ((MODE & kModeFinal) && !CARRY) || SPLIT;
     if (with_rect) {
         // FINAL: the one gather by Gaussian index of the LSD depth sort.  SPLIT (the partition pass of the sampled
         // sort): v lies in this chunk's own 2048 indices -- 16 KB of rect, read once -- and the rectangles travel
@@ -567,8 +588,16 @@ __global__ void __launch_bounds__(kThreads)
         for (uint32_t j = threadIdx.x; j < live; j += kThreads) {
             const Key k = skey[j];
             const uint32_t dst = gbase[((uint32_t)k >> shift) & mask] + j;
-            kout[dst] = k;
+            if (!(MODE & kModeFinal)) kout[dst] = k;
             vout[dst] = sval[j];
+            if (CARRY) {
+                const uint32_t c = scarry[j];
+                if (MODE & kModeFinal)
+                    rrect[dst] = TileRect{(uint16_t)(c & 255u), (uint16_t)((c >> 8) & 255u), (uint16_t)((c >> 16) & 255u),
+                                          (uint16_t)(c >> 24)};
+                else
+                    cout[dst] = c;
+            }
         }
     }
 }
@@ -1198,7 +1227,8 @@ inline int pass_bits(int key_bits) {
 template <typename Key, int MODE, int BITS>
 void launch_pass(const PassPlan &p, const Key *kc, const uint32_t *vc, Key *ka, uint32_t *va, const uint32_t *n_dev,
                  int64_t bound, int shift, uint32_t *m_out, uint32_t *culled, const TileRect *rect, TileRect *rrect,
-                 hipStream_t s, uint32_t *samples_out = nullptr, uint32_t sample_step = 0) {
+                 hipStream_t s, uint32_t *samples_out = nullptr, uint32_t sample_step = 0, const uint32_t *cin = nullptr,
+                 uint32_t *cout = nullptr, bool carry = false) {
     constexpr uint32_t mask = (1u << BITS) - 1u;
     constexpr bool first = (MODE & kModeFirst) != 0;
     if (p.self_scan) {
@@ -1219,10 +1249,17 @@ void launch_pass(const PassPlan &p, const Key *kc, const uint32_t *vc, Key *ka, 
                                                                                p.table, p.nbp, culled, nullptr, nullptr, nullptr,
                                                                                samples_out, sample_step);
         row_scan_kernel<<<1u << BITS, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
-        scatter_kernel<Key, kScanRows, MODE, BITS><<<(p.nblocks + 7) & ~7, kThreads, 0, s>>>(     // (whole groups of 8: see chunk_id)
-            kc, vc, ka, va, n_dev, (uint32_t)bound,
-                                                                                   shift, p.table, p.totals, p.nbp, m_out, rect,
-                                                                                   rrect);
+        const unsigned grid = (unsigned)((p.nblocks + 7) & ~7);     // (whole groups of 8: see chunk_id)
+        if constexpr (sizeof(Key) == 4 && BITS == 8) {
+            if (carry) {
+                scatter_kernel<Key, kScanRows, MODE, BITS, 0, true><<<grid, kThreads, 0, s>>>(
+                    kc, vc, ka, va, n_dev, (uint32_t)bound, shift, p.table, p.totals, p.nbp, m_out, rect, rrect, nullptr, nullptr,
+                    nullptr, cin, cout);
+                return;
+            }
+        }
+        scatter_kernel<Key, kScanRows, MODE, BITS><<<grid, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound, shift,
+                                                                             p.table, p.totals, p.nbp, m_out, rect, rrect);
     }
 }
 
@@ -1281,7 +1318,9 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
 // count 35, sample 39), 512 buckets 293 (buckets of 9 300 keys overflow the LDS too often: bucket sort 166);  3M: LSD
 // 148, 512 buckets 161;  2.2M: LSD 124, 512 buckets 135, 1024 buckets 158.  Without their 40 us sample kernel --
 // i.e. with splitters handed over by the previous frame, which today exists for 256 buckets only -- 512 buckets would
-// win by ~25 us between 1.5M and 3.5M kept keys and 1024 buckets by ~20 us at 5M: not built.
+// win by ~25 us between 1.5M and 3.5M kept keys and 1024 buckets by ~20 us at 5M: not built.  (And the LSD passes have
+// since stopped gathering the rectangles -- scatter_kernel CARRY: 5M 222 -> 186 us, 2.2M 123 -> 106 us --, which takes
+// most of that margin away.)
 constexpr int64_t kSampledMin = 8 * kSamples, kKeptMax256 = 1536 * 1024;
 
 DepthRoute depth_sort_route(int64_t n, int64_t kept_hint) {
@@ -1378,24 +1417,32 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
 // On return vals_cur[0 .. *m_dev) = Gaussian index of each depth rank.
 hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
-                              hipStream_t s, uint32_t *samples_out) {
+                              hipStream_t s, uint32_t *samples_out, uint32_t *carry0, uint32_t *carry1) {
     if (n <= 0) return hipSuccess;
     const PassPlan p = plan_for(temp, n);
     uint32_t *kc = keys0, *ka = keys1;
+    // carry0 / carry1 (n words each, or null): the packed rectangles travel with the items (scatter_kernel, CARRY) --
+    // the caller offers them when the tile grid fits 8-bit coordinates; worth it from ~1M keys (a row-scan pass)
+    const bool carry = carry0 && carry1 && p.scan == kScanRows && n >= (1 << 20);
+    uint32_t *cc = carry0, *ca = carry1;
     auto flip = [&]() {
         uint32_t *tk = kc; kc = ka; ka = tk;
         uint32_t *tv = vals_cur; vals_cur = vals_alt; vals_alt = tv;
+        uint32_t *tc = cc; cc = ca; ca = tc;
     };
     // (samples_out: GsxParams.hints -- pass 0's count kernel leaves the sample of kept keys a later frame's splitters
     // are ranked from, should that frame take the 256-bucket route: a rank's strip does, once its kept count is known)
-    launch_pass<uint32_t, kModeFirst, 8>(p, kc, vals_cur, ka, vals_alt, nullptr, n, 0, m_dev, culled_dev, nullptr, nullptr, s,
-                                         samples_out, samples_out && n >= kSamples ? (uint32_t)(n / kSamples) : 0u);
+    launch_pass<uint32_t, kModeFirst, 8>(p, kc, vals_cur, ka, vals_alt, nullptr, n, 0, m_dev, culled_dev, carry ? rect : nullptr,
+                                         nullptr, s, samples_out, samples_out && n >= kSamples ? (uint32_t)(n / kSamples) : 0u,
+                                         nullptr, ca, carry);
     flip();
     for (int shift = 8; shift < 24; shift += 8) {
-        launch_pass<uint32_t, kModePlain, 8>(p, kc, vals_cur, ka, vals_alt, m_dev, n, shift, nullptr, nullptr, nullptr, nullptr, s);
+        launch_pass<uint32_t, kModePlain, 8>(p, kc, vals_cur, ka, vals_alt, m_dev, n, shift, nullptr, nullptr, nullptr, nullptr, s,
+                                             nullptr, 0u, cc, ca, carry);
         flip();
     }
-    launch_pass<uint32_t, kModeFinal, 8>(p, kc, vals_cur, ka, vals_alt, m_dev, n, 24, nullptr, nullptr, rect, rrect, s);
+    launch_pass<uint32_t, kModeFinal, 8>(p, kc, vals_cur, ka, vals_alt, m_dev, n, 24, nullptr, nullptr, rect, rrect, s, nullptr, 0u,
+                                         cc, nullptr, carry);
     flip();
     return hipGetLastError();
 }

@@ -462,7 +462,11 @@ def test_tiles_handed_out_by_list_length_render_the_same_frame(tmp_path):
     (70_000, 2, 0, "depth"), (2_200_000, 2, 0, "sorted"), (2_200_000, 2, 0, "reverse"), (5_000_000, 2, 0, "strip"),
     # the route gsx_render_forward takes (mode -1): by n alone, and with a hint of how many keys are kept
     (1_200_000, -1, 0, "depth"), (2_200_000, -1, 0, "depth"), (5_000_000, -1, 0, "strip"), (5_000_000, -1, 0, "depth"),
-    (7_000_000, -1, 0, "depth")])
+    (7_000_000, -1, 0, "depth"),
+    # mode 4: the LSD passes carrying the rectangles along, packed into 4 bytes (what a frame of more than 1.5M kept
+    # Gaussians on a tile grid of up to 256 x 256 takes); below 2^20 keys it is the plain LSD route
+    (5_000_000, 4, 0, "depth"), (2_200_000, 4, 0, "random"), (1_048_576, 4, 0, "two"), (3_000_001, 4, 0, "strip"),
+    (600_000, 4, 0, "depth")])
 def test_depth_sort_paths_are_the_stable_argsort(n, mode, lds_cap, kind):
     """The depth sort of the whole-path entry (gsx_debug_depth_sort in libgsx_test.so): four compacting LSD passes
     (mode 0) and the sample-partitioned sorts (mode 1: 2048 / 8192 samples -> 255 splitters, mode 2: 8192 samples ->
@@ -508,12 +512,12 @@ def test_depth_sort_paths_are_the_stable_argsort(n, mode, lds_cap, kind):
         keys[(drop >= 0.08) & (drop < 0.2)] = 0xFFFFFFFE
     kept = np.nonzero(keys < 0xFFFFFFFE)[0]
     expect = kept[np.argsort(keys[kept], kind="stable")]
-    rect = rs.randint(0, 65535, size=(n, 4)).astype(np.uint16)
+    rect = rs.randint(0, 256 if mode == 4 else 65535, size=(n, 4)).astype(np.uint16)
     d_keys = torch.from_numpy(keys.view(np.int32).copy()).cuda()
     d_rect = torch.from_numpy(rect.view(np.int16).copy()).cuda()
     d_rrect = torch.zeros_like(d_rect)
     d_order = torch.zeros(n, dtype=torch.int32, device="cuda:0")
-    nbytes = 16 * n + 4096 + lib.gsx_workspace_bytes(n, 16, 16, 16, 1)
+    nbytes = 24 * n + 8192 + lib.gsx_workspace_bytes(n, 16, 16, 16, 1)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
     counts = (ctypes.c_int64 * 3)()
     hint = int(kept.size) if kind == "strip" else 0

@@ -1,6 +1,7 @@
 """Per-kernel times of the depth sort alone (gsx_debug_depth_sort in libgsx_test.so) -- run under rocprofv3:
     rocprofv3 --kernel-trace --stats ... -- python3 tools/sort_probe.py N MODE [KEPT_FRACTION]
-MODE: 0 LSD, 1 = 256 buckets, 2 = 1024 buckets, -1 = the route of gsx_render_forward."""
+MODE: 0 LSD, 1 = 256 buckets, 2 = 1024 buckets, 4 = LSD with the rectangles carried along, -1 = the route of
+gsx_render_forward."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,7 +17,7 @@ d_keys0 = torch.from_numpy(keys.view(np.int32).copy()).cuda()
 d_rect = torch.from_numpy(rect.view(np.int16).copy()).cuda()
 d_rrect = torch.zeros_like(d_rect)
 d_order = torch.zeros(n, dtype=torch.int32, device="cuda")
-nbytes = 16 * n + 4096 + lib.gsx_workspace_bytes(n, 16, 16, 16, 1)
+nbytes = 24 * n + 8192 + lib.gsx_workspace_bytes(n, 16, 16, 16, 1)
 scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
 counts = (ctypes.c_int64 * 3)()
 hint = int((keys < 0xFFFFFFFE).sum()) if kept < 0.9 else 0
