@@ -131,7 +131,13 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
         } else {
             const uint32_t *sorted_vals = nullptr;
             const bool split = p.split && cap > 0 && gsx::blend_splits_long_tiles(p.grid, p.semantics, p.generic);
-            const gsx::LongTiles lt{counters + kCtrLong, (uint32_t *)(ws + c.longs), split ? gsx::kMaxLongTiles : 0u};
+            gsx::LongTiles lt{counters + kCtrLong, (uint32_t *)(ws + c.longs), split ? gsx::kMaxLongTiles : 0u};
+            if (fh.blend.lens) {        // GsxParams.hints: the tiles' costs decide who is long (tile_ranges_kernel)
+                lt.cost = fh.blend.lens;
+                lt.header = fh.blend.header;
+                lt.cost_pct = (uint32_t)gsx::knob("GSX_LONG_COST_PCT", 30);      // (test library only)
+                if (!fh.sched || lt.cost_pct == 0) lt.header = nullptr;
+            }
             GSX_HIP(gsx::sort_instances(temp, cap, p.grid, ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0),
                                         (uint32_t *)(ws + c.tvals1), ranges, counters + kCtrPairs, lt, &sorted_vals, s));
             if (p.tile_counts) GSX_HIP(gsx::launch_tile_counts(ranges, p.grid.count(), p.tile_counts, s));

@@ -395,11 +395,31 @@ __global__ void __launch_bounds__(kBlock)
         if (j == 0 || k[e] != cur) ranges[cur].x = j;
         if (j == d - 1 || k[e + 2] != cur) {           // j closes the run of tile `cur`
             uint32_t end = j + 1;
-            if (lt.max && j >= long_len && keys[j - long_len] == cur) {
+            bool is_long = lt.max && j >= long_len && keys[j - long_len] == cur;
+            const bool by_cost = lt.max && lt.cost && lt.header && lt.header[kHintLens] == ntiles && lt.header[kHintSched] == ntiles;
+            if (by_cost) {
+                // What the tile COST last time decides (records staged until it was done: a dense tile that saturates
+                // early is cheap however long its list), against a SIMD's share of the whole frame: a wave that is
+                // alone on its SIMD at the end of the launch walks ~3x slower than the SIMD's eight waves together, so
+                // a tile above a third of that share is still running when everything else has finished.  (By length,
+                // 4x the mean: the heavy-tailed test scene ended with ~100 single waves of 1 500 .. 2 500 records each
+                // running alone for 150 us; lowering the length threshold instead put 500 tiles on four waves, most
+                // of them cheap, and cost 50 %.)  A long tile's cost is the largest of its four helpers' -- what one
+                // wave would have walked --, so a tile does not change sides from frame to frame.
+                uint32_t total = 0;
+#pragma unroll
+                for (int xcd = 0; xcd < 8; ++xcd) total += lt.header[kHintXcdCost + xcd];
+                // (the percentage: the caller's, or what the compositing launch has raised it to -- see gsx_plan.h)
+                const uint32_t pct = max(lt.cost_pct, lt.header[kHintLongPct]);
+                const uint32_t thr = max(256u, (uint32_t)(((uint64_t)(total >> 10) * pct) / 100u));
+                is_long = (lt.cost[cur] & 0x7FFFFFFFu) >= thr && j >= 127u && keys[j - 127u] == cur;     // (and 128 entries now)
+            }
+            if (is_long) {
                 const uint32_t slot = atomicAdd(lt.count, 1u);
                 if (slot < lt.max) {
                     lt.list[slot] = (uint32_t)cur;
                     end |= kLongFlag;
+                    if (lt.cost) lt.cost[cur] = 0x80000000u;      // the helpers raise it to their largest cost
                 }
             }
             ranges[cur].y = end;

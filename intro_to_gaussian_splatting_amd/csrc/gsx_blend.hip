@@ -70,6 +70,7 @@ namespace gsx {
 namespace {
 
 constexpr float kStopRefCpu = 0.000001f;  // gaussian_scene.py:153
+constexpr uint32_t kBatchCost = 5;        // staging a batch of 64 costs about as much as compositing five records (a tile's cost, gsx_plan.h)
 // A staged batch holds up to 64 records followed by kPad NULL records (log2 op = -inf: alpha = exp2(-inf) = 0 at every
 // pixel, colour 0), so that the compositing loops always take whole trips of 4 or 8 records with no per-record branch
 // (a branch between the records of a trip keeps the compiler from interleaving their dependent chains, and a wave
@@ -435,7 +436,7 @@ __device__ __forceinline__ void rank_samples(uint32_t group, int lane, const Ble
 __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                                                         const uint2 *__restrict__ ranges, const TileGrid &g,
                                                         const OutDesc &out, uint32_t t, int quarter,
-                                                        float4 (*sh)[kSlots], uint32_t budget) {
+                                                        float4 (*sh)[kSlots], uint32_t budget, uint32_t *cost_out = nullptr) {
     const int lane = threadIdx.x;
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
@@ -454,6 +455,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     uint2 rg = ranges[t];
     rg.y &= ~kLongFlag;
     uint32_t skipped = 0;            // colour this tile has left out so far (stage_batch)
+    uint32_t cost = 0;               // what this quarter walked (GsxParams.hints: see the tile kernel)
     constexpr int kTrip = 8;
     // The gather runs AHEAD of the compositing: while batch i is composited, the records of batch i + 1 and the
     // list entries of batch i + 2 are in flight.  A long tile's wave is nearly alone on its SIMD at the end of the
@@ -477,6 +479,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
         if (base + 128u + (uint32_t)lane < rg.y) idx2 = vals[base + 128u + lane];
         const int kind = stage_records(ra, rb, rc, (uint32_t)lane < nb, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f,
                                        skipped, budget);
+        cost += nb + kBatchCost;
 #ifdef GSX_TEST_HOOKS
         probe_staged += nb;
         if (checked && probe_checked_at == 0xFFFFFFu) probe_checked_at = probe_batch;
@@ -550,6 +553,8 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
         __syncthreads();
         if (__ballot(T > 0.0f) == 0ull) break;
     }
+    // (the largest of the four quarters' costs = the records one wave would have walked until all 256 pixels are done)
+    if (cost_out && lane == 0) atomicMax(cost_out, cost | 0x80000000u);
 #ifdef GSX_TEST_HOOKS
     if (g_blend_probe && lane == 0)
         g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t | 0x40000000u, rg.y - rg.x,
@@ -613,7 +618,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         const uint32_t b = block, slot = (b >> 5) * 8u + (b & 7u);
         const int quarter = (int)((b >> 3) & 3u);
         if (slot >= min(*lt.count, lt.max)) return;
-        blend_long_tile_quarter(rec, vals, ranges, g, out, lt.list[slot], quarter, sh, budget);
+        const uint32_t lt_tile = lt.list[slot];
+        blend_long_tile_quarter(rec, vals, ranges, g, out, lt_tile, quarter, sh, budget, hints.lens ? hints.lens + lt_tile : nullptr);
         return;
     }
     const uint32_t bid = block - nhelpers;
@@ -652,11 +658,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     uint2 rg = ranges[t];            // the same in every lane: kept in scalar registers
     rg.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.x);
     rg.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.y);
-    if (hints.lens && lane == 0) {  // what the next frame's schedule is made from (GsxParams.hints; long tiles count as empty)
-        hints.lens[t] = (rg.y & kLongFlag) ? 0u : rg.y - rg.x;
-        if (t == 0) hints.header[kHintLens] = (uint32_t)g.count();
+    // What the next frame's schedule and its choice of long tiles are made from (GsxParams.hints): the tile's COST --
+    // records actually staged until the tile was done (a dense tile that saturates after a tenth of its list costs a
+    // tenth; records that cannot matter are not staged) plus a few per batch for the staging itself -- stored when the
+    // tile ends.  (A long tile's entry is the helpers': tile_ranges_kernel flagged it, they raise it.)
+    if (hints.lens && lane == 0 && t == 0) {
+        const bool by_cost = hints.header[kHintLens] == (uint32_t)g.count() && hints.header[kHintSched] == (uint32_t)g.count();
+        hints.header[kHintLens] = (uint32_t)g.count();
+        // How many tiles qualified as long this frame steers the threshold of the next (gsx_plan.h: kHintLongPct).  A
+        // split tile is staged four times over, so splitting hundreds costs more than it saves (512 split tiles of the
+        // heavy-tailed test scene: 0.60 ms of compositing against 0.38 for none and 0.31 for the 176 most expensive).
+        if (lt.max && by_cost) {       // (a frame that chose by list length says nothing about the threshold)
+            const uint32_t found = *lt.count, pct = max(hints.header[kHintLongPct], 30u);
+            hints.header[kHintLongPct] = found > 192u ? min(pct + pct / 4u, 1000u) : (found < 64u ? max(pct - pct / 8u, 30u) : pct);
+        }
     }
     if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
+    uint32_t cost = 0;
     uint32_t skipped = 0;            // colour this tile has left out so far (stage_batch)
     // the list entries of the next batch are requested while this one is composited (one register): one of the two
     // dependent trips to memory per batch leaves the path of a wave that has its SIMD to itself
@@ -668,6 +686,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         const int kind = stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skipped, budget,
                                      &idx_now);
         const bool wild = kind != kBatchRegular;     // wave-uniform
+        cost += nb + kBatchCost;
 #ifdef GSX_TEST_HOOKS
         probe_staged += nb;
         if (checked && probe_checked_at == 0xFFFFFFu) probe_checked_at = (base - rg.x) >> 6;
@@ -768,6 +787,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         for (uint32_t base = rg.x; base < rg.y; base += 64) {
             uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
             (void)stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skipped, budget);
+            cost += 4u * nb;
             __syncthreads();
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
@@ -782,6 +802,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         c2[0] = c2a.x; c2[1] = c2a.y; c2[2] = c2b.x; c2[3] = c2b.y;
     }
 
+    if (hints.lens && lane == 0) hints.lens[t] = cost;
 #ifdef GSX_TEST_HOOKS
     if (g_blend_probe && lane == 0)
         g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t, rg.y - rg.x,

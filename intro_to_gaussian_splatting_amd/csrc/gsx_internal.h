@@ -56,6 +56,12 @@ struct LongTiles {
     uint32_t *count;   // number of long tiles found (may exceed max)
     uint32_t *list;    // window-local tile ids, max entries
     uint32_t max;      // 0: the split is off for this frame
+    // When the previous frame of the view left its tiles' costs (GsxParams.hints; header[kHintLens] and
+    // header[kHintSched] name this window) a tile is long when it COST more than cost_pct % of a SIMD's share of the
+    // frame (sum of all costs / 1024) -- see tile_ranges_kernel; cost == nullptr: by list length alone.
+    uint32_t *cost = nullptr;
+    const uint32_t *header = nullptr;
+    uint32_t cost_pct = 30;
 };
 __host__ __device__ inline uint32_t long_tile_threshold(uint32_t pairs, uint32_t tiles) {
     const uint32_t mean = tiles ? pairs / tiles : 0u;

@@ -93,10 +93,20 @@ inline int clear_blocks_for(int64_t rows, int64_t fw) {
 //                      [kHintLens]      number of tiles `lens` was written for, [kHintSched] the same for `sched`
 //   splitters[256]     depth-sort splitters of the last frame (written by spare workgroups of its compositing launch)
 //   samples[2048]      regularly spaced KEPT depth keys of the last frame (written by its partition count kernel)
-//   lens[max_tiles]    list length of every tile of the window (written by the compositing launch; long tiles: 0)
+//   lens[max_tiles]    COST of every tile of the window, written by the compositing launch: records staged until the tile
+//                      was done + 5 per batch (a dense tile that saturates early is cheap however long its list).  Bit 31:
+//                      composited as a long tile, on four helper workgroups (set by tile_ranges_kernel with cost 0, raised
+//                      by the helpers to the largest of their four costs -- which is what the tile would have cost on one
+//                      wave); the schedule counts such a tile as empty, tile_ranges_kernel decides by the cost who is
+//                      long next time
 //   sched[..]          per XCD, its tiles by falling list length (eight spare workgroups of the projection launch,
 //                      gsx_schedule_device.h; header[kHintXcdTiles + x] = how many tiles XCD x has)
-enum { kHintSplitters = 0, kHintSamples = 1, kHintLens = 2, kHintSched = 3, kHintXcdTiles = 8 /* .. 15 */, kHintHeaderWords = 64 };
+//                      header[kHintXcdCost + x] = sum of the costs of XCD x's tiles (same workgroups)
+//                      header[kHintLongPct] = the share of a SIMD's load (in %) from which a tile counts as long
+//                      (0 = 30; the compositing launch raises it while more than 192 tiles qualify and lowers it again
+//                      below 64: the threshold, not the order of arrival, decides who gets the helper slots)
+enum { kHintSplitters = 0, kHintSamples = 1, kHintLens = 2, kHintSched = 3, kHintLongPct = 4, kHintXcdTiles = 8 /* .. 15 */,
+       kHintXcdCost = 16 /* .. 23 */, kHintHeaderWords = 64 };
 struct HintsLayout {
     size_t splitters, samples, lens, sched, total;   // byte offsets
 };

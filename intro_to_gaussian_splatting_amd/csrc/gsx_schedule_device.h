@@ -78,7 +78,7 @@ __host__ __device__ inline uint32_t sched_tile_of(uint32_t j, uint32_t x, const 
 __device__ __forceinline__ void schedule_from_lengths(const SchedJob &job, uint32_t x) {
     constexpr uint32_t kClasses = 256;
     __shared__ uint32_t hist[kClasses];
-    __shared__ uint32_t s_lo, s_hi, s_wsum[4];
+    __shared__ uint32_t s_lo, s_hi, s_total, s_wsum[4];
     const uint32_t tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63, w = tid >> 6;
     const uint32_t nt = job.nt;
@@ -88,26 +88,36 @@ __device__ __forceinline__ void schedule_from_lengths(const SchedJob &job, uint3
         return;
     }
     const uint32_t mine_n = sched_count(nt, job.nwy, x);
-    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-    for (uint32_t j = tid; j < mine_n; j += nthreads) {
+    // (a tile's entry is its COST, gsx_plan.h; bit 31: it ran as a long tile on helper workgroups and will again -- to
+    // the hand-out it is empty, to the XCD's total it counts)
+    auto cost_of = [&](uint32_t j) -> uint32_t {
         const uint32_t l = job.lens[sched_tile_of(j, x, cut)];
+        return (l >> 31) ? 0u : l;
+    };
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u, total = 0u;
+    for (uint32_t j = tid; j < mine_n; j += nthreads) {
+        const uint32_t raw = job.lens[sched_tile_of(j, x, cut)], l = (raw >> 31) ? 0u : raw;
         mn = min(mn, l);
         mx = max(mx, l);
+        total += min(raw & 0x7FFFFFFFu, 1u << 20);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+        total += (uint32_t)__shfl_xor((int)total, o);
     }
     if (tid < kClasses) hist[tid] = 0;
     if (tid == 0) {
         s_lo = 0xFFFFFFFFu;
         s_hi = 0u;
+        s_total = 0u;
     }
     __syncthreads();
     if (lane == 0 && mn <= mx) {
         atomicMin(&s_lo, mn);
         atomicMax(&s_hi, mx);
+        atomicAdd(&s_total, total);
     }
     __syncthreads();
     const uint32_t shortest = s_lo;
@@ -115,7 +125,7 @@ __device__ __forceinline__ void schedule_from_lengths(const SchedJob &job, uint3
     auto cls = [&](uint32_t l) -> uint32_t {   // class 0 = the longest lists
         return (kClasses - 1u) - min((uint32_t)((float)(l - shortest) * per_entry), kClasses - 1u);
     };
-    for (uint32_t j = tid; j < mine_n; j += nthreads) atomicAdd(&hist[cls(job.lens[sched_tile_of(j, x, cut)])], 1u);
+    for (uint32_t j = tid; j < mine_n; j += nthreads) atomicAdd(&hist[cls(cost_of(j))], 1u);
     __syncthreads();
     const uint32_t mine = tid < kClasses ? hist[tid] : 0u;     // (256 threads: one class each)
     uint32_t v = mine;
@@ -133,10 +143,11 @@ __device__ __forceinline__ void schedule_from_lengths(const SchedJob &job, uint3
     uint32_t *out = job.sched + (size_t)x * job.cap;
     for (uint32_t j = tid; j < mine_n; j += nthreads) {
         const uint32_t t = sched_tile_of(j, x, cut);
-        out[atomicAdd(&hist[cls(job.lens[t])], 1u)] = t;
+        out[atomicAdd(&hist[cls(cost_of(j))], 1u)] = t;
     }
     if (tid == 0) {
         job.header[kHintXcdTiles + x] = mine_n;
+        job.header[kHintXcdCost + x] = s_total;
         if (x == 0) job.header[kHintSched] = nt;
     }
 }
