@@ -21,7 +21,7 @@ st = {}
 scene.render_image_hip(1, stats=st, timing=True)
 torch.cuda.synchronize()
 lib.gsx_debug_set_blend_probe(None)
-d = buf.cpu().numpy().view(np.uint32)
+d = buf.cpu().numpy().view(np.uint32)[:grid]       # (the second record of every workgroup lies behind: tools/simd_balance.py)
 cyc = d[:, 0].astype(np.int64)
 used = np.nonzero(d[:, 2] | d[:, 1])[0]
 print(wl, "blend stage %.3f ms, D %d" % (st["stage_ms"]["blend"], st["n_instances"]))
