@@ -136,9 +136,11 @@ typedef struct GsxParams {
      * order in which tiles are handed to the SIMDs -- so with GSX_FLAG_HINTS_VALID a frame takes both from what the
      * PREVIOUS frame of this view left in the buffer instead of computing them on its own critical path (two
      * dependent kernels, ~20 us of a 0.42 ms frame), and every frame given the buffer leaves fresh ones for the next
-     * (computed by spare workgroups of launches that run anyway).  Stale hints (the camera moved) cost time -- unevenly
-     * filled sort buckets -- never a pixel: the frame is the same bit for bit (tested).  Frames in flight on different
-     * streams need a buffer each. */
+     * (computed by spare workgroups of launches that run anyway).  The buffer also holds what every tile COST in the
+     * previous frame, which decides which tiles are composited by four waves instead of one (the same pixels either
+     * way).  Stale hints (the camera moved) cost time -- unevenly filled sort buckets, an unbalanced hand-out --
+     * never a pixel: the frame is the same bit for bit (tested).  Frames in flight on different streams need a
+     * buffer each. */
     void *hints;
 } GsxParams;
 

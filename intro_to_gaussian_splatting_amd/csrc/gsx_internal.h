@@ -83,7 +83,7 @@ struct PreprocessedIn {  // argument list of splat/c/render.cu:90-101
 };
 
 // The projection launch's share: one spare workgroup puts the compositing schedule of THIS frame together from the
-// tile-list lengths the previous frame left (gsx_schedule_device.h; sched == nullptr: not wanted).
+// tiles' costs the previous frame left (gsx_schedule_device.h; sched == nullptr: not wanted).
 struct ScheduleHint {
     const uint32_t *lens;
     uint32_t *sched, *header;

@@ -1,10 +1,11 @@
-// The compositing schedule from the tile-list lengths of the PREVIOUS frame (GsxParams.hints), put together by eight
+// The compositing schedule from the tiles' costs in the PREVIOUS frame (GsxParams.hints: records staged until the tile
+// was done, gsx_plan.h; a frame's first schedule, tile_schedule_kernel, goes by list length), put together by eight
 // spare workgroups of the projection launch (the frame's first kernel and, of those in front of the compositing
 // launch, its longest: 25 us at 1M Gaussians, 116 us at 5M) -- one per XCD:
 //   * the window's tiles are dealt to the XCDs in chunks of ~32 consecutive tile ids (ids are column-major: half a
 //     tile column at 1080p; chunk c goes to XCD c % 8, see sched_cut): vertical neighbours, which share most of their
 //     Gaussians, stay in one 4 MiB L2, and every XCD gets its share of a dense region;
-//   * inside an XCD the tiles are ranked by list length (256 classes between its shortest and its longest list) and
+//   * inside an XCD the tiles are ranked by cost (256 classes between its cheapest and its most expensive tile) and
 //     the compositing launch hands them to the XCD's 128 SIMDs round by round, alternately forwards and backwards
 //     (blend_tile16_kernel), so that every SIMD gets one tile of every length class.
 // Round 2 ranked the tiles over the whole frame (tile_schedule_kernel: one workgroup, 10 us at 1080p, 22 us at 4K, on
@@ -24,7 +25,7 @@
 namespace gsx {
 
 struct SchedJob {
-    const uint32_t *lens;       // list length of every tile of the window, left by the previous frame's compositing launch
+    const uint32_t *lens;       // cost of every tile of the window, left by the previous frame's compositing launch (gsx_plan.h)
     uint32_t *sched, *header;
     uint32_t nt, nwy, cap;
 };

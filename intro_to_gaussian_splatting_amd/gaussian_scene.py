@@ -301,7 +301,7 @@ class GaussianScene:
         ``tile_counts`` (int32 / uint32 device tensor, one entry per tile of the window, x-major) receives
         the length of every tile's Gaussian list (GsxParams.tile_counts; ``strips.balanced_plan``).
         ``use_hints`` (default): every (camera, tile size, window, rule set, stream) of this scene keeps a small
-        device buffer (GsxParams.hints) in which a frame leaves the depth-sort splitters and the tile-list lengths
+        device buffer (GsxParams.hints) in which a frame leaves the depth-sort splitters and what every tile cost
         for the NEXT frame of that view, which then skips the two kernels that would compute them on its own critical
         path; stale hints (the Gaussians or the camera changed) cost time, never a pixel.  ``use_hints=False``
         renders every frame from scratch (tests hold the two against each other).
