@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(kThreads)
     // HBM as a partial sector of its own -- 2.0x the algorithmic bytes written, and as much again read for the
     // read-modify-write, in the 4K frame's tile sort (PMC, round 3).
     uint32_t chunk_id = blockIdx.x;
-    if (SCAN == kScanRows && kXcdChunks) {
+    if (kXcdChunks) {       // (every mode: the small passes without a row-scan launch write the same short runs)
         const uint32_t chunks = (n + (uint32_t)kItems - 1u) / (uint32_t)kItems, per = (chunks + 7u) >> 3;
         const uint32_t x = blockIdx.x & 7u, i = blockIdx.x >> 3;
         if (i >= per) return;
@@ -1238,14 +1238,14 @@ void launch_pass(const PassPlan &p, const Key *kc, const uint32_t *vc, Key *ka, 
         count_kernel<Key, true, first><<<p.nblocks, kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, mask, p.table,
                                                                        p.nbp, culled, nullptr, nullptr, nullptr, samples_out,
                                                                        sample_step);
-        scatter_kernel<Key, kScanSelf, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
+        scatter_kernel<Key, kScanSelf, MODE, BITS><<<(p.nblocks + 7) & ~7, kThreads, 0, s>>>(kc, vc, ka, va, n_dev, (uint32_t)bound,
                                                                                    shift, p.table, p.totals, p.nbp, m_out, rect,
                                                                                    rrect);
     } else if (p.scan == kScanQuads) {
         count_kernel<Key, false, first><<<p.nquads, kQuad * kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, mask,
                                                                                p.table, p.nbp, culled, nullptr, p.quad_totals,
                                                                                nullptr, samples_out, sample_step);
-        scatter_kernel<Key, kScanQuads, MODE, BITS><<<p.nblocks, kThreads, 0, s>>>(
+        scatter_kernel<Key, kScanQuads, MODE, BITS><<<(p.nblocks + 7) & ~7, kThreads, 0, s>>>(
             kc, vc, ka, va, n_dev, (uint32_t)bound, shift, p.table, p.totals, p.nbp, m_out, rect, rrect, nullptr, p.quad_totals);
     } else {
         count_kernel<Key, false, first><<<p.nquads, kQuad * kThreads, 0, s>>>(kc, n_dev, (uint32_t)bound, shift, mask,
@@ -1345,14 +1345,14 @@ static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1
         count_kernel<uint32_t, true, true, kBins><<<p.nblocks, kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u, p.table,
                                                                                  p.nbp, culled_dev, splitters, nullptr, hdr,
                                                                                  samples_out, step, zero_sums, nsums);
-        scatter_kernel<uint32_t, kScanSelf, kModeFirst, 8, kBins><<<p.nblocks, kThreads, 0, s>>>(
+        scatter_kernel<uint32_t, kScanSelf, kModeFirst, 8, kBins><<<(p.nblocks + 7) & ~7, kThreads, 0, s>>>(
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
             nullptr, hdr);
     } else if (NB == kBins && p.scan == kScanQuads) {
         count_kernel<uint32_t, false, true, kBins><<<p.nquads, kQuad * kThreads, 0, s>>>(
             keys0, nullptr, (uint32_t)n, 0, 255u, p.table, p.nbp, culled_dev, splitters, p.quad_totals, hdr, samples_out, step,
             zero_sums, nsums);
-        scatter_kernel<uint32_t, kScanQuads, kModeFirst, 8, kBins><<<p.nblocks, kThreads, 0, s>>>(
+        scatter_kernel<uint32_t, kScanQuads, kModeFirst, 8, kBins><<<(p.nblocks + 7) & ~7, kThreads, 0, s>>>(
             keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
             p.quad_totals, hdr);
     } else {
