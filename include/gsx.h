@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define GSX_VERSION 300 /* major*10000 + minor*100 + patch.  300: GsxParams.kept_hint, GsxFrameStats.n_kept,
+#define GSX_VERSION 301 /* major*10000 + minor*100 + patch.  301: GsxParams.struct_size (in reserved0's place), a larger
+                         * schedule region in gsx_hints_bytes.  300: GsxParams.kept_hint, GsxFrameStats.n_kept,
                            * tile_counts zeroed when nothing is rendered, tile_x1 == tile_x0 is an empty window,
                            * GsxCamera.camera_center; the library exports exactly the functions declared here */
 
@@ -123,7 +124,12 @@ typedef struct GsxParams {
      * `colors` argument is ignored and may be NULL. */
     const float *sh;
     int32_t sh_degree;
-    int32_t reserved0;
+    /* sizeof(GsxParams) as the CALLER compiled it; gsx_default_params() fills it in.  The fields below it were
+     * appended in ABI 300: a struct_size that ends before one of them makes the library ignore that field (a client
+     * built against an older header hands over a shorter struct -- whatever lies behind it is not read).  0 = not
+     * stated: the struct is taken to be the current one (callers of ABI 300 zeroed this word).  Callers should also
+     * check gsx_version() == GSX_VERSION once: the version is bumped whenever a struct or a signature changes. */
+    int32_t struct_size;
     /* gsx_render_forward only.  How many Gaussians are expected to reach a tile of the window
      * (GsxFrameStats.n_kept of an earlier frame of this view and window); 0 (default) = unknown, assume all n.
      * A hint, never a bound: it only selects the depth-sort route (the sample-partitioned routes sort what is
@@ -140,7 +146,7 @@ typedef struct GsxParams {
      * previous frame, which decides which tiles are composited by four waves instead of one (the same pixels either
      * way).  Stale hints (the camera moved) cost time -- unevenly filled sort buckets, an unbalanced hand-out --
      * never a pixel: the frame is the same bit for bit (tested).  Frames in flight on different streams need a
-     * buffer each. */
+     * buffer each.  The buffer must be 256-byte aligned (GSX_ERR_INVALID_ARGUMENT otherwise). */
     void *hints;
 } GsxParams;
 

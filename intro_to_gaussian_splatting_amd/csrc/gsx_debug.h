@@ -22,10 +22,15 @@ GSX_API int gsx_debug_sort_pairs(void *keys, uint32_t *vals, int64_t n, int32_t 
 /* The depth sort of the whole-path entry on caller-provided keys.  keys (n, device; >= 0xFFFFFFFE = dropped;
  * overwritten), rect / rrect (n x 4 uint16), order_out (n): on return order_out[0 .. counts_host[0]) = index of
  * each rank, rrect[rank] = rect[index]; counts_host (3 entries) = {kept, culled, route taken}.
- * mode 0: four LSD passes; 1: sample-partitioned, 256 buckets; 2: sample-partitioned, 1024 buckets;
- * -1: the route gsx_render_forward would take for (n, kept_hint).  lds_cap: bucket size above which the bucket
- * kernel sorts through global memory (0 = its LDS capacity).  scratch: 16 n + 4096 +
- * gsx_workspace_bytes(n, 16, 16, 16, 1) bytes.  Synchronises. */
+ * mode 0: four LSD passes (the last one gathers rect[index]); 1: sample-partitioned, 256 buckets; 2: sample-partitioned,
+ * 1024 buckets (a route nothing in gsx_render_forward selects: measured slower, kept as a tested alternative);
+ * 4: the LSD passes with the rectangles CARRIED along, packed into 4 bytes -- every coordinate of `rect` must then be
+ * below 256 (GSX_ERR_INVALID_ARGUMENT is NOT detected on the device: the caller guarantees it) and the scratch holds two
+ * more arrays; -1: the route gsx_render_forward would take for (n, kept_hint).  Any other mode:
+ * GSX_ERR_INVALID_ARGUMENT.  lds_cap: bucket size above which the bucket kernel sorts through global memory (0 = its
+ * LDS capacity).  scratch: 3 x align256(4 n) + 256 + gsx_workspace_bytes(n, 16, 16, 16, 1) bytes, + 2 x align256(4 n) for
+ * mode 4 (24 n + 4096 + gsx_workspace_bytes(..) covers every mode; too little: GSX_ERR_WORKSPACE_TOO_SMALL).
+ * Synchronises. */
 GSX_API int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, void *rrect, uint32_t *order_out,
                                  int32_t mode, uint32_t lds_cap, int64_t kept_hint, int64_t *counts_host,
                                  void *scratch, size_t scratch_bytes, void *stream);

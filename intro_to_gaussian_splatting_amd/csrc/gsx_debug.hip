@@ -48,6 +48,7 @@ int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, void *rrec
                          void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (n <= 0 || !keys || !rect || !rrect || !order_out || !scratch) return GSX_ERR_INVALID_ARGUMENT;
+    if (mode != -1 && mode != 0 && mode != 1 && mode != 2 && mode != 4) return GSX_ERR_INVALID_ARGUMENT;
     const size_t words = align_up((size_t)n * 4);
     const size_t need = 3 * words + 256 + binning_temp_bytes(n, 1) + (mode == 4 ? 2 * words : 0);
     if (scratch_bytes < need) return GSX_ERR_WORKSPACE_TOO_SMALL;

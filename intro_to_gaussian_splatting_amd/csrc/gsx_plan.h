@@ -107,18 +107,45 @@ inline int clear_blocks_for(int64_t rows, int64_t fw) {
 //                      below 64: the threshold, not the order of arrival, decides who gets the helper slots)
 enum { kHintSplitters = 0, kHintSamples = 1, kHintLens = 2, kHintSched = 3, kHintLongPct = 4, kHintXcdTiles = 8 /* .. 15 */,
        kHintXcdCost = 16 /* .. 23 */, kHintHeaderWords = 64 };
+constexpr uint32_t kSchedXcds = 8;
+// The window's nt tiles are cut into 8 k chunks of consecutive ids, k = max(1, nt / 256) per XCD, whose sizes differ
+// by at most one (the first `rem` chunks hold s + 1 tiles, the others s), and chunk c goes to XCD c % 8: every XCD's
+// share of the TILES is within k tiles of an eighth, its share of the list entries as even as ~30 chunks spread over
+// the frame make it.  (Chunks of two whole tile columns -- 59.5 of them at 1080p -- gave four XCDs 8 chunks and four
+// 7, and the compositing launch waited 18 us for the first four: round 3, measured.)
+struct SchedCut {
+    uint32_t k, s, rem;        // chunks per XCD, size of the small chunks, number of chunks of size s + 1
+};
+GSX_HD inline SchedCut sched_cut(uint32_t nt) {
+    SchedCut c;
+    c.k = nt / (kSchedXcds * 32u) ? nt / (kSchedXcds * 32u) : 1u;
+    c.s = nt / (kSchedXcds * c.k);
+    c.rem = nt - c.s * kSchedXcds * c.k;
+    return c;
+}
+GSX_HD inline uint32_t sched_cap(uint32_t nt, uint32_t /*nwy*/) {
+    const SchedCut c = sched_cut(nt);
+    return (c.s + 1u) * c.k;
+}
 struct HintsLayout {
     size_t splitters, samples, lens, sched, total;   // byte offsets
 };
-// max_tiles: tiles of the frame; max_axis: tiles along its longer axis (a window is at most that high).
-inline HintsLayout hints_layout(int64_t max_tiles, int64_t max_axis) {
+// max_tiles: tiles of the frame (a window has at most as many).  The schedule region holds 8 x sched_cap(nt) entries for
+// the LARGEST number any window of up to max_tiles tiles needs: 8 k (s + 1) <= nt + 8 k <= nt + nt / 32 + 8, which
+// grows with nt (tests/host/plan_sanitize.cpp sweeps it; round 3 sized it nt + 16 x the longer axis, which a frame of
+// more than ~512 tiles along its SHORTER axis overran: a 10 000 x 10 000 frame by 900 entries).
+inline size_t hints_sched_entries(int64_t max_tiles) {
+    const size_t t = (size_t)(max_tiles > 0 ? max_tiles : 1);
+    return t + t / 32 + 64;
+}
+inline HintsLayout hints_layout(int64_t max_tiles, int64_t /*max_axis*/) {
     HintsLayout h;
-    const size_t t = (size_t)(max_tiles > 0 ? max_tiles : 1), a = (size_t)(max_axis > 0 ? max_axis : 1);
+    const size_t t = (size_t)(max_tiles > 0 ? max_tiles : 1);
     h.splitters = kHintHeaderWords * 4;
     h.samples = h.splitters + (size_t)kSortBins * 4;
     h.lens = h.samples + (size_t)kSortSamples * 4;
     h.sched = h.lens + ((t * 4 + 255) & ~(size_t)255);
-    h.total = h.sched + (((t + 16 * a) * 4 + 255) & ~(size_t)255);   // 8 x sched_cap(nt, nwy) <= nt + 16 nwy entries
+    h.total = h.sched + ((hints_sched_entries(max_tiles) * 4 + 255) & ~(size_t)255);
     return h;
 }
 
@@ -130,6 +157,7 @@ inline size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 
 inline void default_params(GsxParams *params) {
     memset(params, 0, sizeof *params);
+    params->struct_size = (int32_t)sizeof *params;
     params->semantics = GSX_SEM_REF_CPU;
     params->layout = GSX_LAYOUT_WH3;
     params->tile_x1 = -1;
@@ -241,7 +269,18 @@ inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_ima
     };
     GsxParams d;
     default_params(&d);
-    if (params) d = *params;
+    if (params) {
+        d = *params;
+        // GsxParams.struct_size: fields the caller's struct ends before are not read (include/gsx.h)
+        const int32_t have = params->struct_size;
+        if (have != 0) {
+            if (have < (int32_t)offsetof(GsxParams, kept_hint) || have > (int32_t)sizeof(GsxParams))
+                return fail(GSX_ERR_INVALID_ARGUMENT, "GsxParams.struct_size %d is not a size this library knows (%zu)", have,
+                            sizeof(GsxParams));
+            if (have < (int32_t)(offsetof(GsxParams, kept_hint) + sizeof d.kept_hint)) d.kept_hint = 0;
+            if (have < (int32_t)(offsetof(GsxParams, hints) + sizeof d.hints)) d.hints = nullptr;
+        }
+    }
     if (width <= 0 || height <= 0) return fail(GSX_ERR_INVALID_ARGUMENT, "image size %dx%d is not positive", width, height);
     if (tile <= 0 || tile > 1024) return fail(GSX_ERR_INVALID_ARGUMENT, "tile size %d out of range [1,1024]", tile);
     if (d.semantics != GSX_SEM_REF_CPU && d.semantics != GSX_SEM_REF_CUDA && d.semantics != GSX_SEM_STD_3DGS)

@@ -30,27 +30,8 @@ struct SchedJob {
     uint32_t nt, nwy, cap;
 };
 
-constexpr uint32_t kSchedXcds = 8;
 
-// The window's nt tiles are cut into 8 k chunks of consecutive ids, k = max(1, nt / 256) per XCD, whose sizes differ
-// by at most one (the first `rem` chunks hold s + 1 tiles, the others s), and chunk c goes to XCD c % 8: every XCD's
-// share of the TILES is within k tiles of an eighth, its share of the list entries as even as ~30 chunks spread over
-// the frame make it.  (Chunks of two whole tile columns -- 59.5 of them at 1080p -- gave four XCDs 8 chunks and four
-// 7, and the compositing launch waited 18 us for the first four: round 3, measured.)
-struct SchedCut {
-    uint32_t k, s, rem;        // chunks per XCD, size of the small chunks, number of chunks of size s + 1
-};
-__host__ __device__ inline SchedCut sched_cut(uint32_t nt) {
-    SchedCut c;
-    c.k = nt / (kSchedXcds * 32u) ? nt / (kSchedXcds * 32u) : 1u;
-    c.s = nt / (kSchedXcds * c.k);
-    c.rem = nt - c.s * kSchedXcds * c.k;
-    return c;
-}
-__host__ __device__ inline uint32_t sched_cap(uint32_t nt, uint32_t /*nwy*/) {
-    const SchedCut c = sched_cut(nt);
-    return (c.s + 1u) * c.k;
-}
+// (SchedCut, sched_cut, sched_cap: gsx_plan.h -- the hints buffer is sized from them)
 // chunks of XCD x that hold s + 1 tiles (they come first among its chunks x, x + 8, ...)
 __host__ __device__ inline uint32_t sched_big_chunks(const SchedCut &c, uint32_t x) {
     return c.rem > x ? (c.rem - x + kSchedXcds - 1u) / kSchedXcds : 0u;

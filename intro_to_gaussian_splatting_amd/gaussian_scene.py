@@ -16,6 +16,7 @@ Added: ``.render_image_hip`` (explicit layout / tile window / stats), ``.render_
 from __future__ import annotations
 
 import ctypes
+from collections import OrderedDict
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -39,23 +40,48 @@ def _check_f32(name: str, t: torch.Tensor, device: torch.device) -> torch.Tensor
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _Lru(OrderedDict):
+    """A dict that forgets its least recently used entry beyond ``limit`` (device buffers keyed by stream handles or
+    by views: a viewer that keeps creating streams, a sweep over hundreds of cameras or a strip plan that moves with
+    every rebalance would otherwise grow them for the life of the process)."""
+
+    def __init__(self, limit: int) -> None:
+        super().__init__()
+        self.limit = int(limit)
+
+    def lookup(self, key):
+        val = self.get(key)
+        if val is not None:
+            self.move_to_end(key)
+        return val
+
+    def store(self, key, val):
+        self[key] = val
+        self.move_to_end(key)
+        while len(self) > self.limit:
+            self.popitem(last=False)      # (freed on its own stream: torch's allocator orders the reuse behind its last kernel)
+        return val
+
+
 class _Workspace:
     """Caller-owned device scratch for libgsx (the library never allocates)."""
 
-    def __init__(self) -> None:
-        self.buffers: Dict[tuple, torch.Tensor] = {}
+    def __init__(self, limit: int = 8) -> None:
+        self.buffers = _Lru(limit)
 
     def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
-        # one buffer per (device, stream): frames in flight on different streams must not share scratch
+        # one buffer per (device, stream): frames in flight on different streams must not share scratch; the
+        # buffers of the `limit` most recently used streams are kept (a C3 frame's is ~130 MB)
         key = (device, torch.cuda.current_stream(device).cuda_stream)
-        buf = self.buffers.get(key)
+        buf = self.buffers.lookup(key)
         if buf is None or buf.numel() < nbytes:
-            self.buffers[key] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            buf = self.buffers.store(key, torch.empty(nbytes, dtype=torch.uint8, device=device))
         return buf
 
 
 _WORKSPACE = _Workspace()
 _PINNED_SLOTS = 256
+_HINT_VIEWS = 64          # GsxParams.hints buffers a scene keeps (83 KB each at 1080p, 300 KB at 4K): the most recent views
 _SEMANTICS = {"ref_cpu": _ffi.GSX_SEM_REF_CPU, "ref_cuda": _ffi.GSX_SEM_REF_CUDA,
               "std_3dgs": _ffi.GSX_SEM_STD_3DGS}
 
@@ -191,7 +217,7 @@ class GaussianScene:
         self._last_instances = 0      # instance count of the latest full frame
         self._cap_hints = {}          # (image, tile, window, semantics) -> pair capacity for the next frame
         self._kept_hints = {}         # same key -> Gaussians that reached a tile of the window (GsxParams.kept_hint)
-        self._hints = {}              # (same key, stream) -> [GsxParams.hints buffer, filled?]
+        self._hints = _Lru(_HINT_VIEWS)   # (same key, stream) -> [GsxParams.hints buffer, a frame has run with it?]
         self._pending = []            # speculative frames awaiting confirm_frames()
         self._pinned_pool = None
         self._pinned_next = 0
@@ -392,10 +418,10 @@ class GaussianScene:
                 hint_slot = own["hints"]
             else:
                 hkey = (cap_key, torch.cuda.current_stream(dev).cuda_stream)
-                hint_slot = self._hints.get(hkey)
+                hint_slot = self._hints.lookup(hkey)
                 hbytes = lib.gsx_hints_bytes(width, height, tile_size)
                 if hint_slot is None or hint_slot[0].numel() != hbytes or hint_slot[0].device != dev:
-                    hint_slot = self._hints[hkey] = [torch.zeros(hbytes, dtype=torch.uint8, device=dev), False]
+                    hint_slot = self._hints.store(hkey, [torch.zeros(hbytes, dtype=torch.uint8, device=dev), False])
             params.hints = hint_slot[0].data_ptr()
             if hint_slot[1]:
                 params.flags |= _ffi.GSX_FLAG_HINTS_VALID
@@ -433,7 +459,9 @@ class GaussianScene:
                 cap = int(st.n_instances * 1.25) + 4096
         _ffi.check(rc)
         if hint_slot is not None:
-            hint_slot[1] = True         # (stream order: the next frame on this stream finds what this one left)
+            # (stream order: the next frame on this stream finds what this one left -- or, where the library took a
+            # path that does not use the buffer, the zeros it was created with: its header then says "nothing here")
+            hint_slot[1] = True
         if own:
             if stats is not None and not speculative:
                 stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles, n_kept=st.n_kept)

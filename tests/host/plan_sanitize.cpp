@@ -156,6 +156,27 @@ int main() {
     }
     // a buffer far larger than any frame needs (a 288 GB part can hand over > 68 GB): the capacity stays < 2^31
     CHECK(capacity_for((size_t)200 << 30, 1000000, 8100) == kMaxPairs);
+    // ---- GsxParams.hints: the per-XCD schedule of ANY window of up to max_tiles tiles fits the region hints_layout
+    //      reserves (the projection launch's spare workgroups write 8 x sched_cap(nt) entries behind h.sched)
+    {
+        auto fits = [&](int64_t max_tiles, int64_t nt) {
+            const HintsLayout h = hints_layout(max_tiles, 0);
+            const size_t need = (size_t)kSchedXcds * sched_cap((uint32_t)nt, 0u) * sizeof(uint32_t);
+            CHECK(h.sched + need <= h.total);
+            CHECK(h.lens + (size_t)max_tiles * 4 <= h.sched);
+        };
+        for (int64_t nt = 1; nt <= 70000; ++nt) fits(nt, nt);                       // every window size of small frames
+        const int64_t frames[] = {8100, 32400, 389376, 625 * 625, 1024 * 1024, 4096 * 4096};
+        for (int64_t mt : frames) {
+            fits(mt, mt);
+            for (int it = 0; it < 20000; ++it) fits(mt, rnd_in(1, mt));
+        }
+        for (int it = 0; it < 200000; ++it) {
+            const int64_t mt = rnd_in(1, (int64_t)1 << 26);
+            fits(mt, rnd_in(1, mt));
+            fits(mt, mt);
+        }
+    }
     // ---- plans: frames, tile sizes, semantics, layouts, windows (empty ones at tile 0 included)
     const int sems[] = {GSX_SEM_REF_CPU, GSX_SEM_REF_CUDA, GSX_SEM_STD_3DGS};
     for (int it = 0; it < 300000; ++it) {

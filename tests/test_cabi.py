@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), "libgsx.so does not export %s" % name
         assert name in _ffi.SIGNATURES, "ctypes binding lacks %s" % name
-    assert lib.gsx_version() == 300
+    assert lib.gsx_version() == 301
 
 
 def _exported(path):
@@ -82,14 +82,38 @@ def test_argument_errors_do_not_need_a_gpu():
     small, big = lib.gsx_workspace_bytes(1000, 256, 256, 16, 8000), lib.gsx_workspace_bytes(1_000_000, 1920, 1080, 16, 5_000_000)
     assert 0 < small < big and big % 256 == 0
     assert lib.gsx_hints_bytes(0, 64, 16) == 0
-    # header + 256 splitters + 2048 samples + list lengths (120 x 68 tiles at 1080p) + per-XCD schedule (tiles + 16 x 120)
-    assert lib.gsx_hints_bytes(1920, 1080, 16) == 256 + 1024 + 8192 + 32768 + 40448
+    # header + 256 splitters + 2048 samples + list lengths (120 x 68 tiles at 1080p) + per-XCD schedule (tiles + tiles / 32 + 64)
+    assert lib.gsx_hints_bytes(1920, 1080, 16) == 256 + 1024 + 8192 + 32768 + 34048
+    # (round 3 sized the schedule by the frame's LONGER axis and a frame of more than ~512 tiles along the shorter one
+    # overran it; the bound itself is swept in tests/host/plan_sanitize.cpp)
+    t = 625 * 625
+    assert lib.gsx_hints_bytes(10000, 10000, 16) >= 256 + 1024 + 8192 + 4 * t + 4 * (t + t // 32 + 8)
     assert big >= 1_000_000 * (16 + 48 + 8 + 8 + 16) + 5_000_000 * 16
     rc = lib.gsx_project_points(None, None, 0, None, None, None)
     assert rc == _ffi.GSX_ERR_INVALID_ARGUMENT
     assert b"camera" in lib.gsx_last_error()
     with pytest.raises(_ffi.GsxError):
         _ffi.check(rc)
+
+
+def test_params_struct_size_is_checked_before_anything_runs():
+    """GsxParams.struct_size (include/gsx.h): gsx_default_params states the size this build knows; a size the library
+    does not know is refused; a struct that ends before `hints` (a client built against an older header) has that
+    field ignored -- here: a misaligned pointer in it is not even looked at."""
+    lib = _ffi.load()
+    p = _ffi.default_params()
+    assert p.struct_size == ctypes.sizeof(_ffi.GsxParams)
+    cam = _ffi.GsxCamera()
+    cam.width, cam.height = 64, 64
+    out = ctypes.c_void_p(256)          # never dereferenced: the workspace check fails first
+    args = lambda par: (ctypes.byref(cam), None, None, None, None, None, 0, 16, out, ctypes.byref(par), None, None, 0, None)  # noqa: E731
+    p.struct_size = 12
+    assert lib.gsx_render_forward(*args(p)) == _ffi.GSX_ERR_INVALID_ARGUMENT and b"struct_size" in lib.gsx_last_error()
+    p = _ffi.default_params()
+    p.hints = 257                       # misaligned: refused when the field counts ...
+    assert lib.gsx_render_forward(*args(p)) == _ffi.GSX_ERR_INVALID_ARGUMENT and b"hints" in lib.gsx_last_error()
+    p.struct_size = _ffi.GsxParams.hints.offset     # ... and not read when the caller's struct ends before it
+    assert lib.gsx_render_forward(*args(p)) == _ffi.GSX_ERR_INVALID_ARGUMENT and b"workspace" in lib.gsx_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -243,3 +243,20 @@ def test_bench_gpus_n_never_reports_fewer_gpus_than_asked(tmp_path):
     r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "1"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
     assert r.returncode != 0 and "n_gpus" not in r.stdout and "WORLD_SIZE=2" in r.stderr
+
+
+def test_device_buffer_caches_are_bounded():
+    """The workspace keeps one scratch buffer per (device, stream) and a scene one hints buffer per view: both forget
+    their least recently used entry beyond a limit (a viewer that creates streams, a sweep over hundreds of cameras
+    or a strip plan that moves with every rebalance must not grow device memory for the life of the process)."""
+    from intro_to_gaussian_splatting_amd.gaussian_scene import _HINT_VIEWS, _Lru, _Workspace
+
+    lru = _Lru(3)
+    for k in "abc":
+        lru.store(k, k.upper())
+    assert lru.lookup("a") == "A"            # refreshed: "b" is now the oldest
+    lru.store("d", "D")
+    assert list(lru) == ["c", "a", "d"] and lru.lookup("b") is None
+    lru.store("a", "A2")                     # an entry that is replaced (a larger buffer) keeps one slot
+    assert len(lru) == 3 and lru.lookup("a") == "A2"
+    assert _Workspace().buffers.limit == 8 and _HINT_VIEWS == 64
