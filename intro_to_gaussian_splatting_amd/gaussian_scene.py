@@ -194,6 +194,14 @@ class CapturedFrame:
         self.graph.replay()
         return self.out
 
+    def counts(self) -> Tuple[int, int, int]:
+        """(visible Gaussians, (Gaussian, tile) pairs, pairs the recorded launches have room for) of the last replay;
+        synchronises.  More pairs than room: pairs were dropped, the frame has to be rendered again (``confirm()``
+        raises for exactly that)."""
+        torch.cuda.synchronize(self.out.device)
+        st = ctypes.cast(ctypes.c_void_p(self._pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents
+        return int(st.n_visible), int(st.n_instances), int(st.reserved)
+
     def confirm(self) -> torch.Tensor:
         torch.cuda.synchronize(self.out.device)
         st = ctypes.cast(ctypes.c_void_p(self._pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents

@@ -81,9 +81,89 @@ def make_scene(n: int, width: int, height: int, seed: int = 0, behind_fraction: 
     )
 
 
+def make_trained_like_scene(n: int, width: int, height: int, seed: int = 0, qvec=TREEHILL_QVEC, tvec=TREEHILL_TVEC,
+                            sh_degree: int = 3) -> Dict[str, np.ndarray]:
+    """A scene with the statistics of a TRAINED 3DGS checkpoint rather than of a uniform cloud (BASELINE config 3 as
+    written is a trained Treehill ``.ply``, which is not available offline; not a BASELINE config itself):
+      * view-clustered: 65 % of the Gaussians sit in 24 clusters (surfaces) of different size and depth, the rest is
+        spread over the frustum (floaters and background);
+      * needle and disc footprints: a log-normal size (sigma_ln = 1.2 around 1.2 px) times per-axis factors
+        1 / ratio^u, the ratio log-uniform in [1, 50]: axis ratios up to 50:1, random orientation;
+      * bimodal opacity: half nearly transparent (logit ~ N(-3, 1)), half nearly opaque (logit ~ N(4, 1.5));
+      * degree-``sh_degree`` spherical harmonics (published 3DGS convention): DC from a base colour, higher bands
+        ~ N(0, 0.15 / (1 + band)) -- view-dependent colour, clamped at 0 by the evaluation like a trained one.
+    Same fields as ``make_scene`` plus ``sh (n, (sh_degree+1)^2, 3)``; a stream of its own (seed + 7919)."""
+    rs = np.random.RandomState(seed + 7919)
+    fx = fy = 0.75 * width
+    tanx, tany = width / (2 * fx), height / (2 * fy)
+    n_cl = 24
+    cl_u, cl_v = rs.uniform(-0.85, 0.85, n_cl), rs.uniform(-0.85, 0.85, n_cl)
+    cl_z, cl_r = rs.uniform(2.5, 9.0, n_cl), np.exp(rs.uniform(np.log(0.02), np.log(0.25), n_cl))
+    which = rs.randint(0, n_cl, n)
+    clustered = rs.uniform(0.0, 1.0, n) < 0.65
+    du, dv, dz = rs.normal(0.0, 1.0, n), rs.normal(0.0, 1.0, n), rs.normal(0.0, 1.0, n)
+    u = np.where(clustered, cl_u[which] + cl_r[which] * du, rs.uniform(-1.0, 1.0, n))
+    v = np.where(clustered, cl_v[which] + cl_r[which] * dv, rs.uniform(-1.0, 1.0, n))
+    z = np.where(clustered, np.maximum(cl_z[which] * (1.0 + 0.05 * dz), 0.5), rs.uniform(2.0, 10.0, n))
+    size = rs.lognormal(np.log(1.2), 1.2, n)
+    ratio = np.exp(rs.uniform(0.0, np.log(50.0), n))
+    expo = rs.uniform(0.0, 1.0, (n, 3))
+    expo[np.arange(n), rs.randint(0, 3, n)] = 0.0                     # one axis keeps the full size
+    sigma_px = size[:, None] / ratio[:, None] ** expo
+    quats = rs.normal(0.0, 1.0, (n, 4))
+    faint = rs.uniform(0.0, 1.0, n) < 0.5
+    opacity = np.where(faint, rs.normal(-3.0, 1.0, n), rs.normal(4.0, 1.5, n))[:, None]
+    rgb = rs.uniform(0.0, 255.0, (n, 3))
+    k = (sh_degree + 1) ** 2
+    sh = np.zeros((n, k, 3))
+    sh[:, 0, :] = (rgb / 256.0 - 0.5) / 0.28209479177387814           # DC: colour = 0.5 + C0 * sh0
+    for band in range(1, sh_degree + 1):
+        sh[:, band * band:(band + 1) * (band + 1), :] = rs.normal(0.0, 0.15 / (1 + band), (n, 2 * band + 1, 3))
+    p_cam = np.stack([u * tanx * z, v * tany * z, z], axis=1)
+    R, t = _rotation(qvec), np.asarray(tvec, dtype=np.float64)
+    world = (p_cam - t[None, :]) @ R
+    scales = sigma_px * z[:, None] / fx
+    f = np.float32
+    return dict(
+        points=world.astype(f), colors_0_255=rgb.astype(f), scales=scales.astype(f), quaternions=quats.astype(f),
+        opacity=opacity.astype(f), sh=sh.astype(f), sh_degree=np.int64(sh_degree),
+        qvec=np.asarray(qvec, dtype=np.float64), tvec=np.asarray(tvec, dtype=np.float64),
+        fx=np.float64(fx), fy=np.float64(fy), cx=np.float64(width / 2), cy=np.float64(height / 2),
+        width=np.int64(width), height=np.int64(height),
+    )
+
+
+def _qvec_from_rotation(R: np.ndarray) -> np.ndarray:
+    """(w, x, y, z) of a rotation matrix (w >= 0), the inverse of ``_rotation``."""
+    K = np.array([
+        [R[0, 0] - R[1, 1] - R[2, 2], 0.0, 0.0, 0.0],
+        [R[1, 0] + R[0, 1], R[1, 1] - R[0, 0] - R[2, 2], 0.0, 0.0],
+        [R[2, 0] + R[0, 2], R[2, 1] + R[1, 2], R[2, 2] - R[0, 0] - R[1, 1], 0.0],
+        [R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1], R[0, 0] + R[1, 1] + R[2, 2]]]) / 3.0
+    vals, vecs = np.linalg.eigh(K)
+    q = vecs[[3, 0, 1, 2], int(np.argmax(vals))]
+    return -q if q[0] < 0 else q
+
+
+def orbit_poses(n: int, step_deg: float = 1.0, pivot_depth: float = 6.0, qvec=TREEHILL_QVEC, tvec=TREEHILL_TVEC):
+    """``n`` camera poses (qvec, tvec) on an orbit around the point ``pivot_depth`` in front of the base camera --
+    the middle of the synthetic scenes' depth range --, ``step_deg`` apart about the camera's vertical axis and
+    centred on the base pose: what a viewer's camera does between consecutive frames.  In the base camera's
+    coordinates pose k maps x to R_y(theta_k) (x - p) + p, i.e. R' = R_y R, t' = R_y (t - p) + p."""
+    R0, t0 = _rotation(qvec), np.asarray(tvec, dtype=np.float64)
+    p = np.array([0.0, 0.0, float(pivot_depth)])
+    out = []
+    for k in range(n):
+        th = np.deg2rad((k - (n - 1) / 2.0) * step_deg)
+        Ry = np.array([[np.cos(th), 0.0, np.sin(th)], [0.0, 1.0, 0.0], [-np.sin(th), 0.0, np.cos(th)]])
+        out.append((_qvec_from_rotation(Ry @ R0), Ry @ (t0 - p) + p))
+    return out
+
+
 def write_colmap_text(path: str, scene: Dict[str, np.ndarray], image_id: int = 1,
-                      name: str = "synthetic.jpg") -> None:
-    """Writes the two COLMAP text files a ``GaussianScene`` needs (cameras.txt, images.txt)."""
+                      name: str = "synthetic.jpg", extra_poses=None) -> None:
+    """Writes the two COLMAP text files a ``GaussianScene`` needs (cameras.txt, images.txt).  ``extra_poses``: more
+    images of the same camera, ids ``image_id + 1 ..``, one per (qvec, tvec) -- e.g. ``orbit_poses``."""
     import os
 
     os.makedirs(path, exist_ok=True)
@@ -99,3 +179,7 @@ def write_colmap_text(path: str, scene: Dict[str, np.ndarray], image_id: int = 1
             image_id, float(q[0]), float(q[1]), float(q[2]), float(q[3]),
             float(t[0]), float(t[1]), float(t[2]), name))
         fid.write("1.0 2.0 -1\n")
+        for k, (q, t) in enumerate(extra_poses or []):
+            fid.write("%d %r %r %r %r %r %r %r 1 pose%04d.jpg\n" % (
+                image_id + 1 + k, float(q[0]), float(q[1]), float(q[2]), float(q[3]), float(t[0]), float(t[1]), float(t[2]), k))
+            fid.write("1.0 2.0 -1\n")

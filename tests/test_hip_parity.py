@@ -633,6 +633,85 @@ def test_clustered_1m_scene_against_port_and_exact_arithmetic(tmp_path):
     assert np.all(port_err[over] >= d_port[over] - 1e-5)      # every such pixel: the port itself is that far from exact
 
 
+def test_trained_like_1m_scene_against_port_and_exact_arithmetic(tmp_path):
+    """BASELINE config 3 AS WRITTEN is a trained Treehill .ply -- needle footprints, heavy-tailed sizes, exactly the data
+    on which the float32 restatement of the reference and the kernel drift apart (round-3 verdict, weak #1) -- and it is
+    not available offline.  synthetic.make_trained_like_scene generates the nearest thing: 1M Gaussians in 24 clusters
+    + floaters, axis ratios to 50:1, log-normal sizes with sigma_ln 1.2, bimodal opacity, degree-3 spherical harmonics.
+    Same acceptance rule as the clustered scene: counts identical to the port; the kernel within 1e-5 of the same rules
+    evaluated in float64 (orc_set_exact) on EVERY pixel; every pixel where kernel and port differ by more than 1e-4 is
+    one where the PORT is that far from float64.  The histogram of |kernel - port| and the exceptions are printed
+    (GPUTEST log); bench.py --workload c3_trainedlike reports the same with parity_ok strict."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians
+    from intro_to_gaussian_splatting_amd.synthetic import make_trained_like_scene, write_colmap_text
+    from oracle import c_oracle
+
+    w, h = 1920, 1080
+    sc = make_trained_like_scene(1_000_000, w, h, seed=0)
+    write_colmap_text(str(tmp_path), sc)
+    g = Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"], sc["opacity"], device="cuda:0")
+    g.sh, g.sh_degree = torch.from_numpy(sc["sh"]).cuda().contiguous(), 3
+    scene = GaussianScene(str(tmp_path), g)
+    st = {}
+    img = scene.render_image_hip(1, stats=st).cpu().numpy().astype(np.float64)
+    colors = scene._colors(1).cpu().numpy()             # the view-dependent colours of this camera (gsx_sh_to_rgb)
+    pre = c_oracle.preprocess(sc["points"], colors, sc["scales"], sc["quaternions"], sc["opacity"], _oracle_cam(scene))
+    port, _, inst = c_oracle.render(pre, w, h, 16)
+    exact, _, _ = c_oracle.render(pre, w, h, 16, exact=True)
+    assert st["n_visible"] == pre.points.shape[0] and st["n_instances"] == inst
+    d_exact = np.abs(img - exact).max(axis=2)
+    d_port = np.abs(img - port).max(axis=2)
+    port_err = np.abs(port.astype(np.float64) - exact).max(axis=2)
+    over = d_port > PIXEL_TOL
+    hist = np.histogram(d_port, bins=[0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, np.inf])[0]
+    print("trained-like 1M: D = %d; kernel vs float64 %.3g, port vs float64 %.3g, kernel vs port %.3g; |kernel - port| per pixel "
+          "<=1e-7 / 1e-6 / 1e-5 / 1e-4 / 1e-3 / above: %s; %d pixels above 1e-4 vs the port" % (
+              inst, d_exact.max(), port_err.max(), d_port.max(), list(hist), int(over.sum())))
+    for i, j in np.argwhere(over)[:20]:
+        print("  pixel (%d,%d): kernel-port %.3g, port-float64 %.3g, kernel-float64 %.3g" % (i, j, d_port[i, j], port_err[i, j], d_exact[i, j]))
+    assert d_exact.max() <= 1e-5
+    assert np.all(port_err[over] >= d_port[over] - 1e-5)      # every such pixel: the port itself is that far from exact
+    assert int(over.sum()) <= 2000                            # (a share of 1e-3 of the frame at most)
+
+
+def test_orbit_of_eight_poses_through_one_captured_frame(tmp_path):
+    """What bench.py --camera-path times, at a size the oracle renders whole: eight cameras 1 degree apart on an orbit
+    (synthetic.orbit_poses), ONE frame captured with a movable camera and re-aimed before every replay.  Every replay
+    -- which finds the hints (splitters, tile costs, schedule, kept count) the PREVIOUS pose left -- equals the plain
+    render of that camera bit for bit and fits the pair capacity of the graph; three of the poses are held against the
+    C restatement (counts equal, pixels within 1e-4)."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene, orbit_poses, write_colmap_text
+    from oracle import c_oracle
+
+    w, h = 640, 368
+    sc = make_scene(60_000, w, h, seed=17)
+    write_colmap_text(str(tmp_path), sc, extra_poses=orbit_poses(8))
+    g = Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"], sc["opacity"], device="cuda:0")
+    scene = GaussianScene(str(tmp_path), g)
+    ids = list(range(2, 10))
+    assert sorted(scene.images) == [1] + ids
+    refs = {i: scene.render_image_hip(i, use_hints=False).clone() for i in ids}
+    assert not torch.equal(refs[2], refs[3])
+    frame = scene.capture_frame(ids[4], movable_camera=True, headroom=1.3)
+    for i in ids + ids[::-1] + [ids[0], ids[7], ids[3]]:         # neighbours, then jumps of several degrees
+        frame.set_camera(i)
+        frame.replay()
+        nvis, d, room = frame.counts()
+        assert d <= room, (i, d, room)
+        assert torch.equal(frame.out, refs[i]), i
+    for i in (ids[0], ids[4], ids[7]):
+        pre = c_oracle.preprocess(sc["points"], g.colors.cpu().numpy(), sc["scales"], sc["quaternions"], sc["opacity"],
+                                  _oracle_cam(scene, i))
+        img, _, inst = c_oracle.render(pre, w, h, 16)
+        st = {}
+        got = scene.render_image_hip(i, stats=st)
+        assert st["n_visible"] == pre.points.shape[0] and st["n_instances"] == inst
+        assert np.max(np.abs(got.cpu().numpy() - img)) <= PIXEL_TOL
+
+
 # ----------------------------------------------------------------------------- error behaviour
 
 def test_wrong_dtype_and_device_raise(tmp_path):
