@@ -12,7 +12,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 src = "gpurun_out/%s" % tag
 LABELS = {"c3": "C3: 1M Gaussians, 1920x1080", "c2": "C2: 100k Gaussians, 1920x1080", "c4": "C4: 5M Gaussians, 3840x2160",
           "c3_clustered": "clustered: 1M Gaussians, half of them in 5 % of the frame",
@@ -62,7 +62,9 @@ def k2(n):
     if m:
         key = "u16" if "short" in m.group(1) else "u32"
         return "count_kernel<u32,split>" if m.group(3) != "0" else ("count_kernel<%s%s>" % (key, ",first" if m.group(2) == "true" else ""))
-    m = re.match(r"scatter_kernel<(unsigned short|unsigned int), \d+, (\d+), \d+, (\d+)>", n)
+    # (template arguments: key type, scan variant, mode, digit bits, splitter bins, carried rectangles -- the last one was
+    # added in round 3 and this pattern, still written for five, then matched none of the scatter launches)
+    m = re.match(r"scatter_kernel<(unsigned short|unsigned int), \d+, (\d+), \d+, (\d+)(?:, (?:true|false))?>", n)
     if m:
         key = "u16" if "short" in m.group(1) else "u32"
         return "scatter_kernel<%s%s>" % (key, {"0": "", "1": ",first", "2": ",final"}[m.group(2)])
@@ -146,9 +148,25 @@ def pmc_summary(w):
         tl.append("| `%s` | %.1f (%.1f) | %.1f (%.1f) | %.2f |" % (k, rd / 1e6, ar / 1e6, wr / 1e6, aw / 1e6, ratio))
     out["traffic_vs_algorithmic"] = traffic
     b = out["kernels"]["blend_tile16_kernel"]
-    out["blend_traffic_bytes_per_launch"] = {"read_corrected": b["FETCH_SIZE"] * 1024 * corr, "write": b["WRITE_SIZE"] * 1024,
-                                             "total": b["FETCH_SIZE"] * 1024 * corr + b["WRITE_SIZE"] * 1024,
-                                             "algorithmic": 40.0 * D + 12.0 * ntiles * 256}
+    # The compositing launch reads its lists as a coalesced stream (4 B x D: FETCH_SIZE reports half of that, like every
+    # wide read) and its records as 48-byte GATHERS, for which FETCH_SIZE needs NO doubling: profiles/r4_fetch_calibration.json
+    # (tools/microbench_gather.hip: 1M .. 8M gathers of known footprint; FETCH_SIZE x 1024 = 74 .. 81 B per gathered
+    # record, cold or warm -- the counter sits between the L2 and the fabric, in front of the Infinity Cache -- against
+    # 2.00 x for a streaming read).  Rounds 1-3 doubled all of it and overstated this kernel's traffic by ~1.9x.
+    raw = b["FETCH_SIZE"] * 1024
+    rd_blend = max(raw - 2.0 * D, 0.0) * GATHER_CORR + 4.0 * D
+    out["blend_traffic_bytes_per_launch"] = {"read_corrected": rd_blend, "write": b["WRITE_SIZE"] * 1024,
+                                             "total": rd_blend + b["WRITE_SIZE"] * 1024,
+                                             "algorithmic": 40.0 * D + 12.0 * ntiles * 256,
+                                             "read_if_doubled_like_a_stream": raw * corr,
+                                             "how": "(FETCH_SIZE bytes - 2 D) x %.2f [record gathers] + 4 D [list entries, streamed]; "
+                                                    "L2-miss side: part of it is served by the 256 MiB Infinity Cache, not HBM" % GATHER_CORR}
+    if "blend_tile16_kernel" in traffic:
+        t = traffic["blend_tile16_kernel"]
+        t["read_bytes"] = rd_blend
+        t["ratio"] = round((rd_blend + t["write_bytes"]) / (t["algorithmic_read"] + t["algorithmic_write"]), 3)
+        tl.append("| `blend_tile16_kernel`, gathers calibrated (see below) | %.1f (%.1f) | %.1f (%.1f) | %.2f |" % (
+            rd_blend / 1e6, t["algorithmic_read"] / 1e6, t["write_bytes"] / 1e6, t["algorithmic_write"] / 1e6, t["ratio"]))
     cyc = b["GRBM_GUI_ACTIVE"] / 8.0
     out["blend_valu"] = {"kernel_cycles_per_xcd": cyc, "valu_busy_frac": round(b["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc, 4),
                          "valu_instructions": b["SQ_INSTS_VALU"],
@@ -161,6 +179,7 @@ def pmc_summary(w):
 
 
 CORR = {}
+GATHER_CORR = 1.0       # profiles/r4_fetch_calibration.json: 0.92 .. 1.0 for isolated 48-byte records (an upper bound is kept)
 for w in ("c3", "c2", "c4", "strip"):
     tl = pmc_summary(w)
     if tl:
