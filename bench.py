@@ -635,6 +635,14 @@ def main() -> None:
                     help="N > 1: strips balanced by the per-tile-row pair counts of a planning frame, gathered point to "
                          "point (default: equal strips and ONE dist.gather -- the plainer collective stays the default "
                          "until a multi-GPU node has confirmed strips_equal_single_gpu for the balanced path)")
+    ap.add_argument("--substrips", type=int, default=4,
+                    help="N > 1: every rank composites its strip in this many parts and sends part j to rank 0 while part "
+                         "j + 1 is composited (strips.render_overlapped, GsxParams.n_substrips); 1 = the plain path (one "
+                         "dist.gather, or one point-to-point message per rank with --balance).  The overlapped path is "
+                         "checked against the single-GPU frame during setup and the plain one takes over if it fails")
+    ap.add_argument("--link-gbs", type=float, default=54.0,
+                    help="N > 1 with --balance: GB/s one xGMI link is assumed to deliver into rank 0 (70 %% of 77): rank 0 "
+                         "sends nothing, so it gets rows until its render time equals a peer's render + unhidden send time")
     ap.add_argument("--strip-of", type=int, default=0,
                     help="profiling aid, 1 GPU: render only the strip that rank N/2 of an N-rank run would own (equal "
                          "strips of tile columns) -- what one rank of BASELINE config 5 spends per frame before the gather; "
@@ -707,11 +715,31 @@ def main() -> None:
         counts = torch.zeros(max(1, ntx * nty), dtype=torch.int32, device=device)
         scene.render_image_hip(1, tile_size=tile, layout=layout, tile_counts=counts, semantics=sem)
         n_lead, n_other = (ntx, nty) if layout == "wh3" else (nty, ntx)
-        strip_plan = strips.balanced_plan(strips.tile_row_costs(counts, n_lead, n_other, lead_is_x=(layout == "wh3")), world)
+        row_cost = strips.tile_row_costs(counts, n_lead, n_other, lead_is_x=(layout == "wh3"))
+        # what a row costs a peer on top of rendering it: sending it (16 pixel rows of float32 RGB over one link) minus the
+        # compositing it hides behind (~65 % of a row's render time); in the plan's units (pairs), with the time of a
+        # whole frame on rank 0 as the yardstick -- broadcast, so that every rank cuts the same plan
+        t_frame = torch.zeros(1, dtype=torch.float64, device=device)
+        if rank == 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            scene.render_image_hip(1, tile_size=tile, layout=layout, semantics=sem)
+            e0.record()
+            scene.render_image_hip(1, tile_size=tile, layout=layout, semantics=sem)
+            e1.record()
+            torch.cuda.synchronize()
+            t_frame[0] = e0.elapsed_time(e1) * 1e-3
+        dist.broadcast(t_frame, src=0)
+        unit_s = float(t_frame.item()) / max(sum(row_cost), 1.0)
+        send_row_s = tile * (height if layout == "wh3" else width) * 12.0 / (args.link_gbs * 1e9)
+        mean_row = sum(row_cost) / max(len(row_cost), 1)
+        peer_extra = max(0.0, send_row_s / max(unit_s, 1e-12) - 0.65 * mean_row) if args.substrips > 1 else send_row_s / max(unit_s, 1e-12)
+        strip_plan = strips.balanced_plan(row_cost, world, peer_extra=peer_extra)
 
-    def render_strip(window, out, origin):
+    def render_strip(window, out, origin, bounds=None):
+        evs = [] if bounds is not None else None
         scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=window, out=out, out_origin=origin,
-                               no_sync=not args.sync_frames, semantics=sem)
+                               no_sync=not args.sync_frames, semantics=sem, substrips=bounds, substrip_events=evs)
+        return evs
 
     def step():
         # 1 GPU: speculative frames (GSX_FLAG_NO_SYNC) -- the pair list is sized by the previous
@@ -757,6 +785,9 @@ def main() -> None:
         if strip_window is not None:
             return scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=strip_window, out=strip_out,
                                           out_origin=(strip_window[0] * tile, 0), no_sync=not args.sync_frames, semantics=sem)
+        if world > 1 and overlapped["on"]:
+            return strips.render_overlapped(render_strip, width, height, tile, layout, device, parts=args.substrips,
+                                            cache=strip_cache, semantics=sem, plan=strip_plan)
         if world > 1:
             return strips.render_sharded(render_strip, width, height, tile, layout, device, cache=strip_cache,
                                          semantics=sem, plan=strip_plan)
@@ -769,6 +800,29 @@ def main() -> None:
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # N > 1: the overlapped gather is new code on first contact with a multi-GPU node -- check one frame of it against the
+    # single-GPU frame before anything is timed, and let the plain path take over if it does not hold
+    overlapped = {"on": world > 1 and args.substrips > 1, "why": None}
+    if overlapped["on"]:
+        ok = torch.ones(1, dtype=torch.int32, device=device)
+        try:
+            first = single_frame()
+            torch.cuda.synchronize()
+            scene.confirm_frames()
+            if rank == 0:
+                alone = scene.render_image_hip(1, tile_size=tile, layout=layout, semantics=sem)
+                if not torch.equal(first, alone):
+                    ok[0] = 0
+                    overlapped["why"] = "frame != single-GPU frame"
+        except Exception as exc:        # noqa: BLE001  (whatever the transport says: report it, use the plain path)
+            ok[0] = 0
+            overlapped["why"] = "%s: %s" % (type(exc).__name__, exc)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            overlapped["on"] = False
+            if rank == 0:
+                print("bench.py: overlapped gather failed its self-check (%s): plain gather" % overlapped["why"], file=sys.stderr)
 
     # setup, untimed: let clocks and caches settle (the first ~100 frames after start-up run 5-10 % slow)
     single_frame()              # the first frame learns the counts every later one is sized and routed by
@@ -947,7 +1001,9 @@ def main() -> None:
                        "ms_per_frame_separate_launches": None if launches_ms is None else round(launches_ms, 4),
                        "frame_sync": "host reads instance count every frame" if args.sync_frames
                        else "speculative (GSX_FLAG_NO_SYNC), counts confirmed after the timed region",
-                       "parallelism": "1 GPU" if world == 1 else "%d column strips + RCCL gather" % world,
+                       "parallelism": "1 GPU" if world == 1 else "%d column strips + RCCL gather (%s)" % (
+                           world, "sub-strips sent while the next is composited, %d parts" % args.substrips if overlapped["on"]
+                           else "one gather behind the frame" + ("; overlapped path failed: %s" % overlapped["why"] if overlapped["why"] else "")),
                        "strip_plan": None if world == 1 else (strip_plan or "equal")},
             "fps": round(1e3 / median_ms, 2),
             "roofline": {"bound": "hbm", "kernel": "blend_tile16_kernel" if ref_rules else "blend_rules_kernel",

@@ -26,8 +26,9 @@
 extern "C" {
 #endif
 
-#define GSX_VERSION 301 /* major*10000 + minor*100 + patch.  301: GsxParams.struct_size (in reserved0's place), a larger
-                         * schedule region in gsx_hints_bytes.  300: GsxParams.kept_hint, GsxFrameStats.n_kept,
+#define GSX_VERSION 302 /* major*10000 + minor*100 + patch.  302: GsxParams.n_substrips .. substrip_events (appended;
+                         * a struct_size of 104 -- or 0 -- still means the ABI-300 struct).  301: GsxParams.struct_size (in
+                         * reserved0's place), a larger schedule region in gsx_hints_bytes.  300: GsxParams.kept_hint, GsxFrameStats.n_kept,
                            * tile_counts zeroed when nothing is rendered, tile_x1 == tile_x0 is an empty window,
                            * GsxCamera.camera_center; the library exports exactly the functions declared here */
 
@@ -127,7 +128,7 @@ typedef struct GsxParams {
     /* sizeof(GsxParams) as the CALLER compiled it; gsx_default_params() fills it in.  The fields below it were
      * appended in ABI 300: a struct_size that ends before one of them makes the library ignore that field (a client
      * built against an older header hands over a shorter struct -- whatever lies behind it is not read).  0 = not
-     * stated: the struct is taken to be the current one (callers of ABI 300 zeroed this word).  Callers should also
+     * stated: the struct is taken to be the ABI-300 one, which ends behind `hints` (its callers zeroed this word).  Callers should also
      * check gsx_version() == GSX_VERSION once: the version is bumped whenever a struct or a signature changes. */
     int32_t struct_size;
     /* gsx_render_forward only.  How many Gaussians are expected to reach a tile of the window
@@ -148,6 +149,20 @@ typedef struct GsxParams {
      * never a pixel: the frame is the same bit for bit (tested).  Frames in flight on different streams need a
      * buffer each.  The buffer must be 256-byte aligned (GSX_ERR_INVALID_ARGUMENT otherwise). */
     void *hints;
+    /* gsx_render_forward only (ABI 302).  Compositing in PARTS, for a caller that wants to start moving a finished part
+     * of the window -- a multi-GPU rank sending its strip to the rank that assembles the frame -- while the rest is still
+     * being composited: projection, depth order and binning run ONCE for the window, then the compositing launch is
+     * issued n_substrips times, part k covering the tiles whose coordinate along `substrip_axis` (0: tile column x, 1:
+     * tile row y) lies in [substrip_bounds[k], substrip_bounds[k + 1]), and after the launch of part k the library
+     * records substrip_events[k] (a hipEvent_t the caller created) on `stream`.  The pixels are the same bit for bit
+     * as those of the one-launch frame.  substrip_bounds: HOST array of n_substrips + 1 absolute tile coordinates,
+     * ascending, [0] = the window's first and [n_substrips] = its last + 1 tile along that axis; substrip_events: HOST
+     * array of n_substrips events.  n_substrips 0 or 1 (default): one launch, nothing recorded.  At most 16 parts.
+     * Rule sets / tile sizes without a partial launch composite in one launch and record every event behind it. */
+    int32_t n_substrips;
+    int32_t substrip_axis;
+    const int32_t *substrip_bounds;
+    void *const *substrip_events;
 } GsxParams;
 
 /* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call

@@ -50,7 +50,9 @@ class GsxParams(ctypes.Structure):
                 ("out_x0", c_int32), ("out_y0", c_int32), ("out_w", c_int32), ("out_h", c_int32),
                 ("flags", c_int32), ("background", c_float * 3), ("camera_device", c_void_p),
                 ("tile_counts", c_void_p), ("sh", c_void_p), ("sh_degree", c_int32), ("struct_size", c_int32),
-                ("kept_hint", c_int64), ("hints", c_void_p)]
+                ("kept_hint", c_int64), ("hints", c_void_p),
+                ("n_substrips", c_int32), ("substrip_axis", c_int32), ("substrip_bounds", POINTER(c_int32)),
+                ("substrip_events", POINTER(c_void_p))]
 
 
 class GsxFrameStats(ctypes.Structure):

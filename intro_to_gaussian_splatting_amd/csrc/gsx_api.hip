@@ -95,6 +95,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
     int64_t *dev2 = (int64_t *)(counters + 4);
     uint2 *ranges = (uint2 *)(ws + c.ranges);
     bool counts_on_device = false, counts_in_host = false;
+    bool parts_marked = false;      // GsxParams.substrip_events recorded (every path records them once, behind its last launch at the latest)
     // no Gaussians: every tile's list is empty -- GsxParams.tile_counts says so (an empty WINDOW has no entries)
     if (n == 0 && p.tile_counts && p.grid.count() > 0)
         GSX_HIP(gsx::launch_zero_words(p.tile_counts, (size_t)p.grid.count(), s));
@@ -159,12 +160,31 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             const int64_t ntl = p.grid.count();
             bh.rank_last = (fh.sched && ntl > 7400 && ntl <= 8192 && (int64_t)cap >= 128 * ntl) ? 1u : 0u;
             if (gsx::knob("GSX_RANK_LAST", -1) >= 0) bh.rank_last = (uint32_t)gsx::knob("GSX_RANK_LAST", -1);   // test library only
-            GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
-                                      ranges, p.grid, p.out, p.semantics, p.background, p.generic,
-                                      make_clear_plan(p, false), lt, sched, bh, s));
+            if (p.n_parts > 1 && gsx::blend_in_parts(p.grid, p.semantics, p.generic)) {
+                // GsxParams.n_substrips: the same launch once per part of the window, an event of the caller's behind each
+                // (a part without tiles is not launched; its event still marks "everything before it is done")
+                bool first = true;
+                for (int k = 0; k < p.n_parts; ++k) {
+                    const gsx::TileSpan span{p.part_axis, p.part_bounds[k], p.part_bounds[k + 1], first ? 1u : 0u};
+                    if (span.hi > span.lo || (first && k == p.n_parts - 1)) {
+                        GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
+                                                  ranges, p.grid, p.out, p.semantics, p.background, p.generic,
+                                                  make_clear_plan(p, false), lt, sched, bh, s, &span));
+                        first = false;
+                    }
+                    GSX_HIP(hipEventRecord((hipEvent_t)p.part_events[k], s));
+                }
+                parts_marked = true;
+            } else {
+                GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
+                                          ranges, p.grid, p.out, p.semantics, p.background, p.generic,
+                                          make_clear_plan(p, false), lt, sched, bh, s));
+            }
             tm.mark();  // 5: blend
         }
     }
+    if (!parts_marked)
+        for (int k = 0; k < p.n_parts; ++k) GSX_HIP(hipEventRecord((hipEvent_t)p.part_events[k], s));
     if (p.no_sync) {
         if (stats) {
             // stats must be pinned host memory; the two counts land when the stream gets here

@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     blend_tile16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                         const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
                         uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints,
-                        uint32_t tile_blocks, uint32_t sched_cap_) {
+                        uint32_t tile_blocks, uint32_t sched_cap_, TileSpan span) {
     __shared__ float4 sh[3][kSlots];
     // block order: [spare workgroups: the next frame's splitters] [helpers of long tiles (dispatched first: they have
     // the most to do)] [tiles] [clears]
@@ -589,8 +589,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // last in the grid instead)
     const uint32_t nrank = hints.samples ? kRankGroups : 0u;
     const uint32_t rank0 = hints.rank_last ? gridDim.x - nrank : 0u;
+    // span (GsxParams.n_substrips): this launch composites only the tiles whose column (axis 0) / row (axis 1) lies in
+    // [lo, hi) -- one part of the window; the launch of the first part also runs what a frame does once (the next
+    // frame's splitters, the zero fill of what no tile covers).  The whole grid is launched every time: a workgroup of
+    // another part exits at once (~2 us per launch for the 8 000 of a 1080p frame).
     if (blockIdx.x - rank0 < nrank) {
-        rank_samples(blockIdx.x - rank0, (int)threadIdx.x, hints);
+        if (span.first) rank_samples(blockIdx.x - rank0, (int)threadIdx.x, hints);
         return;
     }
     const uint32_t block = hints.rank_last ? blockIdx.x : blockIdx.x - nrank;
@@ -619,12 +623,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         const int quarter = (int)((b >> 3) & 3u);
         if (slot >= min(*lt.count, lt.max)) return;
         const uint32_t lt_tile = lt.list[slot];
+        {
+            const int lead = span.axis ? g.wy0 + (int)(lt_tile % (uint32_t)g.nwy()) : g.wx0 + (int)(lt_tile / (uint32_t)g.nwy());
+            if (lead < span.lo || lead >= span.hi) return;
+        }
         blend_long_tile_quarter(rec, vals, ranges, g, out, lt_tile, quarter, sh, budget, hints.lens ? hints.lens + lt_tile : nullptr);
         return;
     }
     const uint32_t bid = block - nhelpers;
     if (bid >= tile_blocks) {       // (tile_blocks = number of tiles, or 8 x cap with the per-XCD schedule)
-        clear_block(bid - tile_blocks, cp, out.ptr);
+        if (span.first) clear_block(bid - tile_blocks, cp, out.ptr);
         return;
     }
     const int lane = threadIdx.x;
@@ -637,6 +645,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     uint32_t probe_staged = 0, probe_checked_at = 0xFFFFFFu;
 #endif
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
+    if ((span.axis ? ty : tx) < span.lo || (span.axis ? ty : tx) >= span.hi) return;      // another part's tile
     // WH3: lanes 4q..4q+3 cover one x (contiguous 192 B); HW3: lanes 16q..16q+15 cover one y-quad
     const bool y_contig = out.stride_y < out.stride_x;
     const int lx = y_contig ? (lane >> 2) : (lane & 15);            // the lane's pixels: offsets inside the tile
@@ -1157,10 +1166,15 @@ bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int6
     return n >= 300000 && grid.count() > 2048;
 }
 
+bool blend_in_parts(const TileGrid &grid, int semantics, bool generic) {
+    return semantics == GSX_SEM_REF_CPU && grid.tile == 16 && !generic && grid.count() > (int64_t)knob("GSX_QUARTERS_BELOW", kQuartersBelow);
+}
+
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
                         bool generic, const ClearPlan &cp, const LongTiles &lt, const uint32_t *sched,
-                        const BlendHints &hints, hipStream_t s) {
+                        const BlendHints &hints, hipStream_t s, const TileSpan *part) {
+    const TileSpan span = part ? *part : TileSpan{0, -2147483647 - 1, 2147483647, 1u};
     const int64_t nt = grid.count();
     if (nt <= 0) return launch_clear(cp, out.ptr, s);
     const unsigned nb = (unsigned)nt + (unsigned)(cp.n > 0 ? cp.first[cp.n] : 0);
@@ -1199,13 +1213,13 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
         grid_blocks += bh.samples ? kRankGroups : 0u;
         const uint32_t q = quarters ? 1u : 0u;
         if (variant == 0)
-            blend_tile16_kernel<0><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap);
+            blend_tile16_kernel<0><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         else if (variant == 2)
-            blend_tile16_kernel<2><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap);
+            blend_tile16_kernel<2><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         else if (variant == 3)
-            blend_tile16_kernel<3><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap);
+            blend_tile16_kernel<3><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         else
-            blend_tile16_kernel<1><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap);
+            blend_tile16_kernel<1><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
     } else {
         blend_generic_kernel<<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp);
     }

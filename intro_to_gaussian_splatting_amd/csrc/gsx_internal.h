@@ -208,10 +208,19 @@ hipError_t launch_sh_to_rgb(const float *means3d, const float *sh, int degree, i
 // sched: launch_tile_schedule's order, or nullptr (tiles in index order); used by the tile-16 REF_CPU kernel.
 // asked: Plan.schedule (1 / 0 from the caller's flags, -1: by the size of the scene).
 bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int64_t n, int asked);
+// One part of the window (GsxParams.n_substrips): the tiles whose column (axis 0) / row (axis 1) -- absolute tile
+// coordinate -- lies in [lo, hi); first: this launch also does what a frame does once (zero fill, next frame's splitters).
+struct TileSpan {
+    int32_t axis, lo, hi;
+    uint32_t first;
+};
+// can this kernel family composite a window in parts?  (tile-16 REF_CPU kernel only; the others take one launch)
+bool blend_in_parts(const TileGrid &grid, int semantics, bool generic);
+// part: nullptr = the whole window in one launch
 hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *sorted_vals, const uint2 *ranges,
                         const TileGrid &grid, const OutDesc &out, int semantics, const float *background,
                         bool generic, const ClearPlan &cp, const LongTiles &lt, const uint32_t *sched,
-                        const BlendHints &hints, hipStream_t s);
+                        const BlendHints &hints, hipStream_t s, const TileSpan *part = nullptr);
 bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic);
 hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s);   // the zero fill alone
 hipError_t launch_zero_words(uint32_t *p, size_t n, hipStream_t s);

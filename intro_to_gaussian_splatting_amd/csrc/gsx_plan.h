@@ -26,6 +26,8 @@ constexpr int kSortQuad = 4;           // chunks per count workgroup
 constexpr int kSortBins = 256;         // digit-table rows
 constexpr int kEmitChunk = 1024;       // depth ranks per workgroup of chunk_sums / emit (gsx_binning.hip)
 constexpr uint32_t kMaxLongTiles = 512;
+constexpr int kMaxSubstrips = 16;      // GsxParams.n_substrips
+constexpr size_t kParamsBytesAbi300 = 104;   // sizeof(GsxParams) before struct_size existed: what struct_size == 0 means
 constexpr int kClearFloats = 6144;     // floats zeroed per clear workgroup (gsx_blend.hip)
 constexpr size_t kRecordBytes = 48, kTileRectBytes = 8, kBboxBytes = 16, kRangeBytes = 8;
 
@@ -256,6 +258,10 @@ struct Plan {
     char *hints;         // GsxParams.hints (or null)
     bool hints_valid;    // GSX_FLAG_HINTS_VALID
     float background[3];
+    // GsxParams.n_substrips: the compositing launch in parts (0: one launch)
+    int n_parts, part_axis;
+    int32_t part_bounds[kMaxSubstrips + 1];
+    void *part_events[kMaxSubstrips];
 };
 
 inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_image, const GsxParams *params, Plan &p,
@@ -270,16 +276,13 @@ inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_ima
     GsxParams d;
     default_params(&d);
     if (params) {
-        d = *params;
-        // GsxParams.struct_size: fields the caller's struct ends before are not read (include/gsx.h)
+        // GsxParams.struct_size: only the bytes the caller's struct has are read; fields behind them keep their defaults
+        // (include/gsx.h).  0 = the ABI-300 struct, which ends behind `hints`.
         const int32_t have = params->struct_size;
-        if (have != 0) {
-            if (have < (int32_t)offsetof(GsxParams, kept_hint) || have > (int32_t)sizeof(GsxParams))
-                return fail(GSX_ERR_INVALID_ARGUMENT, "GsxParams.struct_size %d is not a size this library knows (%zu)", have,
-                            sizeof(GsxParams));
-            if (have < (int32_t)(offsetof(GsxParams, kept_hint) + sizeof d.kept_hint)) d.kept_hint = 0;
-            if (have < (int32_t)(offsetof(GsxParams, hints) + sizeof d.hints)) d.hints = nullptr;
-        }
+        if (have != 0 && (have < (int32_t)offsetof(GsxParams, kept_hint) || have > (int32_t)sizeof(GsxParams) || (have & 7) != 0))
+            return fail(GSX_ERR_INVALID_ARGUMENT, "GsxParams.struct_size %d is not a size this library knows (%zu)", have,
+                        sizeof(GsxParams));
+        memcpy(&d, params, have ? (size_t)have : kParamsBytesAbi300);
     }
     if (width <= 0 || height <= 0) return fail(GSX_ERR_INVALID_ARGUMENT, "image size %dx%d is not positive", width, height);
     if (tile <= 0 || tile > 1024) return fail(GSX_ERR_INVALID_ARGUMENT, "tile size %d out of range [1,1024]", tile);
@@ -329,6 +332,27 @@ inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_ima
     // (a 12.9 GB float frame, e.g. 32768 x 32768) is the most one call renders into
     if ((int64_t)o.w * o.h > ((int64_t)1 << 30))
         return fail(GSX_ERR_UNSUPPORTED, "output buffer of %dx%d pixels is larger than 2^30 pixels", o.w, o.h);
+    p.n_parts = 0;
+    p.part_axis = 0;
+    if (d.n_substrips > 1) {
+        if (d.n_substrips > kMaxSubstrips) return fail(GSX_ERR_INVALID_ARGUMENT, "n_substrips %d > %d", d.n_substrips, kMaxSubstrips);
+        if (d.substrip_axis != 0 && d.substrip_axis != 1) return fail(GSX_ERR_INVALID_ARGUMENT, "substrip_axis %d is neither 0 nor 1", d.substrip_axis);
+        if (!d.substrip_bounds || !d.substrip_events) return fail(GSX_ERR_INVALID_ARGUMENT, "substrip_bounds / substrip_events is NULL");
+        const int32_t lo = d.substrip_axis == 0 ? g.wx0 : g.wy0, hi = d.substrip_axis == 0 ? g.wx1 : g.wy1;
+        for (int k = 0; k <= d.n_substrips; ++k) {
+            p.part_bounds[k] = d.substrip_bounds[k];
+            if (k && p.part_bounds[k] < p.part_bounds[k - 1]) return fail(GSX_ERR_INVALID_ARGUMENT, "substrip_bounds are not ascending");
+        }
+        if (p.part_bounds[0] != lo || p.part_bounds[d.n_substrips] != hi)
+            return fail(GSX_ERR_INVALID_ARGUMENT, "substrip_bounds span [%d, %d), the window spans [%d, %d) along axis %d",
+                        p.part_bounds[0], p.part_bounds[d.n_substrips], lo, hi, d.substrip_axis);
+        for (int k = 0; k < d.n_substrips; ++k) {
+            p.part_events[k] = d.substrip_events[k];
+            if (!p.part_events[k]) return fail(GSX_ERR_INVALID_ARGUMENT, "substrip_events[%d] is NULL", k);
+        }
+        p.n_parts = d.n_substrips;
+        p.part_axis = d.substrip_axis;
+    }
     if (d.layout == GSX_LAYOUT_WH3) {
         o.stride_x = (int64_t)o.h * 3;
         o.stride_y = 3;

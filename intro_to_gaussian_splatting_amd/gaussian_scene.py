@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import ctypes
 from collections import OrderedDict
-from typing import Dict, Optional, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import torch
 
@@ -227,6 +227,7 @@ class GaussianScene:
         self._kept_hints = {}         # same key -> Gaussians that reached a tile of the window (GsxParams.kept_hint)
         self._hints = _Lru(_HINT_VIEWS)   # (same key, stream) -> [GsxParams.hints buffer, a frame has run with it?]
         self._pending = []            # speculative frames awaiting confirm_frames()
+        self._part_events = {}        # (stream, K) -> K HIP events the library records behind the parts of a frame
         self._pinned_pool = None
         self._pinned_next = 0
 
@@ -319,6 +320,7 @@ class GaussianScene:
                          camera_buffer: Optional[torch.Tensor] = None,
                          tile_counts: Optional[torch.Tensor] = None, split_long_tiles: bool = True,
                          tile_schedule: Optional[bool] = None, use_hints: bool = True,
+                         substrips: Optional[Sequence[int]] = None, substrip_events: Optional[list] = None,
                          _private: Optional[dict] = None) -> torch.Tensor:
         """Full forward render in libgsx (gsx_render_forward).
 
@@ -339,6 +341,11 @@ class GaussianScene:
         for the NEXT frame of that view, which then skips the two kernels that would compute them on its own critical
         path; stale hints (the Gaussians or the camera changed) cost time, never a pixel.  ``use_hints=False``
         renders every frame from scratch (tests hold the two against each other).
+        ``substrips`` (GsxParams.n_substrips): K + 1 ascending tile coordinates along the layout's LEADING axis (x for
+        "wh3", y for "hw3") that cut the window into K parts; projection, depth order and binning run once, the
+        compositing launch once per part, and ``substrip_events`` (a list the caller passes in) receives K ``_hip.Event``
+        objects, event k recorded on the current stream right behind part k -- a multi-GPU rank starts sending part k
+        while part k + 1 is composited (``strips.render_overlapped``).  Same pixels bit for bit.
         ``no_sync`` (GSX_FLAG_NO_SYNC) enqueues the frame without waiting for the device at all: the
         counts arrive later in pinned memory and ``confirm_frames()`` must be called (it
         synchronises) before the images are trusted -- it re-renders, on the normal path, any frame
@@ -376,6 +383,21 @@ class GaussianScene:
             params.camera_device = camera_buffer.data_ptr()
         if tile_window is not None:
             params.tile_x0, params.tile_x1, params.tile_y0, params.tile_y1 = [int(v) for v in tile_window]
+        keep_alive = []
+        if substrips is not None and len(substrips) > 2:
+            from . import _hip
+
+            k_parts = len(substrips) - 1
+            bounds = (ctypes.c_int32 * (k_parts + 1))(*[int(v) for v in substrips])
+            evs = self._part_events.setdefault((torch.cuda.current_stream(dev).cuda_stream, k_parts),
+                                               [_hip.Event() for _ in range(k_parts)])
+            handles = (ctypes.c_void_p * k_parts)(*[e.handle for e in evs])
+            params.n_substrips, params.substrip_axis = k_parts, 0 if layout == "wh3" else 1
+            params.substrip_bounds = ctypes.cast(bounds, ctypes.POINTER(ctypes.c_int32))
+            params.substrip_events = ctypes.cast(handles, ctypes.POINTER(ctypes.c_void_p))
+            keep_alive += [bounds, handles]
+            if substrip_events is not None:
+                substrip_events[:] = evs
         if tile_counts is not None:
             if tile_counts.device != dev or tile_counts.dtype not in (torch.int32, torch.uint32) or \
                     not tile_counts.is_contiguous():

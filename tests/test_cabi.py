@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), "libgsx.so does not export %s" % name
         assert name in _ffi.SIGNATURES, "ctypes binding lacks %s" % name
-    assert lib.gsx_version() == 301
+    assert lib.gsx_version() == 302
 
 
 def _exported(path):
@@ -65,8 +65,9 @@ def test_shipping_library_reads_no_environment_variable():
 
 def test_struct_layouts():
     assert ctypes.sizeof(_ffi.GsxCamera) == 16 * 4 * 2 + 4 * 4 + 2 * 4 + 3 * 4
-    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16 + 8 + 8 and _ffi.GsxParams.kept_hint.offset == 88
-    assert _ffi.GsxParams.hints.offset == 96
+    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16 + 8 + 8 + 24 and _ffi.GsxParams.kept_hint.offset == 88
+    assert _ffi.GsxParams.hints.offset == 96 and _ffi.GsxParams.n_substrips.offset == 104       # (104 = the ABI-300 struct)
+    assert _ffi.GsxParams.substrip_bounds.offset == 112 and _ffi.GsxParams.substrip_events.offset == 120
     assert _ffi.GsxFrameStats.n_kept.offset == 56 and _ffi.GsxFrameStats.stage_ms.offset == 32
     assert ctypes.sizeof(_ffi.GsxFrameStats) == 64
     p = _ffi.default_params()

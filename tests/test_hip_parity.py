@@ -712,6 +712,71 @@ def test_orbit_of_eight_poses_through_one_captured_frame(tmp_path):
         assert np.max(np.abs(got.cpu().numpy() - img)) <= PIXEL_TOL
 
 
+def test_compositing_in_parts_equals_the_one_launch_frame(tmp_path):
+    """GsxParams.n_substrips (round 4): projection, depth order and binning once, the compositing launch once per part of
+    the window, an event of the caller's behind each part.  Whole frames and a strip window, both layouts, 2 .. 16
+    parts incl. empty ones, with hints and long tiles in play: every frame equals the one-launch frame bit for bit,
+    and a stream that waits for event k alone sees part k complete.  Rule sets without a partial launch (std_3dgs
+    here) composite in one launch and still mark every event."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import _hip, strips
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    w, h, tile = 1280, 720, 16
+    sc = make_scene(150_000, w, h, seed=5, cluster_fraction=0.4, cluster_area=0.04, sigma_ln=0.9)
+    scene = _scene_from_arrays(tmp_path, sc)
+    for layout in ("wh3", "hw3"):
+        ref = scene.render_image_hip(1, layout=layout).clone()
+        n_lead = strips.tiles_along(w if layout == "wh3" else h, tile)
+        n_other = strips.tiles_along(h if layout == "wh3" else w, tile)
+        for parts in (2, 4, 16):
+            bounds = strips.substrip_bounds(0, n_lead, parts)
+            evs = []
+            for _ in range(3):                  # cold frame, then frames with hints
+                got = scene.render_image_hip(1, layout=layout, substrips=bounds, substrip_events=evs)
+                assert len(evs) == parts
+                torch.cuda.synchronize()
+                assert torch.equal(got, ref), (layout, parts)
+        # a strip window (what a rank renders), parts that do not divide it, one part empty
+        t0, t1 = n_lead // 3, n_lead // 3 + 7
+        window = (t0, t1, 0, n_other) if layout == "wh3" else (0, n_other, t0, t1)
+        rows = (t1 - t0) * tile
+        shape = (rows, h, 3) if layout == "wh3" else (rows, w, 3)
+        origin = (t0 * tile, 0) if layout == "wh3" else (0, t0 * tile)
+        whole = torch.empty(shape, dtype=torch.float32, device="cuda:0")
+        scene.render_image_hip(1, layout=layout, tile_window=window, out=whole, out_origin=origin)
+        assert torch.equal(whole, ref[t0 * tile:t1 * tile])
+        bounds = [t0, t0 + 3, t0 + 3, t0 + 5, t1]
+        out = torch.full(shape, -1.0, dtype=torch.float32, device="cuda:0")
+        evs = []
+        side = torch.cuda.Stream()
+        seen = torch.empty_like(out)
+        scene.render_image_hip(1, layout=layout, tile_window=window, out=out, out_origin=origin, substrips=bounds,
+                               substrip_events=evs)
+        for k in range(4):                      # another stream copies part k as soon as event k allows it
+            a, b = (bounds[k] - t0) * tile, (bounds[k + 1] - t0) * tile
+            evs[k].wait_on(side)
+            with torch.cuda.stream(side):
+                seen[a:b].copy_(out[a:b])
+        torch.cuda.synchronize()
+        assert torch.equal(out, whole) and torch.equal(seen, whole), layout
+    # a rule set without a partial launch
+    ref = scene.render_image_hip(1, semantics="std_3dgs").clone()
+    evs = []
+    got = scene.render_image_hip(1, semantics="std_3dgs", substrips=strips.substrip_bounds(0, strips.tiles_along(w, tile, "std_3dgs"), 3),
+                                 substrip_events=evs)
+    evs[2].synchronize()
+    assert torch.equal(got, ref)
+    # bounds that do not span the window are refused
+    with pytest.raises(_ffi_error()):
+        scene.render_image_hip(1, substrips=[0, 5, 9])
+
+
+def _ffi_error():
+    from intro_to_gaussian_splatting_amd import _ffi
+    return _ffi.GsxError
+
+
 # ----------------------------------------------------------------------------- error behaviour
 
 def test_wrong_dtype_and_device_raise(tmp_path):

@@ -183,6 +183,16 @@ def test_balanced_plan_minimises_the_largest_strip():
             edges = (0,) + cuts + (n,)
             others.append(max(sum(cost[a:b]) for a, b in zip(edges, edges[1:])))
         assert best <= min(others) + 1e-9
+    # peer_extra: every row costs a rank behind rank 0 that much more (the unhidden part of sending it): rank 0 takes more
+    assert strips.balanced_plan([5.0] * 8, 2, peer_extra=5.0) == [(0, 6), (6, 8)]
+    for cost, world, extra in (([7, 2, 9, 4, 4, 1, 8, 3, 3, 6], 4, 3.0), ([1, 1, 1, 1, 1, 1], 2, 1.0), ([4] * 8, 3, 2.0)):
+        import itertools
+        value = lambda pl: max(sum(cost[a:b]) + (extra * (b - a) if i else 0.0) for i, (a, b) in enumerate(pl))  # noqa: E731
+        plan = strips.balanced_plan(cost, world, peer_extra=extra)
+        n = len(cost)
+        best = min(value(list(zip((0,) + cuts + (n,), cuts + (n,))))
+                   for cuts in itertools.combinations_with_replacement(range(n + 1), world - 1))
+        assert len(plan) == world and value(plan) <= best + 1e-9
     counts = torch.arange(12, dtype=torch.int32).reshape(4, 3)          # x-major: 4 tile columns x 3 tile rows
     assert strips.tile_row_costs(counts, 4, 3, lead_is_x=True, per_tile=0.0) == [3.0, 12.0, 21.0, 30.0]
     assert strips.tile_row_costs(counts, 3, 4, lead_is_x=False, per_tile=1.0) == [22.0, 26.0, 30.0]
@@ -267,3 +277,74 @@ def test_strip_plans_are_validated():
     assert np.array_equal(frame[t:], full[t:]) and not frame[:t].any()
     part = strips.render_sharded(fn, w, h, t, "wh3", torch.device("cpu"), plan=[(1, n_lead)]).numpy()
     assert np.array_equal(part[t:], full[t:]) and not part[:t].any()
+
+
+# ---- render_overlapped: the gather of a frame overlapped with its compositing (sub-strips sent as they finish)
+
+def _overlap_worker(rank, world, port, name, layout, plan, parts, result_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden(name)
+        w, h, t = int(g["width"]), int(g["height"]), int(g["tile"])
+        base = _oracle_strip_renderer(golden_preprocessed(g), w, h, t, layout)
+        seen = []
+
+        def fn(window, out, origin, bounds):
+            # the CPU stand-in renders the strip whole and returns None ("complete on return"); what is checked here is
+            # the protocol: the bounds cut THIS rank's strip, ascending, into at most `parts` runs
+            lo, hi = (window[0], window[1]) if layout == "wh3" else (window[2], window[3])
+            assert bounds[0] == lo and bounds[-1] == hi and len(bounds) == parts + 1
+            assert all(a <= b for a, b in zip(bounds, bounds[1:]))
+            seen.append(tuple(bounds))
+            base(window, out, origin)
+            return None
+
+        cache = {}
+        for _ in range(2):                  # twice: the cached frame / strip buffers are reused
+            frame = strips.render_overlapped(fn, w, h, t, layout, torch.device("cpu"), parts=parts, plan=plan, cache=cache)
+        assert (frame is not None) == (rank == 0)
+        if frame is not None:
+            np.save(os.path.join(result_dir, "frame_%d.npy" % rank), frame.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,layout,plan,parts", [
+    ("c1_256x256_n2000", "wh3", None, 4),                                  # 2 ranks, equal strips of 8 and 7 tile rows
+    ("c1_256x256_n2000", "hw3", [(0, 9), (9, 10), (10, 15)], 4),           # a one-row strip: three of its parts are empty
+    ("pose_70x50_n250", "wh3", [(0, 1), (1, 4)], 2),
+    ("c1_256x256_n2000", "wh3", "balanced8", 3),                           # world 8, one rank without rows
+    ("c1_256x256_n2000", "hw3", "balanced8", 1),                           # parts = 1: one message per peer
+])
+def test_overlapped_gather_equals_single_frame(tmp_path, name, layout, plan, parts):
+    """strips.render_overlapped (round 4): every rank cuts its strip into sub-strips, peers send sub-strip j while j + 1
+    is composited, rank 0 posts receive group j = sub-strip j of every peer before it renders its own strip.  On CPU
+    ranks the renderer is the oracle and every part is ready at once -- the message protocol (K groups on rank 0, up
+    to K sends per peer, empty parts skipped on both sides) is what runs -- and the frame must equal the
+    one-process render bit for bit."""
+    if plan == "balanced8":
+        plan = strips.balanced_plan([1, 1, 1, 2, 9, 9, 9, 9, 9, 9, 2, 1, 1, 1, 1], 8)
+        if all(b > a for a, b in plan):
+            plan = plan[:6] + [(plan[6][0], 15), (15, 15)]
+    world = 2 if plan is None else len(plan)
+    mp.spawn(_overlap_worker, args=(world, _free_port(), name, layout, plan, parts, str(tmp_path)), nprocs=world, join=True)
+    g = load_golden(name)
+    full, _, _ = c_oracle.render(golden_preprocessed(g), int(g["width"]), int(g["height"]), int(g["tile"]))
+    full = full if layout == "wh3" else full.transpose(1, 0, 2)
+    assert np.array_equal(np.load(tmp_path / "frame_0.npy"), full)
+    assert not any((tmp_path / ("frame_%d.npy" % r)).exists() for r in range(1, world))
+
+
+def test_substrip_bounds():
+    assert strips.substrip_bounds(0, 8, 4) == [0, 2, 4, 6, 8]
+    assert strips.substrip_bounds(3, 10, 4) == [3, 5, 7, 9, 10]
+    assert strips.substrip_bounds(9, 10, 4) == [9, 10, 10, 10, 10]          # fewer rows than parts: trailing parts empty
+    assert strips.substrip_bounds(5, 5, 3) == [5, 5, 5, 5]
+    assert strips.substrip_bounds(0, 30, 1) == [0, 30]
+    g = load_golden("small_64x48_n300")
+    w, h, t = int(g["width"]), int(g["height"]), int(g["tile"])
+    base = _oracle_strip_renderer(golden_preprocessed(g), w, h, t, "wh3")
+    frame = strips.render_overlapped(lambda win, out, org, b: base(win, out, org), w, h, t, "wh3", torch.device("cpu"))
+    full, _, _ = c_oracle.render(golden_preprocessed(g), w, h, t)
+    assert np.array_equal(frame.numpy(), full)                              # one process: no group needed
