@@ -85,5 +85,50 @@ def main():
     print("(pairs whose alpha stays below 1/255 in the whole tile: %.1f %%)" % (100.0 * negligible(px, py, 16).mean()))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 2 and sys.argv[2] == "blocks"):
     main()
+
+
+def block_lists(wl="c2"):
+    """Round 4: if every 16-lane group of the wave (an 8x8 block of the tile, 4 pixels per lane) walked its OWN list of
+    non-negligible records, a tile would cost max over its four blocks of the block's list length instead of the tile's
+    list length.  Prints the mean of that ratio, weighted by list length."""
+    n, w, h, _ = bench.WORKLOADS[wl]
+    sc = make_scene(n, w, h, seed=0, **bench.GENERATOR_ARGS.get(wl, {}))
+    cam = cpu_ref.build_camera(sc["qvec"], sc["tvec"], sc["fx"], sc["fy"], w, h)
+    pre = c_oracle.preprocess(sc["points"], sc["colors_0_255"] / 255.0, sc["scales"], sc["quaternions"], sc["opacity"], cam)
+    tile = 16
+    ntx, nty = len(cpu_ref.tile_origins(w, tile)), len(cpu_ref.tile_origins(h, tile))
+    inv = pre.inverse_covariance_2d.astype(np.float64)
+    a, b, c = inv[:, 0, 0], 0.5 * (inv[:, 0, 1] + inv[:, 1, 0]), inv[:, 1, 1]
+    mx, my = pre.points_xy[:, 0].astype(np.float64), pre.points_xy[:, 1].astype(np.float64)
+    ln_op = -np.log1p(np.exp(-pre.sigmoid_opacity[:, 0].astype(np.float64)))
+    tx0 = np.maximum(np.ceil((pre.min_x.astype(np.float64) - tile) / tile), 0).astype(np.int64)
+    tx1 = np.minimum(np.floor(pre.max_x.astype(np.float64) / tile), ntx - 1).astype(np.int64)
+    ty0 = np.maximum(np.ceil((pre.min_y.astype(np.float64) - tile) / tile), 0).astype(np.int64)
+    ty1 = np.minimum(np.floor(pre.max_y.astype(np.float64) / tile), nty - 1).astype(np.int64)
+    nx, ny = np.maximum(tx1 - tx0 + 1, 0), np.maximum(ty1 - ty0 + 1, 0)
+    cnt = nx * ny
+    D = int(cnt.sum())
+    g = np.repeat(np.arange(len(cnt)), cnt)
+    k = np.arange(D) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    tx, ty = tx0[g] + k % np.maximum(nx[g], 1), ty0[g] + k // np.maximum(nx[g], 1)
+    tid = tx * nty + ty
+    thr = -26.0 * np.log(2.0)
+    per_block = []
+    for (bw, bh, label) in ((8, 8, "8x8 blocks (16 lanes x 4 px)"), (16, 4, "16x4 strips"), (4, 16, "4x16 strips")):
+        counts = []
+        for qy in range(16 // bh):
+            for qx in range(16 // bw):
+                q = min_quadratic_over_box(a[g], b[g], c[g], mx[g], my[g], tx * 16 + bw * qx, tx * 16 + bw * qx + bw - 1,
+                                           ty * 16 + bh * qy, ty * 16 + bh * qy + bh - 1)
+                live = ln_op[g] - 0.5 * q >= thr
+                counts.append(np.bincount(tid[live], minlength=ntx * nty))
+        counts = np.stack(counts)
+        full = np.bincount(tid, minlength=ntx * nty)
+        print("%s, %s: sum over tiles of max block list / sum of tile lists = %.3f (mean block list %.3f)" % (
+            wl, label, counts.max(axis=0).sum() / full.sum(), counts.mean(axis=0).sum() / full.sum()))
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "blocks":
+    block_lists(sys.argv[1])

@@ -34,6 +34,7 @@ struct Lds {
     float2 hb[kRec + 8], rg[kRec + 8], h3[kRec + 8];
     float4 xa[kRec / 2 + 4], xb[kRec / 2 + 4], xc[kRec / 2 + 4], xd[kRec / 2 + 4], he[kRec / 2 + 4];
     float bl[kRec + 8];
+    uint8_t lists[4][kRec + 8];
 };
 
 __device__ __forceinline__ v4f lds4(const float4 *p) { return *reinterpret_cast<const v4f *>(p); }
@@ -52,6 +53,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         sh.h3[lane] = make_float2(hx, hx * hx * hx);
         sh.rg[lane] = make_float2(0.25f, 0.75f);
         sh.bl[lane] = 0.5f;
+        for (int g4 = 0; g4 < 4; ++g4) sh.lists[g4][lane] = (uint8_t)((lane * 5 + 16 * g4 + 3 * (lane >> 2)) & 63);   // four different walks
         float *xa = reinterpret_cast<float *>(sh.xa), *xb = reinterpret_cast<float *>(sh.xb), *xc = reinterpret_cast<float *>(sh.xc);
         float *xd = reinterpret_cast<float *>(sh.xd), *he = reinterpret_cast<float *>(sh.he);
         const int p = lane >> 1, q = lane & 1;
@@ -72,12 +74,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         for (uint32_t k = 0; k < kRec; k += 4) {
             v2f aa[4], ab[4];
             float cb[4];
+            uint32_t slots[4] = {k, k + 1, k + 2, k + 3};
             if (V == 0) {           // round 3: direct, four v_exp_f32 per record
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const v4f A = lds4(&sh.a[k + u]);
                     const v2f Bq = *reinterpret_cast<const v2f *>(&sh.b[k + u]);
                     cb[u] = sh.bl[k + u];
+                    const float e_x = A.x - cx;
+                    const float s0 = __builtin_fmaf(-(A.z * e_x), e_x, Bq.y);
+                    const float c = __builtin_fmaf(-A.w, cx, A.y);
+                    const v2f wa = pk_fma(splat2(-Bq.x), cya, splat2(c)), wb = pk_fma(splat2(-Bq.x), cyb, splat2(c));
+                    const v2f ea = pk_fma(-wa, wa, splat2(s0)), eb = pk_fma(-wb, wb, splat2(s0));
+                    aa[u] = v2f{ex2(ea.x), ex2(ea.y)};
+                    ab[u] = v2f{ex2(eb.x), ex2(eb.y)};
+                }
+            } else if (V == 5) {    // round 3's arithmetic, but every 16-lane group (an 8x8 block of the tile) walks its OWN list
+                const int grp = lane >> 4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t slot = sh.lists[grp][k + u];            // 4 distinct addresses per wave instruction
+                    const v4f A = lds4(&sh.a[slot]);
+                    const v2f Bq = *reinterpret_cast<const v2f *>(&sh.b[slot]);
+                    cb[u] = sh.bl[slot];
+                    slots[u] = slot;
                     const float e_x = A.x - cx;
                     const float s0 = __builtin_fmaf(-(A.z * e_x), e_x, Bq.y);
                     const float c = __builtin_fmaf(-A.w, cx, A.y);
@@ -164,11 +184,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 tb = splat2(1.0f);
                 ++stops;
             }
+            if (V == 5) {
 #pragma unroll
-            for (int u = 0; u < 4; u += 2) {
-                const v4f RG = lds4(reinterpret_cast<const float4 *>(&sh.rg[k + u]));
-                ACC(ta_a[u], ta_b[u], RG.x, RG.y, cb[u]);
-                ACC(ta_a[u + 1], ta_b[u + 1], RG.z, RG.w, cb[u + 1]);
+                for (int u = 0; u < 4; ++u) {
+                    const v2f RG = *reinterpret_cast<const v2f *>(&sh.rg[slots[u]]);
+                    ACC(ta_a[u], ta_b[u], RG.x, RG.y, cb[u]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {
+                    const v4f RG = lds4(reinterpret_cast<const float4 *>(&sh.rg[k + u]));
+                    ACC(ta_a[u], ta_b[u], RG.x, RG.y, cb[u]);
+                    ACC(ta_a[u + 1], ta_b[u + 1], RG.z, RG.w, cb[u + 1]);
+                }
             }
             Ta = ta;
             Tb = tb;
@@ -221,6 +249,7 @@ int main() {
         run<2>("V2 recurrence, pixel-pair products (2 exp + 1 mul + 3 pk)", mhz, buf);
         run<3>("V3 = V2 with x terms / w0 / exponents packed over 2 records", mhz, buf);
         run<4>("V4 = V0 with x terms packed over 2 records", mhz, buf);
+        run<5>("V5 = V0, every 16-lane group walks its own list", mhz, buf);
     }
     return 0;
 }
