@@ -77,6 +77,20 @@ constexpr uint32_t kBatchCost = 5;        // staging a batch of 64 costs about a
 // that has its SIMD to itself -- the long, saturated tiles of a heavy-tailed frame -- then pays every chain in full).
 // A null record changes nothing under either form of the rule: T alpha = 0, T - 0 = T, fma(0, 0, C) = C.
 constexpr int kPad = 8, kSlots = 64 + kPad;
+// Round 4: a 16x16 tile is composited as FOUR 8x8 BLOCKS, each with its own list.  The reference lists a Gaussian for a
+// tile when its bounding box touches the tile (plus a tile of slack), and under its rules every listed Gaussian is
+// evaluated at every pixel -- but a record whose alpha stays below 2^-26 on a whole 8x8 block changes nothing there
+// (see stage_records), and only 58 % of the (record, block) combinations of the benchmark scene are above that
+// (tools/analyze_skip.py; 91 % of the (record, tile) pairs).  The lane -> pixel assignment puts a block on 16 lanes
+// (4 pixels each), every 16-lane group walks ITS block's list -- four different records per wave instruction, read
+// from LDS with four addresses -- and a tile costs the LONGEST of its four block lists (64 % of its list on the
+// benchmark scene) instead of all of it, at ~10 % more per trip (tools/microbench_trip.hip, V5).
+// Block g covers x offsets [8 (g & 1), +8) and y offsets [8 (g >> 1), +8) of the tile.
+constexpr int kBlocks = 4;
+struct __attribute__((aligned(16))) Staged {
+    float4 rec[3][kSlots];            // the staged records, by slot (see read_splat)
+    uint8_t list[kBlocks][kSlots];    // per block: the slots of the records it keeps, in list order, padded with a null record's slot
+};
 
 // Contiguous-chunk remap: hardware places block b on XCD b % 8; give XCD x the x-th eighth of
 // the tile list.  Bijective for every n_tiles.
@@ -147,14 +161,13 @@ __global__ void __launch_bounds__(64) clear_kernel(ClearPlan cp, float *__restri
 struct Splat {  // one staged record, unpacked (wave-uniform values); mono: monomial coefficients in (d1, h, r11)
     float mx, c0, d1, h, r11, lop, cr, cg, cb, my;
     bool mono;
+    uint32_t blocks;        // bit g: block g of the tile keeps the record (all ones where blocks are not distinguished)
 };
 
-// Staged record (stage_batch): a = (x', c0, D1, h)  b = (r11, log2 op, r, g)  c = (b, y', monomial flag, -)
-__device__ __forceinline__ Splat read_splat(const float4 (*sh)[kSlots], uint32_t k) {
-    const float4 A = sh[0][k], B = sh[1][k];
-    const float2 C = *reinterpret_cast<const float2 *>(&sh[2][k]);
-    const float flag = sh[2][k].z;
-    return Splat{A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, flag != 0.0f};
+// Staged record (stage_records): a = (x', c0, D1, h)  b = (r11, log2 op, r, g)  c = (b, y', monomial flag, block bits)
+__device__ __forceinline__ Splat read_splat(const Staged &sh, uint32_t k) {
+    const float4 A = sh.rec[0][k], B = sh.rec[1][k], C = sh.rec[2][k];
+    return Splat{A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, C.z != 0.0f, __float_as_uint(C.w)};
 }
 
 // Exponent of one pixel.  px, p = the pixel's offsets inside the tile (px shared by the lane's pixels); g.mx, g.my =
@@ -180,15 +193,18 @@ __device__ __forceinline__ float exponent_y(const Splat &g, float p, float s0, f
 
 // NPX pixels of one lane against one Gaussian.  The lane's pixels share x (px = their x offset inside the tile) and
 // differ in y (e_p[j] = the pixel's y offset inside the tile).
+// blk: the block of the tile the lane's pixels lie in -- a record the block does not keep (Splat.blocks) is not composited
+// there: alpha = 0, which leaves T and the colour exactly as they are, like not visiting the record at all.
 template <int NPX>
 __device__ __forceinline__ void composite(float px, const float (&e_p)[NPX], const Splat &g, float (&T)[NPX],
-                                          float (&c0)[NPX], float (&c1)[NPX], float (&c2)[NPX]) {
+                                          float (&c0)[NPX], float (&c1)[NPX], float (&c2)[NPX], int blk = 0) {
     float s0, t0;
     exponent_x(g, px, s0, t0);
+    const bool kept = (g.blocks >> blk) & 1u;
     float ta[NPX], test[NPX];
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
-        const float alpha = __builtin_amdgcn_exp2f(exponent_y(g, e_p[j], s0, t0));
+        const float alpha = kept ? __builtin_amdgcn_exp2f(exponent_y(g, e_p[j], s0, t0)) : 0.0f;
         ta[j] = T[j] * alpha;
         test[j] = T[j] - ta[j];
     }
@@ -244,14 +260,50 @@ __device__ __forceinline__ void composite(float px, const float (&e_p)[NPX], con
 // a decision of the compositing kernel, the same in every REF_CPU kernel (it depends only on the tile and its
 // list, walked 64 records at a time from the start), so the kernel families stay bit-identical to each other.
 // nb: in = records of the batch, out = records staged (wave-uniform).
-constexpr uint32_t kSkipBudget = 1u << 23;   // 2^-17 of colour per tile and channel, in units of 2^-40 (colours are < 1)
+//
+// BLOCKS (round 4, see Staged): the test and the budget are per 8x8 block of a 16x16 tile.  Three ways to stage:
+//   kStageWhole     the tile is one block (any tile size): a record is staged when the tile keeps it;
+//   kStageBlocks    tile 16: a record is staged when ANY of the four blocks keeps it, the bits of the blocks that do ride
+//                   in its c.w, and every block's list -- the slots of its records, in order -- is written to sh.list,
+//                   padded with the slot of a null record (count[g] entries each; the four-pixels-per-lane kernel walks
+//                   the lists, the one-pixel-per-lane kernels walk the slots and test the bits);
+//   kStageOneBlock  tile 16: only what block `blk` keeps (a helper wave of a long tile composites ONE block).
+// A block's decisions depend on the tile, the block and the list alone -- walked 64 entries at a time from the start --,
+// so every kernel arrives at the same ones and the kernel families stay bit-identical to each other.
+constexpr uint32_t kSkipBudget = 1u << 23;   // 2^-17 of colour per block and channel, in units of 2^-40 (colours are < 1)
 enum { kBatchRegular = 0, kBatchWild = 1, kBatchMono = 2 };
-// The second half of staging: `have` lanes hold a record (a, b, c) of the batch in registers.
-__device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool have, uint32_t &nb, float4 (*sh)[kSlots],
-                                             int lane, float tile_x0, float tile_y0, float tile_side, uint32_t &skipped,
-                                             uint32_t budget) {
-    bool irregular = false, keep = false, mono = false;
-    float bound = 0.0f;                 // < -26: a candidate, alpha < 2^bound on the whole tile
+enum { kStageWhole = 0, kStageBlocks = 1, kStageOneBlock = 2 };
+
+// Which of the three classes of far-away records does this batch still skip in one block?  bound: the lane's record's
+// log2 of its largest alpha on the block (0 for lanes without a candidate).  Returns the threshold below which a record
+// is skipped (-inf: none) and charges the skipped ones to the block's running total (wave-uniform, scalar).
+__device__ __forceinline__ float skip_threshold(float bound, uint32_t &skipped, uint32_t budget) {
+    const unsigned long long far1 = __ballot(bound < -26.0f), far2 = __ballot(bound < -33.0f), far3 = __ballot(bound < -40.0f);
+    const uint32_t n3 = (uint32_t)__popcll(far3), n2 = (uint32_t)__popcll(far2) - n3, n1 = (uint32_t)__popcll(far1) - n2 - n3;
+    const uint32_t cost3 = n3, cost23 = cost3 + (n2 << 7), cost123 = cost23 + (n1 << 14);
+    if (skipped + cost123 <= budget) {
+        skipped += cost123;
+        return -26.0f;
+    }
+    if (skipped + cost23 <= budget) {
+        skipped += cost23;
+        return -33.0f;
+    }
+    if (skipped + cost3 <= budget) {
+        skipped += cost3;
+        return -40.0f;
+    }
+    return -__builtin_inff();
+}
+
+// The second half of staging: `have` lanes hold a record (a, b, c) of the batch in registers.  skipped: the running
+// totals of the blocks (kStageWhole: [0], kStageOneBlock: [blk]).  count (kStageBlocks): entries of every block's list.
+template <int MODE>
+__device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool have, uint32_t &nb, Staged &sh, int lane,
+                                             float tile_x0, float tile_y0, float tile_side, uint32_t (&skipped)[kBlocks],
+                                             uint32_t budget, int blk, uint32_t (&count)[kBlocks]) {
+    bool irregular = false, mono = false;
+    float bound[kBlocks] = {0.0f, 0.0f, 0.0f, 0.0f};   // < -26: a candidate, alpha < 2^bound on the whole block
     if (have) {
         a.x -= tile_x0;                // tile-relative mean (see the head of this file)
         a.y -= tile_y0;
@@ -259,57 +311,94 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
         // irregular: the monomial fallback, or D1 < 0: alpha may exceed 1 there, T is no longer monotone, and the
         // batch tests T after every record
         irregular = mono || !(a.z >= 0.0f);
-        keep = true;
         if (!irregular) {               // (x', y', D1, h) (r11, log2 op, ..): completed square, D1 >= 0
-            const float ex0 = a.x, ex1 = a.x - (tile_side - 1.0f);
-            const float ey0 = a.y, ey1 = a.y - (tile_side - 1.0f);
-            const float ex_min2 = ex0 * ex1 <= 0.0f ? 0.0f : fminf(ex0 * ex0, ex1 * ex1);
-            const float w00 = __builtin_fmaf(b.x, ey0, a.w * ex0), w01 = __builtin_fmaf(b.x, ey1, a.w * ex0);
-            const float w10 = __builtin_fmaf(b.x, ey0, a.w * ex1), w11 = __builtin_fmaf(b.x, ey1, a.w * ex1);
-            const float wlo = fminf(fminf(w00, w01), fminf(w10, w11)), whi = fmaxf(fmaxf(w00, w01), fmaxf(w10, w11));
-            const float wabs = fminf(fabsf(wlo), fabsf(whi));
-            const float w_min2 = (wlo <= 0.0f && whi >= 0.0f) ? 0.0f : wabs * wabs;
-            bound = b.y - a.z * ex_min2 - w_min2;      // NaN anywhere: every comparison below is false, the record stays
+            // log2 of the largest alpha over the pixel rectangle [x_lo, x_hi] x [y_lo, y_hi] (offsets inside the tile):
+            // D1 min(e0^2) and min(w^2), w = r11 e1 + h e0 being linear in the pixel -- its extremes are at the corners
+            auto over = [&](float x_lo, float x_hi, float y_lo, float y_hi) -> float {
+                const float ex0 = a.x - x_lo, ex1 = a.x - x_hi;
+                const float ey0 = a.y - y_lo, ey1 = a.y - y_hi;
+                const float ex_min2 = ex0 * ex1 <= 0.0f ? 0.0f : fminf(ex0 * ex0, ex1 * ex1);
+                const float w00 = __builtin_fmaf(b.x, ey0, a.w * ex0), w01 = __builtin_fmaf(b.x, ey1, a.w * ex0);
+                const float w10 = __builtin_fmaf(b.x, ey0, a.w * ex1), w11 = __builtin_fmaf(b.x, ey1, a.w * ex1);
+                const float wlo = fminf(fminf(w00, w01), fminf(w10, w11)), whi = fmaxf(fmaxf(w00, w01), fmaxf(w10, w11));
+                const float wabs = fminf(fabsf(wlo), fabsf(whi));
+                const float w_min2 = (wlo <= 0.0f && whi >= 0.0f) ? 0.0f : wabs * wabs;
+                return b.y - a.z * ex_min2 - w_min2;      // NaN anywhere: every comparison below is false, the record stays
+            };
+            if (MODE == kStageWhole) {
+                bound[0] = over(0.0f, tile_side - 1.0f, 0.0f, tile_side - 1.0f);
+            } else if (MODE == kStageOneBlock) {
+                bound[0] = over(8.0f * (float)(blk & 1), 8.0f * (float)(blk & 1) + 7.0f, 8.0f * (float)(blk >> 1), 8.0f * (float)(blk >> 1) + 7.0f);
+            } else {
+#pragma unroll
+                for (int g = 0; g < kBlocks; ++g)
+                    bound[g] = over(8.0f * (float)(g & 1), 8.0f * (float)(g & 1) + 7.0f, 8.0f * (float)(g >> 1), 8.0f * (float)(g >> 1) + 7.0f);
+            }
         }
     }
-    // the three classes of this batch and what skipping them would add to the tile's total (units of 2^-40)
-    const unsigned long long far1 = __ballot(bound < -26.0f), far2 = __ballot(bound < -33.0f), far3 = __ballot(bound < -40.0f);
-    const uint32_t n3 = (uint32_t)__popcll(far3), n2 = (uint32_t)__popcll(far2) - n3, n1 = (uint32_t)__popcll(far1) - n2 - n3;
-    const uint32_t cost3 = n3, cost23 = cost3 + (n2 << 7), cost123 = cost23 + (n1 << 14);
-    if (skipped + cost123 <= budget) {              // (wave-uniform, scalar)
-        skipped += cost123;
-        keep = keep && !(bound < -26.0f);
-    } else if (skipped + cost23 <= budget) {
-        skipped += cost23;
-        keep = keep && !(bound < -33.0f);
-    } else if (skipped + cost3 <= budget) {
-        skipped += cost3;
-        keep = keep && !(bound < -40.0f);
+    // who keeps the record: the classes every block still skips (skip_threshold) against the record's bound there
+    uint32_t bits = 0;
+    unsigned long long kept_by[kBlocks] = {0ull, 0ull, 0ull, 0ull};      // (lane order)
+    if (MODE == kStageBlocks) {
+#pragma unroll
+        for (int g = 0; g < kBlocks; ++g) {
+            const float thr = skip_threshold(bound[g], skipped[g], budget);
+            const bool k = have && !(bound[g] < thr);
+            bits |= k ? (1u << g) : 0u;
+            kept_by[g] = __ballot(k);
+        }
+    } else {
+        const float thr = skip_threshold(bound[0], skipped[MODE == kStageOneBlock ? blk : 0], budget);
+        bits = (have && !(bound[0] < thr)) ? 0xFu : 0u;
     }
+    const bool keep = bits != 0u;
     const unsigned long long mask = __ballot(keep);
-    if (keep) {
-        const uint32_t slot = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        c.y = a.y;                                             // y' (the depth is not needed here)
-        if (!mono) a.y = __builtin_fmaf(b.x, a.y, a.w * a.x);  // c0 = w at the tile's origin
-        sh[0][slot] = a;
-        sh[1][slot] = b;
-        sh[2][slot] = c;
-    }
     nb = (uint32_t)__popcll(mask);
+    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));   // kept lanes below this one
+    if (MODE == kStageBlocks) {
+        // every block's list starts out as nothing but the first null record's slot (the loops take whole trips) ...
+        const uint8_t null_slot = (uint8_t)nb;
+#pragma unroll
+        for (int g = 0; g < kBlocks; ++g) {
+            sh.list[g][lane] = null_slot;
+            if (lane < kPad) sh.list[g][64 + lane] = null_slot;
+        }
+    }
+    if (keep) {
+        c.y = a.y;                                             // y' (the depth is not needed here)
+        c.w = __uint_as_float(bits);
+        if (!mono) a.y = __builtin_fmaf(b.x, a.y, a.w * a.x);  // c0 = w at the tile's origin
+        sh.rec[0][slot] = a;
+        sh.rec[1][slot] = b;
+        sh.rec[2][slot] = c;
+        if (MODE == kStageBlocks) {
+            // ... and receives the slots of the records the block keeps, in list order (the DS operations of one wave
+            // execute in issue order: these land after the fill above)
+#pragma unroll
+            for (int g = 0; g < kBlocks; ++g)
+                if ((bits >> g) & 1u)
+                    sh.list[g][__builtin_amdgcn_mbcnt_hi((uint32_t)(kept_by[g] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kept_by[g], 0u))] = (uint8_t)slot;
+        }
+    }
+    if (MODE == kStageBlocks) {
+#pragma unroll
+        for (int g = 0; g < kBlocks; ++g) count[g] = (uint32_t)__popcll(kept_by[g]);
+    }
     if (lane < kPad) {                  // the null records behind the batch (see kPad)
-        sh[0][nb + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        sh[1][nb + lane] = make_float4(0.0f, -__builtin_inff(), 0.0f, 0.0f);
-        sh[2][nb + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        sh.rec[0][nb + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        sh.rec[1][nb + lane] = make_float4(0.0f, -__builtin_inff(), 0.0f, 0.0f);
+        sh.rec[2][nb + lane] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFu));
     }
     return __any(mono && keep) ? kBatchMono : (__any(irregular && keep) ? kBatchWild : kBatchRegular);
 }
 
 // Gather + staging of one batch.  idx: this lane's entry of the tile's list (vals[base + lane]) when the caller has
 // requested it ahead (a batch earlier: one of the two dependent trips to memory of a batch is then off its path).
+template <int MODE>
 __device__ __forceinline__ int stage_batch(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
-                                           uint32_t base, uint32_t &nb, float4 (*sh)[kSlots], int lane, float tile_x0,
-                                           float tile_y0, float tile_side, uint32_t &skipped, uint32_t budget = kSkipBudget,
-                                           const uint32_t *idx = nullptr) {
+                                           uint32_t base, uint32_t &nb, Staged &sh, int lane, float tile_x0,
+                                           float tile_y0, float tile_side, uint32_t (&skipped)[kBlocks], uint32_t (&count)[kBlocks],
+                                           uint32_t budget = kSkipBudget, const uint32_t *idx = nullptr, int blk = 0) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
     const bool have = (uint32_t)lane < nb;
     if (have) {
@@ -318,7 +407,7 @@ __device__ __forceinline__ int stage_batch(const Record *__restrict__ rec, const
         b = q->b;
         c = q->c;
     }
-    return stage_records(a, b, c, have, nb, sh, lane, tile_x0, tile_y0, tile_side, skipped, budget);
+    return stage_records<MODE>(a, b, c, have, nb, sh, lane, tile_x0, tile_y0, tile_side, skipped, budget, blk, count);
 }
 
 // ---- packed-math form of the same arithmetic (two pixels per VGPR pair) ----------------------
@@ -426,7 +515,7 @@ __device__ __forceinline__ void rank_samples(uint32_t group, int lane, const Ble
     }
 }
 
-// ---- long tiles: a quarter of the tile per wave, one pixel per lane, eight records per trip ----------
+// ---- long tiles: a quarter of the tile -- one of its four 8x8 blocks -- per wave, one pixel per lane, eight records per trip
 // Same per-(pixel, record) arithmetic as the kernels above (bit-identical frames, tested): what changes is
 // the shape of the loop.  A lone wave spends ~430 cycles per record in the two-records-per-trip loop (LDS
 // wait, the dependent exponent -> exp2 -> T chain); with the eight alphas of a trip computed independently
@@ -436,7 +525,7 @@ __device__ __forceinline__ void rank_samples(uint32_t group, int lane, const Ble
 __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                                                         const uint2 *__restrict__ ranges, const TileGrid &g,
                                                         const OutDesc &out, uint32_t t, int quarter,
-                                                        float4 (*sh)[kSlots], uint32_t budget, uint32_t *cost_out = nullptr) {
+                                                        Staged &sh, uint32_t budget, uint32_t *cost_out = nullptr) {
     const int lane = threadIdx.x;
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
@@ -444,17 +533,17 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
 #endif
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     const bool y_contig = out.stride_y < out.stride_x;
-    // WH3: a quarter = 4 columns of x, lanes run along y (192 contiguous bytes per column);
-    // HW3: a quarter = 4 rows of y, lanes run along x
-    const int lx = y_contig ? 4 * quarter + (lane >> 4) : (lane & 15);      // the pixel's offset inside the tile
-    const int ly = y_contig ? (lane & 15) : 4 * quarter + (lane >> 4);
+    // a quarter = block `quarter` of the tile (see Staged): 8 x 8 pixels; WH3: lanes run along y (96 contiguous bytes per
+    // column), HW3: along x
+    const int lx = 8 * (quarter & 1) + (y_contig ? (lane >> 3) : (lane & 7));      // the pixel's offset inside the tile
+    const int ly = 8 * (quarter >> 1) + (y_contig ? (lane & 7) : (lane >> 3));
     const int px = tx * 16 + lx, py = ty * 16 + ly;
     const float cx = (float)lx, cy = (float)ly;
     float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     bool checked = false;   // wave-uniform: some pixel of this quarter has saturated
     uint2 rg = ranges[t];
     rg.y &= ~kLongFlag;
-    uint32_t skipped = 0;            // colour this tile has left out so far (stage_batch)
+    uint32_t skipped[kBlocks] = {0u, 0u, 0u, 0u}, unused[kBlocks];   // colour this block has left out so far (stage_records)
     uint32_t cost = 0;               // what this quarter walked (GsxParams.hints: see the tile kernel)
     constexpr int kTrip = 8;
     // The gather runs AHEAD of the compositing: while batch i is composited, the records of batch i + 1 and the
@@ -477,8 +566,8 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
             na = q->a; nb4 = q->b; nc = q->c;
         }
         if (base + 128u + (uint32_t)lane < rg.y) idx2 = vals[base + 128u + lane];
-        const int kind = stage_records(ra, rb, rc, (uint32_t)lane < nb, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f,
-                                       skipped, budget);
+        const int kind = stage_records<kStageOneBlock>(ra, rb, rc, (uint32_t)lane < nb, nb, sh, lane, (float)(tx * 16), (float)(ty * 16),
+                                                       16.0f, skipped, budget, quarter, unused);
         cost += nb + kBatchCost;
 #ifdef GSX_TEST_HOOKS
         probe_staged += nb;
@@ -508,8 +597,8 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
                 float alpha[kTrip];
 #pragma unroll
                 for (int u = 0; u < kTrip; ++u) {
-                    const float4 A = sh[0][k + u];
-                    const float2 Bq = *reinterpret_cast<const float2 *>(&sh[1][k + u]);   // (r11, log2 op)
+                    const float4 A = sh.rec[0][k + u];
+                    const float2 Bq = *reinterpret_cast<const float2 *>(&sh.rec[1][k + u]);   // (r11, log2 op)
                     const float e_x = A.x - cx;
                     const float s0 = __builtin_fmaf(-(A.z * e_x), e_x, Bq.y);
                     const float w = __builtin_fmaf(-Bq.x, cy, __builtin_fmaf(-A.w, cx, A.y));
@@ -541,8 +630,8 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
                 }
 #pragma unroll
                 for (int u = 0; u < kTrip; ++u) {
-                    const float2 rg_ = *reinterpret_cast<const float2 *>(&sh[1][k + u].z);    // (r, g)
-                    const float cb = sh[2][k + u].x;
+                    const float2 rg_ = *reinterpret_cast<const float2 *>(&sh.rec[1][k + u].z);    // (r, g)
+                    const float cb = sh.rec[2][k + u].x;
                     c0 = __builtin_fmaf(ta[u], rg_.x, c0);
                     c1 = __builtin_fmaf(ta[u], rg_.y, c1);
                     c2 = __builtin_fmaf(ta[u], cb, c2);
@@ -582,7 +671,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
                         const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
                         uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints,
                         uint32_t tile_blocks, uint32_t sched_cap_, TileSpan span) {
-    __shared__ float4 sh[3][kSlots];
+    __shared__ Staged sh;
     // block order: [spare workgroups: the next frame's splitters] [helpers of long tiles (dispatched first: they have
     // the most to do)] [tiles] [clears]
     // (hints.rank_last -- gsx_api.hip: a window whose tiles just about fill the chip once -- : the spare workgroups come
@@ -656,6 +745,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll
     for (int j = 0; j < 4; ++j) cy[j] = (float)(ly0 + j);
     const v2f cya = v2f{cy[0], cy[1]}, cyb = v2f{cy[2], cy[3]};
+    // the block of the tile the lane's four pixels lie in (see Staged): the lane walks THAT block's list
+    const int blk = (lx >> 3) | ((ly0 >> 3) << 1);
+    const uint8_t *my_list = sh.list[blk];
 
     float T[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     float c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
@@ -684,7 +776,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
     if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
     uint32_t cost = 0;
-    uint32_t skipped = 0;            // colour this tile has left out so far (stage_batch)
+    uint32_t skipped[kBlocks] = {0u, 0u, 0u, 0u};    // colour every block has left out so far (stage_records)
     // the list entries of the next batch are requested while this one is composited (one register): one of the two
     // dependent trips to memory per batch leaves the path of a wave that has its SIMD to itself
     uint32_t idx = rg.x + (uint32_t)lane < rg.y ? vals[rg.x + lane] : 0u;
@@ -692,19 +784,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
         const uint32_t idx_now = idx;
         if (base + 64u + (uint32_t)lane < rg.y) idx = vals[base + 64u + lane];
-        const int kind = stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skipped, budget,
-                                     &idx_now);
+        uint32_t count[kBlocks];
+        const int kind = stage_batch<kStageBlocks>(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skipped,
+                                                   count, budget, &idx_now);
         const bool wild = kind != kBatchRegular;     // wave-uniform
-        cost += nb + kBatchCost;
+        // the wave walks as far as its LONGEST block list; the other blocks' lists are padded with a null record
+        const uint32_t nl = max(max(count[0], count[1]), max(count[2], count[3]));
+        cost += nl + kBatchCost;
 #ifdef GSX_TEST_HOOKS
-        probe_staged += nb;
+        probe_staged += nl;
         if (checked && probe_checked_at == 0xFFFFFFu) probe_checked_at = (base - rg.x) >> 6;
 #endif
         __syncthreads();
         if (VARIANT == 0) {
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
-                composite<4>(cx, cy, s, T, c0, c1, c2);
+                composite<4>(cx, cy, s, T, c0, c1, c2, blk);
             }
         } else if (kind == kBatchMono) {
             // A record in the monomial fallback (caller-given inverse covariances on the stage-2 entry; a degenerate
@@ -714,26 +809,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             restart_scalar = true;
             break;
         } else {
-            // Common path: whole trips of four records (the batch is padded with null records, see kPad), ONE
-            // wave-level saturation test per trip, no per-pixel selects: twice the independent work of two records
-            // between two tests hides more of the wave's own LDS reads and exponentials -- 264 -> 254 us at 1M
-            // Gaussians in round 2, more where a SIMD holds fewer than 8 waves (a rank's strip).  From the first
+            // Common path: whole trips of four list entries (the lists are padded with a null record's slot, see
+            // stage_records), ONE wave-level saturation test per trip, no per-pixel selects: twice the independent work
+            // of two records between two tests hides more of the wave's own LDS reads and exponentials -- 264 -> 254 us
+            // at 1M Gaussians in round 2, more where a SIMD holds fewer than 8 waves (a rank's strip).  From the first
             // trip in which any pixel of the tile saturates -- that trip is done again -- the reference's exact rule
             // per pixel and record (checked_pair) on trips of two; a saturated pixel has T = 0, adds 0 and stays 0.
             // Same operations per pixel and record in both forms, same order: same bits.
+            // Entry k of the lane's list names the slot of ITS block's k-th record: the four blocks read four different
+            // records per instruction (four LDS addresses; a 16-lane group shares one).
             constexpr int kTrip = VARIANT == 2 ? 6 : 4;
             uint32_t k = 0;
-            // one trip of N records from k; false: some pixel saturates inside it (nothing is committed)
-            auto trip = [&](auto n_tag) -> bool {
+            // one trip of N list entries from k; false: some pixel saturates inside it (nothing is committed)
+            auto trip = [&](auto n_tag) __attribute__((always_inline)) -> bool {
                 constexpr int N = decltype(n_tag)::value;
                 // geometry now, colour after the test: what stays live across the saturation test is T alpha of
-                // the trip (16 registers), not its records (36) -- the colours are read again from LDS (uniform
-                // address: one broadcast read), which keeps the kernel at 64 VGPRs without spills
+                // the trip (16 registers) and the slots (N), not the records (36) -- the colours are read again from
+                // LDS, which keeps the kernel at 64 VGPRs without spills
                 v2f ta_a[N], ta_b[N], ta = Ta, tb = Tb;
+                uint32_t slot[N];
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
-                    const float4 A = sh[0][k + u];
-                    const float2 Bq = *reinterpret_cast<const float2 *>(&sh[1][k + u]);   // (r11, log2 op)
+                    slot[u] = my_list[k + u];
+                    const float4 A = sh.rec[0][slot[u]];
+                    const float2 Bq = *reinterpret_cast<const float2 *>(&sh.rec[1][slot[u]]);   // (r11, log2 op)
                     v2f aa, ab;
                     alphas(A, Bq.x, Bq.y, cx, cya, cyb, aa, ab);
                     ta_a[u] = ta * aa;
@@ -747,8 +846,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 if (__builtin_expect(__any(!(min4(ta, tb) >= kStopRefCpu)), 0)) return false;
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
-                    const float2 rg_ = *reinterpret_cast<const float2 *>(&sh[1][k + u].z);    // (r, g)
-                    const float cb = sh[2][k + u].x;
+                    const float2 rg_ = *reinterpret_cast<const float2 *>(&sh.rec[1][slot[u]].z);    // (r, g)
+                    const float cb = sh.rec[2][slot[u]].x;
                     GSX_ACCUMULATE(ta_a[u], ta_b[u], rg_.x, rg_.y, cb);
                 }
                 Ta = ta;
@@ -759,12 +858,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             // (a wild batch -- alpha > 1 possible, T may rise again inside a trip -- goes straight to the exact rule
             // below, for this batch only: that rule is valid for any batch, it just costs a few selects per record)
             if (!wild) {
-                while (!checked && k + kTrip <= nb) checked = !trip(std::integral_constant<int, kTrip>());
-                while (!checked && k < nb) checked = !trip(std::integral_constant<int, 2>());   // what is left: trips of two (+ a null record)
+                while (!checked && k + kTrip <= nl) checked = !trip(std::integral_constant<int, kTrip>());
+                while (!checked && k < nl) checked = !trip(std::integral_constant<int, 2>());   // what is left: trips of two (+ a null record)
             }
-            for (; k < nb; k += 2) {       // the exact rule, two records per trip (their alphas are independent)
-                const float4 A0 = sh[0][k], B0 = sh[1][k], A1 = sh[0][k + 1], B1 = sh[1][k + 1];
-                const float cb0 = sh[2][k].x, cb1 = sh[2][k + 1].x;
+            for (; k < nl; k += 2) {       // the exact rule, two list entries per trip (their alphas are independent)
+                const uint32_t s0_ = my_list[k], s1_ = my_list[k + 1];
+                const float4 A0 = sh.rec[0][s0_], B0 = sh.rec[1][s0_], A1 = sh.rec[0][s1_], B1 = sh.rec[1][s1_];
+                const float cb0 = sh.rec[2][s0_].x, cb1 = sh.rec[2][s1_].x;
                 v2f aa0, ab0, aa1, ab1, ta0a, ta0b, ta1a, ta1b;
                 alphas(A0, B0.x, B0.y, cx, cya, cyb, aa0, ab0);
                 alphas(A1, B1.x, B1.y, cx, cya, cyb, aa1, ab1);
@@ -792,15 +892,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             T[j] = 1.0f;
             c0[j] = c1[j] = c2[j] = 0.0f;
         }
-        skipped = 0;
+#pragma unroll
+        for (int gb = 0; gb < kBlocks; ++gb) skipped[gb] = 0u;
         for (uint32_t base = rg.x; base < rg.y; base += 64) {
             uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
-            (void)stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skipped, budget);
+            uint32_t count[kBlocks];
+            (void)stage_batch<kStageBlocks>(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skipped, count,
+                                            budget);
             cost += 4u * nb;
             __syncthreads();
-            for (uint32_t k = 0; k < nb; ++k) {
+            for (uint32_t k = 0; k < nb; ++k) {         // every staged record, in order; a lane's block takes what it keeps
                 const Splat s = read_splat(sh, k);
-                composite<4>(cx, cy, s, T, c0, c1, c2);
+                composite<4>(cx, cy, s, T, c0, c1, c2, blk);
             }
             __syncthreads();
             if (__ballot((T[0] > 0.0f) | (T[1] > 0.0f) | (T[2] > 0.0f) | (T[3] > 0.0f)) == 0ull) break;
@@ -846,7 +949,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 __global__ void __launch_bounds__(64)
     blend_generic_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                          const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp) {
-    __shared__ float4 sh[3][kSlots];
+    __shared__ Staged sh;
     if (blockIdx.x >= (uint32_t)g.count()) {
         clear_block(blockIdx.x - (uint32_t)g.count(), cp, out.ptr);
         return;
@@ -857,23 +960,30 @@ __global__ void __launch_bounds__(64)
     const int Ts = g.tile, npx = Ts * Ts;
     const uint2 rg = ranges[t];
     const bool fast_y = out.stride_y < out.stride_x;
+    // tile 16: the four 8x8 blocks of the tile decide for themselves what they keep, like in blend_tile16_kernel (a lane
+    // composites a staged record only if its pixel's block keeps it); any other tile size: the tile is one block
+    const bool blocks = Ts == 16;
     for (int chunk = 0; chunk < npx; chunk += 64) {
-        uint32_t skipped = 0;        // colour the tile leaves out (stage_batch): every sweep over the list decides alike
+        uint32_t skipped[kBlocks] = {0u, 0u, 0u, 0u}, count[kBlocks];   // colour left out (stage_records): every sweep over the list decides alike
         const int p = chunk + lane;
         const bool valid = p < npx;
         const int pf = p % Ts, ps = p / Ts;
         const int lx = fast_y ? ps : pf, ly = fast_y ? pf : ps;      // the pixel's offset inside the tile
         const int px = tx * Ts + lx, py = ty * Ts + ly;
         const float fx = (float)lx, fy = (float)ly;
+        const int blk = blocks ? ((lx >> 3) | ((ly >> 3) << 1)) & 3 : 0;
         float T[1] = {1.0f}, c0[1] = {0.0f}, c1[1] = {0.0f}, c2[1] = {0.0f};
         for (uint32_t base = rg.x; base < rg.y; base += 64) {
             uint32_t nb = min(64u, rg.y - base);
-            (void)stage_batch(rec, vals, base, nb, sh, lane, (float)(tx * Ts), (float)(ty * Ts), (float)Ts, skipped);
+            if (blocks)
+                (void)stage_batch<kStageBlocks>(rec, vals, base, nb, sh, lane, (float)(tx * Ts), (float)(ty * Ts), (float)Ts, skipped, count);
+            else
+                (void)stage_batch<kStageWhole>(rec, vals, base, nb, sh, lane, (float)(tx * Ts), (float)(ty * Ts), (float)Ts, skipped, count);
             __syncthreads();
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
                 const float e_p[1] = {fy};
-                composite<1>(fx, e_p, s, T, c0, c1, c2);
+                composite<1>(fx, e_p, s, T, c0, c1, c2, blk);
             }
             __syncthreads();
             if (__ballot(valid && T[0] > 0.0f) == 0ull) break;
