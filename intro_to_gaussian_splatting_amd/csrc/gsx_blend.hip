@@ -89,7 +89,8 @@ constexpr int kPad = 8, kSlots = 64 + kPad;
 constexpr int kBlocks = 4;
 struct __attribute__((aligned(16))) Staged {
     float4 rec[3][kSlots];            // the staged records, by slot (see read_splat)
-    uint8_t list[kBlocks][kSlots];    // per block: the slots of the records it keeps, in list order, padded with a null record's slot
+    uint16_t list[kBlocks][kSlots];   // per block: the records it keeps, in list order, as BYTE OFFSETS of their slots in rec[0]
+                                      // (16 x slot: one shift less per record and lane), padded with a null record's
 };
 
 // Contiguous-chunk remap: hardware places block b on XCD b % 8; give XCD x the x-th eighth of
@@ -357,7 +358,7 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
     const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));   // kept lanes below this one
     if (MODE == kStageBlocks) {
         // every block's list starts out as nothing but the first null record's slot (the loops take whole trips) ...
-        const uint8_t null_slot = (uint8_t)nb;
+        const uint16_t null_slot = (uint16_t)(nb * 16u);
 #pragma unroll
         for (int g = 0; g < kBlocks; ++g) {
             sh.list[g][lane] = null_slot;
@@ -377,7 +378,7 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
 #pragma unroll
             for (int g = 0; g < kBlocks; ++g)
                 if ((bits >> g) & 1u)
-                    sh.list[g][__builtin_amdgcn_mbcnt_hi((uint32_t)(kept_by[g] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kept_by[g], 0u))] = (uint8_t)slot;
+                    sh.list[g][__builtin_amdgcn_mbcnt_hi((uint32_t)(kept_by[g] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kept_by[g], 0u))] = (uint16_t)(slot * 16u);
         }
     }
     if (MODE == kStageBlocks) {
@@ -747,7 +748,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const v2f cya = v2f{cy[0], cy[1]}, cyb = v2f{cy[2], cy[3]};
     // the block of the tile the lane's four pixels lie in (see Staged): the lane walks THAT block's list
     const int blk = (lx >> 3) | ((ly0 >> 3) << 1);
-    const uint8_t *my_list = sh.list[blk];
+    const uint16_t *my_list = sh.list[blk];
+    const char *rec_a = reinterpret_cast<const char *>(&sh.rec[0][0]), *rec_b = reinterpret_cast<const char *>(&sh.rec[1][0]),
+               *rec_c = reinterpret_cast<const char *>(&sh.rec[2][0]);
 
     float T[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     float c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
@@ -830,9 +833,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 uint32_t slot[N];
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
-                    slot[u] = my_list[k + u];
-                    const float4 A = sh.rec[0][slot[u]];
-                    const float2 Bq = *reinterpret_cast<const float2 *>(&sh.rec[1][slot[u]]);   // (r11, log2 op)
+                    slot[u] = my_list[k + u];                  // (byte offset of the record's slot)
+                    const float4 A = *reinterpret_cast<const float4 *>(rec_a + slot[u]);
+                    const float2 Bq = *reinterpret_cast<const float2 *>(rec_b + slot[u]);   // (r11, log2 op)
                     v2f aa, ab;
                     alphas(A, Bq.x, Bq.y, cx, cya, cyb, aa, ab);
                     ta_a[u] = ta * aa;
@@ -846,8 +849,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 if (__builtin_expect(__any(!(min4(ta, tb) >= kStopRefCpu)), 0)) return false;
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
-                    const float2 rg_ = *reinterpret_cast<const float2 *>(&sh.rec[1][slot[u]].z);    // (r, g)
-                    const float cb = sh.rec[2][slot[u]].x;
+                    const float2 rg_ = *reinterpret_cast<const float2 *>(rec_b + slot[u] + 8);    // (r, g)
+                    const float cb = *reinterpret_cast<const float *>(rec_c + slot[u]);
                     GSX_ACCUMULATE(ta_a[u], ta_b[u], rg_.x, rg_.y, cb);
                 }
                 Ta = ta;
@@ -863,8 +866,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
             for (; k < nl; k += 2) {       // the exact rule, two list entries per trip (their alphas are independent)
                 const uint32_t s0_ = my_list[k], s1_ = my_list[k + 1];
-                const float4 A0 = sh.rec[0][s0_], B0 = sh.rec[1][s0_], A1 = sh.rec[0][s1_], B1 = sh.rec[1][s1_];
-                const float cb0 = sh.rec[2][s0_].x, cb1 = sh.rec[2][s1_].x;
+                const float4 A0 = *reinterpret_cast<const float4 *>(rec_a + s0_), B0 = *reinterpret_cast<const float4 *>(rec_b + s0_);
+                const float4 A1 = *reinterpret_cast<const float4 *>(rec_a + s1_), B1 = *reinterpret_cast<const float4 *>(rec_b + s1_);
+                const float cb0 = *reinterpret_cast<const float *>(rec_c + s0_), cb1 = *reinterpret_cast<const float *>(rec_c + s1_);
                 v2f aa0, ab0, aa1, ab1, ta0a, ta0b, ta1a, ta1b;
                 alphas(A0, B0.x, B0.y, cx, cya, cyb, aa0, ab0);
                 alphas(A1, B1.x, B1.y, cx, cya, cyb, aa1, ab1);

@@ -116,7 +116,8 @@ def block_lists(wl="c2"):
     tid = tx * nty + ty
     thr = -26.0 * np.log(2.0)
     per_block = []
-    for (bw, bh, label) in ((8, 8, "8x8 blocks (16 lanes x 4 px)"), (16, 4, "16x4 strips"), (4, 16, "4x16 strips")):
+    for (bw, bh, label) in ((8, 8, "8x8 blocks (16 lanes x 4 px)"), (16, 4, "16x4 strips"), (4, 16, "4x16 strips"), (8, 4, "8x4 blocks"),
+                            (4, 8, "4x8 blocks"), (4, 4, "4x4 blocks")):
         counts = []
         for qy in range(16 // bh):
             for qx in range(16 // bw):
