@@ -6,7 +6,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for w in "$@"; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o $w -- python3 $R/bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline --streams 1 > $O/prof_$w.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o $w -- python3 $R/bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline --streams 1 --camera-path none > $O/prof_$w.log 2>&1
   f=$(find $O/prof_$w -name "*kernel_stats.csv" | head -1)
   cp $f $O/${w}_kernel_stats.csv
   python3 - "$f" <<'PY'

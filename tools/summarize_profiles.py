@@ -188,7 +188,7 @@ for w in ("c3", "c2", "c4", "strip"):
 lines.append("\n## Bench lines (profiles/%s_bench_*.json)\n" % tag)
 lines.append("| workload | Mpixel/s (value: median single frame) | ms/frame median [min, max] | ms/frame, 3 in flight | blend ms | "
              "max abs dpixel vs CPU port | parity_ok | CPU port Mpix/s |\n|---|---|---|---|---|---|---|---|")
-for w in ("c1", "c2", "c3", "c4", "c3_clustered", "c3_1m2", "strip", "c3_std3dgs", "c3_sh3"):
+for w in ("c1", "c2", "c3", "c4", "c3_clustered", "c3_trainedlike", "c3_1m2", "strip", "c3_std3dgs", "c3_sh3"):
     p = "%s/bench_%s.json" % (src, w)
     if not os.path.exists(p) or os.path.getsize(p) == 0:
         continue
