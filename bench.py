@@ -563,7 +563,13 @@ def launch_ranks(n: int) -> int:
 
     have = visible_gpus()                       # from sysfs: nothing in this process opens the GPU
     if have < n:
-        print("bench.py: --gpus %d asked for, %d visible: refusing to report a %d-GPU number" % (n, have, n), file=sys.stderr)
+        kfd = False
+        try:
+            kfd = any("kfd" in os.readlink("/proc/self/fd/%s" % fd) for fd in os.listdir("/proc/self/fd"))
+        except OSError:
+            pass
+        print("bench.py: --gpus %d asked for, %d visible: refusing to report a %d-GPU number (this process has /dev/kfd open: %s)"
+              % (n, have, n, kfd), file=sys.stderr)
         return 3
     with socket.socket() as sock:              # a free rendezvous port on the loopback interface
         sock.bind(("127.0.0.1", 0))

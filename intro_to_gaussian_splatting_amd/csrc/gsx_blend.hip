@@ -16,6 +16,10 @@
 //     axis, so each record fetched from LDS is amortised over 4 evaluations, the terms of the
 //     quadratic form that depend only on the shared coordinate are computed once per lane, and
 //     the per-lane output is 48 contiguous bytes;
+//   - (round 4) the tile's four 8x8 BLOCKS -- 16 lanes each -- walk lists of their own: a record whose alpha
+//     stays below 2^-26 on a whole block is not on that block's list (it would change nothing there), the
+//     wave's instructions read four different records from LDS, and a tile costs its LONGEST block list:
+//     64 % of the tile's list on the benchmark scene (see Staged, stage_records);
 //   - a single-wave workgroup needs no cross-wave barrier and no LDS flag: "every pixel of the
 //     tile is saturated" is one __ballot over the wave;
 //   - each lane gathers one 48-B record per batch of 64 (3 x dwordx4) into LDS; the k-loop then
