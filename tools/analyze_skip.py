@@ -85,7 +85,7 @@ def main():
     print("(pairs whose alpha stays below 1/255 in the whole tile: %.1f %%)" % (100.0 * negligible(px, py, 16).mean()))
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 2 and sys.argv[2] == "blocks"):
+if __name__ == "__main__" and not (len(sys.argv) > 2 and sys.argv[2] in ("blocks", "bound")):
     main()
 
 
@@ -133,3 +133,52 @@ def block_lists(wl="c2"):
 
 if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "blocks":
     block_lists(sys.argv[1])
+
+
+def kernel_bound(wl="c2"):
+    """How much does the kernel's SEPARABLE bound (D1 min e0^2 + min w^2 over the block, stage_records) keep beyond the exact
+    minimum of the quadratic over the block?  Prints kept shares per 8x8 block for both."""
+    n, w, h, _ = bench.WORKLOADS[wl]
+    sc = make_scene(n, w, h, seed=0, **bench.GENERATOR_ARGS.get(wl, {}))
+    cam = cpu_ref.build_camera(sc["qvec"], sc["tvec"], sc["fx"], sc["fy"], w, h)
+    pre = c_oracle.preprocess(sc["points"], sc["colors_0_255"] / 255.0, sc["scales"], sc["quaternions"], sc["opacity"], cam)
+    tile = 16
+    ntx, nty = len(cpu_ref.tile_origins(w, tile)), len(cpu_ref.tile_origins(h, tile))
+    inv = pre.inverse_covariance_2d.astype(np.float64)
+    a, b, c = inv[:, 0, 0], 0.5 * (inv[:, 0, 1] + inv[:, 1, 0]), inv[:, 1, 1]
+    mx, my = pre.points_xy[:, 0].astype(np.float64), pre.points_xy[:, 1].astype(np.float64)
+    ln_op = -np.log1p(np.exp(-pre.sigmoid_opacity[:, 0].astype(np.float64)))
+    tx0 = np.maximum(np.ceil((pre.min_x.astype(np.float64) - tile) / tile), 0).astype(np.int64)
+    tx1 = np.minimum(np.floor(pre.max_x.astype(np.float64) / tile), ntx - 1).astype(np.int64)
+    ty0 = np.maximum(np.ceil((pre.min_y.astype(np.float64) - tile) / tile), 0).astype(np.int64)
+    ty1 = np.minimum(np.floor(pre.max_y.astype(np.float64) / tile), nty - 1).astype(np.int64)
+    nx, ny = np.maximum(tx1 - tx0 + 1, 0), np.maximum(ty1 - ty0 + 1, 0)
+    cnt = nx * ny
+    D = int(cnt.sum())
+    g = np.repeat(np.arange(len(cnt)), cnt)
+    k = np.arange(D) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    tx, ty = tx0[g] + k % np.maximum(nx[g], 1), ty0[g] + k // np.maximum(nx[g], 1)
+    thr = -26.0 * np.log(2.0)
+    # completed square in y (gsx_project.hip pack_record): M = Q/2 (natural log units here), r11 = sqrt(M11), hh = M01 / r11, D1 = M00 - hh^2
+    m00, m01, m11 = 0.5 * a[g], 0.5 * b[g], 0.5 * c[g]
+    r11 = np.sqrt(m11)
+    hh = m01 / r11
+    d1 = m00 - hh * hh
+    kept_exact = kept_sep = 0
+    for qy in range(2):
+        for qx in range(2):
+            x0, y0 = tx * 16 + 8 * qx, ty * 16 + 8 * qy
+            q = min_quadratic_over_box(a[g], b[g], c[g], mx[g], my[g], x0, x0 + 7, y0, y0 + 7)
+            kept_exact += int((ln_op[g] - 0.5 * q >= thr).sum())
+            ex0, ex1, ey0, ey1 = mx[g] - x0, mx[g] - (x0 + 7), my[g] - y0, my[g] - (y0 + 7)
+            ex_min2 = np.where(ex0 * ex1 <= 0, 0.0, np.minimum(ex0 * ex0, ex1 * ex1))
+            ws = np.stack([r11 * ey0 + hh * ex0, r11 * ey1 + hh * ex0, r11 * ey0 + hh * ex1, r11 * ey1 + hh * ex1])
+            wlo, whi = ws.min(axis=0), ws.max(axis=0)
+            w_min2 = np.where((wlo <= 0) & (whi >= 0), 0.0, np.minimum(np.abs(wlo), np.abs(whi)) ** 2)
+            kept_sep += int((ln_op[g] - d1 * ex_min2 - w_min2 >= thr).sum())
+    print("%s: (record, 8x8 block) combinations kept -- exact minimum of the quadratic: %.3f; the kernel's separable bound: %.3f" % (
+        wl, kept_exact / (4 * D), kept_sep / (4 * D)))
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "bound":
+    kernel_bound(sys.argv[1])
