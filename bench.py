@@ -549,6 +549,20 @@ def moving_camera_leg(args, scene, sc, tile: int, layout: str, sem: str, stream)
 
         out["cold_frame_ms"] = round(separate(False), 4)
         out["hinted_separate_launches_ms"] = round(separate(True), 4)
+        # the reference's host-tensor contract (render_image returns a CPU tensor): per call, and as a loop over the orbit
+        # with the copy of frame i overlapped with the render of frame i + 1 (GaussianScene.render_images); PCIe-inclusive,
+        # never `value`
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in ids[:16]:
+            scene.render_image(i, tile_size=tile)
+        per_call = (time.perf_counter() - t0) / 16 * 1e3
+        t0 = time.perf_counter()
+        cnt = sum(1 for _ in scene.render_images(ids[:32], tile_size=tile))
+        looped = (time.perf_counter() - t0) / max(cnt, 1) * 1e3
+        out["host_frames"] = {"render_image_ms_per_call": round(per_call, 4), "render_images_ms_per_frame": round(looped, 4),
+                              "frame_bytes": int(frame.out.numel() * 4),
+                              "note": "device -> page-locked host frames, wall clock; the boundary itself takes and returns device pointers"}
     return out
 
 

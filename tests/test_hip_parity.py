@@ -712,6 +712,29 @@ def test_orbit_of_eight_poses_through_one_captured_frame(tmp_path):
         assert np.max(np.abs(got.cpu().numpy() - img)) <= PIXEL_TOL
 
 
+def test_render_images_overlaps_the_copy_and_returns_the_same_frames(tmp_path):
+    """GaussianScene.render_images: the reference's image-after-image loop with the device-to-host copy of frame i
+    overlapped with the rendering of frame i + 1 (two device frames, two pinned host buffers): every yielded host
+    tensor equals render_image of that camera bit for bit, also when the same camera repeats and when the sequence has
+    one or no element."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene, orbit_poses, write_colmap_text
+
+    sc = make_scene(30_000, 480, 272, seed=23)
+    write_colmap_text(str(tmp_path), sc, extra_poses=orbit_poses(4, step_deg=2.0))
+    g = Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"], sc["opacity"], device="cuda:0")
+    scene = GaussianScene(str(tmp_path), g)
+    order = [1, 2, 3, 3, 4, 5, 1, 2]
+    refs = {i: scene.render_image(i).clone() for i in set(order)}
+    got = [f.clone() for f in scene.render_images(order)]      # (a yielded tensor is reused two frames later: clone)
+    assert len(got) == len(order)
+    for i, f in zip(order, got):
+        assert not f.is_cuda and torch.equal(f, refs[i]), i
+    assert [f.clone() for f in scene.render_images([4])][0].equal(refs[4])
+    assert list(scene.render_images([])) == []
+
+
 def test_compositing_in_parts_equals_the_one_launch_frame(tmp_path):
     """GsxParams.n_substrips (round 4): projection, depth order and binning once, the compositing launch once per part of
     the window, an event of the caller's behind each part.  Whole frames and a strip window, both layouts, 2 .. 16
