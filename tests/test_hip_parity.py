@@ -6,11 +6,13 @@ rounding decides sort order and tile membership (depth, radius, bounding box, pe
 instance count) bit-identical to the C restatement, which shares the kernel's float32
 operation order.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden_preprocessed, load_golden, oracle_camera
+from conftest import ROOT, golden_preprocessed, load_golden, oracle_camera
 
 pytestmark = pytest.mark.gpu
 
@@ -733,6 +735,29 @@ def test_render_images_overlaps_the_copy_and_returns_the_same_frames(tmp_path):
         assert not f.is_cuda and torch.equal(f, refs[i]), i
     assert [f.clone() for f in scene.render_images([4])][0].equal(refs[4])
     assert list(scene.render_images([])) == []
+
+
+@pytest.mark.parametrize("world,extra", [(2, []), (3, ["--balance"])])
+def test_ranks_sharing_one_gpu_assemble_the_single_gpu_frame(world, extra):
+    """bench.py's N > 1 path end to end on the ONE GPU of the test box (tools/bench_two_ranks_one_gpu.py: `world` processes
+    share GPU 0, the process group is gloo -- RCCL refuses two ranks per device -- everything else is the real code):
+    strips, the overlapped gather (every rank composites its strip in four parts behind HIP events the library records,
+    sends part j from a communication stream while part j + 1 is composited, rank 0 posts its receive groups first),
+    bench.py's self-check and timing protocol.  The frame rank 0 assembles must equal the single-GPU frame bit for bit
+    (`strips_equal_single_gpu`) and the line must say that the overlapped path was the one that ran."""
+    _need_gpu()
+    import json
+    import subprocess
+    import sys
+
+    tool = os.path.join(ROOT, "tools", "bench_two_ranks_one_gpu.py")
+    r = subprocess.run([sys.executable, tool, str(world), "--workload", "c2", "--steps", "3", "--warmup", "1", "--repeats", "1",
+                        "--no-cpu-baseline", "--streams", "1"] + extra, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == world and d["strips_equal_single_gpu"] is True
+    assert "sub-strips sent while the next is composited" in d["config"]["parallelism"], d["config"]["parallelism"]
 
 
 def test_compositing_in_parts_equals_the_one_launch_frame(tmp_path):
