@@ -1397,11 +1397,18 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
     uint32_t *samples_out = hinted ? hints.samples : nullptr;
     const uint32_t step = hinted && n >= kSamples ? (uint32_t)(n / kSamples) : 0u;
     if (nb > kBins) {
+#ifndef GSX_TEST_HOOKS
+        // the 1 024-bucket route measured slower than the LSD passes everywhere and nothing in the
+        // shipping library selects it (depth_sort_route): its kernels are compiled into libgsx_test.so only, where
+        // gsx_debug_depth_sort and the GSX_DEPTH_SORT knob keep it tested
+        return hipErrorNotSupported;
+#else
         sample_rank_kernel<kSortBinsMax><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
         launch_partition<kSortBinsMax>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect, splitters, nullptr,
                                        nullptr, 0u, nullptr, 0u, s);
         bucket_sort_kernel<kSortBinsMax><<<kSortBinsMax, kBigThreads, 0, s>>>(p.totals, p.table, 0, keys1, vals_alt, keys0, vals_cur,
                                                                               rect, rrect, lds_cap, cs);
+#endif
     } else {
         const bool use = hinted && hints.use;
         if (!use) sample_rank_kernel<kBins><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
