@@ -1124,7 +1124,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     blend_std16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                        const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, float bg0, float bg1, float bg2, ClearPlan cp,
                        const uint32_t *__restrict__ sched) {
-    __shared__ float4 sh[3][64];
+    __shared__ float4 sh[3][64 + 1];
+    __shared__ uint16_t lists[kBlocks][64];     // per 8x8 block of the tile: byte offsets of the records it keeps (see Staged)
     if (blockIdx.x >= (uint32_t)g.count()) {
         clear_block(blockIdx.x - (uint32_t)g.count(), cp, out.ptr);
         return;
@@ -1133,8 +1134,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const uint32_t t = scheduled_tile(blockIdx.x, (uint32_t)g.count(), sched);
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     const bool y_contig = out.stride_y < out.stride_x;
-    const int px = tx * 16 + (y_contig ? (lane >> 2) : (lane & 15));
-    const int py0 = ty * 16 + 4 * (y_contig ? (lane & 3) : (lane >> 4));
+    const int lx = y_contig ? (lane >> 2) : (lane & 15), ly0 = 4 * (y_contig ? (lane & 3) : (lane >> 4));
+    const int px = tx * 16 + lx;
+    const int py0 = ty * 16 + ly0;
+    const int blk = (lx >> 3) | ((ly0 >> 3) << 1);            // the 8x8 block the lane's four pixels lie in
+    const uint16_t *my_list = lists[blk];
+    const char *rec_a = reinterpret_cast<const char *>(&sh[0][0]), *rec_b = reinterpret_cast<const char *>(&sh[1][0]),
+               *rec_c = reinterpret_cast<const char *>(&sh[2][0]);
     const float cx = (float)px;
     float cy[4], T[4], c0[4], c1[4], c2[4], thr[4];
     bool valid[4];
@@ -1150,50 +1156,72 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const float tile_x0 = (float)(tx * 16), tile_y0 = (float)(ty * 16);
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
         uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
-        // A record whose alpha stays below 1/255 at every pixel of the tile is skipped at every pixel by the
-        // published rule, so it need not be staged: the frame is the same bit for bit (the tile lists -- tight
-        // rectangles around the alpha = 1/255 ellipse -- keep the corner tiles the ellipse does not reach: ~7 %
-        // of the pairs on the benchmark scene).  The bound is the one of stage_batch: with M = -Q'' the exponent
-        // is -(D1 e0^2 + m11 w^2), w = e1 + (m01 / m11) e0 linear in the pixel, minimised over the tile's pixel
-        // rectangle term by term -- and taken with 1 % + 0.01 of slack, far above the rounding of either side,
-        // so that no record whose alpha could round to 1/255 anywhere is dropped.
-        bool keep = false;
+        // A record whose alpha stays below 1/255 at every pixel of a BLOCK of the tile (8 x 8 pixels, 16 lanes: round 4,
+        // see Staged) is skipped at every pixel there by the published rule, so it need not be on that block's list: the
+        // frame is the same bit for bit (the tile lists -- tight rectangles around the alpha = 1/255 ellipse -- keep the
+        // corner tiles the ellipse does not reach, and most of a tile's blocks lie outside most of its ellipses).  The
+        // bound is the one of stage_records: with M = -Q'' the exponent is -(D1 e0^2 + m11 w^2), w = e1 + (m01 / m11) e0
+        // linear in the pixel, minimised over the block's pixel rectangle term by term -- and taken with 1 % + 0.01 of
+        // slack, far above the rounding of either side, so that no record whose alpha could round to 1/255 anywhere is
+        // dropped.  Every 16-lane group then walks ITS block's list; the wave goes as far as the longest of the four.
+        uint32_t bits = 0;
         float4 a, b, c;
         if ((uint32_t)lane < nb) {
             const Record *q = rec + vals[base + lane];
             a = q->a;     // (x, y, Q''00, Q''01 + Q''10)
             b = q->b;     // (Q''11, opacity, r, g)
             c = q->c;
-            keep = true;
+            bits = 0xFu;
             const float m00 = -a.z, m01 = -0.5f * a.w, m11 = -b.x;
             if (m11 > 0.0f && b.y > 0.0f) {
                 const float k = m01 / m11, d1 = m00 - m01 * k;
                 if (d1 >= 0.0f) {
-                    const float ex0 = a.x - tile_x0, ex1 = a.x - (tile_x0 + 15.0f);
-                    const float ey0 = a.y - tile_y0, ey1 = a.y - (tile_y0 + 15.0f);
-                    const float ex_min2 = ex0 * ex1 <= 0.0f ? 0.0f : fminf(ex0 * ex0, ex1 * ex1);
-                    const float w00 = __builtin_fmaf(k, ex0, ey0), w01 = __builtin_fmaf(k, ex0, ey1);
-                    const float w10 = __builtin_fmaf(k, ex1, ey0), w11 = __builtin_fmaf(k, ex1, ey1);
-                    const float wlo = fminf(fminf(w00, w01), fminf(w10, w11)), whi = fmaxf(fmaxf(w00, w01), fmaxf(w10, w11));
-                    const float wabs = fminf(fabsf(wlo), fabsf(whi));
-                    const float w_min2 = (wlo <= 0.0f && whi >= 0.0f) ? 0.0f : wabs * wabs;
-                    const float least = 0.99f * (d1 * ex_min2 + m11 * w_min2);       // -exponent is at least this
-                    if (__builtin_amdgcn_logf(b.y) - least < -7.994353f - 0.01f) keep = false;   // log2(1/255); NaN keeps
+                    const float lop = __builtin_amdgcn_logf(b.y);
+                    bits = 0u;
+#pragma unroll
+                    for (int gb = 0; gb < kBlocks; ++gb) {
+                        const float bx0 = tile_x0 + 8.0f * (float)(gb & 1), by0 = tile_y0 + 8.0f * (float)(gb >> 1);
+                        const float ex0 = a.x - bx0, ex1 = a.x - (bx0 + 7.0f);
+                        const float ey0 = a.y - by0, ey1 = a.y - (by0 + 7.0f);
+                        const float ex_min2 = ex0 * ex1 <= 0.0f ? 0.0f : fminf(ex0 * ex0, ex1 * ex1);
+                        const float w00 = __builtin_fmaf(k, ex0, ey0), w01 = __builtin_fmaf(k, ex0, ey1);
+                        const float w10 = __builtin_fmaf(k, ex1, ey0), w11 = __builtin_fmaf(k, ex1, ey1);
+                        const float wlo = fminf(fminf(w00, w01), fminf(w10, w11)), whi = fmaxf(fmaxf(w00, w01), fmaxf(w10, w11));
+                        const float wabs = fminf(fabsf(wlo), fabsf(whi));
+                        const float w_min2 = (wlo <= 0.0f && whi >= 0.0f) ? 0.0f : wabs * wabs;
+                        const float least = 0.99f * (d1 * ex_min2 + m11 * w_min2);       // -exponent is at least this
+                        if (!(lop - least < -7.994353f - 0.01f)) bits |= 1u << gb;      // log2(1/255); NaN keeps
+                    }
                 }
             }
         }
-        const unsigned long long kept = __ballot(keep);
-        if (keep) {
-            const uint32_t slot = (uint32_t)__popcll(kept & ((1ull << lane) - 1ull));
+        const unsigned long long kept = __ballot(bits != 0u);
+        nb = (uint32_t)__popcll(kept);
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(kept >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kept, 0u));
+        uint32_t nl = 0;
+#pragma unroll
+        for (int gb = 0; gb < kBlocks; ++gb) {
+            const unsigned long long kb = __ballot((bits >> gb) & 1u);
+            lists[gb][lane] = (uint16_t)(nb * 16u);                       // the null record behind the batch ...
+            if ((bits >> gb) & 1u)                                        // ... then the block's own records, in order
+                lists[gb][__builtin_amdgcn_mbcnt_hi((uint32_t)(kb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kb, 0u))] = (uint16_t)(slot * 16u);
+            nl = max(nl, (uint32_t)__popcll(kb));
+        }
+        if (bits != 0u) {
             sh[0][slot] = a;
             sh[1][slot] = b;
             sh[2][slot] = c;
         }
-        nb = (uint32_t)__popcll(kept);
+        if (lane == 0) {        // a null record: opacity 0 -> alpha 0 < 1/255, skipped by the rule itself
+            sh[0][nb] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            sh[1][nb] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            sh[2][nb] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
         __syncthreads();
-        for (uint32_t k = 0; k < nb; ++k) {
-            const float4 A = sh[0][k], B = sh[1][k];
-            const float cb = sh[2][k].x;
+        for (uint32_t k = 0; k < nl; ++k) {
+            const uint32_t off = my_list[k];
+            const float4 A = *reinterpret_cast<const float4 *>(rec_a + off), B = *reinterpret_cast<const float4 *>(rec_b + off);
+            const float cb = *reinterpret_cast<const float *>(rec_c + off);
             const float e_x = A.x - cx;
             const float a0 = (e_x * e_x) * A.z, b0 = e_x * A.w;
 #pragma unroll
