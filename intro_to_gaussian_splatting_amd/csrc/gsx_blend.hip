@@ -306,7 +306,7 @@ __device__ __forceinline__ float skip_threshold(float bound, uint32_t &skipped, 
 template <int MODE>
 __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool have, uint32_t &nb, Staged &sh, int lane,
                                              float tile_x0, float tile_y0, float tile_side, uint32_t (&skipped)[kBlocks],
-                                             uint32_t budget, int blk, uint32_t (&count)[kBlocks]) {
+                                             uint32_t budget, int blk, uint32_t (&count)[kBlocks], uint32_t dead = 0u) {
     bool irregular = false, mono = false;
     float bound[kBlocks] = {0.0f, 0.0f, 0.0f, 0.0f};   // < -26: a candidate, alpha < 2^bound on the whole block
     if (have) {
@@ -347,6 +347,7 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
     if (MODE == kStageBlocks) {
 #pragma unroll
         for (int g = 0; g < kBlocks; ++g) {
+            if ((dead >> g) & 1u) continue;       // (wave-uniform) every pixel of the block has saturated: it keeps nothing more
             const float thr = skip_threshold(bound[g], skipped[g], budget);
             const bool k = have && !(bound[g] < thr);
             bits |= k ? (1u << g) : 0u;
@@ -403,7 +404,8 @@ template <int MODE>
 __device__ __forceinline__ int stage_batch(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
                                            uint32_t base, uint32_t &nb, Staged &sh, int lane, float tile_x0,
                                            float tile_y0, float tile_side, uint32_t (&skipped)[kBlocks], uint32_t (&count)[kBlocks],
-                                           uint32_t budget = kSkipBudget, const uint32_t *idx = nullptr, int blk = 0) {
+                                           uint32_t budget = kSkipBudget, const uint32_t *idx = nullptr, int blk = 0,
+                                           uint32_t dead = 0u) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
     const bool have = (uint32_t)lane < nb;
     if (have) {
@@ -412,7 +414,7 @@ __device__ __forceinline__ int stage_batch(const Record *__restrict__ rec, const
         b = q->b;
         c = q->c;
     }
-    return stage_records<MODE>(a, b, c, have, nb, sh, lane, tile_x0, tile_y0, tile_side, skipped, budget, blk, count);
+    return stage_records<MODE>(a, b, c, have, nb, sh, lane, tile_x0, tile_y0, tile_side, skipped, budget, blk, count, dead);
 }
 
 // ---- packed-math form of the same arithmetic (two pixels per VGPR pair) ----------------------
@@ -736,7 +738,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
     const uint32_t probe_w0 = (uint32_t)wall_clock64();
-    uint32_t probe_staged = 0, probe_checked_at = 0xFFFFFFu;
+    uint32_t probe_staged = 0, probe_checked_at = 0xFFFu, probe_after = 0;
 #endif
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     if ((span.axis ? ty : tx) < span.lo || (span.axis ? ty : tx) >= span.hi) return;      // another part's tile
@@ -784,6 +786,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
     uint32_t cost = 0;
     uint32_t skipped[kBlocks] = {0u, 0u, 0u, 0u};    // colour every block has left out so far (stage_records)
+    // A block whose 64 pixels have all saturated keeps nothing more (stage_records): a dead pixel has T = 0, adds 0 and
+    // stays 0, so the records it no longer sees change nothing -- the wave walks on for the blocks that are still alive
+    // only (a tile over the edge of an opaque object: its covered half is done after a fraction of the list).
+    unsigned long long lanes_of[kBlocks];
+#pragma unroll
+    for (int gb = 0; gb < kBlocks; ++gb) lanes_of[gb] = __ballot(blk == gb);
+    uint32_t dead = 0u;              // wave-uniform: bit g = block g is done
     // the list entries of the next batch are requested while this one is composited (one register): one of the two
     // dependent trips to memory per batch leaves the path of a wave that has its SIMD to itself
     uint32_t idx = rg.x + (uint32_t)lane < rg.y ? vals[rg.x + lane] : 0u;
@@ -793,14 +802,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (base + 64u + (uint32_t)lane < rg.y) idx = vals[base + 64u + lane];
         uint32_t count[kBlocks];
         const int kind = stage_batch<kStageBlocks>(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skipped,
-                                                   count, budget, &idx_now);
+                                                   count, budget, &idx_now, 0, dead);
         const bool wild = kind != kBatchRegular;     // wave-uniform
         // the wave walks as far as its LONGEST block list; the other blocks' lists are padded with a null record
         const uint32_t nl = max(max(count[0], count[1]), max(count[2], count[3]));
         cost += nl + kBatchCost;
 #ifdef GSX_TEST_HOOKS
         probe_staged += nl;
-        if (checked && probe_checked_at == 0xFFFFFFu) probe_checked_at = (base - rg.x) >> 6;
+        if (checked && probe_checked_at == 0xFFFu) probe_checked_at = min(0xFFEu, (base - rg.x) >> 6);
+        if (checked) probe_after += nl;           // (entries walked under the exact rule, whole batches)
 #endif
         __syncthreads();
         if (VARIANT == 0) {
@@ -862,13 +872,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 k += N;
                 return true;
             };
-            // (a wild batch -- alpha > 1 possible, T may rise again inside a trip -- goes straight to the exact rule
-            // below, for this batch only: that rule is valid for any batch, it just costs a few selects per record)
-            if (!wild) {
-                while (!checked && k + kTrip <= nl) checked = !trip(std::integral_constant<int, kTrip>());
-                while (!checked && k < nl) checked = !trip(std::integral_constant<int, 2>());   // what is left: trips of two (+ a null record)
-            }
-            for (; k < nl; k += 2) {       // the exact rule, two list entries per trip (their alphas are independent)
+            // the exact rule, two list entries from k (their alphas are independent)
+            auto exact_pair = [&]() __attribute__((always_inline)) {
                 const uint32_t s0_ = my_list[k], s1_ = my_list[k + 1];
                 const float4 A0 = *reinterpret_cast<const float4 *>(rec_a + s0_), B0 = *reinterpret_cast<const float4 *>(rec_b + s0_);
                 const float4 A1 = *reinterpret_cast<const float4 *>(rec_a + s1_), B1 = *reinterpret_cast<const float4 *>(rec_b + s1_);
@@ -882,7 +887,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 checked_pair(aa1, Ta, ta1a);
                 checked_pair(ab1, Tb, ta1b);
                 GSX_ACCUMULATE(ta1a, ta1b, B1.z, B1.w, cb1);
+                k += 2;
+            };
+            // (a wild batch -- alpha > 1 possible, T may rise again inside a trip -- goes straight to the exact rule, for
+            // this batch only: that rule is valid for any batch, it just costs a few selects per record.  Whole trips
+            // that only a pixel saturating INSIDE them stops, tried again after the first saturation, lost: once the
+            // first pixel of a tile is done the others follow record by record, nearly every trip met one and was
+            // done twice -- trained-like scene 206 -> 231 us, round 4.)
+            if (!wild) {
+                while (!checked && k + kTrip <= nl) checked = !trip(std::integral_constant<int, kTrip>());
+                while (!checked && k < nl) checked = !trip(std::integral_constant<int, 2>());   // what is left: trips of two (+ a null record)
             }
+            while (k < nl) exact_pair();
         }
         __syncthreads();
         bool live;
@@ -890,7 +906,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             live = (T[0] > 0.0f) | (T[1] > 0.0f) | (T[2] > 0.0f) | (T[3] > 0.0f);
         else
             live = (Ta.x > 0.0f) | (Ta.y > 0.0f) | (Tb.x > 0.0f) | (Tb.y > 0.0f);
-        if (__ballot(live) == 0ull) break;
+        const unsigned long long alive = __ballot(live);
+        if (alive == 0ull) break;
+        if (checked || VARIANT == 0) {
+#pragma unroll
+            for (int gb = 0; gb < kBlocks; ++gb) dead |= (alive & lanes_of[gb]) == 0ull ? (1u << gb) : 0u;
+        }
     }
     if (VARIANT != 0 && restart_scalar) {
         // the whole tile again, one record at a time on the scalar form (composite<4>: same bits as the packed loops)
@@ -930,7 +951,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // (where and when: HW_ID = register 4, XCC_ID = register 20; wall_clock64 ticks at 100 MHz on every XCD alike)
     if (g_blend_probe && lane == 1)
         g_blend_probe[kProbeSecond + blockIdx.x] =
-            make_uint4(probe_checked_at, (uint32_t)wall_clock64(),
+            make_uint4(probe_checked_at | (probe_after << 12), (uint32_t)wall_clock64(),
                        (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16),
                        probe_w0);
 #endif
@@ -1154,6 +1175,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
     const uint2 rg = ranges[t];
     const float tile_x0 = (float)(tx * 16), tile_y0 = (float)(ty * 16);
+    // a block whose pixels are all done takes no more records (blend_tile16_kernel: `dead`)
+    unsigned long long lanes_of[kBlocks];
+#pragma unroll
+    for (int gb = 0; gb < kBlocks; ++gb) lanes_of[gb] = __ballot(blk == gb);
+    uint32_t dead = 0u;
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
         uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
         // A record whose alpha stays below 1/255 at every pixel of a BLOCK of the tile (8 x 8 pixels, 16 lanes: round 4,
@@ -1195,6 +1221,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 }
             }
         }
+        bits &= ~dead;
         const unsigned long long kept = __ballot(bits != 0u);
         nb = (uint32_t)__popcll(kept);
         const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(kept >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kept, 0u));
@@ -1233,7 +1260,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
         }
         __syncthreads();
-        if (__ballot(fminf(fminf(thr[0], thr[1]), fminf(thr[2], thr[3])) < 1.0f) == 0ull) break;
+        const unsigned long long alive = __ballot(fminf(fminf(thr[0], thr[1]), fminf(thr[2], thr[3])) < 1.0f);
+        if (alive == 0ull) break;
+#pragma unroll
+        for (int gb = 0; gb < kBlocks; ++gb) dead |= (alive & lanes_of[gb]) == 0ull ? (1u << gb) : 0u;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

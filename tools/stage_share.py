@@ -1,0 +1,35 @@
+"""How much of the compositing walk runs under the exact rule (after a tile's first saturated pixel)?  One frame of a bench
+workload on libgsx_test.so with the blend probe on.   python tools/stage_share.py [workload]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from intro_to_gaussian_splatting_amd import _ffi
+_ffi.use_test_library()
+import bench
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+sc, scene = bench.build_scene(wl, "cuda")
+lib = _ffi.load()
+for _ in range(4):
+    scene.render_image_hip(1)
+torch.cuda.synchronize()
+half = 1 << 17
+buf = torch.zeros((2 * half, 4), dtype=torch.int32, device="cuda")
+lib.gsx_debug_set_blend_probe(buf.data_ptr())
+st = {}
+scene.render_image_hip(1, stats=st, timing=True)
+torch.cuda.synchronize()
+lib.gsx_debug_set_blend_probe(None)
+d = buf.cpu().numpy().view(np.uint32)
+rows = np.nonzero((d[:half, 2] > 0) & (d[:half, 1] < 0x40000000))[0]
+length = d[rows, 2].astype(np.float64)
+walked = (d[rows, 3] & 0x7FFFFFFF).astype(np.float64)
+sat = (d[rows, 3] >> 31) != 0
+sec = d[half + rows, 0]
+at, after = (sec & 0xFFF).astype(np.float64), (sec >> 12).astype(np.float64)
+print(wl, "blend %.3f ms; %d tiles, %d (%.1f %%) meet a saturated pixel" % (st["stage_ms"]["blend"], len(rows), sat.sum(), 100 * sat.mean()))
+print("list entries %.3g, walked %.3g (%.3f), of those under the exact rule (whole batches after the first saturation) %.3g = %.1f %%" % (
+    length.sum(), walked.sum(), walked.sum() / length.sum(), after.sum(), 100 * after.sum() / walked.sum()))
+m = sat & (at < 0xFFF)
+if m.any():
+    print("tiles that saturate: first saturation seen at batch (median) %.0f of %.0f; their share of all walked entries %.1f %%" % (
+        np.median(at[m]), np.median(np.ceil(length[m] / 64)), 100 * walked[m].sum() / walked.sum()))
