@@ -90,3 +90,21 @@ print("tile cost: mean slot load %.0f (all tiles / 1024); largest tiles %s; p99 
 durs = end - start
 o = np.argsort(durs)[::-1][:8]
 print("longest-running tile workgroups: us %s cost %s listed %s" % (durs[o].round(0), cost[o].astype(int), lens[o]))
+if os.environ.get("STARTS"):
+    print("start time percentiles (us): " + " ".join("p%d %.1f" % (p, np.percentile(start, p)) for p in (10, 50, 75, 80, 85, 90, 95, 99, 100)))
+    late = start > 10
+    print("late starters: %d; their block ids (relative): min %d median %d max %d of %d; corr(block id, start) %.2f" % (
+        late.sum(), (first[late] - first.min()).min() if late.any() else -1, np.median(first[late] - first.min()) if late.any() else -1,
+        (first[late] - first.min()).max() if late.any() else -1, first.max() - first.min(), np.corrcoef(first, start)[0, 1]))
+    # when a late starter starts, has some wave of its SIMD just ended?
+    ends_by_simd = {}
+    for s_, e_ in zip(simd, end):
+        ends_by_simd.setdefault(int(s_), []).append(e_)
+    gaps = []
+    for s_, st_ in zip(simd[late], start[late]):
+        prev = [e_ for e_ in ends_by_simd[int(s_)] if e_ <= st_ + 0.05]
+        gaps.append(st_ - max(prev) if prev else np.nan)
+    gaps = np.asarray(gaps)
+    print("late starters whose SIMD had a wave end before their start: %d of %d; median gap %.2f us" % (
+        np.isfinite(gaps).sum(), len(gaps), np.nanmedian(gaps) if np.isfinite(gaps).any() else -1))
+    print("durations of workgroups ending before 40 us: %d, (all tiles: median duration %.1f us)" % ((end < 40).sum(), np.median(end - start)))
