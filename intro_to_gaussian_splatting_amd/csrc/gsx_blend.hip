@@ -536,6 +536,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     const int lane = threadIdx.x;
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
+    const uint32_t probe_w0h = (uint32_t)wall_clock64();
     uint32_t probe_staged = 0, probe_checked_at = 0xFFFFFFu, probe_batch = 0;
 #endif
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
@@ -655,7 +656,10 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     if (g_blend_probe && lane == 0)
         g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t | 0x40000000u, rg.y - rg.x,
                                                probe_staged | (checked ? 0x80000000u : 0u));
-    if (g_blend_probe && lane == 1) g_blend_probe[kProbeSecond + blockIdx.x] = make_uint4(probe_checked_at, 0, 0, 0);
+    if (g_blend_probe && lane == 1)
+        g_blend_probe[kProbeSecond + blockIdx.x] =
+            make_uint4(probe_checked_at, (uint32_t)wall_clock64(),
+                       (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16), probe_w0h);
 #endif
     float *o = out.ptr + (int64_t)(px - out.x0) * out.stride_x + (int64_t)(py - out.y0) * out.stride_y;
     o[0] = c0;
@@ -738,7 +742,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
     const uint32_t probe_w0 = (uint32_t)wall_clock64();
-    uint32_t probe_staged = 0, probe_checked_at = 0xFFFu, probe_after = 0;
+    uint32_t probe_staged = 0, probe_batches = 0, probe_after = 0;
 #endif
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     if ((span.axis ? ty : tx) < span.lo || (span.axis ? ty : tx) >= span.hi) return;      // another part's tile
@@ -809,7 +813,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         cost += nl + kBatchCost;
 #ifdef GSX_TEST_HOOKS
         probe_staged += nl;
-        if (checked && probe_checked_at == 0xFFFu) probe_checked_at = min(0xFFEu, (base - rg.x) >> 6);
+        probe_batches = min(0xFFFu, probe_batches + 1u);
         if (checked) probe_after += nl;           // (entries walked under the exact rule, whole batches)
 #endif
         __syncthreads();
@@ -951,7 +955,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // (where and when: HW_ID = register 4, XCC_ID = register 20; wall_clock64 ticks at 100 MHz on every XCD alike)
     if (g_blend_probe && lane == 1)
         g_blend_probe[kProbeSecond + blockIdx.x] =
-            make_uint4(probe_checked_at | (probe_after << 12), (uint32_t)wall_clock64(),
+            make_uint4(probe_batches | (probe_after << 12), (uint32_t)wall_clock64(),
                        (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16),
                        probe_w0);
 #endif

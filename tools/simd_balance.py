@@ -21,7 +21,7 @@ scene.render_image_hip(1, stats=st, timing=True)
 torch.cuda.synchronize()
 lib.gsx_debug_set_blend_probe(None)
 d = buf.cpu().numpy().view(np.uint32)
-first = np.nonzero(d[:, 2])[0]
+first = np.nonzero(d[:half, 2])[0]
 first = first[d[first, 1] < 0x40000000]                 # tile workgroups of the main kernel (not helpers)
 sec = d[half + first]
 start, end, hw, xcc = sec[:, 3].astype(np.int64), sec[:, 1].astype(np.int64), sec[:, 2] & 0xFFFF, sec[:, 2] >> 16

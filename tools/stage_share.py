@@ -31,5 +31,5 @@ print("list entries %.3g, walked %.3g (%.3f), of those under the exact rule (who
     length.sum(), walked.sum(), walked.sum() / length.sum(), after.sum(), 100 * after.sum() / walked.sum()))
 m = sat & (at < 0xFFF)
 if m.any():
-    print("tiles that saturate: first saturation seen at batch (median) %.0f of %.0f; their share of all walked entries %.1f %%" % (
+    print("tiles that saturate: batches staged (median) %.0f of %.0f; their share of all walked entries %.1f %%" % (
         np.median(at[m]), np.median(np.ceil(length[m] / 64)), 100 * walked[m].sum() / walked.sum()))
