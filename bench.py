@@ -32,6 +32,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -694,7 +695,9 @@ def main() -> None:
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+        # ("nccl" is RCCL on ROCm; a collective that never completes -- a rank that died, a transport that does not come
+        # up -- ends the run after three minutes instead of the default ten: the driver's clock is running)
+        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=180))
     if args.workload == "notebook":
         if world != 1:
             raise SystemExit("--workload notebook is the reference's single-GPU flow")
