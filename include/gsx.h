@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define GSX_VERSION 302 /* major*10000 + minor*100 + patch.  302: GsxParams.n_substrips .. substrip_events (appended;
+#define GSX_VERSION 303 /* major*10000 + minor*100 + patch.  303: gsx_default_params_sized (gsx_default_params is a macro over
+                         * it; the exported function of that name serves ABI 300 / 301 binaries), GSX_FLAG_SMALL_BATCH,
+                         * stage 1 in the operation order torch executes.  302: GsxParams.n_substrips .. substrip_events (appended;
                          * a struct_size of 104 -- or 0 -- still means the ABI-300 struct).  301: GsxParams.struct_size (in
                          * reserved0's place), a larger schedule region in gsx_hints_bytes.  300: GsxParams.kept_hint, GsxFrameStats.n_kept,
                            * tile_counts zeroed when nothing is rendered, tile_x1 == tile_x0 is an empty window,
@@ -125,11 +127,12 @@ typedef struct GsxParams {
      * `colors` argument is ignored and may be NULL. */
     const float *sh;
     int32_t sh_degree;
-    /* sizeof(GsxParams) as the CALLER compiled it; gsx_default_params() fills it in.  The fields below it were
-     * appended in ABI 300: a struct_size that ends before one of them makes the library ignore that field (a client
-     * built against an older header hands over a shorter struct -- whatever lies behind it is not read).  0 = not
-     * stated: the struct is taken to be the ABI-300 one, which ends behind `hints` (its callers zeroed this word).  Callers should also
-     * check gsx_version() == GSX_VERSION once: the version is bumped whenever a struct or a signature changes. */
+    /* sizeof(GsxParams) as the CALLER compiled it; gsx_default_params() -- a macro that passes that sizeof -- fills it
+     * in.  The fields below it were appended in ABI 300: a struct_size that ends before one of them makes the library
+     * ignore that field (a client built against an older header hands over a shorter struct -- whatever lies behind it
+     * is neither written by gsx_default_params nor read by any call).  0 = not stated: the struct is taken to be the
+     * ABI-300 one, which ends behind `hints` (its callers zeroed this word).  Callers should also check
+     * gsx_version() == GSX_VERSION once: the version is bumped whenever a struct or a signature changes. */
     int32_t struct_size;
     /* gsx_render_forward only.  How many Gaussians are expected to reach a tile of the window
      * (GsxFrameStats.n_kept of an earlier frame of this view and window); 0 (default) = unknown, assume all n.
@@ -213,6 +216,16 @@ typedef struct GsxParams {
  * there: use it.  Without the flag a frame given a hints buffer only fills it. */
 #define GSX_FLAG_HINTS_VALID 128
 
+/* gsx_render_forward / gsx_preprocess, GSX_SEM_REF_CPU and GSX_SEM_REF_CUDA.  The reference's J @ W
+ * (splat/utils.py:354) is one BLAS call over all its N_vis visible Gaussians, and the BLAS it runs on (MKL under
+ * torch) sums the three products of an output as a sequential FMA chain -- unless N_vis <= 3, when another of
+ * its kernels adds them as (k0 + k2) + k1 with nothing fused (oracle/probe_torch_order.py).  The library follows
+ * the first order, and the second whenever n <= 3.  A frame of MORE than three Gaussians of which at most three
+ * pass the cull (GsxFrameStats.n_visible <= 3 < n) cannot know that while it projects: a caller that wants the
+ * reference's bits there too issues the call again with this flag (the Python surface does), which selects the
+ * second order whatever n is.  The difference is at most one unit in the last place of the 2D covariance. */
+#define GSX_FLAG_SMALL_BATCH 256
+
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
 enum {
     GSX_STAGE_PROJECT = 0,    /* projection, depth keys, record packing         */
@@ -236,7 +249,13 @@ typedef struct GsxFrameStats {
 
 GSX_API int gsx_version(void);
 GSX_API const char *gsx_last_error(void);
+/* Fills the first `struct_size` bytes of *params -- sizeof(GsxParams) as the caller compiled it -- with the reference's
+ * behaviour and states that size in GsxParams.struct_size.  Nothing behind those bytes is touched. */
+GSX_API void gsx_default_params_sized(GsxParams *params, size_t struct_size);
+/* What callers write: the size is this header's.  (The exported FUNCTION of this name exists for binaries built
+ * against the ABI 300 / 301 headers, where the struct had 104 bytes: it fills those and states struct_size = 104.) */
 GSX_API void gsx_default_params(GsxParams *params);
+#define gsx_default_params(params) gsx_default_params_sized((params), sizeof(GsxParams))
 
 /*
  * Bytes of device workspace needed by any entry point below for up to `n` Gaussians, a

@@ -35,6 +35,7 @@ GSX_FLAG_NO_LONG_TILE_SPLIT = 16
 GSX_FLAG_TILE_SCHEDULE = 32
 GSX_FLAG_NO_TILE_SCHEDULE = 64
 GSX_FLAG_HINTS_VALID = 128
+GSX_FLAG_SMALL_BATCH = 256
 STAGE_NAMES = ("project", "depth_sort", "scan", "bin", "blend", "total")
 
 
@@ -65,7 +66,8 @@ _FP = c_void_p  # device float*
 SIGNATURES = {
     "gsx_version": (ctypes.c_int, []),
     "gsx_last_error": (ctypes.c_char_p, []),
-    "gsx_default_params": (None, [POINTER(GsxParams)]),
+    "gsx_default_params": (None, [POINTER(GsxParams)]),      # (the symbol of ABI 300 / 301 binaries: 104 bytes)
+    "gsx_default_params_sized": (None, [POINTER(GsxParams), c_size_t]),
     "gsx_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32, c_int64]),
     "gsx_hints_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "gsx_preprocess": (ctypes.c_int, [POINTER(GsxCamera)] + [_FP] * 5 + [c_int64] + [_FP] * 11 +
@@ -151,5 +153,5 @@ def check(code: int) -> None:
 
 def default_params() -> GsxParams:
     p = GsxParams()
-    load().gsx_default_params(ctypes.byref(p))
+    load().gsx_default_params_sized(ctypes.byref(p), ctypes.sizeof(GsxParams))
     return p

@@ -236,8 +236,14 @@ int gsx_version(void) { return GSX_VERSION; }
 
 const char *gsx_last_error(void) { return g_error; }
 
-void gsx_default_params(GsxParams *params) {
-    if (params) default_params(params);
+void gsx_default_params_sized(GsxParams *params, size_t struct_size) {
+    if (params) default_params(params, struct_size);
+}
+
+// the symbol binaries built against the ABI 300 / 301 headers call (there a plain function, the struct 104 bytes):
+// the name is parenthesised because this header makes it a macro
+void (gsx_default_params)(GsxParams *params) {
+    if (params) default_params(params, kParamsBytesAbi300);
 }
 
 size_t gsx_hints_bytes(int32_t width, int32_t height, int32_t tile) {
@@ -259,10 +265,10 @@ int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *s
                    float *max_x, float *min_y, float *max_y, float *sigmoid_opacity, int32_t *order,
                    int64_t *n_visible_host, const GsxParams *params, void *workspace, size_t workspace_bytes,
                    void *stream) {
-    (void)params;
     hipStream_t s = (hipStream_t)stream;
     if (!camera) return fail(GSX_ERR_INVALID_ARGUMENT, "camera is NULL");
     if (n < 0 || n >= (int64_t)1 << 31) return fail(GSX_ERR_INVALID_ARGUMENT, "n = %lld out of range", (long long)n);
+    const bool small_batch = params && (params->flags & GSX_FLAG_SMALL_BATCH) != 0;
     if (n_visible_host) *n_visible_host = 0;
     if (n == 0) return GSX_OK;
     if (!means3d || !scales || !quats || !opacity_logit || !colors) return fail(GSX_ERR_INVALID_ARGUMENT, "an input array is NULL");
@@ -286,7 +292,7 @@ int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *s
     // gathered the five input arrays by rank.
     gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
     gsx::Record *stage = (gsx::Record *)(ws + c.rec);
-    GSX_HIP(gsx::launch_project_stage(*camera, in, n, k0, stage, counters, s));
+    GSX_HIP(gsx::launch_project_stage(*camera, in, n, k0, stage, counters, small_batch, s));
     const gsx::DepthRoute route = gsx::depth_sort_route(n, 0);
     if (route != gsx::kDepthLsd)
         GSX_HIP(gsx::sort_depth_sampled(route, ws + c.temp, k0, k1, v0, v1, n, 0, counters + kCtrKept, counters + kCtrCulled,
@@ -386,7 +392,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
             fh.sched = sched_hint.sched;
         }
     }
-    GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, p.sh_degree, k0, (gsx::Record *)(ws + c.rec),
+    GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, p.small_batch, p.sh_degree, k0, (gsx::Record *)(ws + c.rec),
                                      (gsx::TileRect *)(ws + c.rect), counters,
                                      p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, sched_hint, s));
     tm.mark();  // 1: project (+ depth keys)

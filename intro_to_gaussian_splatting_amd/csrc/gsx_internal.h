@@ -93,8 +93,9 @@ struct ScheduleHint {
 // ---- gsx_project.hip (compiled with -ffp-contract=off)
 // gsx_preprocess, first kernel: depth keys in original order (kCulledKey behind the cull plane), the 11 floats of
 // every visible Gaussian that the rank-ordered output kernel gathers (in its record slot), the sort's counters zeroed.
+// small_batch: GSX_FLAG_SMALL_BATCH (J @ W in the order the reference's BLAS uses for at most three rows; n <= 3 implies it).
 hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int64_t n, uint32_t *keys, Record *stage,
-                                uint32_t *counters, hipStream_t s);
+                                uint32_t *counters, bool small_batch, hipStream_t s);
 // Original order: depth keys (kCulledKey behind the cull plane, kEmptyKey when no tile of the window is
 // reached), records / rects indexed by the ORIGINAL Gaussian index (only written for the Gaussians that
 // reach a tile; the depth sort generates the identity values itself).
@@ -105,9 +106,9 @@ hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int
 // sh_degree >= 0: in.colors holds spherical-harmonics coefficients, evaluated inline (GsxParams.sh).
 // counters: 4 words this kernel zeroes for the depth sort (culled count, kept count, ...).
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
-                               const TileGrid &grid, int semantics, bool tight_rects, int sh_degree, uint32_t *keys,
-                               Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, const ScheduleHint &sched,
-                               hipStream_t s);
+                               const TileGrid &grid, int semantics, bool tight_rects, bool small_batch, int sh_degree,
+                               uint32_t *keys, Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox,
+                               const ScheduleHint &sched, hipStream_t s);
 // gsx_preprocess, last kernel: all PreprocessedScene fields in depth order; order[r] = Gaussian of rank r, r < *m_dev.
 hipError_t launch_project_full(const Record *stage, const uint32_t *order, const uint32_t *m_dev, int64_t n,
                                const StageOneOut &out, hipStream_t s);

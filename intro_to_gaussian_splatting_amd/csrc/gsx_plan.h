@@ -157,13 +157,20 @@ constexpr size_t kAlign = 256;
 constexpr int64_t kMaxPairs = ((int64_t)1 << 31) - 1;
 inline size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 
-inline void default_params(GsxParams *params) {
-    memset(params, 0, sizeof *params);
-    params->struct_size = (int32_t)sizeof *params;
-    params->semantics = GSX_SEM_REF_CPU;
-    params->layout = GSX_LAYOUT_WH3;
-    params->tile_x1 = -1;
-    params->tile_y1 = -1;
+// Fills the first `bytes` bytes of a caller's GsxParams (what ITS header says the struct has; never more than this
+// library's own struct, never less than the ABI-300 one) and states that size in struct_size: nothing behind the
+// caller's struct is written here or read later (make_plan).
+inline void default_params(GsxParams *params, size_t bytes = sizeof(GsxParams)) {
+    if (bytes > sizeof(GsxParams)) bytes = sizeof(GsxParams);
+    if (bytes < kParamsBytesAbi300) bytes = kParamsBytesAbi300;
+    GsxParams d;
+    memset(&d, 0, sizeof d);
+    d.struct_size = (int32_t)bytes;
+    d.semantics = GSX_SEM_REF_CPU;
+    d.layout = GSX_LAYOUT_WH3;
+    d.tile_x1 = -1;
+    d.tile_y1 = -1;
+    memcpy(params, &d, bytes);
 }
 
 // Number of tiles along an axis.  REF_CPU iterates range(0, extent - tile, tile)
@@ -249,6 +256,7 @@ struct Plan {
     bool generic;  // GSX_FLAG_GENERIC_KERNELS
     bool tight;    // GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS
     bool split;    // long tiles on four waves (not GSX_FLAG_NO_LONG_TILE_SPLIT)
+    bool small_batch;   // GSX_FLAG_SMALL_BATCH
     int schedule;  // tiles handed out by list length: 1 GSX_FLAG_TILE_SCHEDULE, 0 GSX_FLAG_NO_TILE_SCHEDULE, -1 by size
     const GsxCamera *camera_device;
     uint32_t *tile_counts;
@@ -307,6 +315,7 @@ inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_ima
     p.generic = (d.flags & GSX_FLAG_GENERIC_KERNELS) != 0;
     p.tight = d.semantics == GSX_SEM_STD_3DGS && (d.flags & GSX_FLAG_PUBLISHED_RECTS) == 0;
     p.split = (d.flags & GSX_FLAG_NO_LONG_TILE_SPLIT) == 0;
+    p.small_batch = (d.flags & GSX_FLAG_SMALL_BATCH) != 0;
     p.schedule = (d.flags & GSX_FLAG_NO_TILE_SCHEDULE) ? 0 : ((d.flags & GSX_FLAG_TILE_SCHEDULE) ? 1 : -1);
     TileGrid &g = p.grid;
     g.tile = tile;

@@ -1,10 +1,13 @@
 // Stage 1 on gfx950: 3D -> 2D EWA projection, conic, extent, bounding box, tile rectangle.
 //
 // THIS TRANSLATION UNIT IS COMPILED WITH -ffp-contract=off.  The float32 operation order below
-// is the contract shared with the CPU restatement used by the parity tests: with no FMA
-// formed and correctly rounded divide/sqrt (hipcc's default for HIP), view depth, radius and
-// bounding box -- the quantities whose rounding decides sort order and tile membership -- come
-// out bit-identical on both sides.
+// is what torch executes for the reference's expressions (oracle/probe_torch_order.py): the
+// products torch folds into one sgemm -- [p,1] @ M and (N,3,3) @ (3,3) -- are sequential FMA
+// chains, spelled as explicit fmaf here; batched 3x3 products round every product and sum.  With
+// no other FMA formed and correctly rounded divide/sqrt, view depth, radius and bounding box --
+// the quantities whose rounding decides sort order and tile membership -- come out bit-identical
+// to the reference's (0 differing bits at N = 1e5 and 1e6, tests/golden/stage1_*) and to the CPU
+// restatement's.
 //
 // Reference behaviour restated here (paths relative to the reference repository):
 //   splat/gaussian_scene.py:70-144  preprocess
@@ -34,9 +37,13 @@ struct Projected {
     float min_x, max_x, min_y, max_y;
 };
 
-// Column `col` of [p,1] @ M, accumulated left to right.
+// Column `col` of [p,1] @ M as torch's (N,4) @ (4,4) executes it: one sgemm, a sequential FMA chain over k
+// (gaussian_scene.py:79-90, utils.py:305-307, 333); the last step fma(1, M3, acc) is a plain add.
 __device__ __forceinline__ float row4(float p0, float p1, float p2, const float *M, int col) {
-    return ((p0 * M[0 + col] + p1 * M[4 + col]) + p2 * M[8 + col]) + M[12 + col];
+    float acc = p0 * M[0 + col];
+    acc = fmaf(p1, M[4 + col], acc);
+    acc = fmaf(p2, M[8 + col], acc);
+    return acc + M[12 + col];
 }
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -79,9 +86,13 @@ __device__ __forceinline__ void covariance3d(float s0, float s1, float s2, float
 
 // EWA 2D covariance ((((J W) Sigma) W^T) J^T)[:2,:2], left to right (splat/utils.py:320-354), with
 // the view-space point clamped to 1.3 tan(fov/2).  Rows 2 of J (all zero) and the structural
-// zeros J01, J10 are skipped: adding an exact zero does not change a float32 sum.
+// zeros J01, J10 are skipped: adding an exact zero -- or fusing a product with one -- does not change a float32
+// sum.  J @ W and ... @ W^T multiply the whole batch by ONE 3x3: torch folds each into an sgemm (sequential FMA
+// over k); the two products between batched matrices round every product and sum.
+// small_batch: the reference multiplied at most three J's at once (N_vis <= 3), which MKL evaluates as
+// (k0 + k2) + k1 with nothing fused (oracle/probe_torch_order.py).
 __device__ __forceinline__ void ewa_covariance(const GsxCamera &cam, float fx, float fy, float p0, float p1, float p2,
-                                               float tz, const float (&S)[3][3], Projected &o) {
+                                               float tz, const float (&S)[3][3], Projected &o, bool small_batch) {
     const float *V = cam.world2view;
     float tx = row4(p0, p1, p2, V, 0), ty = row4(p0, p1, p2, V, 1);
     float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
@@ -95,8 +106,8 @@ __device__ __forceinline__ void ewa_covariance(const GsxCamera &cam, float fx, f
     float A[2][3], B[2][3], C[2][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        A[0][j] = j00 * V[j * 4 + 0] + j02 * V[j * 4 + 2];
-        A[1][j] = j11 * V[j * 4 + 1] + j12 * V[j * 4 + 2];
+        A[0][j] = small_batch ? j00 * V[j * 4 + 0] + j02 * V[j * 4 + 2] : fmaf(j02, V[j * 4 + 2], j00 * V[j * 4 + 0]);
+        A[1][j] = small_batch ? j12 * V[j * 4 + 2] + j11 * V[j * 4 + 1] : fmaf(j12, V[j * 4 + 2], j11 * V[j * 4 + 1]);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -105,7 +116,7 @@ __device__ __forceinline__ void ewa_covariance(const GsxCamera &cam, float fx, f
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) C[i][j] = (B[i][0] * V[0 * 4 + j] + B[i][1] * V[1 * 4 + j]) + B[i][2] * V[2 * 4 + j];
+        for (int j = 0; j < 3; ++j) C[i][j] = fmaf(B[i][2], V[2 * 4 + j], fmaf(B[i][1], V[1 * 4 + j], B[i][0] * V[0 * 4 + j]));
     o.ca = C[0][0] * j00 + C[0][2] * j02;
     o.cb = C[0][1] * j11 + C[0][2] * j12;
     o.cc = C[1][0] * j00 + C[1][2] * j02;
@@ -139,7 +150,7 @@ __device__ __forceinline__ void finish_projection(float tz, Projected &o) {
 // Everything of stage 1 for one visible Gaussian.
 __device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1, float p2, float tz,
                                         float s0, float s1, float s2, float qw, float qx, float qy, float qz,
-                                        Projected &o) {
+                                        Projected &o, bool small_batch) {
     const float *F = cam.full_proj;
     float S[3][3];
     covariance3d(s0, s1, s2, qw, qx, qy, qz, S);
@@ -151,7 +162,7 @@ __device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1
     o.x = (ndcx + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
     o.y = (ndcy + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
 
-    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o);
+    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o, small_batch);
     finish_projection(tz, o);
 }
 
@@ -168,7 +179,7 @@ __device__ __forceinline__ bool project_std(const GsxCamera &cam, float p0, floa
     o.x = ((ndcx + 1.0f) * (float)cam.width - 1.0f) * 0.5f;
     o.y = ((ndcy + 1.0f) * (float)cam.height - 1.0f) * 0.5f;
     float fx = (float)cam.width / (2.0f * cam.tan_fovx), fy = (float)cam.height / (2.0f * cam.tan_fovy);
-    ewa_covariance(cam, fx, fy, p0, p1, p2, tz, S, o);
+    ewa_covariance(cam, fx, fy, p0, p1, p2, tz, S, o, false);
     o.ca = o.ca + 0.3f;
     o.cd = o.cd + 0.3f;
     o.cc = o.cb;
@@ -298,7 +309,7 @@ __device__ __forceinline__ uint32_t tile_rect(float mnx, float mxx, float mny, f
 // 64-byte sectors per Gaussian -- took 124 us at 1M.)  Also zeroes the sort's device counters (no memset node).
 __global__ void __launch_bounds__(kBlock)
     project_stage_kernel(GsxCamera cam, GaussiansIn in, int64_t n, uint32_t *__restrict__ keys, Record *__restrict__ stage,
-                         uint32_t *__restrict__ counters) {
+                         uint32_t *__restrict__ counters, bool small_batch) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < 4) counters[i] = 0u;
     if (i >= n) return;
@@ -312,7 +323,7 @@ __global__ void __launch_bounds__(kBlock)
     keys[i] = __float_as_uint(tz);
     const float *s = in.scales + 3 * i, *q = in.quats + 4 * i, *c = in.colors + 3 * i;
     Projected o;
-    project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o);
+    project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o, small_batch);
     Record r;
     r.a = make_float4(o.x, o.y, c[0], c[1]);
     r.b = make_float4(c[2], tz, sigmoidf(in.opacity_logit[i]), o.ca);
@@ -378,7 +389,7 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
 template <bool DEVICE_CAMERA, int SHDEG, bool WINDOWED>
 __global__ void __launch_bounds__(kBlock)
     project_pack_kernel(GsxCamera cam_arg, const GsxCamera *__restrict__ cam_dev, GaussiansIn in, int64_t n,
-                        TileGrid grid, int semantics, bool tight,
+                        TileGrid grid, int semantics, bool tight, bool small_batch,
                         uint32_t *__restrict__ keys, Record *__restrict__ rec,
                         TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox,
                         bool sh_vec, SchedJob sched_job) {
@@ -509,7 +520,7 @@ __global__ void __launch_bounds__(kBlock)
     if (std3dgs)
         keep = project_std(cam, p0, p1, p2, tz, s0, s1, s2, q[0], q[1], q[2], q[3], o);
     else
-        project(cam, p0, p1, p2, tz, s0, s1, s2, q[0], q[1], q[2], q[3], o);
+        project(cam, p0, p1, p2, tz, s0, s1, s2, q[0], q[1], q[2], q[3], o, small_batch);
     TileRect tr;
     uint32_t cnt = std3dgs ? tile_rect(o.x, o.radius, o.y, o.radius, grid, semantics, tr)
                            : tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, semantics, tr);
@@ -648,7 +659,7 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
         for (int b = 0; b < 3; ++b) S[a][b] = cov3d[9 * i + 3 * a + b];
     Projected o;
-    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o);
+    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o, n <= 3);
     out[4 * i] = o.ca; out[4 * i + 1] = o.cb; out[4 * i + 2] = o.cc; out[4 * i + 3] = o.cd;
 }
 
@@ -670,16 +681,17 @@ hipError_t launch_covariance3d(const float *scales, const float *quats, int64_t 
 }
 
 hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int64_t n, uint32_t *keys, Record *stage,
-                                uint32_t *counters, hipStream_t s) {
+                                uint32_t *counters, bool small_batch, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    project_stage_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, n, keys, stage, counters);
+    project_stage_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, n, keys, stage, counters, small_batch || n <= 3);
     return hipGetLastError();
 }
 
 template <int SHDEG>
 static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
-                                    const TileGrid &grid, int semantics, bool tight_rects, uint32_t *keys, Record *rec,
-                                    TileRect *rect, uint32_t *counters, float4 *bbox, const ScheduleHint &sh, hipStream_t s) {
+                                    const TileGrid &grid, int semantics, bool tight_rects, bool small_batch, uint32_t *keys,
+                                    Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, const ScheduleHint &sh,
+                                    hipStream_t s) {
     const SchedJob job{sh.lens, sh.sched, sh.header, sh.ntiles, sh.nwy, sched_cap(sh.ntiles, sh.nwy)};
     const unsigned spare = sh.sched ? kSchedXcds : 0u;
     const bool vec = (reinterpret_cast<uintptr_t>(in.colors) & 15u) == 0;
@@ -687,7 +699,7 @@ static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_d
     const bool windowed = grid.wx0 > 0 || grid.wy0 > 0 || grid.wx1 < grid.ntx || grid.wy1 < grid.nty;
 #define GSX_LAUNCH_PP(DC, WIN)                                                                                          \
     project_pack_kernel<DC, SHDEG, WIN><<<blocks_for(n) + spare, kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics, \
-                                                                         tight_rects, keys, rec, rect, counters, bbox, vec, job)
+                                                                         tight_rects, small_batch || n <= 3, keys, rec, rect, counters, bbox, vec, job)
     if (cam_device) {
         if (windowed) GSX_LAUNCH_PP(true, true); else GSX_LAUNCH_PP(true, false);
     } else {
@@ -698,16 +710,16 @@ static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_d
 
 // sh_degree < 0: in.colors is (n,3) RGB; 0..3: in.colors is (n, (degree+1)^2, 3) spherical harmonics.
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
-                               const TileGrid &grid, int semantics, bool tight_rects, int sh_degree, uint32_t *keys,
-                               Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, const ScheduleHint &sched,
-                               hipStream_t s) {
+                               const TileGrid &grid, int semantics, bool tight_rects, bool small_batch, int sh_degree,
+                               uint32_t *keys, Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox,
+                               const ScheduleHint &sched, hipStream_t s) {
     if (n == 0) return hipSuccess;
     switch (sh_degree) {
-        case 0: launch_project_pack_deg<0>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, sched, s); break;
-        case 1: launch_project_pack_deg<1>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, sched, s); break;
-        case 2: launch_project_pack_deg<2>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, sched, s); break;
-        case 3: launch_project_pack_deg<3>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, sched, s); break;
-        default: launch_project_pack_deg<-1>(cam, cam_device, in, n, grid, semantics, tight_rects, keys, rec, rect, counters, bbox, sched, s); break;
+        case 0: launch_project_pack_deg<0>(cam, cam_device, in, n, grid, semantics, tight_rects, small_batch, keys, rec, rect, counters, bbox, sched, s); break;
+        case 1: launch_project_pack_deg<1>(cam, cam_device, in, n, grid, semantics, tight_rects, small_batch, keys, rec, rect, counters, bbox, sched, s); break;
+        case 2: launch_project_pack_deg<2>(cam, cam_device, in, n, grid, semantics, tight_rects, small_batch, keys, rec, rect, counters, bbox, sched, s); break;
+        case 3: launch_project_pack_deg<3>(cam, cam_device, in, n, grid, semantics, tight_rects, small_batch, keys, rec, rect, counters, bbox, sched, s); break;
+        default: launch_project_pack_deg<-1>(cam, cam_device, in, n, grid, semantics, tight_rects, small_batch, keys, rec, rect, counters, bbox, sched, s); break;
     }
     return hipGetLastError();
 }

@@ -295,12 +295,20 @@ class GaussianScene:
         mnx, mxx, mny, mxy, sop = f(n), f(n), f(n), f(n), f(n, 1)
         order = f(n).view(torch.int32)
         nvis = ctypes.c_int64(0)
+        params = _ffi.default_params()
         with torch.cuda.device(dev):
             nbytes = lib.gsx_workspace_bytes(n, cam.width, cam.height, 16, 1)
             ws = _WORKSPACE.get(dev, nbytes)
-            rc = lib.gsx_preprocess(ctypes.byref(cam), *[_ptr(t) for t in tensors], n,
-                                    *[_ptr(t) for t in (xy, col, c2, dep, inv, rad, mnx, mxx, mny, mxy, sop)],
-                                    _ptr(order), ctypes.byref(nvis), None, _ptr(ws), ws.numel(), _stream_handle(dev))
+            for _ in range(2):
+                rc = lib.gsx_preprocess(ctypes.byref(cam), *[_ptr(t) for t in tensors], n,
+                                        *[_ptr(t) for t in (xy, col, c2, dep, inv, rad, mnx, mxx, mny, mxy, sop)],
+                                        _ptr(order), ctypes.byref(nvis), ctypes.byref(params), _ptr(ws), ws.numel(),
+                                        _stream_handle(dev))
+                # at most three of more than three Gaussians pass the cull: the reference's BLAS then sums J @ W in
+                # another order (GSX_FLAG_SMALL_BATCH, include/gsx.h) -- once more, in that order
+                if rc != _ffi.GSX_OK or not (nvis.value <= 3 < n) or params.flags & _ffi.GSX_FLAG_SMALL_BATCH:
+                    break
+                params.flags |= _ffi.GSX_FLAG_SMALL_BATCH
         _ffi.check(rc)
         m = nvis.value
         self.last_order = order[:m]
@@ -484,6 +492,12 @@ class GaussianScene:
                 rc = lib.gsx_render_forward(ctypes.byref(cam), *[_ptr(t) for t in tensors], n, tile_size, _ptr(out),
                                             ctypes.byref(params), st_ref, _ptr(ws), nbytes,
                                             _stream_handle(dev))
+                if rc == _ffi.GSX_OK and not speculative and not own and semantics != "std_3dgs" and \
+                        int(st.n_visible) <= 3 < n and not params.flags & _ffi.GSX_FLAG_SMALL_BATCH:
+                    # at most three of more than three Gaussians pass the cull: the reference's BLAS then sums J @ W in
+                    # another order (GSX_FLAG_SMALL_BATCH, include/gsx.h) -- once more, in that order
+                    params.flags |= _ffi.GSX_FLAG_SMALL_BATCH
+                    continue
                 if rc != _ffi.GSX_ERR_WORKSPACE_TOO_SMALL or "cap" in own:
                     break
                 cap = int(st.n_instances * 1.25) + 4096

@@ -11,9 +11,13 @@ Parity status: PINNED.  ``oracle/capture_golden.py`` imports the reference itsel
 ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this restatement against them.
 
 Every function cites the reference lines it restates (paths relative to /root/reference).
-All arithmetic is float32 with an explicit left-to-right operation order and no fused
-multiply-add; the C restatement (``oracle/raster_cpu.c``) and the HIP projection kernel use
-this same order so that depths, radii and bounding boxes are bit-identical between them.
+All arithmetic is float32 in the operation order torch EXECUTES for the reference's
+expressions (``oracle/probe_torch_order.py``): the products torch folds into one sgemm --
+``[p,1] @ M``, ``(N,3,3) @ (3,3)``, ``(1,2) @ (2,2)`` -- are sequential fused multiply-add chains
+(``fma`` below, exact), batched 3x3 products and the final dot of the weight round every product
+and sum.  The C restatement (``oracle/raster_cpu.c``) and the HIP projection kernel use this same
+order, so that depths, radii and bounding boxes are bit-identical between the three and with the
+reference (tests/test_oracle_golden.py: 0 differing bits at N = 1e5 and 1e6).
 """
 from __future__ import annotations
 
@@ -64,6 +68,22 @@ class Preprocessed(NamedTuple):
     max_y: np.ndarray
     sigmoid_opacity: np.ndarray         # (Nv,1)
     order: np.ndarray                   # (Nv,) original Gaussian index of each sorted row
+
+
+def fma(a, b, c) -> np.ndarray:
+    """float32 fused multiply-add, correctly rounded: the product of two float32 is exact in float64; the
+    float64 sum is rounded to odd (TwoSum tells which way the exact sum lies), which makes the final
+    rounding to float32 immune to double rounding (53 >= 2 * 24 + 2)."""
+    p = np.asarray(a, np.float32).astype(np.float64) * np.asarray(b, np.float32).astype(np.float64)
+    c = np.broadcast_to(np.asarray(c, np.float32).astype(np.float64), p.shape)
+    s = p + c
+    t = s - p
+    e = (p - (s - t)) + (c - t)
+    bits = np.array(s, dtype=np.float64, copy=True).view(np.int64)
+    fix = (e != 0.0) & ((bits & 1) == 0) & np.isfinite(s)
+    step = np.where((e > 0.0) == (s > 0.0), 1, -1)
+    bits += np.where(fix, step, 0)
+    return bits.view(np.float64).astype(np.float32)
 
 
 # --------------------------------------------------------------------------- camera
@@ -138,8 +158,12 @@ def build_camera(qvec, tvec, fx, fy, width: int, height: int) -> Camera:
 # --------------------------------------------------------------------------- stage 1
 
 def _row4(p: np.ndarray, M: np.ndarray, col: int) -> np.ndarray:
-    """Column ``col`` of ``[p,1] @ M`` with left-to-right accumulation."""
-    return ((p[:, 0] * M[0, col] + p[:, 1] * M[1, col]) + p[:, 2] * M[2, col]) + M[3, col]
+    """Column ``col`` of ``[p,1] @ M`` as torch's (N,4) @ (4,4) executes it: a sequential FMA chain
+    (splat/gaussian_scene.py:79-90, splat/utils.py:305-307, 333)."""
+    acc = p[:, 0] * M[0, col]
+    acc = fma(p[:, 1], M[1, col], acc)
+    acc = fma(p[:, 2], M[2, col], acc)
+    return acc + M[3, col]
 
 
 def covariance_3d(scales: np.ndarray, quats: np.ndarray) -> np.ndarray:
@@ -158,9 +182,7 @@ def covariance_3d(scales: np.ndarray, quats: np.ndarray) -> np.ndarray:
 
 
 def _mm3(A: np.ndarray, B: np.ndarray) -> np.ndarray:
-    """Batched 3x3 product, each entry accumulated k=0,1,2 left to right."""
-    if B.ndim == 2:
-        B = np.broadcast_to(B, A.shape)
+    """Batched (N,3,3) @ (N,3,3): each entry accumulated k=0,1,2 left to right, every product and sum rounded."""
     C = np.empty_like(A)
     for i in range(3):
         for j in range(3):
@@ -168,8 +190,22 @@ def _mm3(A: np.ndarray, B: np.ndarray) -> np.ndarray:
     return C
 
 
+def _mm3_single(A: np.ndarray, B: np.ndarray, small: bool = False) -> np.ndarray:
+    """(N,3,3) @ one (3,3): torch folds it into a (3N,3) @ (3,3) sgemm, a sequential FMA chain over k.
+    ``small``: J @ W with N <= 3 goes to another MKL kernel, (k0 + k2) + k1 with nothing fused."""
+    C = np.empty_like(A)
+    for i in range(3):
+        for j in range(3):
+            if small:
+                C[:, i, j] = (A[:, i, 0] * B[0, j] + A[:, i, 2] * B[2, j]) + A[:, i, 1] * B[1, j]
+            else:
+                C[:, i, j] = fma(A[:, i, 2], B[2, j], fma(A[:, i, 1], B[1, j], A[:, i, 0] * B[0, j]))
+    return C
+
+
 def covariance_2d(points: np.ndarray, cov3d: np.ndarray, cam: Camera) -> np.ndarray:
-    """EWA projection of Sigma.  splat/utils.py:320-354."""
+    """EWA projection of Sigma.  splat/utils.py:320-354.  The rows given are the batch the reference
+    multiplies at once (its N_vis), which selects the kernel of ``J @ W`` (see ``_mm3_single``)."""
     V = cam.world2view
     tx, ty, tz = _row4(points, V, 0), _row4(points, V, 1), _row4(points, V, 2)
     limx = FOV_CLAMP * cam.tan_fovx
@@ -183,9 +219,9 @@ def covariance_2d(points: np.ndarray, cov3d: np.ndarray, cam: Camera) -> np.ndar
     J[:, 1, 1] = cam.fy / tz
     J[:, 1, 2] = -(cam.fy * y) / (tz * tz)
     Wm = np.ascontiguousarray(V[:3, :3].T)
-    A = _mm3(J, Wm)
+    A = _mm3_single(J, Wm, small=n <= 3)
     B = _mm3(A, cov3d)
-    C = _mm3(B, np.ascontiguousarray(Wm.T))
+    C = _mm3_single(B, np.ascontiguousarray(Wm.T))
     D = _mm3(C, np.ascontiguousarray(np.transpose(J, (0, 2, 1))))
     return np.ascontiguousarray(D[:, :2, :2])
 
@@ -294,8 +330,9 @@ def render_pixel_scalar(px: int, py: int, means, colors, sig_op, inv) -> np.ndar
     for k in range(means.shape[0]):
         d0 = half * (means[k, 0] - fx_)
         d1 = half * (means[k, 1] - fy_)
-        t0 = f32(d0 * inv[k, 0, 0] + d1 * inv[k, 1, 0])
-        t1 = f32(d0 * inv[k, 0, 1] + d1 * inv[k, 1, 1])
+        # (1,2) @ (2,2) is an sgemm: one FMA per output; the (1,2) @ (2,1) after it rounds both products
+        t0 = f32(fma(d1, inv[k, 1, 0], d0 * inv[k, 0, 0]))
+        t1 = f32(fma(d1, inv[k, 1, 1], d0 * inv[k, 0, 1]))
         e0 = means[k, 0] - fx_
         e1 = means[k, 1] - fy_
         power = f32(t0 * e0 + t1 * e1)
@@ -326,8 +363,8 @@ def render_tile_vector(x0: int, y0: int, tile: int, means, colors, sig_op, inv) 
         e1 = means[k, 1] - PY
         d0 = half * e0
         d1 = half * e1
-        t0 = d0 * inv[k, 0, 0] + d1 * inv[k, 1, 0]
-        t1 = d0 * inv[k, 0, 1] + d1 * inv[k, 1, 1]
+        t0 = fma(d1, inv[k, 1, 0], d0 * inv[k, 0, 0])
+        t1 = fma(d1, inv[k, 1, 1], d0 * inv[k, 0, 1])
         w = np.exp(t0 * e0 + t1 * e1)
         alpha = w * o2[k]
         test = T * (f32(1.0) - alpha)

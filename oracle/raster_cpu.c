@@ -8,9 +8,17 @@
  * Parity status: PINNED through tests/test_oracle_golden.py (golden vectors produced by the
  * reference itself, oracle/capture_golden.py).
  *
- * Same arithmetic, same explicit left-to-right operation order as oracle/cpu_ref.py and as the
- * HIP projection kernel; compile with -ffp-contract=off (see Makefile) so no FMA is formed and
- * depths / radii / bounding boxes are bit-identical across the three.
+ * Same arithmetic, same explicit operation order as oracle/cpu_ref.py and as the HIP projection
+ * kernel; compile with -ffp-contract=off (see Makefile) so that ONLY the fmaf calls written here
+ * fuse and depths / radii / bounding boxes are bit-identical across the three.
+ *
+ * Which products fuse is what torch EXECUTES for the reference's expressions, determined by
+ * oracle/probe_torch_order.py (torch 2.10 + MKL, any N >= 4, 1 or 8 threads):
+ *   (N,4) @ (4,4) and (N,3,3) @ (3,3)   folded into one sgemm: a sequential FMA chain over k
+ *   (N,3,3) @ (N,3,3) (batched)         ATen's own loop: products and sums rounded one by one
+ *   (1,2) @ (2,2) then (1,2) @ (2,1)    the first fuses (sgemm), the second does not (dot)
+ *   N <= 3 rows of J @ W                another MKL kernel: (k0 + k2) + k1, nothing fused
+ * and pinned against the reference itself at N = 1e5 and 1e6 (tests/test_oracle_golden.py).
  *
  * Reference lines restated (paths relative to /root/reference):
  *   orc_preprocess   splat/gaussian_scene.py:70-144, splat/gaussians.py:54-69,
@@ -31,20 +39,42 @@ typedef struct {
     int32_t width, height;
 } OrcCamera;
 
+/* column `col` of [p,1] @ M: what torch's (N,4) @ (4,4) executes (gaussian_scene.py:79-90, utils.py:305-307, 333) */
 static inline float row4(const float *p, const float *M, int col) {
-    return ((p[0] * M[0 * 4 + col] + p[1] * M[1 * 4 + col]) + p[2] * M[2 * 4 + col]) + M[3 * 4 + col];
+    float acc = p[0] * M[0 * 4 + col];
+    acc = fmaf(p[1], M[1 * 4 + col], acc);
+    acc = fmaf(p[2], M[2 * 4 + col], acc);
+    return acc + M[3 * 4 + col];                       /* fma(1, M3, acc) */
 }
 
+/* batched (N,3,3) @ (N,3,3): every product and sum rounded on its own */
 static void mm3(const float *A, const float *B, float *C) {
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j)
             C[i * 3 + j] = (A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j]) + A[i * 3 + 2] * B[2 * 3 + j];
 }
 
+/* (N,3,3) @ one (3,3): torch folds it into a (3N,3) @ (3,3) sgemm, a sequential FMA chain over k */
+static void mm3_fma(const float *A, const float *B, float *C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            C[i * 3 + j] = fmaf(A[i * 3 + 2], B[2 * 3 + j], fmaf(A[i * 3 + 1], B[1 * 3 + j], A[i * 3 + 0] * B[0 * 3 + j]));
+}
+
+/* ... except J @ W (W a transposed view) with at most 3 matrices in the batch, which MKL evaluates as
+ * (k0 + k2) + k1 with nothing fused (probe_torch_order.py, "small batch") */
+static void mm3_small(const float *A, const float *B, float *C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            C[i * 3 + j] = (A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 2] * B[2 * 3 + j]) + A[i * 3 + 1] * B[1 * 3 + j];
+}
+
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-/* (((J W) Sigma) W^T) J^T with the view-space point clamped to 1.3 tan(fov/2) (utils.py:320-354) */
-static void ewa2d(const OrcCamera *cam, float fx, float fy, const float *p, float tz, const float *S, float *D) {
+/* (((J W) Sigma) W^T) J^T with the view-space point clamped to 1.3 tan(fov/2) (utils.py:320-354).
+ * batch = number of rows the reference multiplies at once (its N_vis): selects MKL's kernel for J @ W. */
+static void ewa2d(const OrcCamera *cam, float fx, float fy, const float *p, float tz, const float *S, float *D,
+                  int64_t batch) {
     const float *V = cam->V;
     float tx = row4(p, V, 0), ty = row4(p, V, 1);
     float limx = 1.3f * cam->tan_fovx, limy = 1.3f * cam->tan_fovy;
@@ -61,11 +91,12 @@ static void ewa2d(const OrcCamera *cam, float fx, float fy, const float *p, floa
             Wt[i * 3 + j] = V[i * 4 + j];
             Jt[i * 3 + j] = J[j * 3 + i];
         }
-    mm3(J, Wm, A); mm3(A, S, B); mm3(B, Wt, C); mm3(C, Jt, D);
+    if (batch <= 3) mm3_small(J, Wm, A); else mm3_fma(J, Wm, A);
+    mm3(A, S, B); mm3_fma(B, Wt, C); mm3(C, Jt, D);
 }
 
 /* One Gaussian of stage 1.  Returns 0 when culled (z_view < 0.2). */
-static int project_one(const OrcCamera *cam, const float *p, const float *s, const float *q,
+static int project_one(const OrcCamera *cam, const float *p, const float *s, const float *q, int64_t batch,
                        float *xy, float *c2, float *depth, float *inv, float *radius, float *bbox) {
     const float *V = cam->V, *F = cam->F;
     float tz = row4(p, V, 2);
@@ -101,7 +132,7 @@ static int project_one(const OrcCamera *cam, const float *p, const float *s, con
 
     /* EWA 2D covariance (utils.py:320-354) */
     float D[9];
-    ewa2d(cam, cam->fx, cam->fy, p, tz, S, D);
+    ewa2d(cam, cam->fx, cam->fy, p, tz, S, D, batch);
     float ca = D[0], cb = D[1], cc = D[3], cd = D[4];
 
     /* inverse (utils.py:368-393) */
@@ -158,10 +189,11 @@ int orc_preprocess(const OrcCamera *cam, const float *points, const float *color
     float *t_r = malloc(cap * 4), *t_bb = malloc(cap * 4 * 4);
     uint32_t *key = malloc(cap * 4);
     int64_t *val = malloc(cap * 8);
-    int64_t m = 0;
+    int64_t m = 0, batch = 0;
+    for (int64_t i = 0; i < n; ++i) batch += row4(points + 3 * i, cam->V, 2) >= 0.2f;   /* the reference's N_vis */
     for (int64_t i = 0; i < n; ++i) {
         float d;
-        if (project_one(cam, points + 3 * i, scales + 3 * i, quats + 4 * i, t_xy + 2 * m, t_c2 + 4 * m, &d,
+        if (project_one(cam, points + 3 * i, scales + 3 * i, quats + 4 * i, batch, t_xy + 2 * m, t_c2 + 4 * m, &d,
                         t_inv + 4 * m, t_r + m, t_bb + 4 * m)) {
             memcpy(&key[m], &d, 4);       /* d >= 0.2 > 0: IEEE bits are monotone in d */
             val[m] = m;                   /* position in the compacted arrays */
@@ -256,9 +288,11 @@ static void render_one_tile(RenderJob *jb, int tix, int tiy) {
                 int32_t g = items[k];
                 const float *Q = inv + 4 * (int64_t)g;
                 float e0 = means[2 * (int64_t)g] - fx_, e1 = means[2 * (int64_t)g + 1] - fy_;
-                float d0 = -0.5f * e0, d1 = -0.5f * e1;     /* utils.py:363-364 */
-                float t0 = d0 * Q[0] + d1 * Q[2];
-                float t1 = d0 * Q[1] + d1 * Q[3];
+                /* utils.py:363-364 as torch executes it (probe_torch_order.py): (1,2) @ (2,2) is an sgemm,
+                 * one FMA per output; (1,2) @ (2,1) is a dot whose two products are rounded before the sum */
+                float d0 = -0.5f * e0, d1 = -0.5f * e1;
+                float t0 = fmaf(d1, Q[2], d0 * Q[0]);
+                float t1 = fmaf(d1, Q[3], d0 * Q[1]);
                 float w = expf(t0 * e0 + t1 * e1);
                 float alpha = w * op2[g];                   /* second sigmoid, :164 */
                 float test = Tw * (1.0f - alpha);
@@ -550,7 +584,7 @@ int orc_render_std3dgs(const OrcCamera *cam, const float *points, const float *c
         float pw = 1.0f / (row4(p, F, 3) + 0.0000001f);
         float ndcx = row4(p, F, 0) * pw, ndcy = row4(p, F, 1) * pw;
         float xp = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f, yp = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
-        ewa2d(cam, fx, fy, p, tz, S, D);
+        ewa2d(cam, fx, fy, p, tz, S, D, INT64_MAX);
         float ca = D[0] + 0.3f, cb = D[1], cd = D[4] + 0.3f;
         float det = ca * cd - cb * cb;
         if (det == 0.0f) continue;

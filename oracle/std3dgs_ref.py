@@ -30,7 +30,7 @@ from typing import NamedTuple, Optional, Tuple
 
 import numpy as np
 
-from .cpu_ref import Camera, _mm3, _row4, sigmoid
+from .cpu_ref import Camera, _mm3, _mm3_single, _row4, sigmoid
 
 f32 = np.float32
 
@@ -103,7 +103,8 @@ def stage1(points, scales, quats, opacity_logit, cam: Camera, tile: int = 16) ->
         J[:, 1, 1] = fy / tz
         J[:, 1, 2] = -(fy * cy) / (tz * tz)
         Wm = np.ascontiguousarray(V[:3, :3].T)
-        D = _mm3(_mm3(_mm3(_mm3(J, Wm), S), np.ascontiguousarray(Wm.T)), np.ascontiguousarray(np.transpose(J, (0, 2, 1))))
+        # the same operation order as the reference-rule projection (cpu_ref.covariance_2d): one-matrix factors fused
+        D = _mm3(_mm3_single(_mm3(_mm3_single(J, Wm), S), np.ascontiguousarray(Wm.T)), np.ascontiguousarray(np.transpose(J, (0, 2, 1))))
         ca, cb, cd = D[:, 0, 0] + f32(0.3), D[:, 0, 1], D[:, 1, 1] + f32(0.3)
         det = ca * cd - cb * cb
         det_inv = f32(1.0) / det

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), "libgsx.so does not export %s" % name
         assert name in _ffi.SIGNATURES, "ctypes binding lacks %s" % name
-    assert lib.gsx_version() == 302
+    assert lib.gsx_version() == 303
 
 
 def _exported(path):
@@ -115,6 +115,31 @@ def test_params_struct_size_is_checked_before_anything_runs():
     assert lib.gsx_render_forward(*args(p)) == _ffi.GSX_ERR_INVALID_ARGUMENT and b"hints" in lib.gsx_last_error()
     p.struct_size = _ffi.GsxParams.hints.offset     # ... and not read when the caller's struct ends before it
     assert lib.gsx_render_forward(*args(p)) == _ffi.GSX_ERR_INVALID_ARGUMENT and b"workspace" in lib.gsx_last_error()
+
+
+def test_default_params_never_writes_behind_the_callers_struct():
+    """A client compiled against the 104-byte ABI-300 struct: gsx_default_params_sized(p, 104) -- and the exported
+    legacy function such a binary calls -- fill 104 bytes, state struct_size = 104 and leave the canary behind the
+    struct alone; a later call then reads nothing behind it either (n_substrips there would be refused)."""
+    lib = _ffi.load()
+    for call in (lambda b: lib.gsx_default_params_sized(ctypes.cast(b, ctypes.POINTER(_ffi.GsxParams)), 104),
+                 lambda b: lib.gsx_default_params(ctypes.cast(b, ctypes.POINTER(_ffi.GsxParams)))):
+        buf = (ctypes.c_ubyte * 160)(*([0xAB] * 160))
+        call(buf)
+        assert bytes(buf[104:]) == b"\xab" * 56, "wrote behind a 104-byte struct"
+        p = ctypes.cast(buf, ctypes.POINTER(_ffi.GsxParams)).contents
+        assert p.struct_size == 104 and p.tile_x1 == -1 and p.semantics == _ffi.GSX_SEM_REF_CPU and p.hints is None
+        # 0xABABABAB in n_substrips (offset 104) would be refused if it were read: the call gets as far as the workspace check
+        cam = _ffi.GsxCamera()
+        cam.width, cam.height = 64, 64
+        rc = lib.gsx_render_forward(ctypes.byref(cam), None, None, None, None, None, 0, 16, ctypes.c_void_p(256), p, None,
+                                    None, 0, None)
+        assert rc == _ffi.GSX_ERR_INVALID_ARGUMENT and b"workspace" in lib.gsx_last_error()
+    # sizes this library does not know are clamped to what it has / to the smallest struct there ever was
+    buf = (ctypes.c_ubyte * 256)(*([0xAB] * 256))
+    lib.gsx_default_params_sized(ctypes.cast(buf, ctypes.POINTER(_ffi.GsxParams)), 200)
+    assert ctypes.cast(buf, ctypes.POINTER(_ffi.GsxParams)).contents.struct_size == ctypes.sizeof(_ffi.GsxParams)
+    assert bytes(buf[ctypes.sizeof(_ffi.GsxParams):]) == b"\xab" * (256 - ctypes.sizeof(_ffi.GsxParams))
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
