@@ -133,6 +133,50 @@ def make_trained_like_scene(n: int, width: int, height: int, seed: int = 0, qvec
     )
 
 
+def make_needle_scene(n: int, width: int, height: int, seed: int = 0, qvec=TREEHILL_QVEC, tvec=TREEHILL_TVEC,
+                      long_px=(23.0, 47.0), short_px=(0.1, 0.17)) -> Dict[str, np.ndarray]:
+    """Needle footprints (not a BASELINE config): every Gaussian has one axis of ``long_px`` pixels standard deviation
+    (3 sigma = 70 .. 140 px) and two of ``short_px`` (3 sigma = 0.3 .. 0.5 px), randomly oriented -- axis ratios of ~250:1, the regime in which the
+    three products of ``d Q d^T`` are ~1e4 each and cancel to a few units, so that the float32 operation order of
+    the weight (splat/utils.py:363-364) decides the fourth digit of alpha.  Same fields as ``make_scene``; a stream
+    of its own (seed + 104729)."""
+    rs = np.random.RandomState(seed + 104729)
+    fx = fy = 0.75 * width
+    tanx, tany = width / (2 * fx), height / (2 * fy)
+    z = rs.uniform(2.0, 10.0, n)
+    u, v = rs.uniform(-1.0, 1.0, n), rs.uniform(-1.0, 1.0, n)
+    sigma_px = np.stack([rs.uniform(long_px[0], long_px[1], n), rs.uniform(short_px[0], short_px[1], n),
+                         rs.uniform(short_px[0], short_px[1], n)], axis=1)
+    quats = rs.normal(0.0, 1.0, (n, 4))
+    opacity = rs.normal(0.0, 2.0, (n, 1))
+    rgb = rs.uniform(0.0, 255.0, (n, 3))
+    p_cam = np.stack([u * tanx * z, v * tany * z, z], axis=1)
+    R, t = _rotation(qvec), np.asarray(tvec, dtype=np.float64)
+    world = (p_cam - t[None, :]) @ R
+    scales = sigma_px * z[:, None] / fx
+    f = np.float32
+    return dict(
+        points=world.astype(f), colors_0_255=rgb.astype(f), scales=scales.astype(f), quaternions=quats.astype(f),
+        opacity=opacity.astype(f), qvec=np.asarray(qvec, dtype=np.float64), tvec=np.asarray(tvec, dtype=np.float64),
+        fx=np.float64(fx), fy=np.float64(fy), cx=np.float64(width / 2), cy=np.float64(height / 2),
+        width=np.int64(width), height=np.int64(height),
+    )
+
+
+def make_tie_scene(n: int, width: int, height: int, seed: int = 0, levels: int = 33) -> Dict[str, np.ndarray]:
+    """Exact view-depth ties (not a BASELINE config): ``make_scene`` under the identity pose -- view depth is then the
+    world z itself, bit for bit -- with z snapped to ``levels`` values between 2 and 10 (multiples of 0.25), so that
+    every depth is shared by ~n / levels Gaussians that overlap on screen.  What the reference's unstable
+    ``torch.argsort`` (splat/gaussian_scene.py:117) does with equal keys is implementation-defined; this scene makes
+    its effect on the image visible."""
+    sc = make_scene(n=n, width=width, height=height, seed=seed, qvec=(1.0, 0.0, 0.0, 0.0), tvec=(0.0, 0.0, 0.0))
+    step = 8.0 / (levels - 1)
+    pts = sc["points"].copy()
+    pts[:, 2] = (2.0 + np.round((pts[:, 2].astype(np.float64) - 2.0) / step) * step).astype(np.float32)
+    sc["points"] = pts
+    return sc
+
+
 def _qvec_from_rotation(R: np.ndarray) -> np.ndarray:
     """(w, x, y, z) of a rotation matrix (w >= 0), the inverse of ``_rotation``."""
     K = np.array([

@@ -8,7 +8,7 @@ the absent third-party ``plyfile`` module (only used for an IO side effect of th
 ``Gaussians``, overwrite its plain-tensor attributes with the fixture values, call
 ``GaussianScene.preprocess`` and ``GaussianScene.render_image``.
 
-    python oracle/capture_golden.py            # all fixtures (the 256x256 one takes ~3 min)
+    python oracle/capture_golden.py            # all fixtures (~15 min: c1_256x256 3 min, needle 3 min, trainedlike 5 min)
     python oracle/capture_golden.py small      # only those whose name contains "small"
 """
 from __future__ import annotations
@@ -47,6 +47,23 @@ FIXTURES = {
     # the notebook flow: Gaussians(points, colors) with the constructor's own scales / quaternions /
     # opacity (gaussians.py:23-33), nothing overwritten
     "defaults_64x64_n800": dict(n=800, width=64, height=64, seed=29, tile=16, defaults=True),
+    # ill-conditioned footprints, ~250:1 (3 sigma = 70 .. 140 px by 0.3 .. 0.5 px): the products of d Q d^T are ~1e5
+    # and cancel to a few units, so the float32 operation order of the weight decides alpha's fourth digit
+    "needle_160x160_n110": dict(n=110, width=160, height=160, seed=0, tile=16, generator="needle"),
+    # the statistics of a trained checkpoint: clustered, axis ratios up to 50:1, bimodal opacity
+    "trainedlike_128x128_n3000": dict(n=3000, width=128, height=128, seed=0, tile=16, generator="trained"),
+    # exact view-depth ties among overlapping Gaussians: what torch.argsort (unstable, gaussian_scene.py:117) does
+    # with equal keys reaches the image
+    "ties_64x64_n400": dict(n=400, width=64, height=64, seed=31, tile=16, generator="ties"),
+}
+
+# Stage 1 only (the reference's preprocess takes 0.3 .. 1.3 s at these sizes; its render_image would take days):
+# the benchmark configurations C2 and C3 of BASELINE.json, 1080p, SURVEY.md section 8(d) generator, seed 0.
+#   full=True   every by-original-index array of the reference's PreprocessedScene + its permutation
+#   full=False  SHA-256 of each by-index array, the permutation's hash and its tie runs, the tile-list lengths
+STAGE1_FIXTURES = {
+    "stage1_c2_1080p_n100000": dict(n=100_000, width=1920, height=1080, seed=0, tile=16, full=True),
+    "stage1_c3_1080p_n1000000": dict(n=1_000_000, width=1920, height=1080, seed=0, tile=16, full=False),
 }
 
 
@@ -80,15 +97,130 @@ def _import_reference():
     return GaussianScene, Gaussians
 
 
+def _generate(spec: dict) -> dict:
+    from intro_to_gaussian_splatting_amd import synthetic
+
+    spec = dict(spec)
+    gen = {"needle": synthetic.make_needle_scene, "trained": synthetic.make_trained_like_scene,
+           "ties": synthetic.make_tie_scene, None: synthetic.make_scene}[spec.pop("generator", None)]
+    sc = gen(**spec)
+    sc.pop("sh", None)              # the reference has no spherical harmonics: the base colour is what it renders
+    sc.pop("sh_degree", None)
+    return sc
+
+
+def stage1_by_index(pre, order: np.ndarray, n: int) -> dict:
+    """The reference's depth-sorted PreprocessedScene arrays put back in ORIGINAL Gaussian order (rows of culled
+    Gaussians: zero), so that two implementations can be compared array by array whatever they do with equal depths."""
+    out = {}
+    for f in ("points_xy", "covariance_2d", "depths", "inverse_covariance_2d", "radius", "min_x", "max_x", "min_y",
+              "max_y", "sigmoid_opacity", "colors"):
+        a = np.ascontiguousarray(getattr(pre, f).detach().numpy() if hasattr(getattr(pre, f), "detach") else getattr(pre, f))
+        full = np.zeros((n,) + a.shape[1:], dtype=a.dtype)
+        full[order] = a
+        out[f] = full
+    return out
+
+
+def sha256(a: np.ndarray) -> str:
+    import hashlib
+
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def tie_runs(depths_sorted: np.ndarray) -> np.ndarray:
+    """Boolean mask over sorted positions: the position belongs to a run of at least two equal depths."""
+    d = np.ascontiguousarray(depths_sorted, np.float32).view(np.uint32)
+    same_next = np.concatenate([d[1:] == d[:-1], [False]])
+    same_prev = np.concatenate([[False], d[1:] == d[:-1]])
+    return same_next | same_prev
+
+
+def capture_stage1(name: str, spec: dict, GaussianScene, Gaussians) -> None:
+    """Stage 1 of the reference at a benchmark size: ``GaussianScene.preprocess`` itself, its permutation recovered by
+    repeating its own argsort (and checked against the colours it gathered), the tile-list lengths by the reference's
+    own mask expressions (splat/gaussian_scene.py:209-217)."""
+    import torch
+
+    from intro_to_gaussian_splatting_amd.synthetic import write_colmap_text
+
+    spec = dict(spec)
+    tile, full = spec.pop("tile"), spec.pop("full")
+    sc = _generate(spec)
+    n = sc["points"].shape[0]
+    t0 = time.time()
+    with tempfile.TemporaryDirectory() as tmp:
+        write_colmap_text(os.path.join(tmp, "colmap"), sc)
+        with torch.no_grad():
+            g = Gaussians(torch.from_numpy(sc["points"]), torch.from_numpy(sc["colors_0_255"]), model_path=tmp)
+            g.points = torch.from_numpy(sc["points"]).float()
+            g.scales = torch.from_numpy(sc["scales"]).float()
+            g.quaternions = torch.from_numpy(sc["quaternions"]).float()
+            g.opacity = torch.from_numpy(sc["opacity"]).float()
+            scene = GaussianScene(os.path.join(tmp, "colmap"), g)
+            cam = scene.images[1]
+            from splat.utils import in_view_frustum
+
+            in_view = in_view_frustum(points=g.points, view_matrix=cam.world2view)
+            t1 = time.time()
+            pre = scene.preprocess(1)
+            dt = time.time() - t1
+            hom = torch.cat([g.points[in_view], torch.ones(int(in_view.sum()), 1)], dim=1)
+            depth_unsorted = (hom @ cam.world2view)[:, 2]
+            perm = torch.argsort(depth_unsorted)
+            assert torch.equal(depth_unsorted[perm], pre.depths), "argsort is not reproducible"
+            assert torch.equal(g.colors[in_view][perm], pre.colors), "argsort is not reproducible"
+            # tile-list lengths: the reference's masks, column by column and row by row; a Gaussian is in tile
+            # (tx, ty) iff both hold, so the table is the product of the two mask matrices (exact in float32: < 2^24)
+            W, H = int(cam.width.item()), int(cam.height.item())
+            xin = torch.stack([(pre.min_x <= x_min + tile) & (pre.max_x >= x_min) for x_min in range(0, W - tile, tile)])
+            yin = torch.stack([(pre.min_y <= y_min + tile) & (pre.max_y >= y_min) for y_min in range(0, H - tile, tile)])
+            counts = (xin.float() @ yin.float().T).round().to(torch.int64)
+            d_ref = int((xin.sum(0).to(torch.int64) * yin.sum(0).to(torch.int64)).sum())
+            assert d_ref == int(counts.sum())
+    idx = np.nonzero(in_view.numpy())[0]
+    order = idx[perm.numpy()].astype(np.int64)
+    by_index = stage1_by_index(pre, order, n)
+    ties = tie_runs(pre.depths.numpy())
+    out = dict(
+        generator=np.array(repr(sorted(spec.items()))), tile=np.int64(tile), n=np.int64(n), n_visible=np.int64(idx.size),
+        qvec=sc["qvec"], tvec=sc["tvec"], fx=sc["fx"], fy=sc["fy"], width=sc["width"], height=sc["height"],
+        inputs_sha256=np.array(sha256(np.concatenate([sc[k].reshape(-1) for k in ("points", "colors_0_255", "scales",
+                                                                                   "quaternions", "opacity")]))),
+        world2view=cam.world2view.numpy(), full_proj_transform=cam.full_proj_transform.numpy(),
+        tan_fovX=cam.tan_fovX.numpy(), tan_fovY=cam.tan_fovY.numpy(), f_x=cam.f_x.numpy(), f_y=cam.f_y.numpy(),
+        tile_instances=np.int64(d_ref), tile_counts=counts.numpy().astype(np.uint32),
+        order_sha256=np.array(sha256(order.astype(np.int32))),
+        # what the reference's argsort did with equal depths: the Gaussians of every run of equal depths, in ITS order
+        tie_positions=np.nonzero(ties)[0].astype(np.int32), tie_order=order[ties].astype(np.int32),
+        reference_preprocess_seconds=np.float64(dt),
+    )
+    if full:
+        out.update(order=order.astype(np.int32), depths=by_index["depths"], points_xy=by_index["points_xy"],
+                   covariance_2d=by_index["covariance_2d"], sigmoid_opacity=by_index["sigmoid_opacity"],
+                   radius=by_index["radius"].astype(np.int16),
+                   bbox=np.stack([by_index[k] for k in ("min_x", "max_x", "min_y", "max_y")], axis=1).astype(np.int16))
+        for k in ("radius", "min_x", "max_x", "min_y", "max_y"):
+            assert np.array_equal(by_index[k].astype(np.int16).astype(np.float32), by_index[k]), k
+    for k, a in by_index.items():
+        if k != "sigmoid_opacity":      # torch's vectorised sigmoid is not a function of the value alone (1 ulp; see tests)
+            out["sha256_" + k] = np.array(sha256(a))
+    os.makedirs(OUT_DIR, exist_ok=True)
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%s: N=%d in_view=%d D=%d tied=%d ref_preprocess=%.2fs (total %.1fs) -> %s (%.0f KB)" % (
+        name, n, idx.size, d_ref, int(ties.sum()), dt, time.time() - t0, path, os.path.getsize(path) / 1024))
+
+
 def capture(name: str, spec: dict, GaussianScene, Gaussians) -> None:
     import torch
 
-    from intro_to_gaussian_splatting_amd.synthetic import make_scene, write_colmap_text
+    from intro_to_gaussian_splatting_amd.synthetic import write_colmap_text
 
     spec = dict(spec)
     tile = spec.pop("tile")
     defaults = spec.pop("defaults", False)
-    sc = make_scene(**spec)
+    sc = _generate(spec)
     with tempfile.TemporaryDirectory() as tmp:
         write_colmap_text(os.path.join(tmp, "colmap"), sc)
         with torch.no_grad():
@@ -232,6 +364,9 @@ def main() -> None:
     for name, spec in FIXTURES.items():
         if only in name:
             capture(name, spec, GaussianScene, Gaussians)
+    for name, spec in STAGE1_FIXTURES.items():
+        if only in name:
+            capture_stage1(name, spec, GaussianScene, Gaussians)
 
 
 if __name__ == "__main__":

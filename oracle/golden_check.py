@@ -1,0 +1,94 @@
+"""Holds an implementation's stage 1 against what the REFERENCE computed at a benchmark size.
+
+TEST INFRASTRUCTURE ONLY (tests/, bench.py's reference check): the fixtures ``tests/golden/stage1_*.npz`` are made
+by ``oracle/capture_golden.py`` from the reference's own ``GaussianScene.preprocess`` (splat/gaussian_scene.py:70-144)
+on BASELINE's configurations C2 (1e5 Gaussians) and C3 (1e6), 1080p.  Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import ast
+import hashlib
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+STAGE1_FIELDS = ("points_xy", "covariance_2d", "depths", "inverse_covariance_2d", "radius", "min_x", "max_x", "min_y",
+                 "max_y", "colors")
+
+
+def sha256(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load(name: str):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+
+
+def stage1_scene(g):
+    """The inputs of a stage-1 fixture, regenerated from its generator arguments (a frozen numpy stream) and checked
+    against the hash of what the reference was given."""
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    sc = make_scene(**dict(ast.literal_eval(str(g["generator"]))))
+    got = sha256(np.concatenate([sc[k].reshape(-1) for k in ("points", "colors_0_255", "scales", "quaternions", "opacity")]))
+    assert got == str(g["inputs_sha256"]), "the synthetic generator no longer produces the scene the fixture was made from"
+    return sc
+
+
+def compare_stage1_with_reference(g, fields, order, strict: bool = True) -> dict:
+    """``fields``: the PreprocessedScene arrays of an implementation in ITS depth order, ``order``: the original index
+    of each of its rows.  Holds them against what the REFERENCE computed for the same scene (a stage-1 fixture):
+    every array, put back in original Gaussian order, bit for bit (SHA-256 of 1e5 / 1e6 rows; where the fixture holds
+    the array itself, also entry by entry), and the permutation -- equal to the reference's except inside runs of
+    EQUAL depths, where the reference's unstable argsort (splat/gaussian_scene.py:117) leaves the order to its sort
+    library and this build takes the original index.  Returns the counts a report wants; ``strict``: any difference
+    outside equal depths is an AssertionError (tests), otherwise it is only counted (bench.py)."""
+    n = int(g["n"])
+    order = np.asarray(order, np.int64)
+    report = dict(n=n, n_visible_ref=int(g["n_visible"]), n_visible=int(order.size), arrays_differing=[],
+                  depth_bit_diffs=0, radius_flips=0, bbox_flips=0, order_diffs_outside_ties=0)
+    if order.size != int(g["n_visible"]):
+        assert not strict, "visible Gaussians: %d, the reference has %d" % (order.size, int(g["n_visible"]))
+        report["arrays_differing"] = ["n_visible"]
+        return report
+    stored = {"points_xy": "points_xy", "covariance_2d": "covariance_2d", "depths": "depths", "radius": "radius"}
+    for f in STAGE1_FIELDS:
+        a = np.ascontiguousarray(fields[f])
+        full = np.zeros((n,) + a.shape[1:], a.dtype)
+        full[order] = a
+        if sha256(full) == str(g["sha256_" + f]):
+            continue
+        count = -1                      # (unknown: the compact fixture holds only the hash)
+        if f in stored and stored[f] in g:
+            count = int(np.count_nonzero(full.view(np.uint32) != np.asarray(g[stored[f]], np.float32).view(np.uint32)))
+        elif f in ("min_x", "max_x", "min_y", "max_y") and "bbox" in g:
+            count = int(np.count_nonzero(full != g["bbox"][:, ("min_x", "max_x", "min_y", "max_y").index(f)].astype(np.float32)))
+        report["arrays_differing"].append(f)
+        key = {"depths": "depth_bit_diffs", "radius": "radius_flips"}.get(f, "bbox_flips" if f in ("min_x", "max_x", "min_y", "max_y") else None)
+        if key:
+            report[key] = count if report[key] == 0 or count < 0 else report[key] + count
+    assert not (strict and report["arrays_differing"]), "arrays that differ from the reference's: %r" % report
+    # the permutation: ours with the reference's choice inside every tie run == the reference's
+    pos, ref_members = g["tie_positions"].astype(np.int64), g["tie_order"].astype(np.int64)
+    depths = np.ascontiguousarray(fields["depths"], np.float32).reshape(-1).view(np.uint32)
+    in_run = np.zeros(order.size, bool)
+    in_run[pos] = True
+    same_next = np.concatenate([depths[1:] == depths[:-1], [False]])
+    runs_match = bool(np.array_equal(in_run, same_next | np.concatenate([[False], same_next[:-1]])))
+    ours = order[pos] if runs_match else np.zeros(0, np.int64)
+    if runs_match:
+        run_start = np.concatenate([[True], depths[pos][1:] != depths[pos][:-1]])
+        by_index = bool(np.all((np.diff(ours) > 0) | run_start[1:]))      # inside a run: original-index order (stable sort)
+        patched = order.copy()
+        patched[pos] = ref_members
+        outside_ok = sha256(patched.astype(np.int32)) == str(g["order_sha256"])
+    else:
+        by_index = outside_ok = False
+    if strict:
+        assert runs_match, "runs of equal depths are elsewhere than in the reference's output"
+        assert by_index, "equal depths are not in original-index order"
+        assert outside_ok, "the permutation differs from the reference's outside equal depths"
+    report.update(tied=int(pos.size), order_diffs_inside_ties=int(np.count_nonzero(ours != ref_members)) if runs_match else -1,
+                  order_diffs_outside_ties=0 if outside_ok else -1)
+    return report

@@ -11,7 +11,9 @@ if ROOT not in sys.path:
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 GOLDEN_NAMES = ["small_64x48_n300", "small_80x64_n120_tile8", "cull_96x80_n400", "c1_256x256_n2000",
                 "tile2_40x32_n80", "pose_70x50_n250", "dense_48x48_n1500", "wide_64x64_n400", "tiny_48x48_n600",
-                "defaults_64x64_n800"]
+                "defaults_64x64_n800", "needle_160x160_n110", "trainedlike_128x128_n3000"]
+# stage 1 of the reference at the benchmark sizes C2 / C3 (oracle/capture_golden.py: STAGE1_FIXTURES)
+STAGE1_NAMES = ["stage1_c2_1080p_n100000", "stage1_c3_1080p_n1000000"]
 
 
 def pytest_addoption(parser):
@@ -53,3 +55,37 @@ def golden_preprocessed(g):
 @pytest.fixture(params=GOLDEN_NAMES)
 def golden(request):
     return load_golden(request.param)
+
+
+from oracle.golden_check import (STAGE1_FIELDS, compare_stage1_with_reference, sha256,  # noqa: E402,F401
+                                 stage1_scene)
+
+
+def tie_mask(depths_sorted) -> np.ndarray:
+    """Sorted positions that belong to a run of at least two EQUAL depths (bit patterns)."""
+    d = np.ascontiguousarray(depths_sorted, np.float32).reshape(-1).view(np.uint32)
+    eq = d[1:] == d[:-1]
+    return np.concatenate([eq, [False]]) | np.concatenate([[False], eq])
+
+
+def assert_same_order_outside_ties(order, ref_order, depths_sorted) -> int:
+    """The permutation equals the reference's except inside runs of equal depths, where the reference's unstable
+    ``torch.argsort`` (splat/gaussian_scene.py:117) leaves the order to its sort library and this build takes the
+    original index; inside a run both hold the same Gaussians.  Returns the number of positions that differ."""
+    order, ref_order = np.asarray(order, np.int64), np.asarray(ref_order, np.int64)
+    assert order.shape == ref_order.shape
+    tied = tie_mask(depths_sorted)
+    assert np.array_equal(order[~tied], ref_order[~tied]), "depth permutation differs from the reference's argsort"
+    d = np.ascontiguousarray(depths_sorted, np.float32).reshape(-1).view(np.uint32)
+    run = np.concatenate([[0], np.cumsum(d[1:] != d[:-1])])
+    key = lambda o: np.lexsort((o, run))            # noqa: E731  (members of every run, ascending)
+    assert np.array_equal(order[key(order)], ref_order[key(ref_order)]), "a run of equal depths holds other Gaussians"
+    return int(np.count_nonzero(order != ref_order))
+
+
+def rows_by_index(a, order, n):
+    """Depth-ordered rows put back at their original Gaussian index (other rows zero)."""
+    a = np.ascontiguousarray(a)
+    full = np.zeros((n,) + a.shape[1:], a.dtype)
+    full[np.asarray(order, np.int64)] = a
+    return full
