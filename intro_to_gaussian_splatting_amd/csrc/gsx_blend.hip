@@ -163,23 +163,50 @@ __global__ void __launch_bounds__(64) clear_kernel(ClearPlan cp, float *__restri
     clear_block(blockIdx.x, cp, base);
 }
 
-struct Splat {  // one staged record, unpacked (wave-uniform values); mono: monomial coefficients in (d1, h, r11)
+// Record kinds (Record.c.z, set by pack_record in gsx_project.hip): the completed square; the monomial fallback (a
+// caller-given inverse covariance without a finite factorisation); REFERENCE ORDER -- an ill-conditioned footprint, on
+// which the reference's float32 evaluation of d Q d^T (splat/utils.py:363-364) is executed operation for operation
+// (alpha_ref below): its rounding there is part of the reference's result (1e-4 .. 1e-3 of alpha on 100:1 needles).
+constexpr float kRefOrderFlag = 2.0f;      // (the monomial fallback: 1.0f)
+enum { kKindSquare = 0, kKindMono = 1, kKindRefOrder = 2 };
+
+struct Splat {  // one staged record, unpacked (wave-uniform values)
+    // kKindSquare: as named.  kKindMono: monomial coefficients in (d1, h, r11).
+    // kKindRefOrder: (mx, c0) = the mean in FRAME coordinates, (d1, h, r11, my) = (Q00, Q01, Q10, Q11), lop = the opacity factor itself
     float mx, c0, d1, h, r11, lop, cr, cg, cb, my;
-    bool mono;
+    int kind;
     uint32_t blocks;        // bit g: block g of the tile keeps the record (all ones where blocks are not distinguished)
 };
 
-// Staged record (stage_records): a = (x', c0, D1, h)  b = (r11, log2 op, r, g)  c = (b, y', monomial flag, block bits)
+// Staged record (stage_records): a = (x', c0, D1, h)  b = (r11, log2 op, r, g)  c = (b, y', kind flag, block bits)
+//                  kKindRefOrder: a = (x, y, Q00, Q01) b = (Q10, op, r, g)       c = (b, Q11, kRefOrderFlag, block bits)
 __device__ __forceinline__ Splat read_splat(const Staged &sh, uint32_t k) {
     const float4 A = sh.rec[0][k], B = sh.rec[1][k], C = sh.rec[2][k];
-    return Splat{A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, C.z != 0.0f, __float_as_uint(C.w)};
+    return Splat{A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y,
+                 C.z == kRefOrderFlag ? kKindRefOrder : (C.z != 0.0f ? kKindMono : kKindSquare), __float_as_uint(C.w)};
+}
+
+// The reference's alpha of one pixel, operation for operation (splat/utils.py:357-365 as torch executes it,
+// oracle/probe_torch_order.py; splat/gaussian_scene.py:164): d = -1/2 (mean - pixel) -- exact --, (1,2) @ (2,2) one FMA
+// per output, the final (1,2) @ (2,1) two rounded products and a sum (this file is compiled with -ffp-contract=off),
+// exp, times the opacity factor.  px, py: the pixel in FRAME coordinates (integers: exact as floats).  The exponential
+// is v_exp_f32 of power * log2(e): within 2 ulp of expf plus 6e-8 |power| log2(e), i.e. < 2e-6 of alpha wherever
+// alpha >= 1e-7 -- the one step that is not the reference's bit for bit.
+__device__ __forceinline__ float alpha_ref(float x, float y, float q00, float q01, float q10, float q11, float op,
+                                           float px, float py) {
+    const float e0 = x - px, e1 = y - py;
+    const float d0 = -0.5f * e0, d1 = -0.5f * e1;
+    const float t0 = __builtin_fmaf(d1, q10, d0 * q00);
+    const float t1 = __builtin_fmaf(d1, q11, d0 * q01);
+    const float power = t0 * e0 + t1 * e1;
+    return __builtin_amdgcn_exp2f(power * 1.44269504088896340736f) * op;
 }
 
 // Exponent of one pixel.  px, p = the pixel's offsets inside the tile (px shared by the lane's pixels); g.mx, g.my =
 // x', y' (tile-relative), g.c0 = r11 y' + h x'.  The association is fixed; every REF_CPU kernel evaluates exactly this.
 __device__ __forceinline__ void exponent_x(const Splat &g, float px, float &s0, float &t0) {
     const float e_s = g.mx - px;
-    if (g.mono) {   // monomial fallback: s0 = e_s^2 Q''00 + log2 op, t0 = e_s Qs
+    if (g.kind == kKindMono) {   // monomial fallback: s0 = e_s^2 Q''00 + log2 op, t0 = e_s Qs
         s0 = __builtin_fmaf(e_s * e_s, g.d1, g.lop);
         t0 = e_s * g.h;
     } else {        // t0 = c = w at the row of the tile's origin
@@ -188,7 +215,7 @@ __device__ __forceinline__ void exponent_x(const Splat &g, float px, float &s0, 
     }
 }
 __device__ __forceinline__ float exponent_y(const Splat &g, float p, float s0, float t0) {
-    if (g.mono) {
+    if (g.kind == kKindMono) {
         const float e_p = g.my - p;
         return __builtin_fmaf(e_p, __builtin_fmaf(e_p, g.r11, t0), s0);
     }
@@ -200,16 +227,19 @@ __device__ __forceinline__ float exponent_y(const Splat &g, float p, float s0, f
 // differ in y (e_p[j] = the pixel's y offset inside the tile).
 // blk: the block of the tile the lane's pixels lie in -- a record the block does not keep (Splat.blocks) is not composited
 // there: alpha = 0, which leaves T and the colour exactly as they are, like not visiting the record at all.
+// ox, oy: the tile's origin in the frame (a kKindRefOrder record is evaluated in frame coordinates, like the reference).
 template <int NPX>
 __device__ __forceinline__ void composite(float px, const float (&e_p)[NPX], const Splat &g, float (&T)[NPX],
-                                          float (&c0)[NPX], float (&c1)[NPX], float (&c2)[NPX], int blk = 0) {
+                                          float (&c0)[NPX], float (&c1)[NPX], float (&c2)[NPX], int blk, float ox, float oy) {
     float s0, t0;
     exponent_x(g, px, s0, t0);
     const bool kept = (g.blocks >> blk) & 1u;
     float ta[NPX], test[NPX];
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
-        const float alpha = kept ? __builtin_amdgcn_exp2f(exponent_y(g, e_p[j], s0, t0)) : 0.0f;
+        float alpha = g.kind == kKindRefOrder ? alpha_ref(g.mx, g.c0, g.d1, g.h, g.r11, g.my, g.lop, ox + px, oy + e_p[j])
+                                              : __builtin_amdgcn_exp2f(exponent_y(g, e_p[j], s0, t0));
+        alpha = kept ? alpha : 0.0f;
         ta[j] = T[j] * alpha;
         test[j] = T[j] - ta[j];
     }
@@ -276,7 +306,7 @@ __device__ __forceinline__ void composite(float px, const float (&e_p)[NPX], con
 // A block's decisions depend on the tile, the block and the list alone -- walked 64 entries at a time from the start --,
 // so every kernel arrives at the same ones and the kernel families stay bit-identical to each other.
 constexpr uint32_t kSkipBudget = 1u << 23;   // 2^-17 of colour per block and channel, in units of 2^-40 (colours are < 1)
-enum { kBatchRegular = 0, kBatchWild = 1, kBatchMono = 2 };
+enum { kBatchRegular = 0, kBatchWild = 1, kBatchMono = 2, kBatchRefOrder = 3 };   // (kBatchRefOrder: a kKindRefOrder record, no monomial one)
 enum { kStageWhole = 0, kStageBlocks = 1, kStageOneBlock = 2 };
 
 // Which of the three classes of far-away records does this batch still skip in one block?  bound: the lane's record's
@@ -307,28 +337,44 @@ template <int MODE>
 __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool have, uint32_t &nb, Staged &sh, int lane,
                                              float tile_x0, float tile_y0, float tile_side, uint32_t (&skipped)[kBlocks],
                                              uint32_t budget, int blk, uint32_t (&count)[kBlocks], uint32_t dead = 0u) {
-    bool irregular = false, mono = false;
+    bool irregular = false, mono = false, refo = false;
     float bound[kBlocks] = {0.0f, 0.0f, 0.0f, 0.0f};   // < -26: a candidate, alpha < 2^bound on the whole block
     if (have) {
-        a.x -= tile_x0;                // tile-relative mean (see the head of this file)
-        a.y -= tile_y0;
-        mono = c.z != 0.0f;
-        // irregular: the monomial fallback, or D1 < 0: alpha may exceed 1 there, T is no longer monotone, and the
-        // batch tests T after every record
-        irregular = mono || !(a.z >= 0.0f);
-        if (!irregular) {               // (x', y', D1, h) (r11, log2 op, ..): completed square, D1 >= 0
+        refo = c.z == kRefOrderFlag;
+        mono = !refo && c.z != 0.0f;
+        // what the bound below is computed from: tile-relative mean, D1, h, r11, log2 op
+        float bx = a.x - tile_x0, by = a.y - tile_y0, bd1 = a.z, bh = a.w, br11 = b.x, blop = b.y;
+        bool bounded = !mono && a.z >= 0.0f;
+        if (refo) {
+            // a = (x, y, Q00, Q01) b = (Q10, op, ..) c = (.., Q11, ..), frame coordinates: the record is staged as it is;
+            // for the bound alone the square is completed here (float64 from the float32 entries, like pack_record
+            // does for the other records) and a margin of 0.02 covers the reference's own rounding of the exponent
+            const double kd = 0.5 * 1.44269504088896340736;
+            const double m00 = kd * (double)a.z, m01 = kd * 0.5 * ((double)a.w + (double)b.x), m11 = kd * (double)c.y;
+            const double r11 = sqrt(m11), h = m01 / r11, d1 = m00 - h * h;
+            bd1 = (float)d1; bh = (float)h; br11 = (float)r11;
+            blop = __builtin_amdgcn_logf(b.y) + 0.02f;
+            bounded = m11 > 0.0 && d1 >= 0.0 && isfinite(bd1) && isfinite(bh) && isfinite(br11);
+        } else {
+            a.x = bx;                  // tile-relative mean (see the head of this file)
+            a.y = by;
+        }
+        // irregular: the monomial fallback, a reference-order record, or D1 < 0: alpha may exceed 1 there, T is no
+        // longer monotone, and the batch tests T after every record
+        irregular = mono || refo || !(a.z >= 0.0f);
+        if (bounded) {               // (x', y', D1, h) (r11, log2 op, ..): completed square, D1 >= 0
             // log2 of the largest alpha over the pixel rectangle [x_lo, x_hi] x [y_lo, y_hi] (offsets inside the tile):
             // D1 min(e0^2) and min(w^2), w = r11 e1 + h e0 being linear in the pixel -- its extremes are at the corners
             auto over = [&](float x_lo, float x_hi, float y_lo, float y_hi) -> float {
-                const float ex0 = a.x - x_lo, ex1 = a.x - x_hi;
-                const float ey0 = a.y - y_lo, ey1 = a.y - y_hi;
+                const float ex0 = bx - x_lo, ex1 = bx - x_hi;
+                const float ey0 = by - y_lo, ey1 = by - y_hi;
                 const float ex_min2 = ex0 * ex1 <= 0.0f ? 0.0f : fminf(ex0 * ex0, ex1 * ex1);
-                const float w00 = __builtin_fmaf(b.x, ey0, a.w * ex0), w01 = __builtin_fmaf(b.x, ey1, a.w * ex0);
-                const float w10 = __builtin_fmaf(b.x, ey0, a.w * ex1), w11 = __builtin_fmaf(b.x, ey1, a.w * ex1);
+                const float w00 = __builtin_fmaf(br11, ey0, bh * ex0), w01 = __builtin_fmaf(br11, ey1, bh * ex0);
+                const float w10 = __builtin_fmaf(br11, ey0, bh * ex1), w11 = __builtin_fmaf(br11, ey1, bh * ex1);
                 const float wlo = fminf(fminf(w00, w01), fminf(w10, w11)), whi = fmaxf(fmaxf(w00, w01), fmaxf(w10, w11));
                 const float wabs = fminf(fabsf(wlo), fabsf(whi));
                 const float w_min2 = (wlo <= 0.0f && whi >= 0.0f) ? 0.0f : wabs * wabs;
-                return b.y - a.z * ex_min2 - w_min2;      // NaN anywhere: every comparison below is false, the record stays
+                return blop - bd1 * ex_min2 - w_min2;      // NaN anywhere: every comparison below is false, the record stays
             };
             if (MODE == kStageWhole) {
                 bound[0] = over(0.0f, tile_side - 1.0f, 0.0f, tile_side - 1.0f);
@@ -371,9 +417,9 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
         }
     }
     if (keep) {
-        c.y = a.y;                                             // y' (the depth is not needed here)
+        if (!refo) c.y = a.y;                                  // y' (the depth is not needed here)
         c.w = __uint_as_float(bits);
-        if (!mono) a.y = __builtin_fmaf(b.x, a.y, a.w * a.x);  // c0 = w at the tile's origin
+        if (!mono && !refo) a.y = __builtin_fmaf(b.x, a.y, a.w * a.x);  // c0 = w at the tile's origin
         sh.rec[0][slot] = a;
         sh.rec[1][slot] = b;
         sh.rec[2][slot] = c;
@@ -395,7 +441,8 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
         sh.rec[1][nb + lane] = make_float4(0.0f, -__builtin_inff(), 0.0f, 0.0f);
         sh.rec[2][nb + lane] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFu));
     }
-    return __any(mono && keep) ? kBatchMono : (__any(irregular && keep) ? kBatchWild : kBatchRegular);
+    return __any(mono && keep) ? kBatchMono
+                               : (__any(refo && keep) ? kBatchRefOrder : (__any(irregular && keep) ? kBatchWild : kBatchRegular));
 }
 
 // Gather + staging of one batch.  idx: this lane's entry of the tile's list (vals[base + lane]) when the caller has
@@ -452,6 +499,22 @@ __device__ __forceinline__ void alphas_mono(float4 A, float yp, float q11, float
     const v2f ea = splat2(yp) - cya, eb = splat2(yp) - cyb;
     al_a = pk_exp2(pk_fma(ea, pk_fma(ea, splat2(q11), splat2(t0)), splat2(s0)));
     al_b = pk_exp2(pk_fma(eb, pk_fma(eb, splat2(q11), splat2(t0)), splat2(s0)));
+}
+
+// The same for a kKindRefOrder record: alpha_ref's operations, packed.  A = (x, y, Q00, Q01) in frame coordinates;
+// fx = the lane's x in the frame, fya, fyb = its four y.
+__device__ __forceinline__ void alphas_ref(float4 A, float q10, float q11, float op, float fx, v2f fya, v2f fyb, v2f &al_a,
+                                           v2f &al_b) {
+    const float e0 = A.x - fx, d0 = -0.5f * e0;
+    const float p00 = d0 * A.z, p01 = d0 * A.w;
+    const v2f e1a = splat2(A.y) - fya, e1b = splat2(A.y) - fyb;
+    const v2f d1a = splat2(-0.5f) * e1a, d1b = splat2(-0.5f) * e1b;
+    const v2f t0a = pk_fma(d1a, splat2(q10), splat2(p00)), t0b = pk_fma(d1b, splat2(q10), splat2(p00));
+    const v2f t1a = pk_fma(d1a, splat2(q11), splat2(p01)), t1b = pk_fma(d1b, splat2(q11), splat2(p01));
+    const v2f pa = t0a * splat2(e0) + t1a * e1a, pb = t0b * splat2(e0) + t1b * e1b;
+    const float l2e = 1.44269504088896340736f;
+    al_a = pk_exp2(pa * splat2(l2e)) * splat2(op);
+    al_b = pk_exp2(pb * splat2(l2e)) * splat2(op);
 }
 
 #define GSX_ACCUMULATE(ta_a, ta_b, cr, cg, cb)          \
@@ -592,12 +655,14 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
         // left of a batch, and every record of a saturated tile, through a one-record-at-a-time loop: on a
         // heavy-tailed scene, where half the records of a long list are not staged and the dense tiles saturate early,
         // that loop -- ~420 cycles per record for a wave alone on its SIMD -- was the frame's duration.)
-        if (kind == kBatchMono) {       // a record in the monomial fallback (stage-2 entry only): one at a time, exact rule
+        if (kind == kBatchMono || kind == kBatchRefOrder) {
+            // a record in the monomial fallback (stage-2 entry only) or one that keeps the reference's operation order
+            // (an ill-conditioned footprint): one at a time, exact rule
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
                 const float e_p[1] = {cy};
                 float T1[1] = {T}, a0[1] = {c0}, a1[1] = {c1}, a2[1] = {c2};
-                composite<1>(cx, e_p, s, T1, a0, a1, a2);
+                composite<1>(cx, e_p, s, T1, a0, a1, a2, 0, (float)(tx * 16), (float)(ty * 16));
                 T = T1[0]; c0 = a0[0]; c1 = a1[0]; c2 = a2[0];
             }
         } else {
@@ -820,7 +885,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (VARIANT == 0) {
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
-                composite<4>(cx, cy, s, T, c0, c1, c2, blk);
+                composite<4>(cx, cy, s, T, c0, c1, c2, blk, (float)(tx * 16), (float)(ty * 16));
             }
         } else if (kind == kBatchMono) {
             // A record in the monomial fallback (caller-given inverse covariances on the stage-2 entry; a degenerate
@@ -829,6 +894,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             // dead from here, so the two forms do not add up in the register file.
             restart_scalar = true;
             break;
+        } else if (kind == kBatchRefOrder) {
+            // The batch holds an ill-conditioned footprint (kKindRefOrder): one list entry at a time under the exact rule,
+            // the reference's operations on such a record (alphas_ref), the completed square on the others -- every
+            // record's alpha is what it is in any other batch, the exact rule is valid for any batch.
+            const float fx_ = (float)(tx * 16) + cx;
+            const v2f fya = splat2((float)(ty * 16)) + cya, fyb = splat2((float)(ty * 16)) + cyb;
+            for (uint32_t k = 0; k < nl; ++k) {
+                const uint32_t s_ = my_list[k];
+                const float4 A = *reinterpret_cast<const float4 *>(rec_a + s_), B = *reinterpret_cast<const float4 *>(rec_b + s_);
+                const float4 C = *reinterpret_cast<const float4 *>(rec_c + s_);
+                v2f aa, ab, ta_a, ta_b;
+                if (C.z == kRefOrderFlag)
+                    alphas_ref(A, B.x, C.y, B.y, fx_, fya, fyb, aa, ab);
+                else
+                    alphas(A, B.x, B.y, cx, cya, cyb, aa, ab);
+                checked_pair(aa, Ta, ta_a);
+                checked_pair(ab, Tb, ta_b);
+                GSX_ACCUMULATE(ta_a, ta_b, B.z, B.w, C.x);
+            }
         } else {
             // Common path: whole trips of four list entries (the lists are padded with a null record's slot, see
             // stage_records), ONE wave-level saturation test per trip, no per-pixel selects: twice the independent work
@@ -936,7 +1020,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             __syncthreads();
             for (uint32_t k = 0; k < nb; ++k) {         // every staged record, in order; a lane's block takes what it keeps
                 const Splat s = read_splat(sh, k);
-                composite<4>(cx, cy, s, T, c0, c1, c2, blk);
+                composite<4>(cx, cy, s, T, c0, c1, c2, blk, (float)(tx * 16), (float)(ty * 16));
             }
             __syncthreads();
             if (__ballot((T[0] > 0.0f) | (T[1] > 0.0f) | (T[2] > 0.0f) | (T[3] > 0.0f)) == 0ull) break;
@@ -1016,7 +1100,7 @@ __global__ void __launch_bounds__(64)
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
                 const float e_p[1] = {fy};
-                composite<1>(fx, e_p, s, T, c0, c1, c2, blk);
+                composite<1>(fx, e_p, s, T, c0, c1, c2, blk, (float)(tx * Ts), (float)(ty * Ts));
             }
             __syncthreads();
             if (__ballot(valid && T[0] > 0.0f) == 0ull) break;

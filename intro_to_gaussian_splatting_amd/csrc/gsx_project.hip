@@ -366,6 +366,24 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
         const double r11 = sqrt(m11), h = m01 / r11, d1 = m00 - h * h;
         const float fr = (float)r11, fh = (float)h, fd = (float)d1;
         const bool ok = m11 > 0.0 && isfinite(fr) && isfinite(fh) && isfinite(fd) && fr > 0.0f;
+        // ILL-CONDITIONED footprints keep the reference's own float32 evaluation (c.z = 2, kRefOrderFlag).  The
+        // reference sums d Q d^T as four float32 products (splat/utils.py:363-364); where they cancel, their rounding
+        // is part of its result: with S = the sum of their magnitudes the exponent is off by up to ~4 ulp(S), and
+        // S <= rho |exponent|, rho = (1 + c) / (1 - c), c = |Q01 + Q10| / (2 sqrt(Q00 Q11)) (the largest generalised
+        // eigenvalue of |Q| against Q; rho = k^2 for an axis ratio k at 45 degrees).  Weighted by alpha = op exp(-x),
+        // x e^-x <= 1/e: the reference's alpha differs from the exact one by up to 8.8e-8 op rho anywhere on the
+        // footprint (measured: a seventh of that on the 250:1 needles of tests/golden/needle_160x160_n110, 5.4e-4).
+        // Beyond 3e-5 -- rho op > 340, axis ratios from ~20:1 -- the completed square, which is exact to 1e-5, is no
+        // longer "the reference's result to 1e-4": the record then carries the raw float32 entries and the
+        // compositing kernels execute the reference's operations on it, one for one (alphas_ref in gsx_blend.hip).
+        const double cc = 0.5 * fabs((double)q01 + (double)q10) / sqrt((double)q00 * (double)q11);
+        const bool ref_order = ok && q00 > 0.0f && q11 > 0.0f && cc < 1.0 && 8.8e-8 * (double)op * (1.0 + cc) / (1.0 - cc) > 3e-5;
+        if (ref_order) {
+            out.a = make_float4(x, y, q00, q01);
+            out.b = make_float4(q10, op, cr, cg);
+            out.c = make_float4(cb, q11, 2.0f, 0.0f);
+            return;
+        }
         out.a = ok ? make_float4(x, y, fd, fh) : make_float4(x, y, Q00, Qs);
         out.b = make_float4(ok ? fr : Q11, log2f(op), cr, cg);
         out.c = make_float4(cb, depth, ok ? 0.0f : 1.0f, 0.0f);
