@@ -1029,6 +1029,20 @@ def main() -> None:
             alone = scene.render_image_hip(1, tile_size=tile, layout=layout, semantics=sem)
             strips_ok = bool(torch.equal(last, alone))
         dist.barrier()
+    # what the process group actually was (the first multi-GPU run has to explain itself): every rank's device and strip
+    dist_info = None
+    if world > 1:
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(device),
+                "tile_columns": [int(window[0]), int(window[1])], "n_kept": int(stats.get("n_kept") or 0),
+                "tile_instances": int(stats.get("n_instances") or 0), "stage_ms_total": round(stage.get("total", 0.0), 4)}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks,
+                     "gather": ("overlapped: %d sub-strips per rank, point-to-point isend / irecv on a side stream while the "
+                                "next part is composited (strips.render_overlapped)" % args.substrips) if overlapped["on"]
+                     else "plain: one point-to-point gather of whole strips behind the frame (strips.render_sharded)",
+                     "gather_why": overlapped["why"] or ("--substrips %d" % args.substrips),
+                     "frames_in_flight_path": None if pipeline is None else "strips.StripPipeline, depth %d" % pipeline.depth}
     if rank == 0:
         d, nvis = int(stats["n_instances"]), int(stats["n_visible"])
         my_tiles = int(stats["n_tiles"])
@@ -1103,6 +1117,8 @@ def main() -> None:
             out.update(moving)
         if strips_ok is not None:
             out["strips_equal_single_gpu"] = strips_ok
+        if dist_info is not None:
+            out["distributed"] = dist_info
         if world == 1 and not args.no_cpu_baseline:
             base, err, inst, psnr = cpu_baseline(sc, scene, frame, semantics=sem)
             out["cpu_baseline"] = base

@@ -161,6 +161,7 @@ typedef struct GsxParams {
      * as those of the one-launch frame.  substrip_bounds: HOST array of n_substrips + 1 absolute tile coordinates,
      * ascending, [0] = the window's first and [n_substrips] = its last + 1 tile along that axis; substrip_events: HOST
      * array of n_substrips events.  n_substrips 0 or 1 (default): one launch, nothing recorded.  At most 16 parts.
+     * Not while `stream` is being captured into a hipGraph (GSX_ERR_UNSUPPORTED): the events are recorded on the stream.
      * Rule sets / tile sizes without a partial launch composite in one launch and record every event behind it. */
     int32_t n_substrips;
     int32_t substrip_axis;

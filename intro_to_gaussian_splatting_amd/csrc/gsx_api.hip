@@ -353,6 +353,14 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     int rc = make_plan_or_fail(camera->width, camera->height, tile_size, out_image, params, p);
     if (rc != GSX_OK) return rc;
     if (n < 0 || n >= (int64_t)1 << 31) return fail(GSX_ERR_INVALID_ARGUMENT, "n = %lld out of range", (long long)n);
+    if (p.n_parts > 0) {
+        // substrip_events are recorded with plain hipEventRecord: inside a stream capture they would become nodes of
+        // the graph, and the caller's hipStreamWaitEvent on another stream would fail or invalidate the capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        GSX_HIP(hipStreamIsCapturing(s, &cs));
+        if (cs != hipStreamCaptureStatusNone)
+            return fail(GSX_ERR_UNSUPPORTED, "n_substrips cannot be combined with stream capture (the part events are recorded on the stream)");
+    }
     if (n > 0 && (!means3d || !scales || !quats || !opacity_logit || (!colors && !p.sh)))
         return fail(GSX_ERR_INVALID_ARGUMENT, "an input array is NULL");
     Carve c;

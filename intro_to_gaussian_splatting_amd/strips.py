@@ -318,7 +318,9 @@ def render_overlapped(render_fn, width: int, height: int, tile: int, layout: str
             if pb <= pa:
                 continue
             if cs is not None:
-                if ready is not None:
+                # a marker per part -- or none at all (a renderer that is complete on return) or fewer than parts (a
+                # one-part strip composited in one launch records nothing): then the strip's own stream is the marker
+                if ready is not None and j < len(ready):
                     ready[j].wait_on(cs)
                 else:
                     cs.wait_stream(torch.cuda.current_stream(device))

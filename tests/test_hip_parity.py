@@ -660,19 +660,24 @@ def test_skipped_records_stay_below_tolerance_however_long_the_list(tmp_path):
     assert np.max(np.abs(img2 - ref2)) <= 1e-5
 
 
-def test_clustered_1m_scene_against_port_and_exact_arithmetic(tmp_path):
+def _report_against_port(tag, img, port, exact):
+    d_port = np.abs(img - port).max(axis=2)
+    d_exact = np.abs(img - exact).max(axis=2)
+    port_err = np.abs(port.astype(np.float64) - exact).max(axis=2)
+    hist = np.histogram(d_port, bins=[0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, np.inf])[0]
+    print("%s: kernel vs port %.3g (per pixel <=1e-7 / 1e-6 / 1e-5 / 1e-4 / 1e-3 / above: %s); for information, against the "
+          "same rules in float64: kernel %.3g, port %.3g" % (tag, d_port.max(), list(hist), d_exact.max(), port_err.max()))
+    return d_port
+
+
+def test_clustered_1m_scene_within_tolerance_of_the_port(tmp_path):
     """The heavy-tailed stress scene of bench.py (--workload c3_clustered: 1M Gaussians, half of them inside 5 % of
-    a 1080p frame, footprint sigma_ln 1.0; longest tile list ~20x the mean).  Not a BASELINE config, and the one
-    place where the kernel and the pinned float32 restatement are more than 1e-4 apart: on long, thin, rotated
-    footprints seen far along their ridge the REFERENCE's float32 grouping of e Q e^T loses up to 3e-4 of alpha
-    (three products of ~5e4 that cancel to ~3), the kernel completes the square.  What is
-    asserted -- and what bench.py only reports (its parity_ok is strictly `<= 1e-4 against the port`):
-      * counts identical to the port (N_vis, D);
-      * kernel within 1e-5 of the same rules evaluated in float64 from the same float32 stage-1 arrays
-        (orc_set_exact) on EVERY pixel;
-      * the pixels where kernel and port differ by more than 1e-4 are few (<= 100 of 2 073 600; 49 in round 2) and
-        each of them is one where the PORT is that far from float64 -- the difference is the reference's own
-        rounding error, not the kernel's."""
+    a 1080p frame, footprint sigma_ln 1.0; longest tile list ~20x the mean).  Not a BASELINE config.  Long, thin,
+    rotated footprints seen far along their ridge are where the REFERENCE's float32 grouping of d Q d^T loses up to
+    1e-3 of alpha -- and since the restatement executes the reference's operations in the reference's order (pinned on
+    such footprints by tests/golden/needle_160x160_n110: 6e-8), that loss is part of the result to be matched: the
+    kernel keeps the reference's own evaluation on every ill-conditioned record (kKindRefOrder, gsx_blend.hip).
+    The bar is the plain one: counts identical to the port, EVERY pixel within 1e-4 of it."""
     _need_gpu()
     from intro_to_gaussian_splatting_amd.synthetic import make_scene
     from oracle import c_oracle
@@ -688,26 +693,16 @@ def test_clustered_1m_scene_against_port_and_exact_arithmetic(tmp_path):
     port, _, inst = c_oracle.render(pre, w, h, 16)
     exact, _, _ = c_oracle.render(pre, w, h, 16, exact=True)
     assert st["n_visible"] == pre.points.shape[0] and st["n_instances"] == inst
-    d_exact = np.abs(img - exact).max(axis=2)
-    d_port = np.abs(img - port).max(axis=2)
-    port_err = np.abs(port.astype(np.float64) - exact).max(axis=2)
-    over = d_port > PIXEL_TOL
-    print("clustered 1M: kernel vs float64 %.3g, port vs float64 %.3g, kernel vs port %.3g; %d pixels above 1e-4 vs the port" % (
-        d_exact.max(), port_err.max(), d_port.max(), int(over.sum())))
-    assert d_exact.max() <= 1e-5
-    assert int(over.sum()) <= 100
-    assert np.all(port_err[over] >= d_port[over] - 1e-5)      # every such pixel: the port itself is that far from exact
+    d_port = _report_against_port("clustered 1M", img, port, exact)
+    assert d_port.max() <= PIXEL_TOL
 
 
-def test_trained_like_1m_scene_against_port_and_exact_arithmetic(tmp_path):
-    """BASELINE config 3 AS WRITTEN is a trained Treehill .ply -- needle footprints, heavy-tailed sizes, exactly the data
-    on which the float32 restatement of the reference and the kernel drift apart (round-3 verdict, weak #1) -- and it is
+def test_trained_like_1m_scene_within_tolerance_of_the_port(tmp_path):
+    """BASELINE config 3 AS WRITTEN is a trained Treehill .ply -- needle footprints, heavy-tailed sizes -- and it is
     not available offline.  synthetic.make_trained_like_scene generates the nearest thing: 1M Gaussians in 24 clusters
     + floaters, axis ratios to 50:1, log-normal sizes with sigma_ln 1.2, bimodal opacity, degree-3 spherical harmonics.
-    Same acceptance rule as the clustered scene: counts identical to the port; the kernel within 1e-5 of the same rules
-    evaluated in float64 (orc_set_exact) on EVERY pixel; every pixel where kernel and port differ by more than 1e-4 is
-    one where the PORT is that far from float64.  The histogram of |kernel - port| and the exceptions are printed
-    (GPUTEST log); bench.py --workload c3_trainedlike reports the same with parity_ok strict."""
+    Same bar as everywhere: counts identical to the port, every pixel within 1e-4 of it (bench.py --workload
+    c3_trainedlike reports the same as parity_ok)."""
     _need_gpu()
     from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians
     from intro_to_gaussian_splatting_amd.synthetic import make_trained_like_scene, write_colmap_text
@@ -726,19 +721,55 @@ def test_trained_like_1m_scene_against_port_and_exact_arithmetic(tmp_path):
     port, _, inst = c_oracle.render(pre, w, h, 16)
     exact, _, _ = c_oracle.render(pre, w, h, 16, exact=True)
     assert st["n_visible"] == pre.points.shape[0] and st["n_instances"] == inst
-    d_exact = np.abs(img - exact).max(axis=2)
-    d_port = np.abs(img - port).max(axis=2)
-    port_err = np.abs(port.astype(np.float64) - exact).max(axis=2)
-    over = d_port > PIXEL_TOL
-    hist = np.histogram(d_port, bins=[0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, np.inf])[0]
-    print("trained-like 1M: D = %d; kernel vs float64 %.3g, port vs float64 %.3g, kernel vs port %.3g; |kernel - port| per pixel "
-          "<=1e-7 / 1e-6 / 1e-5 / 1e-4 / 1e-3 / above: %s; %d pixels above 1e-4 vs the port" % (
-              inst, d_exact.max(), port_err.max(), d_port.max(), list(hist), int(over.sum())))
-    for i, j in np.argwhere(over)[:20]:
-        print("  pixel (%d,%d): kernel-port %.3g, port-float64 %.3g, kernel-float64 %.3g" % (i, j, d_port[i, j], port_err[i, j], d_exact[i, j]))
-    assert d_exact.max() <= 1e-5
-    assert np.all(port_err[over] >= d_port[over] - 1e-5)      # every such pixel: the port itself is that far from exact
-    assert int(over.sum()) <= 2000                            # (a share of 1e-3 of the frame at most)
+    d_port = _report_against_port("trained-like 1M (D = %d)" % inst, img, port, exact)
+    assert d_port.max() <= PIXEL_TOL
+
+
+def test_needles_through_every_kernel_family(tmp_path):
+    """tests/golden/needle_160x160_n110 (250:1 footprints, rendered by the reference itself; the same rules in float64
+    are 5.4e-4 away from it): the tile-16 kernel (whole path and stage-2 entry), the any-tile-size kernels, the
+    long-tile quarter kernel (every tile on four waves) and another tile size all land within 1e-5 of the reference's
+    image -- the ill-conditioned records take the reference's own operations in each of them."""
+    _need_gpu()
+    from oracle import c_oracle
+
+    g = load_golden("needle_160x160_n110")
+    scene = _scene_from_golden(tmp_path, g)
+    ref = g["image"]
+    a = scene.render_image_hip(1).cpu().numpy()
+    b = scene.render_image_hip(1, generic_kernels=True).cpu().numpy()
+    c = scene.render_image_hip(1, split_long_tiles=False).cpu().numpy()
+    for name, img in (("tile16", a), ("generic", b), ("no split", c)):
+        assert np.max(np.abs(img - ref)) <= 1e-5, (name, np.max(np.abs(img - ref)))
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    sc = {k: g[k] for k in ("points", "scales", "quaternions", "opacity")}
+    for tile in (8, 32):
+        _, port, inst = _oracle_frame(scene, sc, tile)
+        st = {}
+        img = scene.render_image_hip(1, tile_size=tile, stats=st).cpu().numpy()
+        assert st["n_instances"] == inst and np.max(np.abs(img - port)) <= 1e-5
+    # the long-tile quarter kernel: the heavy-tailed scene of test_long_tiles_on_four_waves_... with every 64th Gaussian
+    # stretched 40-fold into a needle -- tiles composited by four waves hold reference-order records; same frame as one
+    # wave per tile bit for bit, within tolerance of the port
+    from intro_to_gaussian_splatting_amd import strips
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    w, h = 640, 400
+    sc2 = make_scene(150_000, w, h, seed=4, cluster_fraction=0.5, cluster_area=0.05, sigma_ln=1.0)
+    sc2["scales"] = sc2["scales"].copy()
+    sc2["scales"][::64, 0] *= 40.0
+    scene2 = _scene_from_arrays(tmp_path / "long", sc2)
+    counts = torch.zeros(strips.tiles_along(w, 16) * strips.tiles_along(h, 16), dtype=torch.int32, device="cuda:0")
+    st = {}
+    split = scene2.render_image_hip(1, tile_counts=counts, stats=st)
+    assert int((counts > max(1024, 4 * (st["n_instances"] // counts.numel()))).sum().item()) > 0      # long tiles exist
+    assert torch.equal(split, scene2.render_image_hip(1, split_long_tiles=False))
+    assert torch.equal(split, scene2.render_image_hip(1, generic_kernels=True))
+    pre2, port2, inst2 = _oracle_frame(scene2, sc2)
+    exact2, _, _ = c_oracle.render(pre2, w, h, 16, exact=True)
+    assert inst2 == st["n_instances"]
+    d = _report_against_port("needles in long tiles", split.cpu().numpy().astype(np.float64), port2, exact2)
+    assert d.max() <= PIXEL_TOL
 
 
 def test_orbit_of_eight_poses_through_one_captured_frame(tmp_path):
