@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define GSX_VERSION 303 /* major*10000 + minor*100 + patch.  303: gsx_default_params_sized (gsx_default_params is a macro over
-                         * it; the exported function of that name serves ABI 300 / 301 binaries), GSX_FLAG_SMALL_BATCH,
+                         * it; the exported function of that name serves ABI 300 / 301 binaries), GSX_FLAG_SMALL_BATCH / _ONE_VISIBLE,
                          * stage 1 in the operation order torch executes.  302: GsxParams.n_substrips .. substrip_events (appended;
                          * a struct_size of 104 -- or 0 -- still means the ABI-300 struct).  301: GsxParams.struct_size (in
                          * reserved0's place), a larger schedule region in gsx_hints_bytes.  300: GsxParams.kept_hint, GsxFrameStats.n_kept,
@@ -217,15 +217,17 @@ typedef struct GsxParams {
  * there: use it.  Without the flag a frame given a hints buffer only fills it. */
 #define GSX_FLAG_HINTS_VALID 128
 
-/* gsx_render_forward / gsx_preprocess, GSX_SEM_REF_CPU and GSX_SEM_REF_CUDA.  The reference's J @ W
- * (splat/utils.py:354) is one BLAS call over all its N_vis visible Gaussians, and the BLAS it runs on (MKL under
- * torch) sums the three products of an output as a sequential FMA chain -- unless N_vis <= 3, when another of
- * its kernels adds them as (k0 + k2) + k1 with nothing fused (oracle/probe_torch_order.py).  The library follows
- * the first order, and the second whenever n <= 3.  A frame of MORE than three Gaussians of which at most three
- * pass the cull (GsxFrameStats.n_visible <= 3 < n) cannot know that while it projects: a caller that wants the
- * reference's bits there too issues the call again with this flag (the Python surface does), which selects the
- * second order whatever n is.  The difference is at most one unit in the last place of the 2D covariance. */
-#define GSX_FLAG_SMALL_BATCH 256
+/* gsx_render_forward / gsx_preprocess, GSX_SEM_REF_CPU and GSX_SEM_REF_CUDA: how many Gaussians the reference has
+ * VISIBLE when that is at most three.  Its matrix products over the visible Gaussians -- [p,1] @ world2view
+ * (splat/gaussian_scene.py:79-85, splat/utils.py:333) and ... @ W.T (splat/utils.py:354) -- are single BLAS calls, and
+ * the BLAS it runs on (MKL under torch) sums an output's products as a sequential FMA chain from four rows up, as
+ * (k0 + k2) + (k1 + k3) unfused on two or three rows and in a third order on one (oracle/probe_torch_order.py).  A
+ * call does not know N_vis while it projects: it assumes all n Gaussians are visible (n <= 3 selects the few-row
+ * orders by itself).  A frame that reports another class (GsxFrameStats.n_visible = 1, or 2..3, out of more) differs
+ * from the reference in the last bit of up to three depths and 2D covariances; a caller that wants the reference's
+ * bits there too issues the call again with the flag that names the class -- the Python surface does. */
+#define GSX_FLAG_SMALL_BATCH 256  /* two or three Gaussians are visible */
+#define GSX_FLAG_ONE_VISIBLE 512  /* exactly one is */
 
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
 enum {

@@ -36,6 +36,17 @@ GSX_FLAG_TILE_SCHEDULE = 32
 GSX_FLAG_NO_TILE_SCHEDULE = 64
 GSX_FLAG_HINTS_VALID = 128
 GSX_FLAG_SMALL_BATCH = 256
+GSX_FLAG_ONE_VISIBLE = 512
+
+
+def visible_rows_flag(n: int, n_visible: int, flags: int) -> int:
+    """include/gsx.h, GSX_FLAG_SMALL_BATCH / GSX_FLAG_ONE_VISIBLE: the flag a call over ``n`` Gaussians has to carry when
+    ``n_visible`` of them turned out visible and it was issued with ``flags`` -- 0 when it already assumed the right
+    number of rows (from four rows up, or n itself at most three and all of them visible)."""
+    cls = lambda k: GSX_FLAG_ONE_VISIBLE if k == 1 else (GSX_FLAG_SMALL_BATCH if k <= 3 else 0)  # noqa: E731
+    assumed = (flags & (GSX_FLAG_ONE_VISIBLE | GSX_FLAG_SMALL_BATCH)) or cls(n)
+    true = cls(n_visible) if n_visible > 0 else assumed
+    return 0 if true == assumed else true
 STAGE_NAMES = ("project", "depth_sort", "scan", "bin", "blend", "total")
 
 

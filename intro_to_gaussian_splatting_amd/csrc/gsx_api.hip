@@ -112,7 +112,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
     } else {
         // the counts are produced by the emit kernel even when no tile is rendered (an empty window
         // still reports n_visible; its pair count is 0 because every rectangle was clamped away)
-        gsx::BinCounts bc{dev2, nullptr, counters + kCtrPairs, counters + kCtrLong, culled_dev, n};
+        gsx::BinCounts bc{dev2, nullptr, counters + kCtrPairs, counters + kCtrLong, (uint32_t *)(ws + c.redo), culled_dev, n};
         if (p.no_sync && stats) {
             // pinned host memory is device-visible: the emit kernel stores the two counts there itself
             void *alias = nullptr;
@@ -133,6 +133,8 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             const uint32_t *sorted_vals = nullptr;
             const bool split = p.split && cap > 0 && gsx::blend_splits_long_tiles(p.grid, p.semantics, p.generic);
             gsx::LongTiles lt{counters + kCtrLong, (uint32_t *)(ws + c.longs), split ? gsx::kMaxLongTiles : 0u};
+            lt.redo = (uint32_t *)(ws + c.redo);
+            if (p.hints_valid) lt.redo_hint = fh.blend.redo_hint;
             if (fh.blend.lens) {        // GsxParams.hints: the tiles' costs decide who is long (tile_ranges_kernel)
                 lt.cost = fh.blend.lens;
                 lt.header = fh.blend.header;
@@ -165,7 +167,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
                 // (a part without tiles is not launched; its event still marks "everything before it is done")
                 bool first = true;
                 for (int k = 0; k < p.n_parts; ++k) {
-                    const gsx::TileSpan span{p.part_axis, p.part_bounds[k], p.part_bounds[k + 1], first ? 1u : 0u};
+                    const gsx::TileSpan span{p.part_axis, p.part_bounds[k], p.part_bounds[k + 1], first ? 1u : 0u, (uint32_t)k};
                     if (span.hi > span.lo || (first && k == p.n_parts - 1)) {
                         GSX_HIP(gsx::launch_blend((const gsx::Record *)(ws + c.rec), (const float4 *)(ws + c.bbox), sorted_vals,
                                                   ranges, p.grid, p.out, p.semantics, p.background, p.generic,
@@ -268,7 +270,7 @@ int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *s
     hipStream_t s = (hipStream_t)stream;
     if (!camera) return fail(GSX_ERR_INVALID_ARGUMENT, "camera is NULL");
     if (n < 0 || n >= (int64_t)1 << 31) return fail(GSX_ERR_INVALID_ARGUMENT, "n = %lld out of range", (long long)n);
-    const bool small_batch = params && (params->flags & GSX_FLAG_SMALL_BATCH) != 0;
+    const int small_batch = !params ? 0 : ((params->flags & GSX_FLAG_ONE_VISIBLE) ? 1 : ((params->flags & GSX_FLAG_SMALL_BATCH) ? 2 : 0));
     if (n_visible_host) *n_visible_host = 0;
     if (n == 0) return GSX_OK;
     if (!means3d || !scales || !quats || !opacity_logit || !colors) return fail(GSX_ERR_INVALID_ARGUMENT, "an input array is NULL");
@@ -336,7 +338,7 @@ int gsx_render_preprocessed(int32_t image_height, int32_t image_width, int32_t t
     gsx::PreprocessedIn in{point_means, point_colors, inverse_covariance_2d, min_x, max_x, min_y, max_y, opacity};
     GSX_HIP(gsx::launch_pack_preprocessed(in, n, p.grid, p.semantics, (gsx::Record *)(ws + c.rec),
                                           (gsx::TileRect *)(ws + c.rect),
-                                          p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, s));
+                                          p.semantics != GSX_SEM_STD_3DGS ? (float4 *)(ws + c.bbox) : nullptr, s));
     tm.mark();  // 2: pack
     // rows are already in compositing order: the rectangles by row ARE the rectangles by rank
     return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rect), nullptr, nullptr, nullptr, false, stats_host,
@@ -392,6 +394,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
         sh = gsx::SortHints{hdr, (const uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.samples),
                             p.hints_valid && route == gsx::kDepth256};
         fh.blend = gsx::BlendHints{hdr, sh.samples, (uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.lens), 0u};
+        fh.blend.redo_hint = (uint8_t *)(p.hints + hl.redo);
         // the schedule costs nothing here (a spare workgroup of the projection launch): every window of more than two
         // tiles per SIMD gets one, unless told not to
         if (p.hints_valid && p.schedule != 0 && p.grid.count() > 2048) {
@@ -402,7 +405,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     }
     GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, p.small_batch, p.sh_degree, k0, (gsx::Record *)(ws + c.rec),
                                      (gsx::TileRect *)(ws + c.rect), counters,
-                                     p.semantics == GSX_SEM_REF_CUDA ? (float4 *)(ws + c.bbox) : nullptr, sched_hint, s));
+                                     p.semantics != GSX_SEM_STD_3DGS ? (float4 *)(ws + c.bbox) : nullptr, sched_hint, s));
     tm.mark();  // 1: project (+ depth keys)
     // the sampled routes also leave the per-chunk tile counts the pair emission starts from (one kernel less)
     if (sampled)

@@ -155,6 +155,7 @@ struct EmitCounts {
     int64_t *stats2_host;        // device-visible alias of pinned host memory, or null
     uint32_t *d32;
     uint32_t *long_count;
+    uint32_t *redo_count;
     const uint32_t *culled_dev;  // Gaussians behind the cull plane (whole-path entry), or null
     int64_t n_total;             // n_visible = n_total - *culled_dev
 };
@@ -256,6 +257,7 @@ __global__ void __launch_bounds__(kBlock)
         }
         *ec.d32 = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d;
         *ec.long_count = 0u;
+        for (uint32_t k = 0; k <= (uint32_t)kMaxSubstrips; ++k) ec.redo_count[k] = 0u;     // entries + the parts' queue heads
     }
 
     // ---- the chunk's pairs, in groups of 8 consecutive pairs aligned in the GLOBAL pair index (8 keys and 8 values
@@ -421,6 +423,13 @@ __global__ void __launch_bounds__(kBlock)
                 // wave would have walked --, so a tile does not change sides from frame to frame.
                 is_long = (lt.cost[cur] & 0x7FFFFFFFu) >= cost_thr && j >= 127u && keys[j - 127u] == cur;     // (and 128 entries now)
             }
+            if (!is_long && lt.redo && lt.redo_hint && lt.redo_hint[cur]) {
+                // it met an ill-conditioned record last frame: straight to the redo list, and out of the first launch
+                const uint32_t slot = atomicAdd(lt.redo, 1u);
+                lt.redo[kRedoHeader + 2 * slot] = (uint32_t)cur;
+                lt.redo[kRedoHeader + 1 + 2 * slot] = 0u;
+                end |= kLongFlag;
+            }
             if (is_long) {
                 const uint32_t slot = atomicAdd(lt.count, 1u);
                 if (slot < lt.max) {
@@ -564,7 +573,7 @@ hipError_t emit_impl(void *temp, const TileRect *rrect, const uint32_t *order, c
     const int nchunks = (int)((n + kChunk - 1) / kChunk);
     uint64_t *sums = sums_of(temp, n, cap);
     if (!sums_ready) chunk_sums_kernel<<<nchunks, kBlock, 0, s>>>(rrect, m_dev, (uint32_t)n, sums);
-    const EmitCounts ec{bc.stats2, bc.stats2_host, bc.d32, bc.long_count, bc.culled_dev, bc.n_total};
+    const EmitCounts ec{bc.stats2, bc.stats2_host, bc.d32, bc.long_count, bc.redo_count, bc.culled_dev, bc.n_total};
     const unsigned tiles_grid = blocks_for(nt);
     const unsigned egrid = (unsigned)nchunks > tiles_grid ? (unsigned)nchunks : tiles_grid;
     if (nchunks <= kSelfScanChunks) {

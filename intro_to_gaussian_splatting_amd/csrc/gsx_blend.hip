@@ -74,6 +74,11 @@ namespace gsx {
 namespace {
 
 constexpr float kStopRefCpu = 0.000001f;  // gaussian_scene.py:153
+#ifndef GSX_REF_IN_KERNEL
+#define GSX_REF_IN_KERNEL 0       // experiment: 1 = the first launch composites reference-order records itself (no redo launch)
+#endif
+constexpr bool kRefInKernel = GSX_REF_IN_KERNEL != 0;
+constexpr bool kRefSimple = GSX_REF_IN_KERNEL == 2;     // ... with the plainest loops: a batch that holds one goes one entry at a time
 constexpr uint32_t kBatchCost = 5;        // staging a batch of 64 costs about as much as compositing five records (a tile's cost, gsx_plan.h)
 // A staged batch holds up to 64 records followed by kPad NULL records (log2 op = -inf: alpha = exp2(-inf) = 0 at every
 // pixel, colour 0), so that the compositing loops always take whole trips of 4 or 8 records with no per-record branch
@@ -85,7 +90,7 @@ constexpr int kPad = 8, kSlots = 64 + kPad;
 // tile when its bounding box touches the tile (plus a tile of slack), and under its rules every listed Gaussian is
 // evaluated at every pixel -- but a record whose alpha stays below 2^-26 on a whole 8x8 block changes nothing there
 // (see stage_records), and only 58 % of the (record, block) combinations of the benchmark scene are above that
-// (tools/analyze_skip.py; 91 % of the (record, tile) pairs).  The lane -> pixel assignment puts a block on 16 lanes
+// (tools/attic/analyze_skip.py; 91 % of the (record, tile) pairs).  The lane -> pixel assignment puts a block on 16 lanes
 // (4 pixels each), every 16-lane group walks ITS block's list -- four different records per wave instruction, read
 // from LDS with four addresses -- and a tile costs the LONGEST of its four block lists (64 % of its list on the
 // benchmark scene) instead of all of it, at ~10 % more per trip (tools/microbench_trip.hip, V5).
@@ -142,7 +147,7 @@ __device__ __forceinline__ uint32_t xcd_scheduled_tile(uint32_t b, uint32_t nt, 
 // Pixels of the output buffer that no tile of the window covers are zeroed by extra workgroups of the
 // compositing launch itself (blockIdx >= number of tiles): no memset nodes on the frame path -- they cost
 // a 5 us dispatch each, and a hipGraph memset node replayed on another stream than the one it was
-// captured on left the border untouched on ROCm 7.2 (tools/debug_border.py).
+// captured on left the border untouched on ROCm 7.2 (tools/attic/debug_border.py).
 
 __device__ __forceinline__ void clear_block(uint32_t cb, const ClearPlan &cp, float *__restrict__ base) {
     int i = 0;
@@ -228,7 +233,9 @@ __device__ __forceinline__ float exponent_y(const Splat &g, float p, float s0, f
 // blk: the block of the tile the lane's pixels lie in -- a record the block does not keep (Splat.blocks) is not composited
 // there: alpha = 0, which leaves T and the colour exactly as they are, like not visiting the record at all.
 // ox, oy: the tile's origin in the frame (a kKindRefOrder record is evaluated in frame coordinates, like the reference).
-template <int NPX>
+// WITH_REF = false: the caller never meets a kKindRefOrder record (the first launch of the tile-16 kernel sends such
+// tiles to the redo list before it gets here) and does not carry the code for one.
+template <int NPX, bool WITH_REF = true>
 __device__ __forceinline__ void composite(float px, const float (&e_p)[NPX], const Splat &g, float (&T)[NPX],
                                           float (&c0)[NPX], float (&c1)[NPX], float (&c2)[NPX], int blk, float ox, float oy) {
     float s0, t0;
@@ -237,8 +244,9 @@ __device__ __forceinline__ void composite(float px, const float (&e_p)[NPX], con
     float ta[NPX], test[NPX];
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
-        float alpha = g.kind == kKindRefOrder ? alpha_ref(g.mx, g.c0, g.d1, g.h, g.r11, g.my, g.lop, ox + px, oy + e_p[j])
-                                              : __builtin_amdgcn_exp2f(exponent_y(g, e_p[j], s0, t0));
+        float alpha = (WITH_REF && g.kind == kKindRefOrder)
+                          ? alpha_ref(g.mx, g.c0, g.d1, g.h, g.r11, g.my, g.lop, ox + px, oy + e_p[j])
+                          : __builtin_amdgcn_exp2f(exponent_y(g, e_p[j], s0, t0));
         alpha = kept ? alpha : 0.0f;
         ta[j] = T[j] * alpha;
         test[j] = T[j] - ta[j];
@@ -333,35 +341,30 @@ __device__ __forceinline__ float skip_threshold(float bound, uint32_t &skipped, 
 
 // The second half of staging: `have` lanes hold a record (a, b, c) of the batch in registers.  skipped: the running
 // totals of the blocks (kStageWhole: [0], kStageOneBlock: [blk]).  count (kStageBlocks): entries of every block's list.
-template <int MODE>
+// WITH_REF: the caller composites reference-order records itself (q4 = the lane's raw conic, see Record): such a
+// record is staged as (x, y, Q00, Q01) (Q10, op, r, g) (b, Q11, flag, bits) in FRAME coordinates; without it the record
+// keeps its completed-square form -- all the caller needs is the batch's kind, it sends the tile to the redo list.
+// Either way the skip bound is the completed square's, computed like any other record's.
+template <int MODE, bool WITH_REF = true>
 __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool have, uint32_t &nb, Staged &sh, int lane,
                                              float tile_x0, float tile_y0, float tile_side, uint32_t (&skipped)[kBlocks],
-                                             uint32_t budget, int blk, uint32_t (&count)[kBlocks], uint32_t dead = 0u) {
+                                             uint32_t budget, int blk, uint32_t (&count)[kBlocks], uint32_t dead = 0u,
+                                             unsigned long long *ref_slots = nullptr, float4 q4 = float4{0.f, 0.f, 0.f, 0.f}) {
     bool irregular = false, mono = false, refo = false;
     float bound[kBlocks] = {0.0f, 0.0f, 0.0f, 0.0f};   // < -26: a candidate, alpha < 2^bound on the whole block
+    float x_abs = 0.0f, y_abs = 0.0f;
     if (have) {
         refo = c.z == kRefOrderFlag;
         mono = !refo && c.z != 0.0f;
-        // what the bound below is computed from: tile-relative mean, D1, h, r11, log2 op
-        float bx = a.x - tile_x0, by = a.y - tile_y0, bd1 = a.z, bh = a.w, br11 = b.x, blop = b.y;
-        bool bounded = !mono && a.z >= 0.0f;
-        if (refo) {
-            // a = (x, y, Q00, Q01) b = (Q10, op, ..) c = (.., Q11, ..), frame coordinates: the record is staged as it is;
-            // for the bound alone the square is completed here (float64 from the float32 entries, like pack_record
-            // does for the other records) and a margin of 0.02 covers the reference's own rounding of the exponent
-            const double kd = 0.5 * 1.44269504088896340736;
-            const double m00 = kd * (double)a.z, m01 = kd * 0.5 * ((double)a.w + (double)b.x), m11 = kd * (double)c.y;
-            const double r11 = sqrt(m11), h = m01 / r11, d1 = m00 - h * h;
-            bd1 = (float)d1; bh = (float)h; br11 = (float)r11;
-            blop = __builtin_amdgcn_logf(b.y) + 0.02f;
-            bounded = m11 > 0.0 && d1 >= 0.0 && isfinite(bd1) && isfinite(bh) && isfinite(br11);
-        } else {
-            a.x = bx;                  // tile-relative mean (see the head of this file)
-            a.y = by;
+        if (WITH_REF) {
+            x_abs = a.x;
+            y_abs = a.y;
         }
-        // irregular: the monomial fallback, a reference-order record, or D1 < 0: alpha may exceed 1 there, T is no
-        // longer monotone, and the batch tests T after every record
-        irregular = mono || refo || !(a.z >= 0.0f);
+        a.x -= tile_x0;                // tile-relative mean (see the head of this file)
+        a.y -= tile_y0;
+        const bool bounded = !mono && a.z >= 0.0f;
+        // (a reference-order record: 0.02 covers the reference's own rounding of the exponent, < 1e-2)
+        const float bx = a.x, by = a.y, bd1 = a.z, bh = a.w, br11 = b.x, blop = refo ? b.y + 0.02f : b.y;
         if (bounded) {               // (x', y', D1, h) (r11, log2 op, ..): completed square, D1 >= 0
             // log2 of the largest alpha over the pixel rectangle [x_lo, x_hi] x [y_lo, y_hi] (offsets inside the tile):
             // D1 min(e0^2) and min(w^2), w = r11 e1 + h e0 being linear in the pixel -- its extremes are at the corners
@@ -385,7 +388,26 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
                 for (int g = 0; g < kBlocks; ++g)
                     bound[g] = over(8.0f * (float)(g & 1), 8.0f * (float)(g & 1) + 7.0f, 8.0f * (float)(g >> 1), 8.0f * (float)(g >> 1) + 7.0f);
             }
+            if (refo) {
+                // A flagged footprint is ill-conditioned SOMEWHERE; whether the reference's rounding can show on THIS
+                // tile is decided here, the same way by every kernel (tile rectangle, not block).  The reference's four
+                // products sum to S = ln2 (M00 e0^2 + 2 |M01| |e0 e1| + M11 e1^2) in magnitude (M00 = D1 + h^2, M01 = h r11,
+                // M11 = r11^2), its exponent is off by at most ~4 ulp(S) = 2.4e-7 S, its alpha by that times alpha: with S
+                // and alpha bounded over the tile's pixels, a record that cannot move any of them by 2e-5 is composited by
+                // the completed square like any other -- a needle matters this way only on the tiles along its ridge.
+                const float hi = tile_side - 1.0f;
+                const float ex = fmaxf(fabsf(bx), fabsf(bx - hi)), ey = fmaxf(fabsf(by), fabsf(by - hi));
+                const float S = 0.69314718f * ((bd1 + bh * bh) * (ex * ex) + 2.0f * fabsf(bh) * br11 * (ex * ey) + (br11 * br11) * (ey * ey));
+                const float amax = __builtin_amdgcn_exp2f(fminf(over(0.0f, hi, 0.0f, hi), 0.0f));
+                if (2.4e-7f * S * amax < 2e-5f) {        // (NaN: stays flagged)
+                    refo = false;
+                    c.z = 0.0f;          // staged as the completed-square record it is on this tile
+                }
+            }
         }
+        // irregular: the monomial fallback, a reference-order record, or D1 < 0: alpha may exceed 1 there, T is no
+        // longer monotone, and the batch tests T after every record
+        irregular = mono || refo || !(a.z >= 0.0f);
     }
     // who keeps the record: the classes every block still skips (skip_threshold) against the record's bound there
     uint32_t bits = 0;
@@ -417,9 +439,16 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
         }
     }
     if (keep) {
-        if (!refo) c.y = a.y;                                  // y' (the depth is not needed here)
         c.w = __uint_as_float(bits);
-        if (!mono && !refo) a.y = __builtin_fmaf(b.x, a.y, a.w * a.x);  // c0 = w at the tile's origin
+        if (WITH_REF && refo) {        // (x, y, Q00, Q01) (Q10, op, r, g) (b, Q11, flag, bits), frame coordinates
+            a = make_float4(x_abs, y_abs, q4.x, q4.y);
+            b.x = q4.z;
+            b.y = c.y;
+            c.y = q4.w;
+        } else {
+            c.y = a.y;                                             // y' (the depth is not needed here)
+            if (!mono) a.y = __builtin_fmaf(b.x, a.y, a.w * a.x);  // c0 = w at the tile's origin
+        }
         sh.rec[0][slot] = a;
         sh.rec[1][slot] = b;
         sh.rec[2][slot] = c;
@@ -441,27 +470,40 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
         sh.rec[1][nb + lane] = make_float4(0.0f, -__builtin_inff(), 0.0f, 0.0f);
         sh.rec[2][nb + lane] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFu));
     }
+    // which SLOTS hold a reference-order record (wave-uniform, scalar: a few iterations at most): the loops look at a
+    // record's kind only in the trips that hold one
+    unsigned long long ref_lanes = __ballot(refo && keep), in_slots = 0ull;
+    while (ref_lanes) {
+        const int l = __builtin_ctzll(ref_lanes);
+        ref_lanes &= ref_lanes - 1ull;
+        in_slots |= 1ull << __popcll(mask & ((1ull << l) - 1ull));
+    }
+    if (ref_slots) *ref_slots = in_slots;
     return __any(mono && keep) ? kBatchMono
-                               : (__any(refo && keep) ? kBatchRefOrder : (__any(irregular && keep) ? kBatchWild : kBatchRegular));
+                               : (in_slots ? kBatchRefOrder : (__any(irregular && keep) ? kBatchWild : kBatchRegular));
 }
 
 // Gather + staging of one batch.  idx: this lane's entry of the tile's list (vals[base + lane]) when the caller has
 // requested it ahead (a batch earlier: one of the two dependent trips to memory of a batch is then off its path).
-template <int MODE>
-__device__ __forceinline__ int stage_batch(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
+template <int MODE, bool WITH_REF = true>
+__device__ __forceinline__ int stage_batch(const Record *__restrict__ rec, const float4 *__restrict__ qraw,
+                                           const uint32_t *__restrict__ vals,
                                            uint32_t base, uint32_t &nb, Staged &sh, int lane, float tile_x0,
                                            float tile_y0, float tile_side, uint32_t (&skipped)[kBlocks], uint32_t (&count)[kBlocks],
                                            uint32_t budget = kSkipBudget, const uint32_t *idx = nullptr, int blk = 0,
-                                           uint32_t dead = 0u) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
+                                           uint32_t dead = 0u, unsigned long long *ref_slots = nullptr) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, q4 = a;
     const bool have = (uint32_t)lane < nb;
     if (have) {
-        const Record *q = rec + (idx ? *idx : vals[base + lane]);
+        const uint32_t gi = idx ? *idx : vals[base + lane];
+        const Record *q = rec + gi;
         a = q->a;
         b = q->b;
         c = q->c;
+        if (WITH_REF && c.z == kRefOrderFlag) q4 = qraw[gi];      // the raw conic of an ill-conditioned footprint
     }
-    return stage_records<MODE>(a, b, c, have, nb, sh, lane, tile_x0, tile_y0, tile_side, skipped, budget, blk, count, dead);
+    return stage_records<MODE, WITH_REF>(a, b, c, have, nb, sh, lane, tile_x0, tile_y0, tile_side, skipped, budget, blk, count, dead,
+                                         ref_slots, q4);
 }
 
 // ---- packed-math form of the same arithmetic (two pixels per VGPR pair) ----------------------
@@ -585,6 +627,19 @@ __device__ __forceinline__ void rank_samples(uint32_t group, int lane, const Ble
     }
 }
 
+// ---- the redo list.  The compositing launch proper keeps to the completed square and has no register to spare for
+// anything else (64 VGPRs, 8 waves per SIMD: DESIGN.md); a tile -- or a long tile's quarter -- that meets a reference-order
+// record in a batch stops there, leaves (tile, mode) in this list and writes nothing, and blend_redo_kernel, launched
+// behind it with twice the registers, composites those tiles from their first record with the same staging, the same
+// rules and the reference's operations on the flagged records.  redo[0] = entries, redo[1 + part] = queue head of
+// a part's redo launch (all zeroed by the emit kernel), entries from redo[kRedoHeader]: (tile, 0 = whole tile | 1 + quarter).  A scene without ill-conditioned footprints leaves
+// the list empty and the second launch 4096 idle workgroups long (~2 us).
+__device__ __forceinline__ void push_redo(uint32_t *redo, uint32_t tile, uint32_t mode) {
+    const uint32_t slot = atomicAdd(redo, 1u);
+    redo[kRedoHeader + 2 * slot] = tile;
+    redo[kRedoHeader + 1 + 2 * slot] = mode;
+}
+
 // ---- long tiles: a quarter of the tile -- one of its four 8x8 blocks -- per wave, one pixel per lane, eight records per trip
 // Same per-(pixel, record) arithmetic as the kernels above (bit-identical frames, tested): what changes is
 // the shape of the loop.  A lone wave spends ~430 cycles per record in the two-records-per-trip loop (LDS
@@ -592,10 +647,15 @@ __device__ __forceinline__ void rank_samples(uint32_t group, int lane, const Ble
 // and only the T / colour chains sequential, and four such waves per tile, a 20 000-entry tile takes about as
 // long as 700 entries did.  The four workgroups of a tile are placed on one XCD (block ids congruent mod 8),
 // so the records they all gather are fetched into that XCD's L2 once.
-__device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
+// REF (see blend_redo_kernel): false -- the quarter does not composite reference-order records itself: the first batch
+// that holds one sends (tile, quarter) to the redo list and the workgroup ends; true -- it does.
+template <bool REF>
+__device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict__ rec, const float4 *__restrict__ qraw,
+                                                        const uint32_t *__restrict__ vals,
                                                         const uint2 *__restrict__ ranges, const TileGrid &g,
                                                         const OutDesc &out, uint32_t t, int quarter,
-                                                        Staged &sh, uint32_t budget, uint32_t *cost_out = nullptr) {
+                                                        Staged &sh, uint32_t budget, uint32_t *cost_out, uint32_t *redo,
+                                                        uint8_t *redo_hint) {
     const int lane = threadIdx.x;
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
@@ -637,14 +697,24 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
             na = q->a; nb4 = q->b; nc = q->c;
         }
         if (base + 128u + (uint32_t)lane < rg.y) idx2 = vals[base + 128u + lane];
-        const int kind = stage_records<kStageOneBlock>(ra, rb, rc, (uint32_t)lane < nb, nb, sh, lane, (float)(tx * 16), (float)(ty * 16),
-                                                       16.0f, skipped, budget, quarter, unused);
+        unsigned long long ref_slots = 0ull;
+        float4 rq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (REF && (uint32_t)lane < nb && rc.z == kRefOrderFlag) rq = qraw[vals[base + lane]];     // (few lanes: the entry is in the cache)
+        const int kind = stage_records<kStageOneBlock, REF>(ra, rb, rc, (uint32_t)lane < nb, nb, sh, lane, (float)(tx * 16),
+                                                            (float)(ty * 16), 16.0f, skipped, budget, quarter, unused, 0u, &ref_slots, rq);
         cost += nb + kBatchCost;
 #ifdef GSX_TEST_HOOKS
         probe_staged += nb;
         if (checked && probe_checked_at == 0xFFFFFFu) probe_checked_at = probe_batch;
         ++probe_batch;
 #endif
+        if (!REF && kind == kBatchRefOrder) {       // (wave-uniform) not here: blend_redo_kernel composites this quarter
+            if (lane == 0) {
+                push_redo(redo, t, (uint32_t)quarter + 1u);
+                if (redo_hint) redo_hint[t] = 1;    // (a long tile's byte is only ever set: its quarters do not agree on it)
+            }
+            return;
+        }
         __syncthreads();
         // Whole trips of eight records (the batch is padded with null records, see kPad).  The alphas of a trip
         // are computed independently of each other and of T -- no branch between them --; then either the plain
@@ -655,18 +725,30 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
         // left of a batch, and every record of a saturated tile, through a one-record-at-a-time loop: on a
         // heavy-tailed scene, where half the records of a long list are not staged and the dense tiles saturate early,
         // that loop -- ~420 cycles per record for a wave alone on its SIMD -- was the frame's duration.)
-        if (kind == kBatchMono || kind == kBatchRefOrder) {
-            // a record in the monomial fallback (stage-2 entry only) or one that keeps the reference's operation order
-            // (an ill-conditioned footprint): one at a time, exact rule
+        if (kind == kBatchMono || (REF && kRefSimple && kind == kBatchRefOrder)) {
+            // a record in the monomial fallback (stage-2 entry only): one at a time, exact rule
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
                 const float e_p[1] = {cy};
                 float T1[1] = {T}, a0[1] = {c0}, a1[1] = {c1}, a2[1] = {c2};
-                composite<1>(cx, e_p, s, T1, a0, a1, a2, 0, (float)(tx * 16), (float)(ty * 16));
+                composite<1, REF>(cx, e_p, s, T1, a0, a1, a2, 0, (float)(tx * 16), (float)(ty * 16));
                 T = T1[0]; c0 = a0[0]; c1 = a1[0]; c2 = a2[0];
             }
         } else {
             for (uint32_t k = 0; k < nb; k += kTrip) {
+                // a trip that holds a reference-order record (wave-uniform: a scalar branch, taken by few trips) goes one
+                // record at a time through the scalar form, which evaluates such a record by the reference's operations
+                // (composite<1>: the exact rule, valid anywhere; a pixel it stops has T = 0, which the next trip's test sees)
+                if (REF && !kRefSimple && __builtin_expect((uint32_t)(ref_slots >> k) & 0xFFu, 0)) {
+                    for (uint32_t u = 0; u < (uint32_t)kTrip; ++u) {
+                        const Splat s = read_splat(sh, k + u);
+                        const float e_p[1] = {cy};
+                        float T1[1] = {T}, a0[1] = {c0}, a1[1] = {c1}, a2[1] = {c2};
+                        composite<1, REF>(cx, e_p, s, T1, a0, a1, a2, 0, (float)(tx * 16), (float)(ty * 16));
+                        T = T1[0]; c0 = a0[0]; c1 = a1[0]; c2 = a2[0];
+                    }
+                    continue;
+                }
                 float alpha[kTrip];
 #pragma unroll
                 for (int u = 0; u < kTrip; ++u) {
@@ -732,78 +814,15 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     o[2] = c2;
 }
 
-// Fast path, tile = 16: one wave per tile, 4 pixels per lane.  A lane owns pixels
-// (x, y..y+3): x is the coordinate its pixels share, so the x-only terms of the exponent are
-// computed once per record.  The assignment (and therefore every bit of the result) is the same
-// for both output layouts; only the store addressing differs:
-//   GSX_LAYOUT_WH3  out[x][y][c]: the lane's 4 pixels are 48 contiguous bytes (3 x dwordx4);
-//   GSX_LAYOUT_HW3  out[y][x][c]: 4 stores of 12 B; the 16 lanes that share a y write 192
-//                   contiguous bytes per store instruction.
-// VARIANT 0: scalar-form composite<4>; VARIANT 1: packed form, four (then two) records per saturation test;
-// VARIANT 2 (test library only): six per test.
-template <int VARIANT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))   // 64 VGPRs: every lost wave costs (DESIGN.md)
-    blend_tile16_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
-                        const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
-                        uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints,
-                        uint32_t tile_blocks, uint32_t sched_cap_, TileSpan span) {
-    __shared__ Staged sh;
-    // block order: [spare workgroups: the next frame's splitters] [helpers of long tiles (dispatched first: they have
-    // the most to do)] [tiles] [clears]
-    // (hints.rank_last -- gsx_api.hip: a window whose tiles just about fill the chip once -- : the spare workgroups come
-    // last in the grid instead)
-    const uint32_t nrank = hints.samples ? kRankGroups : 0u;
-    const uint32_t rank0 = hints.rank_last ? gridDim.x - nrank : 0u;
-    // span (GsxParams.n_substrips): this launch composites only the tiles whose column (axis 0) / row (axis 1) lies in
-    // [lo, hi) -- one part of the window; the launch of the first part also runs what a frame does once (the next
-    // frame's splitters, the zero fill of what no tile covers).  The whole grid is launched every time: a workgroup of
-    // another part exits at once (~2 us per launch for the 8 000 of a 1080p frame).
-    if (blockIdx.x - rank0 < nrank) {
-        if (span.first) rank_samples(blockIdx.x - rank0, (int)threadIdx.x, hints);
-        return;
-    }
-    const uint32_t block = hints.rank_last ? blockIdx.x : blockIdx.x - nrank;
-    if (quarters) {
-        // A window of few tiles (a rank's strip): EVERY tile on four waves, a quarter of its pixels each.  One wave per
-        // tile would leave the SIMDs with one to four waves, and a wave with few neighbours needs up to 3.3x its own
-        // issue time per trip (tools/occupancy_probe.py); the quarter form -- one pixel per lane, eight independent
-        // alphas per trip, the gather running ahead -- is built for exactly that situation.  Same arithmetic, same
-        // pixels.  32 consecutive blocks serve 8 tiles; the 4 quarters of a tile share b % 8, i.e. an XCD, and XCD x
-        // gets the x-th eighth of the window's tiles (neighbouring tiles share most of their Gaussians).
-        const uint32_t b = block, nt = (uint32_t)g.count(), groups = (nt + 7u) >> 3;
-        if (b >= groups * 32u) {
-            clear_block(b - groups * 32u, cp, out.ptr);
-            return;
-        }
-        const uint32_t u = ((b >> 5) << 3) | (b & 7u);          // (XCD = b & 7, index inside it = b >> 5)
-        const uint32_t per = nt >> 3, extra = nt & 7u, xcd = b & 7u, i = b >> 5;
-        if (i >= per + (xcd < extra ? 1u : 0u)) return;
-        (void)u;
-        blend_long_tile_quarter(rec, vals, ranges, g, out, xcd_remap((i << 3) | xcd, nt), (int)((b >> 3) & 3u), sh, budget);
-        return;
-    }
-    if (block < nhelpers) {
-        // 32 consecutive blocks serve 8 long tiles; the 4 quarters of a tile share b % 8, i.e. an XCD
-        const uint32_t b = block, slot = (b >> 5) * 8u + (b & 7u);
-        const int quarter = (int)((b >> 3) & 3u);
-        if (slot >= min(*lt.count, lt.max)) return;
-        const uint32_t lt_tile = lt.list[slot];
-        {
-            const int lead = span.axis ? g.wy0 + (int)(lt_tile % (uint32_t)g.nwy()) : g.wx0 + (int)(lt_tile / (uint32_t)g.nwy());
-            if (lead < span.lo || lead >= span.hi) return;
-        }
-        blend_long_tile_quarter(rec, vals, ranges, g, out, lt_tile, quarter, sh, budget, hints.lens ? hints.lens + lt_tile : nullptr);
-        return;
-    }
-    const uint32_t bid = block - nhelpers;
-    if (bid >= tile_blocks) {       // (tile_blocks = number of tiles, or 8 x cap with the per-XCD schedule)
-        if (span.first) clear_block(bid - tile_blocks, cp, out.ptr);
-        return;
-    }
+// One 16x16 tile on one wave, 4 pixels per lane (the body of blend_tile16_kernel; see there).  REF as in
+// blend_long_tile_quarter: false -- a batch that holds a reference-order record sends the tile to the redo list.
+template <int VARIANT, bool REF>
+__device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, const float4 *__restrict__ qraw,
+                                             const uint32_t *__restrict__ vals,
+                                             const uint2 *__restrict__ ranges, const TileGrid &g, const OutDesc &out,
+                                             const LongTiles &lt, uint32_t budget, const BlendHints &hints, const TileSpan &span,
+                                             uint32_t t, Staged &sh) {
     const int lane = threadIdx.x;
-    const uint32_t t = hints.xcd_sched ? xcd_scheduled_tile(bid, (uint32_t)g.count(), sched_cap_, sched, hints.header)
-                                       : scheduled_tile(bid, (uint32_t)g.count(), sched);
-    if (t >= (uint32_t)g.count()) return;
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
     const uint32_t probe_w0 = (uint32_t)wall_clock64();
@@ -841,7 +860,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     // records actually staged until the tile was done (a dense tile that saturates after a tenth of its list costs a
     // tenth; records that cannot matter are not staged) plus a few per batch for the staging itself -- stored when the
     // tile ends.  (A long tile's entry is the helpers': tile_ranges_kernel flagged it, they raise it.)
-    if (hints.lens && lane == 0 && t == 0) {
+    if ((!REF || kRefInKernel) && hints.lens && lane == 0 && t == 0) {
         const bool by_cost = hints.header[kHintLens] == (uint32_t)g.count() && hints.header[kHintSched] == (uint32_t)g.count();
         hints.header[kHintLens] = (uint32_t)g.count();
         // How many tiles qualified as long this frame steers the threshold of the next (gsx_plan.h: kHintLongPct).  A
@@ -852,7 +871,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             hints.header[kHintLongPct] = found > 192u ? min(pct + pct / 4u, 1000u) : (found < 64u ? max(pct - pct / 8u, 30u) : pct);
         }
     }
-    if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
+    // A long tile: four helper workgroups composite it.  The flag is also how tile_ranges_kernel takes a tile out of this
+    // launch that met an ill-conditioned record last frame (GsxParams.hints: it is in the redo list already --
+    // compositing up to that record here would be in vain); blend_redo_kernel composites such a tile whole.
+    if (REF) rg.y &= ~kLongFlag;
+    if (rg.y & kLongFlag) return;
+    bool saw_ref = false;           // (REF) wave-uniform: a batch of this tile held a reference-order record
     uint32_t cost = 0;
     uint32_t skipped[kBlocks] = {0u, 0u, 0u, 0u};    // colour every block has left out so far (stage_records)
     // A block whose 64 pixels have all saturated keeps nothing more (stage_records): a dead pixel has T = 0, adds 0 and
@@ -870,9 +894,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         const uint32_t idx_now = idx;
         if (base + 64u + (uint32_t)lane < rg.y) idx = vals[base + 64u + lane];
         uint32_t count[kBlocks];
-        const int kind = stage_batch<kStageBlocks>(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skipped,
-                                                   count, budget, &idx_now, 0, dead);
+        unsigned long long ref_slots = 0ull;     // (wave-uniform) the slots of this batch that hold a reference-order record
+        const int kind = stage_batch<kStageBlocks, (REF || VARIANT == 0)>(rec, qraw, vals, base, nb, sh, lane, (float)(tx * 16),
+                                                                          (float)(ty * 16), 16.0f, skipped, count, budget, &idx_now, 0,
+                                                                          dead, &ref_slots);
         const bool wild = kind != kBatchRegular;     // wave-uniform
+        if (REF && kind == kBatchRefOrder) saw_ref = true;
         // the wave walks as far as its LONGEST block list; the other blocks' lists are padded with a null record
         const uint32_t nl = max(max(count[0], count[1]), max(count[2], count[3]));
         cost += nl + kBatchCost;
@@ -885,8 +912,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (VARIANT == 0) {
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
-                composite<4>(cx, cy, s, T, c0, c1, c2, blk, (float)(tx * 16), (float)(ty * 16));
+                composite<4, (REF || VARIANT == 0)>(cx, cy, s, T, c0, c1, c2, blk, (float)(tx * 16), (float)(ty * 16));
             }
+        } else if (!REF && kind == kBatchRefOrder) {
+            // (wave-uniform) an ill-conditioned footprint: not here -- blend_redo_kernel composites this tile
+            if (lane == 0) {
+                push_redo(lt.redo, t, 0u);
+                if (hints.redo_hint) hints.redo_hint[t] = 1;
+            }
+            return;
         } else if (kind == kBatchMono) {
             // A record in the monomial fallback (caller-given inverse covariances on the stage-2 entry; a degenerate
             // footprint): the packed loops cannot evaluate it, and written on the packed state that rare path cost
@@ -894,25 +928,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             // dead from here, so the two forms do not add up in the register file.
             restart_scalar = true;
             break;
-        } else if (kind == kBatchRefOrder) {
-            // The batch holds an ill-conditioned footprint (kKindRefOrder): one list entry at a time under the exact rule,
-            // the reference's operations on such a record (alphas_ref), the completed square on the others -- every
-            // record's alpha is what it is in any other batch, the exact rule is valid for any batch.
-            const float fx_ = (float)(tx * 16) + cx;
-            const v2f fya = splat2((float)(ty * 16)) + cya, fyb = splat2((float)(ty * 16)) + cyb;
-            for (uint32_t k = 0; k < nl; ++k) {
-                const uint32_t s_ = my_list[k];
-                const float4 A = *reinterpret_cast<const float4 *>(rec_a + s_), B = *reinterpret_cast<const float4 *>(rec_b + s_);
-                const float4 C = *reinterpret_cast<const float4 *>(rec_c + s_);
-                v2f aa, ab, ta_a, ta_b;
-                if (C.z == kRefOrderFlag)
-                    alphas_ref(A, B.x, C.y, B.y, fx_, fya, fyb, aa, ab);
-                else
-                    alphas(A, B.x, B.y, cx, cya, cyb, aa, ab);
-                checked_pair(aa, Ta, ta_a);
-                checked_pair(ab, Tb, ta_b);
-                GSX_ACCUMULATE(ta_a, ta_b, B.z, B.w, C.x);
-            }
         } else {
             // Common path: whole trips of four list entries (the lists are padded with a null record's slot, see
             // stage_records), ONE wave-level saturation test per trip, no per-pixel selects: twice the independent work
@@ -986,7 +1001,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 while (!checked && k + kTrip <= nl) checked = !trip(std::integral_constant<int, kTrip>());
                 while (!checked && k < nl) checked = !trip(std::integral_constant<int, 2>());   // what is left: trips of two (+ a null record)
             }
-            while (k < nl) exact_pair();
+            if (!REF || kind != kBatchRefOrder) {
+                while (k < nl) exact_pair();
+            } else {
+                // The batch holds an ill-conditioned footprint (kKindRefOrder; such a batch counts as wild).  A pair of
+                // list entries none of which -- in any of the four blocks -- is such a record goes through exact_pair
+                // like everywhere else; a pair that holds one evaluates it by the reference's operations (alphas_ref;
+                // a 16-lane group at a time: the blocks read different records) and the other by the completed square:
+                // every record's alpha is what it is in any other batch.
+                const float fx_ = (float)(tx * 16) + cx;
+                const v2f fya = splat2((float)(ty * 16)) + cya, fyb = splat2((float)(ty * 16)) + cyb;
+                while (k < nl) {
+                    const uint32_t s0_ = my_list[k], s1_ = my_list[k + 1];
+                    // (a list's padding names the null record's slot, which may be slot 64: no bit of the mask)
+                    const bool r0 = (s0_ >> 4) < 64u && ((ref_slots >> (s0_ >> 4)) & 1ull) != 0ull;
+                    const bool r1 = (s1_ >> 4) < 64u && ((ref_slots >> (s1_ >> 4)) & 1ull) != 0ull;
+                    if (!kRefSimple && !__any(r0 | r1)) {
+                        exact_pair();
+                        continue;
+                    }
+                    (void)r1;
+                    // ONE entry on this path (then the pair test again from the next): what is live here comes on top of
+                    // the packed state, and the kernel has no register to spare
+                    const float4 A0 = *reinterpret_cast<const float4 *>(rec_a + s0_), B0 = *reinterpret_cast<const float4 *>(rec_b + s0_);
+                    const float2 C0 = *reinterpret_cast<const float2 *>(rec_c + s0_);     // (b, Q11 | y')
+                    v2f aa, ab, ta_a, ta_b;
+                    if (r0)
+                        alphas_ref(A0, B0.x, C0.y, B0.y, fx_, fya, fyb, aa, ab);
+                    else
+                        alphas(A0, B0.x, B0.y, cx, cya, cyb, aa, ab);
+                    checked_pair(aa, Ta, ta_a);
+                    checked_pair(ab, Tb, ta_b);
+                    GSX_ACCUMULATE(ta_a, ta_b, B0.z, B0.w, C0.x);
+                    k += 1;
+                }
+            }
         }
         __syncthreads();
         bool live;
@@ -1014,13 +1063,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         for (uint32_t base = rg.x; base < rg.y; base += 64) {
             uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
             uint32_t count[kBlocks];
-            (void)stage_batch<kStageBlocks>(rec, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16), 16.0f, skipped, count,
-                                            budget);
+            (void)stage_batch<kStageBlocks, (REF || VARIANT == 0)>(rec, qraw, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16),
+                                                                   16.0f, skipped, count, budget);
             cost += 4u * nb;
             __syncthreads();
             for (uint32_t k = 0; k < nb; ++k) {         // every staged record, in order; a lane's block takes what it keeps
                 const Splat s = read_splat(sh, k);
-                composite<4>(cx, cy, s, T, c0, c1, c2, blk, (float)(tx * 16), (float)(ty * 16));
+                composite<4, (REF || VARIANT == 0)>(cx, cy, s, T, c0, c1, c2, blk, (float)(tx * 16), (float)(ty * 16));
             }
             __syncthreads();
             if (__ballot((T[0] > 0.0f) | (T[1] > 0.0f) | (T[2] > 0.0f) | (T[3] > 0.0f)) == 0ull) break;
@@ -1032,6 +1081,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
 
     if (hints.lens && lane == 0) hints.lens[t] = cost;
+    if (REF && hints.redo_hint && lane == 0) hints.redo_hint[t] = saw_ref ? 1 : 0;    // for the next frame of the view
 #ifdef GSX_TEST_HOOKS
     if (g_blend_probe && lane == 0)
         g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t, rg.y - rg.x,
@@ -1060,11 +1110,120 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
 }
 
+// Fast path, tile = 16: one wave per tile, 4 pixels per lane.  A lane owns pixels
+// (x, y..y+3): x is the coordinate its pixels share, so the x-only terms of the exponent are
+// computed once per record.  The assignment (and therefore every bit of the result) is the same
+// for both output layouts; only the store addressing differs:
+//   GSX_LAYOUT_WH3  out[x][y][c]: the lane's 4 pixels are 48 contiguous bytes (3 x dwordx4);
+//   GSX_LAYOUT_HW3  out[y][x][c]: 4 stores of 12 B; the 16 lanes that share a y write 192
+//                   contiguous bytes per store instruction.
+// VARIANT 0: scalar-form composite<4>; VARIANT 1: packed form, four (then two) records per saturation test;
+// VARIANT 2 (test library only): six per test.
+template <int VARIANT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))   // 64 VGPRs: every lost wave costs (DESIGN.md)
+    blend_tile16_kernel(const Record *__restrict__ rec, const float4 *__restrict__ qraw, const uint32_t *__restrict__ vals,
+                        const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
+                        uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints,
+                        uint32_t tile_blocks, uint32_t sched_cap_, TileSpan span) {
+    __shared__ Staged sh;
+    // block order: [spare workgroups: the next frame's splitters] [helpers of long tiles (dispatched first: they have
+    // the most to do)] [tiles] [clears]
+    // (hints.rank_last -- gsx_api.hip: a window whose tiles just about fill the chip once -- : the spare workgroups come
+    // last in the grid instead)
+    const uint32_t nrank = hints.samples ? kRankGroups : 0u;
+    const uint32_t rank0 = hints.rank_last ? gridDim.x - nrank : 0u;
+    // span (GsxParams.n_substrips): this launch composites only the tiles whose column (axis 0) / row (axis 1) lies in
+    // [lo, hi) -- one part of the window; the launch of the first part also runs what a frame does once (the next
+    // frame's splitters, the zero fill of what no tile covers).  The whole grid is launched every time: a workgroup of
+    // another part exits at once (~2 us per launch for the 8 000 of a 1080p frame).
+    if (blockIdx.x - rank0 < nrank) {
+        if (span.first) rank_samples(blockIdx.x - rank0, (int)threadIdx.x, hints);
+        return;
+    }
+    const uint32_t block = hints.rank_last ? blockIdx.x : blockIdx.x - nrank;
+    if (quarters) {
+        // A window of few tiles (a rank's strip): EVERY tile on four waves, a quarter of its pixels each.  One wave per
+        // tile would leave the SIMDs with one to four waves, and a wave with few neighbours needs up to 3.3x its own
+        // issue time per trip (tools/attic/occupancy_probe.py); the quarter form -- one pixel per lane, eight independent
+        // alphas per trip, the gather running ahead -- is built for exactly that situation.  Same arithmetic, same
+        // pixels.  32 consecutive blocks serve 8 tiles; the 4 quarters of a tile share b % 8, i.e. an XCD, and XCD x
+        // gets the x-th eighth of the window's tiles (neighbouring tiles share most of their Gaussians).
+        const uint32_t b = block, nt = (uint32_t)g.count(), groups = (nt + 7u) >> 3;
+        if (b >= groups * 32u) {
+            clear_block(b - groups * 32u, cp, out.ptr);
+            return;
+        }
+        const uint32_t u = ((b >> 5) << 3) | (b & 7u);          // (XCD = b & 7, index inside it = b >> 5)
+        const uint32_t per = nt >> 3, extra = nt & 7u, xcd = b & 7u, i = b >> 5;
+        if (i >= per + (xcd < extra ? 1u : 0u)) return;
+        (void)u;
+        blend_long_tile_quarter<kRefInKernel>(rec, qraw, vals, ranges, g, out, xcd_remap((i << 3) | xcd, nt), (int)((b >> 3) & 3u), sh, budget,
+                                       nullptr, lt.redo, hints.redo_hint);
+        return;
+    }
+    if (block < nhelpers) {
+        // 32 consecutive blocks serve 8 long tiles; the 4 quarters of a tile share b % 8, i.e. an XCD
+        const uint32_t b = block, slot = (b >> 5) * 8u + (b & 7u);
+        const int quarter = (int)((b >> 3) & 3u);
+        if (slot >= min(*lt.count, lt.max)) return;
+        const uint32_t lt_tile = lt.list[slot];
+        {
+            const int lead = span.axis ? g.wy0 + (int)(lt_tile % (uint32_t)g.nwy()) : g.wx0 + (int)(lt_tile / (uint32_t)g.nwy());
+            if (lead < span.lo || lead >= span.hi) return;
+        }
+        blend_long_tile_quarter<kRefInKernel>(rec, qraw, vals, ranges, g, out, lt_tile, quarter, sh, budget,
+                                       hints.lens ? hints.lens + lt_tile : nullptr, lt.redo, hints.redo_hint);
+        return;
+    }
+    const uint32_t bid = block - nhelpers;
+    if (bid >= tile_blocks) {       // (tile_blocks = number of tiles, or 8 x cap with the per-XCD schedule)
+        if (span.first) clear_block(bid - tile_blocks, cp, out.ptr);
+        return;
+    }
+    const uint32_t t = hints.xcd_sched ? xcd_scheduled_tile(bid, (uint32_t)g.count(), sched_cap_, sched, hints.header)
+                                       : scheduled_tile(bid, (uint32_t)g.count(), sched);
+    if (t >= (uint32_t)g.count()) return;
+    blend_tile16<VARIANT, kRefInKernel>(rec, qraw, vals, ranges, g, out, lt, budget, hints, span, t, sh);
+}
+
+// The tiles and long-tile quarters the launch above left in the redo list (push_redo), composited with reference-order
+// records evaluated by the reference's own operations.  Same staging, same rules, same pixel assignment as the first
+// launch -- a tile is composited by exactly one of the two, from its first record.  128 VGPRs (4 waves per SIMD): the
+// extra evaluation and the record kinds side by side do not fit the first launch's 64.  A fixed, small grid walks the
+// list (its length exists only in device memory); with nothing in it the launch is ~1.5 us of the frame.
+constexpr unsigned kRedoBlocks = 4096;    // (the chip holds 4096 of its waves at a time)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+    blend_redo_kernel(const Record *__restrict__ rec, const float4 *__restrict__ qraw, const uint32_t *__restrict__ vals,
+                      const uint2 *__restrict__ ranges,
+                      TileGrid g, OutDesc out, LongTiles lt, uint32_t budget, BlendHints hints, TileSpan span, uint32_t capacity) {
+    __shared__ Staged sh;
+    const uint32_t n = min(lt.redo[0], capacity);
+    // the workgroups PULL their entries (one atomic per tile on the part's queue head): tiles differ by orders of magnitude
+    // in length, a fixed stride would leave the launch waiting for whoever drew the long ones
+    // (a workgroup's first entry is its own index -- an empty list costs no atomic at all --, the following ones come from
+    // the queue, which starts behind the grid)
+    for (uint32_t i = blockIdx.x; i < n;) {
+        const uint32_t t = lt.redo[kRedoHeader + 2 * i], mode = lt.redo[kRedoHeader + 1 + 2 * i];
+        if (mode == 0u) {
+            blend_tile16<1, true>(rec, qraw, vals, ranges, g, out, lt, budget, hints, span, t, sh);
+        } else {
+            const int lead = span.axis ? g.wy0 + (int)(t % (uint32_t)g.nwy()) : g.wx0 + (int)(t / (uint32_t)g.nwy());
+            if (lead >= span.lo && lead < span.hi)
+                blend_long_tile_quarter<true>(rec, qraw, vals, ranges, g, out, t, (int)mode - 1, sh, budget,
+                                              hints.lens ? hints.lens + t : nullptr, nullptr, nullptr);
+        }
+        __syncthreads();
+        uint32_t next = 0;
+        if (threadIdx.x == 0) next = gridDim.x + atomicAdd(lt.redo + 1 + span.index, 1u);
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    }
+}
+
 // Any tile size: one wave per tile, one pixel per lane, tile*tile/64 sweeps over the list.
 // Same arithmetic as the fast path; exists so that tile_size is a run-time argument as in the
 // reference (its notebooks use 16 and 2).
 __global__ void __launch_bounds__(64)
-    blend_generic_kernel(const Record *__restrict__ rec, const uint32_t *__restrict__ vals,
+    blend_generic_kernel(const Record *__restrict__ rec, const float4 *__restrict__ qraw, const uint32_t *__restrict__ vals,
                          const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp) {
     __shared__ Staged sh;
     if (blockIdx.x >= (uint32_t)g.count()) {
@@ -1093,9 +1252,9 @@ __global__ void __launch_bounds__(64)
         for (uint32_t base = rg.x; base < rg.y; base += 64) {
             uint32_t nb = min(64u, rg.y - base);
             if (blocks)
-                (void)stage_batch<kStageBlocks>(rec, vals, base, nb, sh, lane, (float)(tx * Ts), (float)(ty * Ts), (float)Ts, skipped, count);
+                (void)stage_batch<kStageBlocks>(rec, qraw, vals, base, nb, sh, lane, (float)(tx * Ts), (float)(ty * Ts), (float)Ts, skipped, count);
             else
-                (void)stage_batch<kStageWhole>(rec, vals, base, nb, sh, lane, (float)(tx * Ts), (float)(ty * Ts), (float)Ts, skipped, count);
+                (void)stage_batch<kStageWhole>(rec, qraw, vals, base, nb, sh, lane, (float)(tx * Ts), (float)(ty * Ts), (float)Ts, skipped, count);
             __syncthreads();
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
@@ -1397,7 +1556,7 @@ hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s) {
 }
 
 // Up to this many tiles in the window every tile is composited by four waves (blend_tile16_kernel, `quarters`).
-// Measured (round 3, tools/strip_probe.py with GSX_QUARTERS_BELOW): it does NOT pay -- a 1/8 strip of the 5M / 4K frame
+// Measured (round 3, tools/attic/strip_probe.py with GSX_QUARTERS_BELOW): it does NOT pay -- a 1/8 strip of the 5M / 4K frame
 // composites in 0.192 ms on one wave per tile and in 0.314 ms on four, 1M / 1080p: 0.073 vs 0.090 ms; the quarter form
 // issues 14 operations per pixel and record where the 4-pixel form shares the x terms (11.25) and stages every
 // record four times.  The mode stays in the kernel (default off) as the strongest test of the quarter path: a frame
@@ -1477,15 +1636,24 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
         grid_blocks += bh.samples ? kRankGroups : 0u;
         const uint32_t q = quarters ? 1u : 0u;
         if (variant == 0)
-            blend_tile16_kernel<0><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
+            blend_tile16_kernel<0><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         else if (variant == 2)
-            blend_tile16_kernel<2><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
+            blend_tile16_kernel<2><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         else if (variant == 3)
-            blend_tile16_kernel<3><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
+            blend_tile16_kernel<3><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         else
-            blend_tile16_kernel<1><<<grid_blocks, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
+            blend_tile16_kernel<1><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
+        // what the launch left for the second one: tiles that hold ill-conditioned footprints (see blend_redo_kernel;
+        // VARIANT 0 -- test library -- evaluates every record kind in place and leaves nothing)
+        if (variant != 0 && lt.redo && !kRefInKernel) {
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            const uint32_t capacity = (uint32_t)nt + 4u * kMaxLongTiles;
+            blend_redo_kernel<<<(unsigned)min((int64_t)kRedoBlocks, nt + 4 * (int64_t)kMaxLongTiles), 64, 0, s>>>(
+                rec, bbox, sorted_vals, ranges, grid, out, lt, budget, bh, span, capacity);
+        }
     } else {
-        blend_generic_kernel<<<nb, 64, 0, s>>>(rec, sorted_vals, ranges, grid, out, cp);
+        blend_generic_kernel<<<nb, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp);
     }
     return hipGetLastError();
 }

@@ -39,7 +39,7 @@ GSX_API int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, vo
  * the probe off.  While set, every workgroup of the tile-16 REF_CPU compositing kernel stores (cycles it ran, window-
  * local tile id | 1 << 30 for a long tile's helper, length of the tile's list, records staged | saturated << 31) at
  * index blockIdx.x and (batches staged | entries walked under the exact rule << 12, wall clock at its end [10 ns], HW_ID & 0xFFFF | XCC_ID << 16,
- * wall clock at its start) at index 2^17 + blockIdx.x (tools/blend_probe.py, tools/simd_balance.py). */
+ * wall clock at its start) at index 2^17 + blockIdx.x (tools/attic/blend_probe.py, tools/attic/simd_balance.py). */
 GSX_API int gsx_debug_set_blend_probe(void *device_buffer);
 
 #ifdef __cplusplus

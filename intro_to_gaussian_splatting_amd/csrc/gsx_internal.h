@@ -62,6 +62,13 @@ struct LongTiles {
     uint32_t *cost = nullptr;
     const uint32_t *header = nullptr;
     uint32_t cost_pct = 30;
+    // the redo list of the tile-16 REF_CPU compositing launch (gsx_blend.hip: push_redo / blend_redo_kernel): [0] = entries,
+    // [1 .. 16] = the queue heads of up to 16 part launches (all zeroed by the emit kernel), entries (tile, mode) from
+    // [kRedoHeader]; kRedoHeader + 2 (tiles + 4 kMaxLongTiles) words
+    uint32_t *redo = nullptr;
+    // GsxParams.hints, one byte per tile: the tile met an ill-conditioned record last frame.  tile_ranges_kernel then
+    // puts it on the redo list itself and flags it like a long tile, so that the first launch skips it (stale: time only)
+    const uint8_t *redo_hint = nullptr;
 };
 __host__ __device__ inline uint32_t long_tile_threshold(uint32_t pairs, uint32_t tiles) {
     const uint32_t mean = tiles ? pairs / tiles : 0u;
@@ -93,9 +100,10 @@ struct ScheduleHint {
 // ---- gsx_project.hip (compiled with -ffp-contract=off)
 // gsx_preprocess, first kernel: depth keys in original order (kCulledKey behind the cull plane), the 11 floats of
 // every visible Gaussian that the rank-ordered output kernel gathers (in its record slot), the sort's counters zeroed.
-// small_batch: GSX_FLAG_SMALL_BATCH (J @ W in the order the reference's BLAS uses for at most three rows; n <= 3 implies it).
+// visible_rows: 0 = as many of the n Gaussians are visible as n suggests (the default), 1 = GSX_FLAG_ONE_VISIBLE,
+// 2 = GSX_FLAG_SMALL_BATCH (two or three): which of its BLAS's orders the reference's products over the VISIBLE rows take.
 hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int64_t n, uint32_t *keys, Record *stage,
-                                uint32_t *counters, bool small_batch, hipStream_t s);
+                                uint32_t *counters, int visible_rows, hipStream_t s);
 // Original order: depth keys (kCulledKey behind the cull plane, kEmptyKey when no tile of the window is
 // reached), records / rects indexed by the ORIGINAL Gaussian index (only written for the Gaussians that
 // reach a tile; the depth sort generates the identity values itself).
@@ -106,7 +114,7 @@ hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int
 // sh_degree >= 0: in.colors holds spherical-harmonics coefficients, evaluated inline (GsxParams.sh).
 // counters: 4 words this kernel zeroes for the depth sort (culled count, kept count, ...).
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
-                               const TileGrid &grid, int semantics, bool tight_rects, bool small_batch, int sh_degree,
+                               const TileGrid &grid, int semantics, bool tight_rects, int visible_rows, int sh_degree,
                                uint32_t *keys, Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox,
                                const ScheduleHint &sched, hipStream_t s);
 // gsx_preprocess, last kernel: all PreprocessedScene fields in depth order; order[r] = Gaussian of rank r, r < *m_dev.
@@ -127,6 +135,7 @@ struct BinCounts {
     int64_t *stats2_host;        // device-visible alias of a pinned GsxFrameStats (fields 0, 1 and n_kept), or null
     uint32_t *d32;               // min(D, 2^32 - 1): element count of the tile sort
     uint32_t *long_count;        // zeroed by the emit kernel for tile_ranges_kernel (LongTiles.count)
+    uint32_t *redo_count;        // zeroed by the emit kernel for the compositing launch (LongTiles.redo[0])
     const uint32_t *culled_dev;  // Gaussians behind the cull plane (counted by the depth sort), or null
     int64_t n_total;             // n_visible = n_total - *culled_dev
 };
@@ -190,6 +199,9 @@ struct BlendHints {
     uint32_t xcd_sched;         // != 0: `sched` is hints.sched, the per-XCD schedule (gsx_schedule_device.h) -- trusted
                                 // only if header[kHintSched] == number of tiles; 0: tile_schedule_kernel's whole-frame order
     uint32_t rank_last = 0;     // the spare workgroups that rank the samples come last in the grid instead of first
+    // one byte per tile (GsxParams.hints): the tile met an ill-conditioned record last frame, so this frame's first
+    // launch sends it to the redo list at once instead of compositing up to that record in vain (stale: time only)
+    uint8_t *redo_hint = nullptr;
 };
 hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
                               uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,
@@ -214,6 +226,7 @@ bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int6
 struct TileSpan {
     int32_t axis, lo, hi;
     uint32_t first;
+    uint32_t index = 0;         // which part (0 .. 15): the redo launch of a part pulls from a queue head of its own
 };
 // can this kernel family composite a window in parts?  (tile-16 REF_CPU kernel only; the others take one launch)
 bool blend_in_parts(const TileGrid &grid, int semantics, bool generic);

@@ -46,6 +46,21 @@ __device__ __forceinline__ float row4(float p0, float p1, float p2, const float 
     return acc + M[12 + col];
 }
 
+// ... when M is world2view -- a TRANSPOSED view in the reference (splat/image.py:51-53), which its BLAS is told about --
+// and the product has at most three rows, other MKL kernels run (oracle/probe_torch_order.py, "few rows"):
+//   kRowsOne       ((p0 M0 + p1 M1 fused) + M3) + p2 M2, the last product rounded on its own
+//   kRowsTwoThree  (p0 M0 + p2 M2) + (p1 M1 + M3), nothing fused
+// (full_proj_transform is a contiguous bmm result: always the chain above.)  How many rows the reference multiplies:
+// ALL n points in the cull (utils.py:305-307), the N_vis visible ones everywhere else (gaussian_scene.py:79-85,
+// utils.py:333) -- which is what the callers' two "rows" classes are.
+enum { kRowsMany = 0, kRowsOne = 1, kRowsTwoThree = 2 };
+__host__ __device__ __forceinline__ int rows_class(int64_t rows) { return rows == 1 ? kRowsOne : (rows <= 3 ? kRowsTwoThree : kRowsMany); }
+__device__ __forceinline__ float row4_view(float p0, float p1, float p2, const float *M, int col, int rows) {
+    if (rows == kRowsOne) return (fmaf(p1, M[4 + col], p0 * M[0 + col]) + M[12 + col]) + p2 * M[8 + col];
+    if (rows == kRowsTwoThree) return (p0 * M[0 + col] + p2 * M[8 + col]) + (p1 * M[4 + col] + M[12 + col]);
+    return row4(p0, p1, p2, M, col);
+}
+
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // Sigma = (R S)(R S)^T with the quaternion normalised twice (F.normalize, then build_rotation's
@@ -89,12 +104,14 @@ __device__ __forceinline__ void covariance3d(float s0, float s1, float s2, float
 // zeros J01, J10 are skipped: adding an exact zero -- or fusing a product with one -- does not change a float32
 // sum.  J @ W and ... @ W^T multiply the whole batch by ONE 3x3: torch folds each into an sgemm (sequential FMA
 // over k); the two products between batched matrices round every product and sum.
-// small_batch: the reference multiplied at most three J's at once (N_vis <= 3), which MKL evaluates as
-// (k0 + k2) + k1 with nothing fused (oracle/probe_torch_order.py).
+// vis: the rows class of the reference's N_vis (rows_class): with at most three visible Gaussians its BLAS also
+// evaluates ... @ W^T -- W^T is world2view[:3,:3], a column-major view -- as (k0 + k2) + k1 with nothing fused
+// (oracle/probe_torch_order.py).
 __device__ __forceinline__ void ewa_covariance(const GsxCamera &cam, float fx, float fy, float p0, float p1, float p2,
-                                               float tz, const float (&S)[3][3], Projected &o, bool small_batch) {
+                                               float tz, const float (&S)[3][3], Projected &o, int vis) {
     const float *V = cam.world2view;
-    float tx = row4(p0, p1, p2, V, 0), ty = row4(p0, p1, p2, V, 1);
+    const bool small_batch = vis != kRowsMany;
+    float tx = row4_view(p0, p1, p2, V, 0, vis), ty = row4_view(p0, p1, p2, V, 1, vis);
     float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
     float cx = fminf(fmaxf(tx / tz, -limx), limx) * tz;
     float cy = fminf(fmaxf(ty / tz, -limy), limy) * tz;
@@ -106,8 +123,8 @@ __device__ __forceinline__ void ewa_covariance(const GsxCamera &cam, float fx, f
     float A[2][3], B[2][3], C[2][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        A[0][j] = small_batch ? j00 * V[j * 4 + 0] + j02 * V[j * 4 + 2] : fmaf(j02, V[j * 4 + 2], j00 * V[j * 4 + 0]);
-        A[1][j] = small_batch ? j12 * V[j * 4 + 2] + j11 * V[j * 4 + 1] : fmaf(j12, V[j * 4 + 2], j11 * V[j * 4 + 1]);
+        A[0][j] = fmaf(j02, V[j * 4 + 2], j00 * V[j * 4 + 0]);
+        A[1][j] = fmaf(j12, V[j * 4 + 2], j11 * V[j * 4 + 1]);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -116,7 +133,9 @@ __device__ __forceinline__ void ewa_covariance(const GsxCamera &cam, float fx, f
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) C[i][j] = fmaf(B[i][2], V[2 * 4 + j], fmaf(B[i][1], V[1 * 4 + j], B[i][0] * V[0 * 4 + j]));
+        for (int j = 0; j < 3; ++j)
+            C[i][j] = small_batch ? (B[i][0] * V[0 * 4 + j] + B[i][2] * V[2 * 4 + j]) + B[i][1] * V[1 * 4 + j]
+                                  : fmaf(B[i][2], V[2 * 4 + j], fmaf(B[i][1], V[1 * 4 + j], B[i][0] * V[0 * 4 + j]));
     o.ca = C[0][0] * j00 + C[0][2] * j02;
     o.cb = C[0][1] * j11 + C[0][2] * j12;
     o.cc = C[1][0] * j00 + C[1][2] * j02;
@@ -150,7 +169,7 @@ __device__ __forceinline__ void finish_projection(float tz, Projected &o) {
 // Everything of stage 1 for one visible Gaussian.
 __device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1, float p2, float tz,
                                         float s0, float s1, float s2, float qw, float qx, float qy, float qz,
-                                        Projected &o, bool small_batch) {
+                                        Projected &o, int vis) {
     const float *F = cam.full_proj;
     float S[3][3];
     covariance3d(s0, s1, s2, qw, qx, qy, qz, S);
@@ -162,7 +181,7 @@ __device__ __forceinline__ void project(const GsxCamera &cam, float p0, float p1
     o.x = (ndcx + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
     o.y = (ndcy + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
 
-    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o, small_batch);
+    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o, vis);
     finish_projection(tz, o);
 }
 
@@ -179,7 +198,7 @@ __device__ __forceinline__ bool project_std(const GsxCamera &cam, float p0, floa
     o.x = ((ndcx + 1.0f) * (float)cam.width - 1.0f) * 0.5f;
     o.y = ((ndcy + 1.0f) * (float)cam.height - 1.0f) * 0.5f;
     float fx = (float)cam.width / (2.0f * cam.tan_fovx), fy = (float)cam.height / (2.0f * cam.tan_fovy);
-    ewa_covariance(cam, fx, fy, p0, p1, p2, tz, S, o, false);
+    ewa_covariance(cam, fx, fy, p0, p1, p2, tz, S, o, kRowsMany);
     o.ca = o.ca + 0.3f;
     o.cd = o.cd + 0.3f;
     o.cc = o.cb;
@@ -309,21 +328,21 @@ __device__ __forceinline__ uint32_t tile_rect(float mnx, float mxx, float mny, f
 // 64-byte sectors per Gaussian -- took 124 us at 1M.)  Also zeroes the sort's device counters (no memset node).
 __global__ void __launch_bounds__(kBlock)
     project_stage_kernel(GsxCamera cam, GaussiansIn in, int64_t n, uint32_t *__restrict__ keys, Record *__restrict__ stage,
-                         uint32_t *__restrict__ counters, bool small_batch) {
+                         uint32_t *__restrict__ counters, int vis) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < 4) counters[i] = 0u;
     if (i >= n) return;
     const float *p = in.means3d + 3 * i;
     const float p0 = p[0], p1 = p[1], p2 = p[2];
-    const float tz = row4(p0, p1, p2, cam.world2view, 2);
-    if (!(tz >= 0.2f)) {                                          // utils.py:293-310
+    if (!(row4_view(p0, p1, p2, cam.world2view, 2, rows_class(n)) >= 0.2f)) {      // utils.py:293-310: all n rows at once
         keys[i] = kCulledKey;
         return;
     }
+    const float tz = row4_view(p0, p1, p2, cam.world2view, 2, vis);                // gaussian_scene.py:79-85: the visible rows
     keys[i] = __float_as_uint(tz);
     const float *s = in.scales + 3 * i, *q = in.quats + 4 * i, *c = in.colors + 3 * i;
     Projected o;
-    project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o, small_batch);
+    project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o, vis);
     Record r;
     r.a = make_float4(o.x, o.y, c[0], c[1]);
     r.b = make_float4(c[2], tz, sigmoidf(in.opacity_logit[i]), o.ca);
@@ -345,7 +364,7 @@ __device__ __forceinline__ float trunc_to_int(float v) {
 
 __device__ __forceinline__ void pack_record(int semantics, float x, float y, float q00, float q01, float q10,
                                             float q11, float op, float cr, float cg, float cb, float depth,
-                                            Record &out) {
+                                            Record &out, float4 *qraw) {
     const float k = -0.5f * 1.44269504088896340736f;
     if (semantics == GSX_SEM_REF_CUDA) {
         x = trunc_to_int(x);
@@ -374,14 +393,19 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
         // x e^-x <= 1/e: the reference's alpha differs from the exact one by up to 8.8e-8 op rho anywhere on the
         // footprint (measured: a seventh of that on the 250:1 needles of tests/golden/needle_160x160_n110, 5.4e-4).
         // Beyond 3e-5 -- rho op > 340, axis ratios from ~20:1 -- the completed square, which is exact to 1e-5, is no
-        // longer "the reference's result to 1e-4": the record then carries the raw float32 entries and the
-        // compositing kernels execute the reference's operations on it, one for one (alphas_ref in gsx_blend.hip).
-        const double cc = 0.5 * fabs((double)q01 + (double)q10) / sqrt((double)q00 * (double)q11);
-        const bool ref_order = ok && q00 > 0.0f && q11 > 0.0f && cc < 1.0 && 8.8e-8 * (double)op * (1.0 + cc) / (1.0 - cc) > 3e-5;
-        if (ref_order) {
-            out.a = make_float4(x, y, q00, q01);
-            out.b = make_float4(q10, op, cr, cg);
-            out.c = make_float4(cb, q11, 2.0f, 0.0f);
+        // longer "the reference's result to 1e-4": the record is flagged, its raw float32 conic goes to the Gaussian's
+        // slot of the side array (`qraw`: the workspace's per-Gaussian float4, which only REF_CUDA uses otherwise) and
+        // the compositing kernels execute the reference's operations on it, one for one (alpha_ref in gsx_blend.hip).
+        // (float32 is plenty for a threshold; the square root is the correctly rounded one of this translation unit)
+        const float cc = 0.5f * fabsf(q01 + q10) / sqrtf(q00 * q11);
+        const bool ref_order = ok && q00 > 0.0f && q11 > 0.0f && cc < 1.0f && 8.8e-8f * op * (1.0f + cc) > 3e-5f * (1.0f - cc);
+        if (ref_order && qraw) {
+            // the completed square as for any record (the skip bounds of the compositing kernels are computed from it),
+            // the opacity factor itself where the depth would be, and the raw conic in the Gaussian's side slot
+            out.a = make_float4(x, y, fd, fh);
+            out.b = make_float4(fr, log2f(op), cr, cg);
+            out.c = make_float4(cb, op, 2.0f, 0.0f);
+            *qraw = make_float4(q00, q01, q10, q11);
             return;
         }
         out.a = ok ? make_float4(x, y, fd, fh) : make_float4(x, y, Q00, Qs);
@@ -407,7 +431,7 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
 template <bool DEVICE_CAMERA, int SHDEG, bool WINDOWED>
 __global__ void __launch_bounds__(kBlock)
     project_pack_kernel(GsxCamera cam_arg, const GsxCamera *__restrict__ cam_dev, GaussiansIn in, int64_t n,
-                        TileGrid grid, int semantics, bool tight, bool small_batch,
+                        TileGrid grid, int semantics, bool tight, int vis,
                         uint32_t *__restrict__ keys, Record *__restrict__ rec,
                         TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox,
                         bool sh_vec, SchedJob sched_job) {
@@ -460,8 +484,8 @@ __global__ void __launch_bounds__(kBlock)
     if (g < n) {
         const float *p = in.means3d + 3 * g;
         const float p0 = p[0], p1 = p[1], p2 = p[2];
-        const float tz = row4(p0, p1, p2, cam.world2view, 2);
-        if (std3dgs ? !(tz > 0.2f) : !(tz >= 0.2f)) {               // utils.py:293-310
+        const float tz = row4_view(p0, p1, p2, cam.world2view, 2, std3dgs ? (int)kRowsMany : rows_class(n));
+        if (std3dgs ? !(tz > 0.2f) : !(tz >= 0.2f)) {               // utils.py:293-310 (all n rows at once)
             keys[g] = kCulledKey;
         } else {
             survives = true;
@@ -526,11 +550,14 @@ __global__ void __launch_bounds__(kBlock)
     // ---- phase 2 (WINDOWED: survivors only, dense): the exact projection
     const float *p = in.means3d + 3 * g;
     const float p0 = p[0], p1 = p[1], p2 = p[2];
-    const float tz = row4(p0, p1, p2, cam.world2view, 2);
-    if (!WINDOWED && (std3dgs ? !(tz > 0.2f) : !(tz >= 0.2f))) {               // utils.py:293-310
+    // the cull multiplies all n points at once (utils.py:305-307), everything after it the visible ones (its rows class
+    // is `vis`): below four rows the two products differ in their last bit (row4_view)
+    const float tz_cull = row4_view(p0, p1, p2, cam.world2view, 2, std3dgs ? (int)kRowsMany : rows_class(n));
+    if (!WINDOWED && (std3dgs ? !(tz_cull > 0.2f) : !(tz_cull >= 0.2f))) {               // utils.py:293-310
         keys[g] = kCulledKey;
         return;
     }
+    const float tz = row4_view(p0, p1, p2, cam.world2view, 2, std3dgs ? (int)kRowsMany : vis);
     const float *s = in.scales + 3 * g, *q = in.quats + 4 * g;
     const float s0 = s[0], s1 = s[1], s2 = s[2];
     Projected o;
@@ -538,7 +565,7 @@ __global__ void __launch_bounds__(kBlock)
     if (std3dgs)
         keep = project_std(cam, p0, p1, p2, tz, s0, s1, s2, q[0], q[1], q[2], q[3], o);
     else
-        project(cam, p0, p1, p2, tz, s0, s1, s2, q[0], q[1], q[2], q[3], o, small_batch);
+        project(cam, p0, p1, p2, tz, s0, s1, s2, q[0], q[1], q[2], q[3], o, vis);
     TileRect tr;
     uint32_t cnt = std3dgs ? tile_rect(o.x, o.radius, o.y, o.radius, grid, semantics, tr)
                            : tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, semantics, tr);
@@ -577,9 +604,9 @@ __global__ void __launch_bounds__(kBlock)
         cr = c[0]; cg = c[1]; cb = c[2];
     }
     Record out;
-    pack_record(semantics, o.x, o.y, o.q00, o.q01, o.q10, o.q11, op, cr, cg, cb, o.depth, out);
+    pack_record(semantics, o.x, o.y, o.q00, o.q01, o.q10, o.q11, op, cr, cg, cb, o.depth, out, bbox ? bbox + g : nullptr);
     rec[g] = out;
-    if (bbox) bbox[g] = make_float4(o.min_x, o.max_x, o.min_y, o.max_y);
+    if (bbox && semantics == GSX_SEM_REF_CUDA) bbox[g] = make_float4(o.min_x, o.max_x, o.min_y, o.max_y);
     rect[g] = tr;
 }
 
@@ -624,9 +651,9 @@ __global__ void __launch_bounds__(kBlock)
     Record out;
     pack_record(semantics, in.means[2 * r], in.means[2 * r + 1], in.inv_cov[4 * r], in.inv_cov[4 * r + 1],
                 in.inv_cov[4 * r + 2], in.inv_cov[4 * r + 3], op, in.colors[3 * r], in.colors[3 * r + 1],
-                in.colors[3 * r + 2], 0.0f, out);
+                in.colors[3 * r + 2], 0.0f, out, bbox ? bbox + r : nullptr);
     rec[r] = out;
-    if (bbox) bbox[r] = make_float4(mnx, mxx, mny, mxy);
+    if (bbox && semantics == GSX_SEM_REF_CUDA) bbox[r] = make_float4(mnx, mxx, mny, mxy);
     TileRect tr;
     tile_rect(mnx, mxx, mny, mxy, grid, semantics, tr);
     rect[r] = tr;
@@ -638,7 +665,7 @@ __global__ void __launch_bounds__(kBlock)
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float p0 = means3d[3 * i], p1 = means3d[3 * i + 1], p2 = means3d[3 * i + 2];
-    float tz = row4(p0, p1, p2, cam.world2view, 2);
+    float tz = row4_view(p0, p1, p2, cam.world2view, 2, rows_class(n));      // in_view_frustum: all n rows at once
     const float *F = cam.full_proj;
     float cw = row4(p0, p1, p2, F, 3);
     float nx = row4(p0, p1, p2, F, 0) / cw, ny = row4(p0, p1, p2, F, 1) / cw, nz = row4(p0, p1, p2, F, 2) / cw;
@@ -670,14 +697,14 @@ __global__ void __launch_bounds__(kBlock)
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float p0 = points[3 * i], p1 = points[3 * i + 1], p2 = points[3 * i + 2];
-    const float tz = row4(p0, p1, p2, cam.world2view, 2);
+    const float tz = row4_view(p0, p1, p2, cam.world2view, 2, rows_class(n));       // the caller's n rows are the batch
     float S[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) S[a][b] = cov3d[9 * i + 3 * a + b];
     Projected o;
-    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o, n <= 3);
+    ewa_covariance(cam, cam.fx, cam.fy, p0, p1, p2, tz, S, o, rows_class(n));
     out[4 * i] = o.ca; out[4 * i + 1] = o.cb; out[4 * i + 2] = o.cc; out[4 * i + 3] = o.cd;
 }
 
@@ -699,15 +726,15 @@ hipError_t launch_covariance3d(const float *scales, const float *quats, int64_t 
 }
 
 hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int64_t n, uint32_t *keys, Record *stage,
-                                uint32_t *counters, bool small_batch, hipStream_t s) {
+                                uint32_t *counters, int visible_rows, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    project_stage_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, n, keys, stage, counters, small_batch || n <= 3);
+    project_stage_kernel<<<blocks_for(n), kBlock, 0, s>>>(cam, in, n, keys, stage, counters, visible_rows ? visible_rows : rows_class(n));
     return hipGetLastError();
 }
 
 template <int SHDEG>
 static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
-                                    const TileGrid &grid, int semantics, bool tight_rects, bool small_batch, uint32_t *keys,
+                                    const TileGrid &grid, int semantics, bool tight_rects, int visible_rows, uint32_t *keys,
                                     Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, const ScheduleHint &sh,
                                     hipStream_t s) {
     const SchedJob job{sh.lens, sh.sched, sh.header, sh.ntiles, sh.nwy, sched_cap(sh.ntiles, sh.nwy)};
@@ -717,7 +744,7 @@ static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_d
     const bool windowed = grid.wx0 > 0 || grid.wy0 > 0 || grid.wx1 < grid.ntx || grid.wy1 < grid.nty;
 #define GSX_LAUNCH_PP(DC, WIN)                                                                                          \
     project_pack_kernel<DC, SHDEG, WIN><<<blocks_for(n) + spare, kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics, \
-                                                                         tight_rects, small_batch || n <= 3, keys, rec, rect, counters, bbox, vec, job)
+                                                                         tight_rects, visible_rows ? visible_rows : rows_class(n), keys, rec, rect, counters, bbox, vec, job)
     if (cam_device) {
         if (windowed) GSX_LAUNCH_PP(true, true); else GSX_LAUNCH_PP(true, false);
     } else {
@@ -728,16 +755,16 @@ static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_d
 
 // sh_degree < 0: in.colors is (n,3) RGB; 0..3: in.colors is (n, (degree+1)^2, 3) spherical harmonics.
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
-                               const TileGrid &grid, int semantics, bool tight_rects, bool small_batch, int sh_degree,
+                               const TileGrid &grid, int semantics, bool tight_rects, int visible_rows, int sh_degree,
                                uint32_t *keys, Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox,
                                const ScheduleHint &sched, hipStream_t s) {
     if (n == 0) return hipSuccess;
     switch (sh_degree) {
-        case 0: launch_project_pack_deg<0>(cam, cam_device, in, n, grid, semantics, tight_rects, small_batch, keys, rec, rect, counters, bbox, sched, s); break;
-        case 1: launch_project_pack_deg<1>(cam, cam_device, in, n, grid, semantics, tight_rects, small_batch, keys, rec, rect, counters, bbox, sched, s); break;
-        case 2: launch_project_pack_deg<2>(cam, cam_device, in, n, grid, semantics, tight_rects, small_batch, keys, rec, rect, counters, bbox, sched, s); break;
-        case 3: launch_project_pack_deg<3>(cam, cam_device, in, n, grid, semantics, tight_rects, small_batch, keys, rec, rect, counters, bbox, sched, s); break;
-        default: launch_project_pack_deg<-1>(cam, cam_device, in, n, grid, semantics, tight_rects, small_batch, keys, rec, rect, counters, bbox, sched, s); break;
+        case 0: launch_project_pack_deg<0>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, s); break;
+        case 1: launch_project_pack_deg<1>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, s); break;
+        case 2: launch_project_pack_deg<2>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, s); break;
+        case 3: launch_project_pack_deg<3>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, s); break;
+        default: launch_project_pack_deg<-1>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, s); break;
     }
     return hipGetLastError();
 }

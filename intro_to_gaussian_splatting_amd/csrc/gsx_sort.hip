@@ -1309,7 +1309,7 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
 //   n <= 16 384                    one workgroup does everything in LDS
 //   kept <= 1.5M                   256 buckets   (1M Gaussians at 1080p; one rank's strip of 5M at 4K)
 //   beyond                         four compacting LSD passes of 8 bits
-// Measured, depth sort alone (tools/sort_probe.py under rocprofv3, round 3):  1.5M keys: 256 buckets 83 us (72 with
+// Measured, depth sort alone (tools/attic/sort_probe.py under rocprofv3, round 3):  1.5M keys: 256 buckets 83 us (72 with
 // the previous frame's splitters), LSD 107;  2.2M: LSD 137, 1024 buckets 179;  5M: LSD 260, 1024 buckets 284;  5M
 // of which 1/8 kept (a rank's strip): 256 buckets 94 (70 hinted).  The 1024-bucket variant (8192 samples, 1023
 // splitters, hybrid LDS-word / ballot matching) was built for 1.5M .. 6M kept keys and LOSES to the LSD passes at

@@ -304,11 +304,13 @@ class GaussianScene:
                                         *[_ptr(t) for t in (xy, col, c2, dep, inv, rad, mnx, mxx, mny, mxy, sop)],
                                         _ptr(order), ctypes.byref(nvis), ctypes.byref(params), _ptr(ws), ws.numel(),
                                         _stream_handle(dev))
-                # at most three of more than three Gaussians pass the cull: the reference's BLAS then sums J @ W in
-                # another order (GSX_FLAG_SMALL_BATCH, include/gsx.h) -- once more, in that order
-                if rc != _ffi.GSX_OK or not (nvis.value <= 3 < n) or params.flags & _ffi.GSX_FLAG_SMALL_BATCH:
+                # at most three Gaussians pass the cull, fewer than the call assumed: the reference's BLAS then sums its
+                # products over the visible ones in another order (GSX_FLAG_SMALL_BATCH / _ONE_VISIBLE, include/gsx.h) --
+                # once more, in that order
+                again = _ffi.visible_rows_flag(n, int(nvis.value), params.flags) if rc == _ffi.GSX_OK else 0
+                if not again:
                     break
-                params.flags |= _ffi.GSX_FLAG_SMALL_BATCH
+                params.flags = (params.flags & ~(_ffi.GSX_FLAG_SMALL_BATCH | _ffi.GSX_FLAG_ONE_VISIBLE)) | again
         _ffi.check(rc)
         m = nvis.value
         self.last_order = order[:m]
@@ -492,11 +494,14 @@ class GaussianScene:
                 rc = lib.gsx_render_forward(ctypes.byref(cam), *[_ptr(t) for t in tensors], n, tile_size, _ptr(out),
                                             ctypes.byref(params), st_ref, _ptr(ws), nbytes,
                                             _stream_handle(dev))
-                if rc == _ffi.GSX_OK and not speculative and not own and semantics != "std_3dgs" and \
-                        int(st.n_visible) <= 3 < n and not params.flags & _ffi.GSX_FLAG_SMALL_BATCH:
-                    # at most three of more than three Gaussians pass the cull: the reference's BLAS then sums J @ W in
-                    # another order (GSX_FLAG_SMALL_BATCH, include/gsx.h) -- once more, in that order
-                    params.flags |= _ffi.GSX_FLAG_SMALL_BATCH
+                again = 0
+                if rc == _ffi.GSX_OK and not speculative and not own and semantics != "std_3dgs":
+                    again = _ffi.visible_rows_flag(n, int(st.n_visible), params.flags)
+                if again:
+                    # at most three Gaussians pass the cull, fewer than the call assumed: the reference's BLAS then sums
+                    # its products over the visible ones in another order (GSX_FLAG_SMALL_BATCH / _ONE_VISIBLE,
+                    # include/gsx.h) -- once more, in that order
+                    params.flags = (params.flags & ~(_ffi.GSX_FLAG_SMALL_BATCH | _ffi.GSX_FLAG_ONE_VISIBLE)) | again
                     continue
                 if rc != _ffi.GSX_ERR_WORKSPACE_TOO_SMALL or "cap" in own:
                     break

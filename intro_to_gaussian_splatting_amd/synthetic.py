@@ -177,6 +177,21 @@ def make_tie_scene(n: int, width: int, height: int, seed: int = 0, levels: int =
     return sc
 
 
+def make_few_visible_scene(n: int, width: int, height: int, seed: int = 0, visible: int = 2) -> Dict[str, np.ndarray]:
+    """``make_scene`` with all but the first ``visible`` Gaussians moved behind the camera (view depth -1 .. -3): the
+    reference then multiplies at most three Jacobians at once in ``J @ W`` (splat/utils.py:354), which its BLAS sums in
+    another order than larger batches (oracle/probe_torch_order.py; GSX_FLAG_SMALL_BATCH in include/gsx.h)."""
+    sc = make_scene(n=n, width=width, height=height, seed=seed)
+    R, t = _rotation(sc["qvec"]), np.asarray(sc["tvec"], dtype=np.float64)
+    rs = np.random.RandomState(seed + 15485863)
+    m = n - visible
+    p_cam = np.stack([rs.uniform(-1.0, 1.0, m), rs.uniform(-1.0, 1.0, m), rs.uniform(-3.0, -1.0, m)], axis=1)
+    pts = sc["points"].copy()
+    pts[visible:] = ((p_cam - t[None, :]) @ R).astype(np.float32)
+    sc["points"] = pts
+    return sc
+
+
 def _qvec_from_rotation(R: np.ndarray) -> np.ndarray:
     """(w, x, y, z) of a rotation matrix (w >= 0), the inverse of ``_rotation``."""
     K = np.array([

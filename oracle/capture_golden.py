@@ -55,6 +55,13 @@ FIXTURES = {
     # exact view-depth ties among overlapping Gaussians: what torch.argsort (unstable, gaussian_scene.py:117) does
     # with equal keys reaches the image
     "ties_64x64_n400": dict(n=400, width=64, height=64, seed=31, tile=16, generator="ties"),
+    # at most three visible Gaussians: the reference's BLAS sums J @ W in another order then (probe_torch_order.py) --
+    # two of nine visible (the count is only known after the cull), and a scene of three
+    "fewvisible_48x48_n9": dict(n=9, width=48, height=48, seed=37, tile=16, generator="few", visible=2),
+    "three_48x48_n3": dict(n=3, width=48, height=48, seed=41, tile=16),
+    # ... and ONE visible Gaussian (of seven; alone): products with world2view take yet another order on one row
+    "onevisible_48x48_n7": dict(n=7, width=48, height=48, seed=43, tile=16, generator="few", visible=1),
+    "single_48x48_n1": dict(n=1, width=48, height=48, seed=47, tile=16),
 }
 
 # Stage 1 only (the reference's preprocess takes 0.3 .. 1.3 s at these sizes; its render_image would take days):
@@ -102,7 +109,8 @@ def _generate(spec: dict) -> dict:
 
     spec = dict(spec)
     gen = {"needle": synthetic.make_needle_scene, "trained": synthetic.make_trained_like_scene,
-           "ties": synthetic.make_tie_scene, None: synthetic.make_scene}[spec.pop("generator", None)]
+           "ties": synthetic.make_tie_scene, "few": synthetic.make_few_visible_scene,
+           None: synthetic.make_scene}[spec.pop("generator", None)]
     sc = gen(**spec)
     sc.pop("sh", None)              # the reference has no spherical harmonics: the base colour is what it renders
     sc.pop("sh_degree", None)

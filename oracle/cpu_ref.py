@@ -157,9 +157,16 @@ def build_camera(qvec, tvec, fx, fy, width: int, height: int) -> Camera:
 
 # --------------------------------------------------------------------------- stage 1
 
-def _row4(p: np.ndarray, M: np.ndarray, col: int) -> np.ndarray:
+def _row4(p: np.ndarray, M: np.ndarray, col: int, view_rows: Optional[int] = None) -> np.ndarray:
     """Column ``col`` of ``[p,1] @ M`` as torch's (N,4) @ (4,4) executes it: a sequential FMA chain
-    (splat/gaussian_scene.py:79-90, splat/utils.py:305-307, 333)."""
+    (splat/gaussian_scene.py:79-90, splat/utils.py:305-307, 333).  ``view_rows``: M is ``world2view`` -- a TRANSPOSED
+    view in the reference (splat/image.py:51-53) -- and the product has that many rows: with one row MKL computes
+    ((p0 M0 + p1 M1 fused) + M3) + p2 M2, with two or three (p0 M0 + p2 M2) + (p1 M1 + M3) unfused
+    (oracle/probe_torch_order.py); ``full_proj_transform`` is contiguous and always takes the chain."""
+    if view_rows is not None and view_rows == 1:
+        return (fma(p[:, 1], M[1, col], p[:, 0] * M[0, col]) + M[3, col]) + p[:, 2] * M[2, col]
+    if view_rows is not None and view_rows <= 3:
+        return (p[:, 0] * M[0, col] + p[:, 2] * M[2, col]) + (p[:, 1] * M[1, col] + M[3, col])
     acc = p[:, 0] * M[0, col]
     acc = fma(p[:, 1], M[1, col], acc)
     acc = fma(p[:, 2], M[2, col], acc)
@@ -192,7 +199,8 @@ def _mm3(A: np.ndarray, B: np.ndarray) -> np.ndarray:
 
 def _mm3_single(A: np.ndarray, B: np.ndarray, small: bool = False) -> np.ndarray:
     """(N,3,3) @ one (3,3): torch folds it into a (3N,3) @ (3,3) sgemm, a sequential FMA chain over k.
-    ``small``: J @ W with N <= 3 goes to another MKL kernel, (k0 + k2) + k1 with nothing fused."""
+    ``small``: ``X @ W.T`` (W.T = world2view[:3,:3], a column-major view) with N <= 3 goes to another MKL kernel,
+    (k0 + k2) + k1 with nothing fused."""
     C = np.empty_like(A)
     for i in range(3):
         for j in range(3):
@@ -205,9 +213,10 @@ def _mm3_single(A: np.ndarray, B: np.ndarray, small: bool = False) -> np.ndarray
 
 def covariance_2d(points: np.ndarray, cov3d: np.ndarray, cam: Camera) -> np.ndarray:
     """EWA projection of Sigma.  splat/utils.py:320-354.  The rows given are the batch the reference
-    multiplies at once (its N_vis), which selects the kernel of ``J @ W`` (see ``_mm3_single``)."""
+    multiplies at once (its N_vis), which selects the kernel of ``... @ W.T`` (see ``_mm3_single``)."""
     V = cam.world2view
-    tx, ty, tz = _row4(points, V, 0), _row4(points, V, 1), _row4(points, V, 2)
+    rows = points.shape[0]
+    tx, ty, tz = _row4(points, V, 0, rows), _row4(points, V, 1, rows), _row4(points, V, 2, rows)
     limx = FOV_CLAMP * cam.tan_fovx
     limy = FOV_CLAMP * cam.tan_fovy
     x = np.minimum(np.maximum(tx / tz, -limx), limx) * tz
@@ -219,9 +228,9 @@ def covariance_2d(points: np.ndarray, cov3d: np.ndarray, cam: Camera) -> np.ndar
     J[:, 1, 1] = cam.fy / tz
     J[:, 1, 2] = -(cam.fy * y) / (tz * tz)
     Wm = np.ascontiguousarray(V[:3, :3].T)
-    A = _mm3_single(J, Wm, small=n <= 3)
+    A = _mm3_single(J, Wm)
     B = _mm3(A, cov3d)
-    C = _mm3_single(B, np.ascontiguousarray(Wm.T))
+    C = _mm3_single(B, np.ascontiguousarray(Wm.T), small=n <= 3)
     D = _mm3(C, np.ascontiguousarray(np.transpose(J, (0, 2, 1))))
     return np.ascontiguousarray(D[:, :2, :2])
 
@@ -265,13 +274,13 @@ def preprocess(points, colors, scales, quats, opacity_logit, cam: Camera,
     """
     points = np.asarray(points, dtype=f32)
     V, F = cam.world2view, cam.full_proj
-    zv = _row4(points, V, 2)
+    zv = _row4(points, V, 2, points.shape[0])               # the cull multiplies all n points at once
     in_view = zv >= MIN_Z                                   # splat/utils.py:293-310
     idx = np.nonzero(in_view)[0]
     p = points[idx]
     cov3 = covariance_3d(np.asarray(scales, f32), np.asarray(quats, f32))[idx]
 
-    depth = _row4(p, V, 2)
+    depth = _row4(p, V, 2, idx.size)                        # ... everything after it the visible ones
     cw = _row4(p, F, 3)
     ndc_x = _row4(p, F, 0) / cw
     ndc_y = _row4(p, F, 1) / cw

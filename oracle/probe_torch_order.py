@@ -19,7 +19,7 @@ Products probed (paths relative to /root/reference):
                                                            splat/utils.py:305-310, 333-337
   normalize       F.normalize(q, p=2, dim=1)               splat/gaussians.py:59
   R @ S, M @ M^T  batched 3x3                              splat/gaussians.py:66-68
-  J @ W           batched x single (W a transposed view)   splat/utils.py:352-354
+  J @ W           batched x single (W = world2view[:3,:3].T)  splat/utils.py:352-354
   (JW) @ Sigma    batched x batched                        splat/utils.py:354
   ... @ W.T       batched x single (a strided view)        splat/utils.py:354
   ... @ J^T       batched x batched (transposed view)      splat/utils.py:354
@@ -96,7 +96,9 @@ def _rand(rs, *shape, scale=1.0):
 
 
 def _camera(rs):
-    """A world2view-like 4x4 in the reference's row-vector form (last column 0,0,0,1)."""
+    """A world2view-like 4x4 in the reference's row-vector form (last column 0,0,0,1) and in the reference's LAYOUT: a
+    transposed VIEW of the row-major extrinsic matrix (splat/image.py:51-53) -- the BLAS is told about the
+    transposition, and which of its kernels runs depends on it when the product has few rows."""
     q = rs.standard_normal(4)
     q /= np.linalg.norm(q)
     w, x, y, z = q
@@ -106,15 +108,59 @@ def _camera(rs):
     E = np.eye(4)
     E[:3, :3] = R
     E[:3, 3] = rs.standard_normal(3)
-    return torch.from_numpy(E.T.astype(np.float32).copy())
+    return torch.from_numpy(E.astype(np.float32)).transpose(0, 1)
+
+
+def few_rows(rs) -> dict:
+    """Products with at most three rows (a scene with at most three visible Gaussians), the operand layouts as in the
+    reference: which of these hand-written orders reproduce torch -- none of the regular candidates does."""
+    f32 = np.float32
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle.cpu_ref import fma            # exact float32 FMA in numpy
+
+    res = {"[p,1] @ world2view, 1 row: ((p0 M0 + p1 M1 fused) + M3) + p2 M2": 0,
+           "[p,1] @ world2view, 2-3 rows: (p0 M0 + p2 M2) + (p1 M1 + M3), unfused": 0,
+           "[p,1] @ full_proj, 1-3 rows: sequential FMA": 0,
+           "X @ world2view[:3,:3] (= W.T), 1-3 batches: (k0 + k2) + k1, unfused": 0,
+           "J @ world2view[:3,:3].T (= W), 1-3 batches: sequential FMA": 0}
+    for _ in range(200):
+        for n in (1, 2, 3):
+            V = _camera(rs)
+            Vn = np.ascontiguousarray(V.numpy())
+            p = _rand(rs, n, 3, scale=3.0)
+            h = torch.cat([p, torch.ones(n, 1)], dim=1)
+            pn = p.numpy()
+            got = (h @ V).numpy()
+            if n == 1:
+                c = np.stack([(fma(pn[:, 1], Vn[1, j], pn[:, 0] * Vn[0, j]) + Vn[3, j]) + pn[:, 2] * Vn[2, j] for j in range(4)], 1)
+                res["[p,1] @ world2view, 1 row: ((p0 M0 + p1 M1 fused) + M3) + p2 M2"] += count_diff(torch.from_numpy(got), c.astype(f32))
+            else:
+                c = np.stack([(pn[:, 0] * Vn[0, j] + pn[:, 2] * Vn[2, j]) + (pn[:, 1] * Vn[1, j] + Vn[3, j]) for j in range(4)], 1)
+                res["[p,1] @ world2view, 2-3 rows: (p0 M0 + p2 M2) + (p1 M1 + M3), unfused"] += count_diff(torch.from_numpy(got), c.astype(f32))
+            F = _rand(rs, 4, 4)
+            res["[p,1] @ full_proj, 1-3 rows: sequential FMA"] += count_diff(h @ F, cand_bmm(h.numpy()[:, None, :], F.numpy(), "fma_seq").reshape(n, 4))
+            X = _rand(rs, n, 3, 3)
+            W = V[:3, :3].T
+            Wt = np.ascontiguousarray(W.T.numpy())
+            Xn = X.numpy()
+            c = np.empty_like(Xn)
+            for i in range(3):
+                for j in range(3):
+                    c[:, i, j] = (Xn[:, i, 0] * Wt[0, j] + Xn[:, i, 2] * Wt[2, j]).astype(f32) + Xn[:, i, 1] * Wt[1, j]
+            res["X @ world2view[:3,:3] (= W.T), 1-3 batches: (k0 + k2) + k1, unfused"] += count_diff(X @ W.T, c)
+            res["J @ world2view[:3,:3].T (= W), 1-3 batches: sequential FMA"] += count_diff(
+                X @ W, cand_bmm(Xn, np.ascontiguousarray(W.numpy()), "fma_seq"))
+    return {"product": "few rows (N_vis <= 3), reference layouts", "elements": None, "bit_differences": res,
+            "exact": [k for k, v in res.items() if v == 0]}
 
 
 def main() -> None:
     global LIB
     LIB = _build()
     rs = np.random.RandomState(0)
-    sizes = [1, 3, 7, 64, 1000, 100_000, 1_000_000]
-    small = [1, 3, 7, 64, 1000, 100_000]
+    # four rows and up (what a product of at most three rows executes is another matter: few_rows)
+    sizes = [4, 5, 7, 64, 1000, 100_000, 1_000_000]
+    small = [4, 5, 7, 64, 1000, 100_000]
     threads = [1, 8]
     out = []
 
@@ -128,8 +174,20 @@ def main() -> None:
         return h, _rand(rs, 4, 4)
 
     f_view.make = mk_view
-    out.append(probe("[p,1] @ M (N,4)@(4,4), cat-built h", f_view,
+    out.append(probe("[p,1] @ full_proj (N,4)@(4,4), contiguous M (a bmm result)", f_view,
                      lambda h, M, m: cand_bmm(h.numpy()[:, None, :], M.numpy(), m), sizes, threads, rs))
+
+    def mk_view_t(n, rs):
+        p = _rand(rs, n, 3, scale=3.0)
+        return torch.cat([p, torch.ones(n, 1)], dim=1), _camera(rs)
+
+    f_view_t = lambda h, M: h @ M  # noqa: E731
+    f_view_t.make = mk_view_t
+    out.append(probe("[p,1] @ world2view (N,4)@(4,4), M a transposed view, N >= 4", f_view_t,
+                     lambda h, M, m: cand_bmm(h.numpy()[:, None, :], np.ascontiguousarray(M.numpy()), m), sizes, threads, rs))
+
+    # few rows (N <= 3): other MKL kernels, found by exhaustive search over orders (see few_rows below)
+    out.append(few_rows(rs))
 
     # in_view_frustum builds h with ones + slice assignment and multiplies by the view matrix (utils.py:305-307)
     def f_frustum(h, M):

@@ -17,7 +17,8 @@
  *   (N,4) @ (4,4) and (N,3,3) @ (3,3)   folded into one sgemm: a sequential FMA chain over k
  *   (N,3,3) @ (N,3,3) (batched)         ATen's own loop: products and sums rounded one by one
  *   (1,2) @ (2,2) then (1,2) @ (2,1)    the first fuses (sgemm), the second does not (dot)
- *   N <= 3 rows of J @ W                another MKL kernel: (k0 + k2) + k1, nothing fused
+ *   ... @ W.T with N_vis <= 3           another MKL kernel: (k0 + k2) + k1, nothing fused (W.T is world2view[:3,:3],
+ *                                       a column-major view -- the layout decides, see the probe)
  * and pinned against the reference itself at N = 1e5 and 1e6 (tests/test_oracle_golden.py).
  *
  * Reference lines restated (paths relative to /root/reference):
@@ -47,6 +48,17 @@ static inline float row4(const float *p, const float *M, int col) {
     return acc + M[3 * 4 + col];                       /* fma(1, M3, acc) */
 }
 
+/* ... when M is world2view -- a TRANSPOSED view in the reference (splat/image.py:51-53), which its BLAS is told about --
+ * and the product has at most three rows, other MKL kernels run (probe_torch_order.py, "few rows"):
+ *   one row          ((p0 M0 + p1 M1 fused) + M3) + p2 M2, the last product rounded on its own
+ *   two, three rows  (p0 M0 + p2 M2) + (p1 M1 + M3), nothing fused
+ * full_proj_transform is a contiguous bmm result: always the chain above. */
+static inline float row4_view(const float *p, const float *M, int col, int64_t rows) {
+    if (rows == 1) return (fmaf(p[1], M[1 * 4 + col], p[0] * M[0 * 4 + col]) + M[3 * 4 + col]) + p[2] * M[2 * 4 + col];
+    if (rows <= 3) return (p[0] * M[0 * 4 + col] + p[2] * M[2 * 4 + col]) + (p[1] * M[1 * 4 + col] + M[3 * 4 + col]);
+    return row4(p, M, col);
+}
+
 /* batched (N,3,3) @ (N,3,3): every product and sum rounded on its own */
 static void mm3(const float *A, const float *B, float *C) {
     for (int i = 0; i < 3; ++i)
@@ -61,8 +73,8 @@ static void mm3_fma(const float *A, const float *B, float *C) {
             C[i * 3 + j] = fmaf(A[i * 3 + 2], B[2 * 3 + j], fmaf(A[i * 3 + 1], B[1 * 3 + j], A[i * 3 + 0] * B[0 * 3 + j]));
 }
 
-/* ... except J @ W (W a transposed view) with at most 3 matrices in the batch, which MKL evaluates as
- * (k0 + k2) + k1 with nothing fused (probe_torch_order.py, "small batch") */
+/* ... except X @ W.T (W.T = world2view[:3,:3], a column-major view of the camera matrix) with at most 3 matrices in the
+ * batch, which MKL evaluates as (k0 + k2) + k1 with nothing fused (probe_torch_order.py, "small batch") */
 static void mm3_small(const float *A, const float *B, float *C) {
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j)
@@ -72,11 +84,11 @@ static void mm3_small(const float *A, const float *B, float *C) {
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 /* (((J W) Sigma) W^T) J^T with the view-space point clamped to 1.3 tan(fov/2) (utils.py:320-354).
- * batch = number of rows the reference multiplies at once (its N_vis): selects MKL's kernel for J @ W. */
+ * batch = number of rows the reference multiplies at once (its N_vis): selects MKL's kernel for ... @ W.T. */
 static void ewa2d(const OrcCamera *cam, float fx, float fy, const float *p, float tz, const float *S, float *D,
                   int64_t batch) {
     const float *V = cam->V;
-    float tx = row4(p, V, 0), ty = row4(p, V, 1);
+    float tx = row4_view(p, V, 0, batch), ty = row4_view(p, V, 1, batch);
     float limx = 1.3f * cam->tan_fovx, limy = 1.3f * cam->tan_fovy;
     float cx = fminf(fmaxf(tx / tz, -limx), limx) * tz;
     float cy = fminf(fmaxf(ty / tz, -limy), limy) * tz;
@@ -91,16 +103,18 @@ static void ewa2d(const OrcCamera *cam, float fx, float fy, const float *p, floa
             Wt[i * 3 + j] = V[i * 4 + j];
             Jt[i * 3 + j] = J[j * 3 + i];
         }
-    if (batch <= 3) mm3_small(J, Wm, A); else mm3_fma(J, Wm, A);
-    mm3(A, S, B); mm3_fma(B, Wt, C); mm3(C, Jt, D);
+    mm3_fma(J, Wm, A); mm3(A, S, B);
+    if (batch <= 3) mm3_small(B, Wt, C); else mm3_fma(B, Wt, C);
+    mm3(C, Jt, D);
 }
 
 /* One Gaussian of stage 1.  Returns 0 when culled (z_view < 0.2). */
-static int project_one(const OrcCamera *cam, const float *p, const float *s, const float *q, int64_t batch,
+static int project_one(const OrcCamera *cam, const float *p, const float *s, const float *q, int64_t n_all, int64_t batch,
                        float *xy, float *c2, float *depth, float *inv, float *radius, float *bbox) {
     const float *V = cam->V, *F = cam->F;
-    float tz = row4(p, V, 2);
-    if (!(tz >= 0.2f)) return 0;                       /* utils.py:293-310 */
+    /* the cull multiplies ALL n points at once (utils.py:305-307), everything after it the visible ones (:79-85) */
+    if (!(row4_view(p, V, 2, n_all) >= 0.2f)) return 0;                       /* utils.py:293-310 */
+    float tz = row4_view(p, V, 2, batch);
     /* Sigma3D: F.normalize then build_rotation's own normalisation (gaussians.py:59-69) */
     float n1 = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
     n1 = fmaxf(n1, 1e-12f);
@@ -190,10 +204,10 @@ int orc_preprocess(const OrcCamera *cam, const float *points, const float *color
     uint32_t *key = malloc(cap * 4);
     int64_t *val = malloc(cap * 8);
     int64_t m = 0, batch = 0;
-    for (int64_t i = 0; i < n; ++i) batch += row4(points + 3 * i, cam->V, 2) >= 0.2f;   /* the reference's N_vis */
+    for (int64_t i = 0; i < n; ++i) batch += row4_view(points + 3 * i, cam->V, 2, n) >= 0.2f;   /* the reference's N_vis */
     for (int64_t i = 0; i < n; ++i) {
         float d;
-        if (project_one(cam, points + 3 * i, scales + 3 * i, quats + 4 * i, batch, t_xy + 2 * m, t_c2 + 4 * m, &d,
+        if (project_one(cam, points + 3 * i, scales + 3 * i, quats + 4 * i, n, batch, t_xy + 2 * m, t_c2 + 4 * m, &d,
                         t_inv + 4 * m, t_r + m, t_bb + 4 * m)) {
             memcpy(&key[m], &d, 4);       /* d >= 0.2 > 0: IEEE bits are monotone in d */
             val[m] = m;                   /* position in the compacted arrays */

@@ -1,6 +1,6 @@
 """How many (Gaussian, tile) pairs of a bench scene contribute nothing anywhere in their tile -- at the
 16x16 tile of the binning and at 8x8 quadrants of it?  CPU only (oracle projection + numpy):
-    python tools/analyze_skip.py [workload]
+    python tools/attic/analyze_skip.py [workload]
 A pair is negligible when ln(alpha) = ln(opacity) + max over the pixel block of the exponent < -26 ln 2
 (the staging test of blend_tile16_kernel)."""
 import os

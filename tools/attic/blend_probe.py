@@ -1,6 +1,6 @@
 """Who is the compositing launch waiting for?  Renders one frame of a bench workload on libgsx_test.so with the blend
 probe on (csrc/gsx_debug.h) and prints the workgroups that ran longest: cycles, tile, list length, records staged,
-whether / when the tile saturated.   python tools/blend_probe.py [workload] [lib suffix]"""
+whether / when the tile saturated.   python tools/attic/blend_probe.py [workload] [lib suffix]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -21,7 +21,7 @@ st = {}
 scene.render_image_hip(1, stats=st, timing=True)
 torch.cuda.synchronize()
 lib.gsx_debug_set_blend_probe(None)
-d = buf.cpu().numpy().view(np.uint32)[:grid]       # (the second record of every workgroup lies behind: tools/simd_balance.py)
+d = buf.cpu().numpy().view(np.uint32)[:grid]       # (the second record of every workgroup lies behind: tools/attic/simd_balance.py)
 cyc = d[:, 0].astype(np.int64)
 used = np.nonzero(d[:, 2] | d[:, 1])[0]
 print(wl, "blend stage %.3f ms, D %d" % (st["stage_ms"]["blend"], st["n_instances"]))

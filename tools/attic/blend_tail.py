@@ -1,6 +1,6 @@
 """What ends the compositing launch?  One converged frame (12 warm-up frames: hints settled) of a bench workload on
 libgsx_test.so with the blend probe on: the workgroups that END last -- wall-clock start / end, tile, helper?, list
-length, entries walked, saturated?.   python tools/blend_tail.py [workload]"""
+length, entries walked, saturated?.   python tools/attic/blend_tail.py [workload]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

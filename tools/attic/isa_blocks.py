@@ -1,4 +1,4 @@
-"""Per basic block instruction mix of one kernel: python tools/isa_blocks.py gsx_blend.hip 'blend_tile16_kernelILi1E' [min_exp]"""
+"""Per basic block instruction mix of one kernel: python tools/attic/isa_blocks.py gsx_blend.hip 'blend_tile16_kernelILi1E' [min_exp]"""
 import os, re, subprocess, sys
 csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "intro_to_gaussian_splatting_amd", "csrc")
 src, pat = sys.argv[1], sys.argv[2]

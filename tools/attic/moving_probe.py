@@ -1,6 +1,6 @@
 """Which kernels pay for stale hints?  One movable-camera hipGraph of a bench workload (bench.py --camera-path), replayed
 with the camera at rest (MODE=rest) or stepping a degree per frame along the orbit (MODE=moving) -- run each under
-    rocprofv3 --kernel-trace --stats --output-format csv -d DIR -o o -- python3 tools/moving_probe.py WORKLOAD MODE
+    rocprofv3 --kernel-trace --stats --output-format csv -d DIR -o o -- python3 tools/attic/moving_probe.py WORKLOAD MODE
 and compare the two kernel tables (tools/kstats.py)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """How long does GaussianScene.preprocess() take (the reference's stage-1 API, gsx_preprocess)?
-    python tools/preprocess_probe.py [workload]"""
+    python tools/attic/preprocess_probe.py [workload]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

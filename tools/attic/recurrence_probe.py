@@ -7,7 +7,7 @@ This script emulates both float32 forms (direct: what round 3 shipped; recurrenc
 synthetic scene, tile by tile, against float64, and prints the error of alpha for records the kernel would stage --
 by class of r11 -- so that the rule that sends steep records to the direct form can be chosen on evidence.
 
-    python tools/recurrence_probe.py [--n 20000] [--clustered]
+    python tools/attic/recurrence_probe.py [--n 20000] [--clustered]
 """
 from __future__ import annotations
 

@@ -1,7 +1,7 @@
 """Is the schedule the projection launch's spare workgroups leave (GsxParams.hints) balanced by the costs it was made
 from?  (Header word 5 = 1 marks the slot-cell layout of a round-4 experiment -- DESIGN.md section 5 --; the shipping layout
 is every XCD's tiles by falling cost, dealt round by round by the compositing launch.)  Renders a bench workload until the hints have settled, reads the hints buffer back and adds up, per XCD
-and SIMD slot, the costs (lens) of the tiles in its cells.   python tools/sched_check.py [workload]"""
+and SIMD slot, the costs (lens) of the tiles in its cells.   python tools/attic/sched_check.py [workload]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,6 @@
 """How evenly does the compositing launch load the SIMDs?  One frame of a bench workload on libgsx_test.so with the blend
 probe on: per workgroup start / end (wall clock, 10 ns) and where it ran (XCC_ID, HW_ID) -> per SIMD: waves, list entries,
-time of its last wave's end relative to the launch.   python tools/simd_balance.py [workload]"""
+time of its last wave's end relative to the launch.   python tools/attic/simd_balance.py [workload]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

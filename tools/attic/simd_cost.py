@@ -1,6 +1,6 @@
 """Does a SIMD's finishing time follow the cost of the waves it ran?  One converged frame of a bench workload on
 libgsx_test.so with the blend probe on; tiles AND helper workgroups, cost = entries walked + 5 per batch.
-   python tools/simd_cost.py [workload]"""
+   python tools/attic/simd_cost.py [workload]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,6 @@
 """What does a SIMD's finishing time depend on?  One converged frame of a bench workload on libgsx_test.so with the blend
 probe on; least squares of every SIMD's last end on what its waves did: entries walked on whole trips, entries walked
-under the exact rule, batches staged, waves.   python tools/simd_fit.py [workload]"""
+under the exact rule, batches staged, waves.   python tools/attic/simd_fit.py [workload]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,5 @@
 """Per-kernel times of the depth sort alone (gsx_debug_depth_sort in libgsx_test.so) -- run under rocprofv3:
-    rocprofv3 --kernel-trace --stats ... -- python3 tools/sort_probe.py N MODE [KEPT_FRACTION]
+    rocprofv3 --kernel-trace --stats ... -- python3 tools/attic/sort_probe.py N MODE [KEPT_FRACTION]
 MODE: 0 LSD, 1 = 256 buckets, 2 = 1024 buckets, 4 = LSD with the rectangles carried along, -1 = the route of
 gsx_render_forward."""
 import ctypes, os, sys

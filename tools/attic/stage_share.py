@@ -1,5 +1,5 @@
 """How much of the compositing walk runs under the exact rule (after a tile's first saturated pixel)?  One frame of a bench
-workload on libgsx_test.so with the blend probe on.   python tools/stage_share.py [workload]"""
+workload on libgsx_test.so with the blend probe on.   python tools/attic/stage_share.py [workload]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

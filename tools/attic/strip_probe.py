@@ -1,5 +1,5 @@
 """Per-stage HIP-event times of one rank's strip for 1, 2, 4, 8 ranks (equal strips, or PLAN=balanced; the slowest of
-three ranks probed), on ONE GPU:   python tools/strip_probe.py [workload]
+three ranks probed), on ONE GPU:   python tools/attic/strip_probe.py [workload]
 What a rank of an N-GPU run would spend per frame before the gather (timing mode: separate launches)."""
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
