@@ -49,6 +49,12 @@
 // lane and record for the x-only part and the same 2 FMAs per pixel as the monomial form.  A record whose
 // M11 is not positive and finite (only possible for caller-given inverse covariances on the stage-2 entry)
 // keeps the monomial coefficients and is flagged; a batch holding one takes the unpacked loop.
+// ILL-CONDITIONED footprints (round 5).  The completed square is the exact value to 1e-5; the REFERENCE is not: where its
+// four float32 products cancel (needles from ~20:1) its own rounding moves alpha by 1e-4 .. 1e-3, and since the
+// restatement this kernel is held against executes the reference's operations in the reference's order, that rounding
+// is part of the result.  pack_record flags such records; on the tiles where the rounding can reach 2e-5 (stage_records:
+// a needle's ridge) they are evaluated by alpha_ref -- the reference's operations one for one -- in blend_redo_kernel,
+// a second launch with twice the registers that composites every tile the first one handed over (push_redo).
 // T(1 - alpha) is evaluated as T - T alpha (1 ulp).
 // Coordinates are TILE-RELATIVE (round 3): the lane that stages a record subtracts the tile's origin from the mean
 // once (x' = x - x0, y' = y - y0; pixel offsets px', py' = 0 .. tile-1 are exact) and forms c0 = fma(r11, y', h x'),
@@ -74,11 +80,6 @@ namespace gsx {
 namespace {
 
 constexpr float kStopRefCpu = 0.000001f;  // gaussian_scene.py:153
-#ifndef GSX_REF_IN_KERNEL
-#define GSX_REF_IN_KERNEL 0       // experiment: 1 = the first launch composites reference-order records itself (no redo launch)
-#endif
-constexpr bool kRefInKernel = GSX_REF_IN_KERNEL != 0;
-constexpr bool kRefSimple = GSX_REF_IN_KERNEL == 2;     // ... with the plainest loops: a batch that holds one goes one entry at a time
 constexpr uint32_t kBatchCost = 5;        // staging a batch of 64 costs about as much as compositing five records (a tile's cost, gsx_plan.h)
 // A staged batch holds up to 64 records followed by kPad NULL records (log2 op = -inf: alpha = exp2(-inf) = 0 at every
 // pixel, colour 0), so that the compositing loops always take whole trips of 4 or 8 records with no per-record branch
@@ -725,8 +726,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
         // left of a batch, and every record of a saturated tile, through a one-record-at-a-time loop: on a
         // heavy-tailed scene, where half the records of a long list are not staged and the dense tiles saturate early,
         // that loop -- ~420 cycles per record for a wave alone on its SIMD -- was the frame's duration.)
-        if (kind == kBatchMono || (REF && kRefSimple && kind == kBatchRefOrder)) {
-            // a record in the monomial fallback (stage-2 entry only): one at a time, exact rule
+        if (kind == kBatchMono) {       // a record in the monomial fallback (stage-2 entry only): one at a time, exact rule
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
                 const float e_p[1] = {cy};
@@ -739,7 +739,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
                 // a trip that holds a reference-order record (wave-uniform: a scalar branch, taken by few trips) goes one
                 // record at a time through the scalar form, which evaluates such a record by the reference's operations
                 // (composite<1>: the exact rule, valid anywhere; a pixel it stops has T = 0, which the next trip's test sees)
-                if (REF && !kRefSimple && __builtin_expect((uint32_t)(ref_slots >> k) & 0xFFu, 0)) {
+                if (REF && __builtin_expect((uint32_t)(ref_slots >> k) & 0xFFu, 0)) {
                     for (uint32_t u = 0; u < (uint32_t)kTrip; ++u) {
                         const Splat s = read_splat(sh, k + u);
                         const float e_p[1] = {cy};
@@ -860,7 +860,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
     // records actually staged until the tile was done (a dense tile that saturates after a tenth of its list costs a
     // tenth; records that cannot matter are not staged) plus a few per batch for the staging itself -- stored when the
     // tile ends.  (A long tile's entry is the helpers': tile_ranges_kernel flagged it, they raise it.)
-    if ((!REF || kRefInKernel) && hints.lens && lane == 0 && t == 0) {
+    if (!REF && hints.lens && lane == 0 && t == 0) {
         const bool by_cost = hints.header[kHintLens] == (uint32_t)g.count() && hints.header[kHintSched] == (uint32_t)g.count();
         hints.header[kHintLens] = (uint32_t)g.count();
         // How many tiles qualified as long this frame steers the threshold of the next (gsx_plan.h: kHintLongPct).  A
@@ -1016,11 +1016,10 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
                     // (a list's padding names the null record's slot, which may be slot 64: no bit of the mask)
                     const bool r0 = (s0_ >> 4) < 64u && ((ref_slots >> (s0_ >> 4)) & 1ull) != 0ull;
                     const bool r1 = (s1_ >> 4) < 64u && ((ref_slots >> (s1_ >> 4)) & 1ull) != 0ull;
-                    if (!kRefSimple && !__any(r0 | r1)) {
+                    if (!__any(r0 | r1)) {
                         exact_pair();
                         continue;
                     }
-                    (void)r1;
                     // ONE entry on this path (then the pair test again from the next): what is live here comes on top of
                     // the packed state, and the kernel has no register to spare
                     const float4 A0 = *reinterpret_cast<const float4 *>(rec_a + s0_), B0 = *reinterpret_cast<const float4 *>(rec_b + s0_);
@@ -1157,7 +1156,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         const uint32_t per = nt >> 3, extra = nt & 7u, xcd = b & 7u, i = b >> 5;
         if (i >= per + (xcd < extra ? 1u : 0u)) return;
         (void)u;
-        blend_long_tile_quarter<kRefInKernel>(rec, qraw, vals, ranges, g, out, xcd_remap((i << 3) | xcd, nt), (int)((b >> 3) & 3u), sh, budget,
+        blend_long_tile_quarter<false>(rec, qraw, vals, ranges, g, out, xcd_remap((i << 3) | xcd, nt), (int)((b >> 3) & 3u), sh, budget,
                                        nullptr, lt.redo, hints.redo_hint);
         return;
     }
@@ -1171,7 +1170,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             const int lead = span.axis ? g.wy0 + (int)(lt_tile % (uint32_t)g.nwy()) : g.wx0 + (int)(lt_tile / (uint32_t)g.nwy());
             if (lead < span.lo || lead >= span.hi) return;
         }
-        blend_long_tile_quarter<kRefInKernel>(rec, qraw, vals, ranges, g, out, lt_tile, quarter, sh, budget,
+        blend_long_tile_quarter<false>(rec, qraw, vals, ranges, g, out, lt_tile, quarter, sh, budget,
                                        hints.lens ? hints.lens + lt_tile : nullptr, lt.redo, hints.redo_hint);
         return;
     }
@@ -1183,7 +1182,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const uint32_t t = hints.xcd_sched ? xcd_scheduled_tile(bid, (uint32_t)g.count(), sched_cap_, sched, hints.header)
                                        : scheduled_tile(bid, (uint32_t)g.count(), sched);
     if (t >= (uint32_t)g.count()) return;
-    blend_tile16<VARIANT, kRefInKernel>(rec, qraw, vals, ranges, g, out, lt, budget, hints, span, t, sh);
+    blend_tile16<VARIANT, false>(rec, qraw, vals, ranges, g, out, lt, budget, hints, span, t, sh);
 }
 
 // The tiles and long-tile quarters the launch above left in the redo list (push_redo), composited with reference-order
@@ -1645,7 +1644,7 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             blend_tile16_kernel<1><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         // what the launch left for the second one: tiles that hold ill-conditioned footprints (see blend_redo_kernel;
         // VARIANT 0 -- test library -- evaluates every record kind in place and leaves nothing)
-        if (variant != 0 && lt.redo && !kRefInKernel) {
+        if (variant != 0 && lt.redo) {
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
             const uint32_t capacity = (uint32_t)nt + 4u * kMaxLongTiles;

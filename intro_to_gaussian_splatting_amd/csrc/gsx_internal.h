@@ -32,6 +32,10 @@ constexpr uint32_t kEmptyKey = 0xFFFFFFFEu;   // visible, but it reaches no tile
 //   GSX_SEM_REF_CPU (square completed in y, M = -Q'': r11 = sqrt(M11), h = M01 / r11, D1 = M00 - h^2):
 //     a = (x_pix, y_pix, D1, h)   b = (r11, log2(opacity factor), r, g)   c = (b, depth, 0, -)
 //     or, when that factorisation does not exist, the monomial form below with c.z = 1
+//     or, for an ILL-CONDITIONED footprint (pack_record in gsx_project.hip), the same completed square with c = (b,
+//     opacity factor, 2, -) and the raw float32 conic (Q00, Q01, Q10, Q11) in the Gaussian's slot of the per-Gaussian
+//     float4 side array (the workspace's `bbox`): the compositing kernels execute the reference's own operation order
+//     on such a record wherever its rounding can show (gsx_blend.hip: kKindRefOrder, blend_redo_kernel)
 //   other semantics:
 //     a = (x_pix, y_pix, Q''00, Q''01 + Q''10)   b = (Q''11, log2(opacity factor) | opacity, r, g)   c = (b, depth, 0, -)
 struct __attribute__((aligned(16))) Record {
