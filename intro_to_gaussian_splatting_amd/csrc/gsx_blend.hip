@@ -634,7 +634,23 @@ __device__ __forceinline__ void rank_samples(uint32_t group, int lane, const Ble
 // behind it with twice the registers, composites those tiles from their first record with the same staging, the same
 // rules and the reference's operations on the flagged records.  redo[0] = entries, redo[1 + part] = queue head of
 // a part's redo launch (all zeroed by the emit kernel), entries from redo[kRedoHeader]: (tile, 0 = whole tile | 1 + quarter).  A scene without ill-conditioned footprints leaves
-// the list empty and the second launch 4096 idle workgroups long (~2 us).
+// the list empty and the second launch 1024 idle workgroups long (~1 us).
+// The barrier between staging a batch and compositing it.  The first launch's workgroups are one wave each: s_barrier.
+// blend_redo_kernel packs FOUR independent waves into a workgroup (a quarter of the dispatches: the launch is mostly
+// idle workgroups when a scene has no ill-conditioned footprint), each with a staging area of its own: all that is
+// needed there is that the wave's LDS reads follow its own LDS writes -- which the hardware guarantees (the DS
+// operations of one wave execute in issue order) once the compiler keeps them in program order.
+template <bool WAVE>
+__device__ __forceinline__ void tile_sync() {
+    if (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ void push_redo(uint32_t *redo, uint32_t tile, uint32_t mode) {
     const uint32_t slot = atomicAdd(redo, 1u);
     redo[kRedoHeader + 2 * slot] = tile;
@@ -657,7 +673,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
                                                         const OutDesc &out, uint32_t t, int quarter,
                                                         Staged &sh, uint32_t budget, uint32_t *cost_out, uint32_t *redo,
                                                         uint8_t *redo_hint) {
-    const int lane = threadIdx.x;
+    const int lane = REF ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;      // (REF: four independent waves per workgroup)
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
     const uint32_t probe_w0h = (uint32_t)wall_clock64();
@@ -716,7 +732,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
             }
             return;
         }
-        __syncthreads();
+        tile_sync<REF>();
         // Whole trips of eight records (the batch is padded with null records, see kPad).  The alphas of a trip
         // are computed independently of each other and of T -- no branch between them --; then either the plain
         // chain T -> T - T alpha with ONE wave-level saturation test per trip, or -- from the first trip in which any
@@ -794,7 +810,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
                 T = Tt;
             }
         }
-        __syncthreads();
+        tile_sync<REF>();
         if (__ballot(T > 0.0f) == 0ull) break;
     }
     // (the largest of the four quarters' costs = the records one wave would have walked until all 256 pixels are done)
@@ -822,7 +838,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
                                              const uint2 *__restrict__ ranges, const TileGrid &g, const OutDesc &out,
                                              const LongTiles &lt, uint32_t budget, const BlendHints &hints, const TileSpan &span,
                                              uint32_t t, Staged &sh) {
-    const int lane = threadIdx.x;
+    const int lane = REF ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;      // (REF: four independent waves per workgroup)
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
     const uint32_t probe_w0 = (uint32_t)wall_clock64();
@@ -908,7 +924,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
         probe_batches = min(0xFFFu, probe_batches + 1u);
         if (checked) probe_after += nl;           // (entries walked under the exact rule, whole batches)
 #endif
-        __syncthreads();
+        tile_sync<REF>();
         if (VARIANT == 0) {
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
@@ -1036,7 +1052,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
                 }
             }
         }
-        __syncthreads();
+        tile_sync<REF>();
         bool live;
         if (VARIANT == 0)
             live = (T[0] > 0.0f) | (T[1] > 0.0f) | (T[2] > 0.0f) | (T[3] > 0.0f);
@@ -1051,7 +1067,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
     }
     if (VARIANT != 0 && restart_scalar) {
         // the whole tile again, one record at a time on the scalar form (composite<4>: same bits as the packed loops)
-        __syncthreads();
+        tile_sync<REF>();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             T[j] = 1.0f;
@@ -1065,12 +1081,12 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
             (void)stage_batch<kStageBlocks, (REF || VARIANT == 0)>(rec, qraw, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16),
                                                                    16.0f, skipped, count, budget);
             cost += 4u * nb;
-            __syncthreads();
+            tile_sync<REF>();
             for (uint32_t k = 0; k < nb; ++k) {         // every staged record, in order; a lane's block takes what it keeps
                 const Splat s = read_splat(sh, k);
                 composite<4, (REF || VARIANT == 0)>(cx, cy, s, T, c0, c1, c2, blk, (float)(tx * 16), (float)(ty * 16));
             }
-            __syncthreads();
+            tile_sync<REF>();
             if (__ballot((T[0] > 0.0f) | (T[1] > 0.0f) | (T[2] > 0.0f) | (T[3] > 0.0f)) == 0ull) break;
         }
     } else if (VARIANT != 0) {
@@ -1190,18 +1206,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 // launch -- a tile is composited by exactly one of the two, from its first record.  128 VGPRs (4 waves per SIMD): the
 // extra evaluation and the record kinds side by side do not fit the first launch's 64.  A fixed, small grid walks the
 // list (its length exists only in device memory); with nothing in it the launch is ~1.5 us of the frame.
-constexpr unsigned kRedoBlocks = 4096;    // (the chip holds 4096 of its waves at a time)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+constexpr unsigned kRedoWaves = 4096;       // workers (the chip holds 4096 waves of this kernel at a time) ...
+constexpr unsigned kRedoWavesPerBlock = 4;  // ... four to a workgroup: 1024 dispatches, ~1 us when there is nothing to do
+__global__ void __launch_bounds__(64 * kRedoWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
     blend_redo_kernel(const Record *__restrict__ rec, const float4 *__restrict__ qraw, const uint32_t *__restrict__ vals,
                       const uint2 *__restrict__ ranges,
                       TileGrid g, OutDesc out, LongTiles lt, uint32_t budget, BlendHints hints, TileSpan span, uint32_t capacity) {
-    __shared__ Staged sh;
+    __shared__ Staged sh_all[kRedoWavesPerBlock];
+    Staged &sh = sh_all[threadIdx.x >> 6];
     const uint32_t n = min(lt.redo[0], capacity);
-    // the workgroups PULL their entries (one atomic per tile on the part's queue head): tiles differ by orders of magnitude
-    // in length, a fixed stride would leave the launch waiting for whoever drew the long ones
-    // (a workgroup's first entry is its own index -- an empty list costs no atomic at all --, the following ones come from
-    // the queue, which starts behind the grid)
-    for (uint32_t i = blockIdx.x; i < n;) {
+    const uint32_t workers = gridDim.x * kRedoWavesPerBlock;
+    // the waves PULL their entries (one atomic per tile on the part's queue head): tiles differ by orders of magnitude
+    // in length, a fixed stride would leave the launch waiting for whoever drew the long ones.  A wave's first entry is
+    // its own index -- an empty list costs no atomic at all --, the following ones come from the queue, which starts
+    // behind the last worker.
+    for (uint32_t i = blockIdx.x * kRedoWavesPerBlock + (threadIdx.x >> 6); i < n;) {
         const uint32_t t = lt.redo[kRedoHeader + 2 * i], mode = lt.redo[kRedoHeader + 1 + 2 * i];
         if (mode == 0u) {
             blend_tile16<1, true>(rec, qraw, vals, ranges, g, out, lt, budget, hints, span, t, sh);
@@ -1211,9 +1230,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
                 blend_long_tile_quarter<true>(rec, qraw, vals, ranges, g, out, t, (int)mode - 1, sh, budget,
                                               hints.lens ? hints.lens + t : nullptr, nullptr, nullptr);
         }
-        __syncthreads();
+        tile_sync<true>();
         uint32_t next = 0;
-        if (threadIdx.x == 0) next = gridDim.x + atomicAdd(lt.redo + 1 + span.index, 1u);
+        if ((threadIdx.x & 63u) == 0u) next = workers + atomicAdd(lt.redo + 1 + span.index, 1u);
         i = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
     }
 }
@@ -1648,7 +1667,8 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
             const uint32_t capacity = (uint32_t)nt + 4u * kMaxLongTiles;
-            blend_redo_kernel<<<(unsigned)min((int64_t)kRedoBlocks, nt + 4 * (int64_t)kMaxLongTiles), 64, 0, s>>>(
+            const int64_t want = (nt + 4 * (int64_t)kMaxLongTiles + kRedoWavesPerBlock - 1) / kRedoWavesPerBlock;
+            blend_redo_kernel<<<(unsigned)min((int64_t)(kRedoWaves / kRedoWavesPerBlock), want), 64 * kRedoWavesPerBlock, 0, s>>>(
                 rec, bbox, sorted_vals, ranges, grid, out, lt, budget, bh, span, capacity);
         }
     } else {

@@ -63,6 +63,30 @@ __device__ __forceinline__ float row4_view(float p0, float p1, float p2, const f
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// torch.sigmoid on the opacity array (splat/gaussian_scene.py:143) as torch executes it on an AVX-512 host: 1 / (1 + e),
+// e = the SIMD exponential of its vector library -- Sleef's 1.0-ulp expf: round-to-nearest reduction by ln 2 in two FMA
+// steps, a degree-5 polynomial, FMA throughout -- restated here operation for operation (oracle/raster_cpu.c: vexpf_;
+// probed against torch: 0 differing bits in 1e6 values).  torch hands the last < 32 elements of every thread's chunk to
+// libm's expf instead; WHICH elements those are depends on N_vis and on the reference run's thread count, which a
+// projection kernel knows nothing about: up to 31 values per thread can differ from the reference's in their last bit.
+__device__ __forceinline__ float sigmoid_torch(float v) {
+    const float d = 0.0f - v;
+    const int q = (int)rintf(d * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+    float s = fmaf((float)q, -0.693145751953125f, d), u;
+    s = fmaf((float)q, -1.428606765330187045e-06f, s);
+    u = 0.000198527617612853646278381f;
+    u = fmaf(u, s, 0.00139304355252534151077271f);
+    u = fmaf(u, s, 0.00833336077630519866943359f);
+    u = fmaf(u, s, 0.0416664853692054748535156f);
+    u = fmaf(u, s, 0.166666671633720397949219f);
+    u = fmaf(u, s, 0.5f);
+    u = 1.0f + fmaf(s * s, u, s);
+    u = u * __uint_as_float((uint32_t)((q >> 1) + 0x7f) << 23) * __uint_as_float((uint32_t)((q - (q >> 1)) + 0x7f) << 23);
+    u = d < -104.0f ? 0.0f : u;
+    u = d > 100.0f ? __builtin_inff() : u;
+    return 1.0f / (1.0f + u);
+}
+
 // Sigma = (R S)(R S)^T with the quaternion normalised twice (F.normalize, then build_rotation's
 // own division): splat/gaussians.py:54-69, splat/utils.py:132-155.
 // `twice` = false (GSX_SEM_STD_3DGS): normalised once, as the 3DGS model's rotation activation does.
@@ -345,7 +369,7 @@ __global__ void __launch_bounds__(kBlock)
     project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o, vis);
     Record r;
     r.a = make_float4(o.x, o.y, c[0], c[1]);
-    r.b = make_float4(c[2], tz, sigmoidf(in.opacity_logit[i]), o.ca);
+    r.b = make_float4(c[2], tz, sigmoid_torch(in.opacity_logit[i]), o.ca);
     r.c = make_float4(o.cb, o.cc, o.cd, 0.0f);
     stage[i] = r;
 }
@@ -396,8 +420,8 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
         // longer "the reference's result to 1e-4": the record is flagged, its raw float32 conic goes to the Gaussian's
         // slot of the side array (`qraw`: the workspace's per-Gaussian float4, which only REF_CUDA uses otherwise) and
         // the compositing kernels execute the reference's operations on it, one for one (alpha_ref in gsx_blend.hip).
-        // (float32 is plenty for a threshold; the square root is the correctly rounded one of this translation unit)
-        const float cc = 0.5f * fabsf(q01 + q10) / sqrtf(q00 * q11);
+        // (float32 and the approximate reciprocal square root are plenty for a threshold)
+        const float cc = 0.5f * fabsf(q01 + q10) * __builtin_amdgcn_rsqf(q00 * q11);
         const bool ref_order = ok && q00 > 0.0f && q11 > 0.0f && cc < 1.0f && 8.8e-8f * op * (1.0f + cc) > 3e-5f * (1.0f - cc);
         if (ref_order && qraw) {
             // the completed square as for any record (the skip bounds of the compositing kernels are computed from it),
@@ -571,7 +595,9 @@ __global__ void __launch_bounds__(kBlock)
                            : tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, semantics, tr);
     float op = 0.0f;
     if (keep && cnt) {
-        op = sigmoidf(in.opacity_logit[g]);
+        // (the reference's first sigmoid runs over the whole array -- torch's SIMD form --, its second on one element at a
+        // time, which torch computes with libm's expf: gaussian_scene.py:143 and :164)
+        op = std3dgs ? sigmoidf(in.opacity_logit[g]) : sigmoid_torch(in.opacity_logit[g]);
         if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);
     }
     if (std3dgs && tight && keep && cnt) {

@@ -210,9 +210,9 @@ def capture_stage1(name: str, spec: dict, GaussianScene, Gaussians) -> None:
                    bbox=np.stack([by_index[k] for k in ("min_x", "max_x", "min_y", "max_y")], axis=1).astype(np.int16))
         for k in ("radius", "min_x", "max_x", "min_y", "max_y"):
             assert np.array_equal(by_index[k].astype(np.int16).astype(np.float32), by_index[k]), k
-    for k, a in by_index.items():
-        if k != "sigmoid_opacity":      # torch's vectorised sigmoid is not a function of the value alone (1 ulp; see tests)
-            out["sha256_" + k] = np.array(sha256(a))
+    for k, a in by_index.items():       # (sigmoid_opacity too: torch's SIMD sigmoid is restated, chunk tails and all)
+        out["sha256_" + k] = np.array(sha256(a))
+    out["torch_num_threads"] = np.int64(torch.get_num_threads())      # the sigmoid's chunking depends on it
     os.makedirs(OUT_DIR, exist_ok=True)
     path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **out)

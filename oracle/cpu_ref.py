@@ -262,6 +262,47 @@ def sigmoid(x: np.ndarray) -> np.ndarray:
     return (f32(1.0) / (f32(1.0) + np.exp(-x))).astype(f32)
 
 
+def _vexp(d: np.ndarray) -> np.ndarray:
+    """The SIMD exponential inside torch's vectorised sigmoid (Sleef's 1.0-ulp expf, FMA throughout)."""
+    d = np.asarray(d, f32)
+    q = np.rint(d * f32(1.442695040888963407359924681001892137426645954152985934135449406931)).astype(np.int32)
+    qf = q.astype(f32)
+    s = fma(qf, f32(-0.693145751953125), d)
+    s = fma(qf, f32(-1.428606765330187045e-06), s)
+    u = np.full_like(s, f32(0.000198527617612853646278381))
+    for c in (0.00139304355252534151077271, 0.00833336077630519866943359, 0.0416664853692054748535156,
+              0.166666671633720397949219, 0.5):
+        u = fma(u, s, f32(c))
+    u = f32(1.0) + fma(s * s, u, s)
+    p2 = lambda e: ((e + 0x7F).astype(np.uint32) << np.uint32(23)).view(f32)  # noqa: E731
+    u = u * p2(q >> 1) * p2(q - (q >> 1))
+    u = np.where(d < f32(-104.0), f32(0.0), u)
+    return np.where(d > f32(100.0), f32(np.inf), u).astype(f32)
+
+
+def sigmoid_torch(x: np.ndarray, threads: int = 8) -> np.ndarray:
+    """``torch.sigmoid`` on a contiguous float32 array as torch 2.10 executes it on an AVX-512 host
+    (splat/gaussian_scene.py:143; probed: the reference's bits): ``1 / (1 + e)`` with ``e`` the SIMD exponential on
+    whole groups of 32 elements and libm's ``expf`` on what is left at the end of every thread's chunk -- chunks of
+    ``ceil(n / t)`` elements, ``t = min(threads, ceil(n / 32768))``.  The value therefore depends on the element's
+    position and on the thread count of the reference run (8 where the fixtures were made)."""
+    x = np.asarray(x, dtype=f32)
+    flat = x.reshape(-1)
+    n = flat.size
+    out = (f32(1.0) / (f32(1.0) + _vexp(f32(0.0) - flat))).astype(f32)
+    if n:
+        parts = max(1, min(int(threads), -(-n // 32768)))
+        chunk = -(-n // parts)
+        i = np.arange(n)
+        begin = (i // chunk) * chunk
+        length = np.minimum(n - begin, chunk)
+        tail = (i - begin) >= length - length % 32
+        # (libm's expf is correctly rounded for all practical purposes: the float64 exponential rounded once stands in
+        # for it; numpy's own float32 exp is another SIMD routine, a last bit off here and there)
+        out[tail] = f32(1.0) / (f32(1.0) + np.exp(-flat[tail].astype(np.float64)).astype(f32))
+    return out.reshape(x.shape)
+
+
 def preprocess(points, colors, scales, quats, opacity_logit, cam: Camera,
                order: Optional[np.ndarray] = None) -> Preprocessed:
     """Stage 1.  splat/gaussian_scene.py:70-144.
@@ -308,7 +349,7 @@ def preprocess(points, colors, scales, quats, opacity_logit, cam: Camera,
         points=xy[perm], colors=cols[perm], covariance_2d=c2[perm], depths=depth[perm],
         inverse_covariance_2d=inv[perm], radius=r[perm], points_xy=xy[perm],
         min_x=min_x[perm], min_y=min_y[perm], max_x=max_x[perm], max_y=max_y[perm],
-        sigmoid_opacity=sigmoid(op[perm]), order=idx[perm],
+        sigmoid_opacity=sigmoid_torch(op[perm]), order=idx[perm],
     )
 
 

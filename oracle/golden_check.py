@@ -36,7 +36,7 @@ def stage1_scene(g):
     return sc
 
 
-def compare_stage1_with_reference(g, fields, order, strict: bool = True) -> dict:
+def compare_stage1_with_reference(g, fields, order, strict: bool = True, sigmoid=None) -> dict:
     """``fields``: the PreprocessedScene arrays of an implementation in ITS depth order, ``order``: the original index
     of each of its rows.  Holds them against what the REFERENCE computed for the same scene (a stage-1 fixture):
     every array, put back in original Gaussian order, bit for bit (SHA-256 of 1e5 / 1e6 rows; where the fixture holds
@@ -68,6 +68,13 @@ def compare_stage1_with_reference(g, fields, order, strict: bool = True) -> dict
         key = {"depths": "depth_bit_diffs", "radius": "radius_flips"}.get(f, "bbox_flips" if f in ("min_x", "max_x", "min_y", "max_y") else None)
         if key:
             report[key] = count if report[key] == 0 or count < 0 else report[key] + count
+    if sigmoid is not None and "sha256_sigmoid_opacity" in g:
+        # sigmoid(opacity) in sorted order, put back by index: the restatements follow torch's SIMD sigmoid down to the
+        # libm tails of its threads' chunks (a kernel cannot know those: it is held to 1 ulp on < 32 values per thread)
+        full = np.zeros((n, 1), np.float32)
+        full[order] = np.asarray(sigmoid, np.float32).reshape(-1, 1)
+        if sha256(full) != str(g["sha256_sigmoid_opacity"]):
+            report["arrays_differing"].append("sigmoid_opacity")
     assert not (strict and report["arrays_differing"]), "arrays that differ from the reference's: %r" % report
     # the permutation: ours with the reference's choice inside every tie run == the reference's
     pos, ref_members = g["tie_positions"].astype(np.int64), g["tie_order"].astype(np.int64)

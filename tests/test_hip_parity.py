@@ -87,8 +87,10 @@ def test_stage1_fields_match_reference_and_oracle(tmp_path, golden):
     for f in ("depths", "radius", "min_x", "max_x", "min_y", "max_y", "points", "covariance_2d",
               "inverse_covariance_2d", "colors"):
         assert np.array_equal(bits(rows_by_index(got[f], order, n)), bits(rows_by_index(g["pre_" + f], g["order"], n))), f
-    assert np.max(np.abs(rows_by_index(got["sigmoid_opacity"], order, n) -
-                         rows_by_index(g["pre_sigmoid_opacity"], g["order"], n))) <= 2.4e-7
+    # sigmoid(opacity): torch's SIMD form, restated in the kernel -- the reference's bits except on the < 32 values at
+    # the end of each of its threads' chunks, which torch gives to libm (one unit in the last place there at most)
+    sa, sb = rows_by_index(got["sigmoid_opacity"], order, n), rows_by_index(g["pre_sigmoid_opacity"], g["order"], n)
+    assert np.max(np.abs(sa - sb)) <= 1.2e-7 and np.count_nonzero(sa != sb) <= 31 * 8
 
 
 @pytest.mark.parametrize("name", STAGE1_NAMES)
@@ -112,7 +114,8 @@ def test_stage1_at_benchmark_size_equals_the_reference_bit_for_bit(tmp_path, nam
     report = compare_stage1_with_reference(g, fields, order)
     print("%s: %r" % (name, report))
     if "sigmoid_opacity" in g:
-        assert np.max(np.abs(rows_by_index(pre.sigmoid_opacity.cpu().numpy(), order, int(g["n"])) - g["sigmoid_opacity"])) <= 2.4e-7
+        sa = rows_by_index(pre.sigmoid_opacity.cpu().numpy(), order, int(g["n"]))
+        assert np.max(np.abs(sa - g["sigmoid_opacity"])) <= 1.2e-7 and np.count_nonzero(sa != g["sigmoid_opacity"]) <= 31 * 8
     ntx, nty = g["tile_counts"].shape
     counts = torch.zeros(ntx * nty, dtype=torch.int32, device="cuda:0")
     st = {}
