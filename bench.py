@@ -86,7 +86,7 @@ FP32_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 
 VALU_OPS_PER_PAIR = 11.25
 # PMC passes of the same command, committed under profiles/ (tools/profile_round.sh; the newest round that has the file)
 def _pmc_file(name: str):
-    for tag in ("r4", "r3"):
+    for tag in ("r5", "r4", "r3"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag, name))
         if os.path.exists(path):
             return path
@@ -1071,6 +1071,9 @@ def main() -> None:
             "value_frames_in_flight": None if inflight_ms is None else round(width * height / (inflight_ms * 1e-3) / 1e6, 2),
             "config": {"workload": desc, "n_gaussians": n, "width": width, "height": height, "tile": tile,
                        "semantics": sem, "layout": layout, "n_visible": nvis, "n_kept": int(stats.get("n_kept") or 0), "tile_instances": d,
+                       # tiles the compositing launch handed to its second launch (ill-conditioned footprints evaluated in the
+                       # reference's operation order); 0: later frames of the view do not issue that launch at all
+                       "tiles_redone": int(stats.get("n_redo") or 0),
                        "frames_in_flight": 1,
                        "launch": "one hipGraph replay per frame" if one is not None else "separate kernel launches",
                        "ms_per_frame_in_flight": None if inflight_ms is None else round(inflight_ms, 4),

@@ -37,6 +37,7 @@ GSX_FLAG_NO_TILE_SCHEDULE = 64
 GSX_FLAG_HINTS_VALID = 128
 GSX_FLAG_SMALL_BATCH = 256
 GSX_FLAG_ONE_VISIBLE = 512
+GSX_FLAG_SKIP_REDO = 1024
 
 
 def visible_rows_flag(n: int, n_visible: int, flags: int) -> int:
@@ -69,7 +70,7 @@ class GsxParams(ctypes.Structure):
 
 class GsxFrameStats(ctypes.Structure):
     _fields_ = [("n_visible", c_int64), ("n_instances", c_int64), ("n_tiles", c_int64), ("reserved", c_int64),
-                ("stage_ms", c_float * 6), ("n_kept", c_int64)]
+                ("stage_ms", c_float * 6), ("n_kept", c_int64), ("n_redo", c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/gsx.h declares.

@@ -95,6 +95,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
     int64_t *dev2 = (int64_t *)(counters + 4);
     uint2 *ranges = (uint2 *)(ws + c.ranges);
     bool counts_on_device = false, counts_in_host = false;
+    bool redo_counted = false;      // the compositing launch ran with a redo list: its length is GsxFrameStats.n_redo
     bool parts_marked = false;      // GsxParams.substrip_events recorded (every path records them once, behind its last launch at the latest)
     // no Gaussians: every tile's list is empty -- GsxParams.tile_counts says so (an empty WINDOW has no entries)
     if (n == 0 && p.tile_counts && p.grid.count() > 0)
@@ -152,6 +153,8 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             tm.mark();  // 4: tile sort (+ the compositing schedule)
             gsx::BlendHints bh = fh.blend;
             bh.xcd_sched = fh.sched ? 1u : 0u;
+            bh.skip_redo = p.skip_redo ? 1u : 0u;
+            redo_counted = p.semantics == GSX_SEM_REF_CPU && p.grid.tile == 16 && !p.generic;
             // The 128 spare workgroups hold 16 wave slots of every XCD for ~15 us.  In front of the tiles that is free
             // -- unless the window's tiles fill the chip's 8 192 wave slots just about once (1080p: 7 973 tiles): then
             // some tiles find no slot until the spare workgroups are done.  Behind the tiles they are dispatched as
@@ -198,18 +201,23 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
                 GSX_HIP(hipMemcpyAsync(stats, dev2, 16, hipMemcpyDeviceToHost, s));
                 GSX_HIP(hipMemcpyAsync(&stats->n_kept, dev2 + 2, 8, hipMemcpyDeviceToHost, s));
             }
+            stats->n_redo = 0;      // (the upper half stays: the device count has 32 bits)
+            if (redo_counted) GSX_HIP(hipMemcpyAsync(&stats->n_redo, ws + c.redo, 4, hipMemcpyDeviceToHost, s));
             stats->n_tiles = p.grid.count();
             stats->reserved = cap;  // > 0: counts are delivered asynchronously; value = pair capacity used
         }
         return GSX_OK;
     }
     int64_t host2[3] = {0, 0, 0};
+    uint32_t redo_host = 0;
     if (counts_on_device) GSX_HIP(hipMemcpyAsync(host2, dev2, 24, hipMemcpyDeviceToHost, s));
+    if (redo_counted) GSX_HIP(hipMemcpyAsync(&redo_host, ws + c.redo, 4, hipMemcpyDeviceToHost, s));
     GSX_HIP(hipStreamSynchronize(s));
     if (stats) {
         stats->n_visible = host2[0];
         stats->n_instances = host2[1];
         stats->n_kept = host2[2];
+        stats->n_redo = redo_host;
         stats->n_tiles = p.grid.count();
         stats->reserved = 0;
     }

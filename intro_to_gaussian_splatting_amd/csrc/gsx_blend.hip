@@ -1663,7 +1663,7 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             blend_tile16_kernel<1><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         // what the launch left for the second one: tiles that hold ill-conditioned footprints (see blend_redo_kernel;
         // VARIANT 0 -- test library -- evaluates every record kind in place and leaves nothing)
-        if (variant != 0 && lt.redo) {
+        if (variant != 0 && lt.redo && !bh.skip_redo) {
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
             const uint32_t capacity = (uint32_t)nt + 4u * kMaxLongTiles;

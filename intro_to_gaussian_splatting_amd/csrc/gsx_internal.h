@@ -203,6 +203,7 @@ struct BlendHints {
     uint32_t xcd_sched;         // != 0: `sched` is hints.sched, the per-XCD schedule (gsx_schedule_device.h) -- trusted
                                 // only if header[kHintSched] == number of tiles; 0: tile_schedule_kernel's whole-frame order
     uint32_t rank_last = 0;     // the spare workgroups that rank the samples come last in the grid instead of first
+    uint32_t skip_redo = 0;     // GSX_FLAG_SKIP_REDO: the second compositing launch is not issued
     // one byte per tile (GsxParams.hints): the tile met an ill-conditioned record last frame, so this frame's first
     // launch sends it to the redo list at once instead of compositing up to that record in vain (stale: time only)
     uint8_t *redo_hint = nullptr;

@@ -260,6 +260,7 @@ struct Plan {
     bool generic;  // GSX_FLAG_GENERIC_KERNELS
     bool tight;    // GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS
     bool split;    // long tiles on four waves (not GSX_FLAG_NO_LONG_TILE_SPLIT)
+    bool skip_redo;     // GSX_FLAG_SKIP_REDO
     int small_batch;    // 1: GSX_FLAG_ONE_VISIBLE, 2: GSX_FLAG_SMALL_BATCH, 0: neither
     int schedule;  // tiles handed out by list length: 1 GSX_FLAG_TILE_SCHEDULE, 0 GSX_FLAG_NO_TILE_SCHEDULE, -1 by size
     const GsxCamera *camera_device;
@@ -319,6 +320,7 @@ inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_ima
     p.generic = (d.flags & GSX_FLAG_GENERIC_KERNELS) != 0;
     p.tight = d.semantics == GSX_SEM_STD_3DGS && (d.flags & GSX_FLAG_PUBLISHED_RECTS) == 0;
     p.split = (d.flags & GSX_FLAG_NO_LONG_TILE_SPLIT) == 0;
+    p.skip_redo = (d.flags & GSX_FLAG_SKIP_REDO) != 0;
     p.small_batch = (d.flags & GSX_FLAG_ONE_VISIBLE) ? 1 : ((d.flags & GSX_FLAG_SMALL_BATCH) ? 2 : 0);
     p.schedule = (d.flags & GSX_FLAG_NO_TILE_SCHEDULE) ? 0 : ((d.flags & GSX_FLAG_TILE_SCHEDULE) ? 1 : -1);
     TileGrid &g = p.grid;

@@ -209,6 +209,10 @@ class CapturedFrame:
             raise _ffi.GsxError(_ffi.GSX_ERR_WORKSPACE_TOO_SMALL,
                                 "the captured frame holds %d pairs but the scene now produces %d: capture it again"
                                 % (st.reserved, st.n_instances))
+        if getattr(self, "_skip_redo", False) and st.n_redo > 0:
+            raise _ffi.GsxError(_ffi.GSX_ERR_UNSUPPORTED,
+                                "the frame was captured without the second compositing launch (GSX_FLAG_SKIP_REDO) and %d tiles "
+                                "now hold ill-conditioned footprints: capture it again" % st.n_redo)
         return self.out
 
 
@@ -225,6 +229,7 @@ class GaussianScene:
         self._last_instances = 0      # instance count of the latest full frame
         self._cap_hints = {}          # (image, tile, window, semantics) -> pair capacity for the next frame
         self._kept_hints = {}         # same key -> Gaussians that reached a tile of the window (GsxParams.kept_hint)
+        self._redo_hints = {}         # same key -> tiles the last frame handed to the second compositing launch (n_redo)
         self._hints = _Lru(_HINT_VIEWS)   # (same key, stream) -> [GsxParams.hints buffer, a frame has run with it?]
         self._pending = []            # speculative frames awaiting confirm_frames()
         self._part_events = {}        # (stream, K) -> K HIP events the library records behind the parts of a frame
@@ -451,6 +456,12 @@ class GaussianScene:
             own["inputs"][:] = passed
         # how many Gaussians reached a tile of this window last time: picks the depth-sort route (a hint)
         params.kept_hint = int(own.get("kept", self._kept_hints.get(cap_key, 0)))
+        # GSX_FLAG_SKIP_REDO: the last frame of this view handed no tile to the second compositing launch (no ill-conditioned
+        # footprint in sight), so this one does not issue it; its own n_redo says whether that held (checked below / by
+        # confirm_frames / by CapturedFrame.confirm: a frame that was wrong about it is rendered again without the flag)
+        skip_redo = bool(own["skip_redo"]) if "skip_redo" in own else (self._redo_hints.get(cap_key) == 0)
+        if skip_redo and semantics == "ref_cpu" and tile_size == 16 and not generic_kernels:
+            params.flags |= _ffi.GSX_FLAG_SKIP_REDO
         # GsxParams.hints: one buffer per view and stream (a captured frame owns its own), valid once a frame has filled it
         hint_slot = None
         if use_hints:
@@ -480,7 +491,7 @@ class GaussianScene:
             st = _ffi.GsxFrameStats()
             st_ref = ctypes.byref(st)
         with torch.cuda.device(dev):
-            for _ in range(3):
+            for _ in range(6):      # (a larger workspace, the second compositing launch after all, another row class: each at most once or twice)
                 nbytes = lib.gsx_workspace_bytes(n, width, height, tile_size, cap)
                 if nbytes == 0:
                     raise _ffi.GsxError(_ffi.GSX_ERR_INVALID_ARGUMENT, "gsx_workspace_bytes rejected the sizes")
@@ -494,6 +505,10 @@ class GaussianScene:
                 rc = lib.gsx_render_forward(ctypes.byref(cam), *[_ptr(t) for t in tensors], n, tile_size, _ptr(out),
                                             ctypes.byref(params), st_ref, _ptr(ws), nbytes,
                                             _stream_handle(dev))
+                if rc == _ffi.GSX_OK and not speculative and params.flags & _ffi.GSX_FLAG_SKIP_REDO and int(st.n_redo) > 0:
+                    # the frame did need the second compositing launch after all: once more, with it
+                    params.flags &= ~_ffi.GSX_FLAG_SKIP_REDO
+                    continue
                 again = 0
                 if rc == _ffi.GSX_OK and not speculative and not own and semantics != "std_3dgs":
                     again = _ffi.visible_rows_flag(n, int(st.n_visible), params.flags)
@@ -513,11 +528,12 @@ class GaussianScene:
             hint_slot[1] = True
         if own:
             if stats is not None and not speculative:
-                stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles, n_kept=st.n_kept)
+                stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles, n_kept=st.n_kept,
+                             n_redo=int(st.n_redo))
             return out
         if speculative:
             # counts are still in flight: remember what has to be confirmed
-            self._pending.append((pinned, cap_key, dict(
+            self._pending.append((pinned, cap_key, bool(params.flags & _ffi.GSX_FLAG_SKIP_REDO), dict(
                 image_idx=image_idx, tile_size=tile_size, layout=layout, tile_window=tile_window, out=out,
                 out_origin=out_origin, semantics=semantics, background=background,
                 generic_kernels=generic_kernels, published_rects=published_rects, camera_buffer=camera_buffer,
@@ -526,17 +542,20 @@ class GaussianScene:
             if stats is not None:
                 stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
             return out
-        self._note_count(cap_key, int(st.n_instances), int(st.n_kept))
+        self._note_count(cap_key, int(st.n_instances), int(st.n_kept), int(st.n_redo))
         if stats is not None:
-            stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles, n_kept=st.n_kept)
+            stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles, n_kept=st.n_kept,
+                         n_redo=int(st.n_redo))
             if timing:
                 stats["stage_ms"] = {k: float(st.stage_ms[i]) for i, k in enumerate(_ffi.STAGE_NAMES)}
         return out
 
-    def _note_count(self, cap_key, n_instances: int, n_kept: int = 0) -> None:
+    def _note_count(self, cap_key, n_instances: int, n_kept: int = 0, n_redo: Optional[int] = None) -> None:
         self._instances_hint = max(self._instances_hint, int(n_instances * 1.1))
         self._cap_hints[cap_key] = int(n_instances * 1.1) + 4096
         self._kept_hints[cap_key] = max(1, int(n_kept))
+        if n_redo is not None:
+            self._redo_hints[cap_key] = int(n_redo)
         if cap_key[2] is None and cap_key[3] == "ref_cpu":
             self._last_instances = n_instances
 
@@ -563,10 +582,11 @@ class GaussianScene:
         torch.cuda.synchronize(self.gaussians.points.device)
         redone = 0
         pending, self._pending = self._pending, []
-        for pinned, cap_key, call in pending:
+        for pinned, cap_key, skipped_redo, call in pending:
             st = ctypes.cast(ctypes.c_void_p(pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents
-            self._note_count(cap_key, int(st.n_instances), int(st.n_kept))
-            if st.n_instances > st.reserved:           # more pairs than the workspace held: dropped
+            self._note_count(cap_key, int(st.n_instances), int(st.n_kept), int(st.n_redo))
+            # more pairs than the workspace held (dropped), or tiles left to a second compositing launch that was not issued
+            if st.n_instances > st.reserved or (skipped_redo and st.n_redo > 0):
                 redone += 1
                 self.render_image_hip(**call)          # synchronising path, same output tensor
         return redone
@@ -604,7 +624,10 @@ class GaussianScene:
         nbytes = lib.gsx_workspace_bytes(n, cam.width, cam.height, tile_size, cap)
         if nbytes == 0:
             raise _ffi.GsxError(_ffi.GSX_ERR_INVALID_ARGUMENT, "gsx_workspace_bytes rejected the sizes")
+        # the graph bakes in whether the second compositing launch is issued: not for a fixed camera whose frame handed it
+        # nothing (confirm() checks every replay's n_redo); a movable camera may turn to ill-conditioned footprints
         private = dict(cap=cap, workspace=torch.empty(nbytes, dtype=torch.uint8, device=dev), kept=int(st["n_kept"]),
+                       skip_redo=(not movable_camera) and int(st.get("n_redo", 1)) == 0,
                        pinned=torch.zeros(ctypes.sizeof(_ffi.GsxFrameStats), dtype=torch.uint8).pin_memory(), inputs=[],
                        hints=[torch.zeros(lib.gsx_hints_bytes(cam.width, cam.height, tile_size), dtype=torch.uint8,
                                           device=dev), False])
@@ -619,6 +642,7 @@ class GaussianScene:
         frame = CapturedFrame(self, graph, out, private["pinned"], call, camera_buffer=cam_buf,
                               workspace=private["workspace"], capacity=cap, inputs=private["inputs"])
         frame._hints = private["hints"][0]     # the recorded kernels read and refresh this buffer on every replay
+        frame._skip_redo = bool(private["skip_redo"])
         return frame
 
     def render_image(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:
@@ -653,10 +677,10 @@ class GaussianScene:
         def finish(k: int) -> torch.Tensor:
             copied[k].synchronize()
             if checks[k] is not None:
-                pinned, cap_key, call = checks[k]
+                pinned, cap_key, skipped_redo, call = checks[k]
                 st = ctypes.cast(ctypes.c_void_p(pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents
-                self._note_count(cap_key, int(st.n_instances), int(st.n_kept))
-                if st.n_instances > st.reserved:        # pairs were dropped: once more, on the synchronising path
+                self._note_count(cap_key, int(st.n_instances), int(st.n_kept), int(st.n_redo))
+                if st.n_instances > st.reserved or (skipped_redo and st.n_redo > 0):    # dropped pairs / tiles left undone: once more, synchronously
                     self.render_image_hip(**call)
                     hosts[k].copy_(frames[k])
             return hosts[k]

@@ -69,7 +69,7 @@ def test_struct_layouts():
     assert _ffi.GsxParams.hints.offset == 96 and _ffi.GsxParams.n_substrips.offset == 104       # (104 = the ABI-300 struct)
     assert _ffi.GsxParams.substrip_bounds.offset == 112 and _ffi.GsxParams.substrip_events.offset == 120
     assert _ffi.GsxFrameStats.n_kept.offset == 56 and _ffi.GsxFrameStats.stage_ms.offset == 32
-    assert ctypes.sizeof(_ffi.GsxFrameStats) == 64
+    assert ctypes.sizeof(_ffi.GsxFrameStats) == 72 and _ffi.GsxFrameStats.n_redo.offset == 64
     p = _ffi.default_params()
     assert p.semantics == _ffi.GSX_SEM_REF_CPU and p.layout == _ffi.GSX_LAYOUT_WH3
     assert p.tile_x1 == -1 and p.tile_y1 == -1 and p.out_w == 0

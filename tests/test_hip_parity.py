@@ -775,6 +775,57 @@ def test_needles_through_every_kernel_family(tmp_path):
     assert d.max() <= PIXEL_TOL
 
 
+def test_second_compositing_launch_is_skipped_only_where_nothing_needs_it(tmp_path):
+    """GsxFrameStats.n_redo / GSX_FLAG_SKIP_REDO: a view without ill-conditioned footprints reports n_redo = 0, its next
+    frame is issued without the second compositing launch and is the same frame; a view with needles reports n_redo > 0
+    and keeps the launch; a frame that wrongly skipped it reports the tiles it left undone and the wrapper renders it
+    again -- on the synchronising path at once, for enqueued frames in confirm_frames(), for a captured frame by
+    raising in confirm()."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import _ffi
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    w, h = 320, 192
+    sc = make_scene(20_000, w, h, seed=9)
+    scene = _scene_from_arrays(tmp_path / "plain", sc)
+    st = {}
+    a = scene.render_image_hip(1, stats=st).clone()
+    assert st["n_redo"] == 0
+    key = (1, 16, None, "ref_cpu")
+    assert scene._redo_hints[key] == 0
+    st = {}
+    assert torch.equal(scene.render_image_hip(1, stats=st), a) and st["n_redo"] == 0        # (issued with GSX_FLAG_SKIP_REDO)
+    frame = scene.capture_frame(1, headroom=8.0)        # (room for the pairs of the needles grown below)
+    assert frame._skip_redo
+    frame.replay()
+    assert torch.equal(frame.confirm(), a)
+    # needles: the launch is needed and kept
+    sc2 = dict(sc)
+    sc2["scales"] = sc["scales"].copy()
+    sc2["scales"][::8, 0] *= 80.0
+    needles = _scene_from_arrays(tmp_path / "needles", sc2)
+    st = {}
+    b = needles.render_image_hip(1, stats=st).clone()
+    assert st["n_redo"] > 0 and needles._redo_hints[key] > 0
+    _, port, inst = _oracle_frame(needles, sc2)
+    assert st["n_instances"] == inst and np.max(np.abs(b.cpu().numpy() - port)) <= PIXEL_TOL
+    assert not needles.capture_frame(1)._skip_redo
+    # a frame that wrongly believes it can skip: the synchronising path notices and renders again ...
+    needles._redo_hints[key] = 0
+    st = {}
+    assert torch.equal(needles.render_image_hip(1, stats=st), b) and st["n_redo"] > 0
+    # ... an enqueued frame is redone by confirm_frames() ...
+    needles._redo_hints[key] = 0
+    out = torch.empty_like(b)
+    needles.render_image_hip(1, out=out, no_sync=True)
+    assert needles.confirm_frames() == 1 and torch.equal(out, b)
+    # ... and a frame captured for a scene that has since grown needles says so
+    scene.gaussians.scales[::8, 0] *= 80.0
+    frame.replay()
+    with pytest.raises(_ffi.GsxError, match="second compositing launch"):
+        frame.confirm()
+
+
 def test_orbit_of_eight_poses_through_one_captured_frame(tmp_path):
     """What bench.py --camera-path times, at a size the oracle renders whole: eight cameras 1 degree apart on an orbit
     (synthetic.orbit_poses), ONE frame captured with a movable camera and re-aimed before every replay.  Every replay
