@@ -135,7 +135,6 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             const bool split = p.split && cap > 0 && gsx::blend_splits_long_tiles(p.grid, p.semantics, p.generic);
             gsx::LongTiles lt{counters + kCtrLong, (uint32_t *)(ws + c.longs), split ? gsx::kMaxLongTiles : 0u};
             lt.redo = (uint32_t *)(ws + c.redo);
-            if (p.hints_valid) lt.redo_hint = fh.blend.redo_hint;
             if (fh.blend.lens) {        // GsxParams.hints: the tiles' costs decide who is long (tile_ranges_kernel)
                 lt.cost = fh.blend.lens;
                 lt.header = fh.blend.header;
@@ -154,6 +153,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             gsx::BlendHints bh = fh.blend;
             bh.xcd_sched = fh.sched ? 1u : 0u;
             bh.skip_redo = p.skip_redo ? 1u : 0u;
+            if (p.skip_redo) bh.redo_hint = nullptr;      // (a tile left to a launch that is not issued would stay undone)
             redo_counted = p.semantics == GSX_SEM_REF_CPU && p.grid.tile == 16 && !p.generic;
             // The 128 spare workgroups hold 16 wave slots of every XCD for ~15 us.  In front of the tiles that is free
             // -- unless the window's tiles fill the chip's 8 192 wave slots just about once (1080p: 7 973 tiles): then

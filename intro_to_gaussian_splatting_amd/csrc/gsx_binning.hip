@@ -423,13 +423,6 @@ __global__ void __launch_bounds__(kBlock)
                 // wave would have walked --, so a tile does not change sides from frame to frame.
                 is_long = (lt.cost[cur] & 0x7FFFFFFFu) >= cost_thr && j >= 127u && keys[j - 127u] == cur;     // (and 128 entries now)
             }
-            if (!is_long && lt.redo && lt.redo_hint && lt.redo_hint[cur]) {
-                // it met an ill-conditioned record last frame: straight to the redo list, and out of the first launch
-                const uint32_t slot = atomicAdd(lt.redo, 1u);
-                lt.redo[kRedoHeader + 2 * slot] = (uint32_t)cur;
-                lt.redo[kRedoHeader + 1 + 2 * slot] = 0u;
-                end |= kLongFlag;
-            }
             if (is_long) {
                 const uint32_t slot = atomicAdd(lt.count, 1u);
                 if (slot < lt.max) {

@@ -632,9 +632,13 @@ __device__ __forceinline__ void rank_samples(uint32_t group, int lane, const Ble
 // anything else (64 VGPRs, 8 waves per SIMD: DESIGN.md); a tile -- or a long tile's quarter -- that meets a reference-order
 // record in a batch stops there, leaves (tile, mode) in this list and writes nothing, and blend_redo_kernel, launched
 // behind it with twice the registers, composites those tiles from their first record with the same staging, the same
-// rules and the reference's operations on the flagged records.  redo[0] = entries, redo[1 + part] = queue head of
-// a part's redo launch (all zeroed by the emit kernel), entries from redo[kRedoHeader]: (tile, 0 = whole tile | 1 + quarter).  A scene without ill-conditioned footprints leaves
-// the list empty and the second launch 1024 idle workgroups long (~1 us).
+// rules and the reference's operations on the flagged records.  redo[0] = entries, redo[1 + part] = queue head
+// of a part's redo launch (all zeroed by the emit kernel), entries from redo[kRedoHeader]: (tile, 0 = whole tile |
+// 1 + quarter).  A scene without ill-conditioned footprints leaves the list empty and the second launch 1024 idle
+// workgroups long (~4 us; GSX_FLAG_SKIP_REDO: not issued).
+// GsxParams.hints carry one byte per tile from frame to frame: 1 = the tile held such a record last frame -- the first
+// launch then leaves it alone, and a few workgroups of that launch put all such tiles on the list, 256 per workgroup and
+// ONE add on the list's counter for them (list_hinted_tiles); 2 = found and listed in this frame.
 // The barrier between staging a batch and compositing it.  The first launch's workgroups are one wave each: s_barrier.
 // blend_redo_kernel packs FOUR independent waves into a workgroup (a quarter of the dispatches: the launch is mostly
 // idle workgroups when a scene has no ill-conditioned footprint), each with a staging area of its own: all that is
@@ -830,6 +834,43 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     o[2] = c2;
 }
 
+// Workgroup b of the hint-list workgroups of the first launch: the tiles 256 b .. 256 b + 255 whose hint byte is 1 go on the
+// redo list -- the same tiles blend_tile16<.., false> returns from early: not long, inside the part's span -- with one add
+// on the list's counter per workgroup.
+__device__ __forceinline__ void list_hinted_tiles(uint32_t b, int lane, const uint8_t *__restrict__ hint,
+                                                  const uint2 *__restrict__ ranges, const TileGrid &g, const TileSpan &span,
+                                                  uint32_t *__restrict__ redo) {
+    const uint32_t nt = (uint32_t)g.count(), t0 = (b * 64u + (uint32_t)lane) * 4u;
+    bool take[4];
+    unsigned long long m[4];
+    uint32_t total = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t t = t0 + (uint32_t)e;
+        take[e] = false;
+        if (t < nt && hint[t] == 1 && !(ranges[t].y & kLongFlag)) {
+            const int lead = span.axis ? g.wy0 + (int)(t % (uint32_t)g.nwy()) : g.wx0 + (int)(t / (uint32_t)g.nwy());
+            take[e] = lead >= span.lo && lead < span.hi;
+        }
+        m[e] = __ballot(take[e]);
+        total += (uint32_t)__popcll(m[e]);
+    }
+    if (total == 0u) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(redo, total);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    uint32_t at = base;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (take[e]) {
+            const uint32_t slot = at + (uint32_t)__popcll(m[e] & ((1ull << lane) - 1ull));
+            redo[kRedoHeader + 2 * slot] = t0 + (uint32_t)e;
+            redo[kRedoHeader + 1 + 2 * slot] = 0u;
+        }
+        at += (uint32_t)__popcll(m[e]);
+    }
+}
+
 // One 16x16 tile on one wave, 4 pixels per lane (the body of blend_tile16_kernel; see there).  REF as in
 // blend_long_tile_quarter: false -- a batch that holds a reference-order record sends the tile to the redo list.
 template <int VARIANT, bool REF>
@@ -887,11 +928,14 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
             hints.header[kHintLongPct] = found > 192u ? min(pct + pct / 4u, 1000u) : (found < 64u ? max(pct - pct / 8u, 30u) : pct);
         }
     }
-    // A long tile: four helper workgroups composite it.  The flag is also how tile_ranges_kernel takes a tile out of this
-    // launch that met an ill-conditioned record last frame (GsxParams.hints: it is in the redo list already --
-    // compositing up to that record here would be in vain); blend_redo_kernel composites such a tile whole.
-    if (REF) rg.y &= ~kLongFlag;
-    if (rg.y & kLongFlag) return;
+    if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
+    if (!REF && hints.redo_hint && hints.redo_hint[t] == 1) {
+        // it met an ill-conditioned record last frame (GsxParams.hints): compositing up to that record here would be in
+        // vain, and list_hinted_tiles has put it on the redo list.  (Not from here: a needle-ridden frame is 8 000 pushes
+        // at once, which queue up on the list's counter at ~12 ns each -- 80 us, measured from here and from
+        // tile_ranges_kernel alike.)  A stale byte costs nothing but the place: blend_redo_kernel composites any tile.
+        return;
+    }
     bool saw_ref = false;           // (REF) wave-uniform: a batch of this tile held a reference-order record
     uint32_t cost = 0;
     uint32_t skipped[kBlocks] = {0u, 0u, 0u, 0u};    // colour every block has left out so far (stage_records)
@@ -934,7 +978,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
             // (wave-uniform) an ill-conditioned footprint: not here -- blend_redo_kernel composites this tile
             if (lane == 0) {
                 push_redo(lt.redo, t, 0u);
-                if (hints.redo_hint) hints.redo_hint[t] = 1;
+                if (hints.redo_hint) hints.redo_hint[t] = 2;      // (2: on the list; 1 would make blend_redo_kernel take it twice)
             }
             return;
         } else if (kind == kBatchMono) {
@@ -1155,7 +1199,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (span.first) rank_samples(blockIdx.x - rank0, (int)threadIdx.x, hints);
         return;
     }
-    const uint32_t block = hints.rank_last ? blockIdx.x : blockIdx.x - nrank;
+    uint32_t block = hints.rank_last ? blockIdx.x : blockIdx.x - nrank;
+    if (!quarters && hints.redo_hint) {      // (the hint-list workgroups: in front of everything else, done in a microsecond)
+        const uint32_t nlist = ((uint32_t)g.count() + 255u) >> 8;
+        if (block < nlist) {
+            list_hinted_tiles(block, (int)threadIdx.x, hints.redo_hint, ranges, g, span, lt.redo);
+            return;
+        }
+        block -= nlist;
+    }
     if (quarters) {
         // A window of few tiles (a rank's strip): EVERY tile on four waves, a quarter of its pixels each.  One wave per
         // tile would leave the SIMDs with one to four waves, and a wave with few neighbours needs up to 3.3x its own
@@ -1215,12 +1267,12 @@ __global__ void __launch_bounds__(64 * kRedoWavesPerBlock) __attribute__((amdgpu
     __shared__ Staged sh_all[kRedoWavesPerBlock];
     Staged &sh = sh_all[threadIdx.x >> 6];
     const uint32_t n = min(lt.redo[0], capacity);
-    const uint32_t workers = gridDim.x * kRedoWavesPerBlock;
-    // the waves PULL their entries (one atomic per tile on the part's queue head): tiles differ by orders of magnitude
-    // in length, a fixed stride would leave the launch waiting for whoever drew the long ones.  A wave's first entry is
-    // its own index -- an empty list costs no atomic at all --, the following ones come from the queue, which starts
-    // behind the last worker.
-    for (uint32_t i = blockIdx.x * kRedoWavesPerBlock + (threadIdx.x >> 6); i < n;) {
+    const uint32_t workers = gridDim.x * kRedoWavesPerBlock, me = blockIdx.x * kRedoWavesPerBlock + (threadIdx.x >> 6);
+    // The waves PULL their entries (one atomic per tile on the part's queue head): tiles differ by orders
+    // of magnitude in length, a fixed stride would leave the launch waiting for whoever drew the long ones.  A wave's
+    // first entry is its own index -- an empty list costs no atomic at all --, the following ones come from the queue,
+    // which starts behind the last worker.
+    for (uint32_t i = me; i < n;) {
         const uint32_t t = lt.redo[kRedoHeader + 2 * i], mode = lt.redo[kRedoHeader + 1 + 2 * i];
         if (mode == 0u) {
             blend_tile16<1, true>(rec, qraw, vals, ranges, g, out, lt, budget, hints, span, t, sh);
@@ -1642,6 +1694,7 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
         const bool quarters = nt <= (int64_t)knob("GSX_QUARTERS_BELOW", kQuartersBelow);
         BlendHints bh = hints;
         if (quarters) bh.lens = nullptr;
+        if (variant == 0 || !lt.redo) bh.redo_hint = nullptr;      // (no second launch: no tile may wait for it)
         // tile workgroups: one per tile, or -- per-XCD schedule from GsxParams.hints -- 8 x cap (gsx_schedule_device.h)
         const uint32_t cap = bh.xcd_sched ? sched_cap((uint32_t)nt, (uint32_t)grid.nwy()) : 0u;
         const unsigned tile_blocks = bh.xcd_sched ? kSchedXcds * cap : (unsigned)nt;
@@ -1652,6 +1705,7 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             grid_blocks = (unsigned)((nt + 7) / 8) * 32u + clear_blocks;
         }
         grid_blocks += bh.samples ? kRankGroups : 0u;
+        if (!quarters && bh.redo_hint) grid_blocks += (unsigned)((nt + 255) / 256);      // list_hinted_tiles
         const uint32_t q = quarters ? 1u : 0u;
         if (variant == 0)
             blend_tile16_kernel<0><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);

@@ -70,9 +70,6 @@ struct LongTiles {
     // [1 .. 16] = the queue heads of up to 16 part launches (all zeroed by the emit kernel), entries (tile, mode) from
     // [kRedoHeader]; kRedoHeader + 2 (tiles + 4 kMaxLongTiles) words
     uint32_t *redo = nullptr;
-    // GsxParams.hints, one byte per tile: the tile met an ill-conditioned record last frame.  tile_ranges_kernel then
-    // puts it on the redo list itself and flags it like a long tile, so that the first launch skips it (stale: time only)
-    const uint8_t *redo_hint = nullptr;
 };
 __host__ __device__ inline uint32_t long_tile_threshold(uint32_t pairs, uint32_t tiles) {
     const uint32_t mean = tiles ? pairs / tiles : 0u;
