@@ -402,7 +402,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
         sh = gsx::SortHints{hdr, (const uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.samples),
                             p.hints_valid && route == gsx::kDepth256};
         fh.blend = gsx::BlendHints{hdr, sh.samples, (uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.lens), 0u};
-        fh.blend.redo_hint = (uint8_t *)(p.hints + hl.redo);
+        fh.blend.redo_hint = (uint32_t *)(p.hints + hl.redo);
         // the schedule costs nothing here (a spare workgroup of the projection launch): every window of more than two
         // tiles per SIMD gets one, unless told not to
         if (p.hints_valid && p.schedule != 0 && p.grid.count() > 2048) {

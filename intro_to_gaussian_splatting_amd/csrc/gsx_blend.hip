@@ -73,7 +73,7 @@
 // Test library only (gsx_debug.h: gsx_debug_set_blend_probe): when set, every workgroup of blend_tile16_kernel leaves
 // (cycles, tile, list length, records staged | flags << 24) there, indexed by blockIdx.x -- who is the frame waiting for?
 __device__ uint4 *g_blend_probe = nullptr;
-constexpr uint32_t kProbeSecond = 1u << 17;     // a second record per workgroup starts here (the buffer holds 2^18 records)
+constexpr uint32_t kProbeSecond = 1u << 17;     // a second record per workgroup starts here, the redo launch's per-tile records at twice this (the buffer holds 3 x 2^17)
 #endif
 
 namespace gsx {
@@ -315,7 +315,8 @@ __device__ __forceinline__ void composite(float px, const float (&e_p)[NPX], con
 // A block's decisions depend on the tile, the block and the list alone -- walked 64 entries at a time from the start --,
 // so every kernel arrives at the same ones and the kernel families stay bit-identical to each other.
 constexpr uint32_t kSkipBudget = 1u << 23;   // 2^-17 of colour per block and channel, in units of 2^-40 (colours are < 1)
-enum { kBatchRegular = 0, kBatchWild = 1, kBatchMono = 2, kBatchRefOrder = 3 };   // (kBatchRefOrder: a kKindRefOrder record, no monomial one)
+// (kBatchRefOrder: kKindRefOrder records among regular ones; kBatchRefWild: and a D1 < 0 record as well; neither holds a monomial one)
+enum { kBatchRegular = 0, kBatchWild = 1, kBatchMono = 2, kBatchRefOrder = 3, kBatchRefWild = 4 };
 enum { kStageWhole = 0, kStageBlocks = 1, kStageOneBlock = 2 };
 
 // Which of the three classes of far-away records does this batch still skip in one block?  bound: the lane's record's
@@ -342,7 +343,10 @@ __device__ __forceinline__ float skip_threshold(float bound, uint32_t &skipped, 
 
 // The second half of staging: `have` lanes hold a record (a, b, c) of the batch in registers.  skipped: the running
 // totals of the blocks (kStageWhole: [0], kStageOneBlock: [blk]).  count (kStageBlocks): entries of every block's list.
-// WITH_REF: the caller composites reference-order records itself (q4 = the lane's raw conic, see Record): such a
+// WITH_REF: the caller composites reference-order records itself (qraw[gi] = the lane's raw conic, see Record -- fetched
+// HERE, for the records that are still flagged after the tile's own test and kept: a heavy-tailed scene has a flagged
+// Gaussian in nearly every batch, and fetched up front for all of them the side array was a dependent trip to memory per
+// batch, ~3 us for a long tile's lone wave, 188 batches long): such a
 // record is staged as (x, y, Q00, Q01) (Q10, op, r, g) (b, Q11, flag, bits) in FRAME coordinates; without it the record
 // keeps its completed-square form -- all the caller needs is the batch's kind, it sends the tile to the redo list.
 // Either way the skip bound is the completed square's, computed like any other record's.
@@ -350,7 +354,8 @@ template <int MODE, bool WITH_REF = true>
 __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool have, uint32_t &nb, Staged &sh, int lane,
                                              float tile_x0, float tile_y0, float tile_side, uint32_t (&skipped)[kBlocks],
                                              uint32_t budget, int blk, uint32_t (&count)[kBlocks], uint32_t dead = 0u,
-                                             unsigned long long *ref_slots = nullptr, float4 q4 = float4{0.f, 0.f, 0.f, 0.f}) {
+                                             unsigned long long *ref_slots = nullptr, const float4 *__restrict__ qraw = nullptr,
+                                             uint32_t gi = 0u) {
     bool irregular = false, mono = false, refo = false;
     float bound[kBlocks] = {0.0f, 0.0f, 0.0f, 0.0f};   // < -26: a candidate, alpha < 2^bound on the whole block
     float x_abs = 0.0f, y_abs = 0.0f;
@@ -427,6 +432,8 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
         bits = (have && !(bound[0] < thr)) ? 0xFu : 0u;
     }
     const bool keep = bits != 0u;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (WITH_REF && refo && keep) q4 = qraw[gi];
     const unsigned long long mask = __ballot(keep);
     nb = (uint32_t)__popcll(mask);
     const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));   // kept lanes below this one
@@ -481,7 +488,8 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
     }
     if (ref_slots) *ref_slots = in_slots;
     return __any(mono && keep) ? kBatchMono
-                               : (in_slots ? kBatchRefOrder : (__any(irregular && keep) ? kBatchWild : kBatchRegular));
+                               : (in_slots ? ((WITH_REF && __any(irregular && !refo && keep)) ? kBatchRefWild : kBatchRefOrder)
+                                           : (__any(irregular && keep) ? kBatchWild : kBatchRegular));
 }
 
 // Gather + staging of one batch.  idx: this lane's entry of the tile's list (vals[base + lane]) when the caller has
@@ -493,18 +501,18 @@ __device__ __forceinline__ int stage_batch(const Record *__restrict__ rec, const
                                            float tile_y0, float tile_side, uint32_t (&skipped)[kBlocks], uint32_t (&count)[kBlocks],
                                            uint32_t budget = kSkipBudget, const uint32_t *idx = nullptr, int blk = 0,
                                            uint32_t dead = 0u, unsigned long long *ref_slots = nullptr) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, q4 = a;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
     const bool have = (uint32_t)lane < nb;
+    uint32_t gi = 0u;
     if (have) {
-        const uint32_t gi = idx ? *idx : vals[base + lane];
+        gi = idx ? *idx : vals[base + lane];
         const Record *q = rec + gi;
         a = q->a;
         b = q->b;
         c = q->c;
-        if (WITH_REF && c.z == kRefOrderFlag) q4 = qraw[gi];      // the raw conic of an ill-conditioned footprint
     }
     return stage_records<MODE, WITH_REF>(a, b, c, have, nb, sh, lane, tile_x0, tile_y0, tile_side, skipped, budget, blk, count, dead,
-                                         ref_slots, q4);
+                                         ref_slots, qraw, gi);
 }
 
 // ---- packed-math form of the same arithmetic (two pixels per VGPR pair) ----------------------
@@ -655,6 +663,10 @@ __device__ __forceinline__ void tile_sync() {
     }
 }
 
+// GsxParams.hints, one word per tile (BlendHints.redo_hint): bits 0 .. 3 = the tile -- bit 0 -- or its quarter q -- bit q,
+// where four waves composite it -- met a reference-order record in the last frame of the view; kHintRedoListed (the tile)
+// / kHintRedoFound << q (a quarter) = found and listed in THIS frame, until the second launch has composited it and says which.
+constexpr uint32_t kHintRedoMask = 0x0Fu, kHintRedoFound = 0x10u, kHintRedoListed = 0x100u;
 __device__ __forceinline__ void push_redo(uint32_t *redo, uint32_t tile, uint32_t mode) {
     const uint32_t slot = atomicAdd(redo, 1u);
     redo[kRedoHeader + 2 * slot] = tile;
@@ -676,12 +688,13 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
                                                         const uint2 *__restrict__ ranges, const TileGrid &g,
                                                         const OutDesc &out, uint32_t t, int quarter,
                                                         Staged &sh, uint32_t budget, uint32_t *cost_out, uint32_t *redo,
-                                                        uint8_t *redo_hint) {
+                                                        uint32_t *redo_hint) {
     const int lane = REF ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;      // (REF: four independent waves per workgroup)
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
     const uint32_t probe_w0h = (uint32_t)wall_clock64();
     uint32_t probe_staged = 0, probe_checked_at = 0xFFFFFFu, probe_batch = 0;
+    uint32_t probe_qc[3] = {0u, 0u, 0u}, probe_qtrips = 0, probe_qref = 0;      // cycles: staging, plain trips, trips with a ref-order record
 #endif
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     const bool y_contig = out.stride_y < out.stride_x;
@@ -693,6 +706,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     const float cx = (float)lx, cy = (float)ly;
     float T = 1.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
     bool checked = false;   // wave-uniform: some pixel of this quarter has saturated
+    bool saw_ref = false;   // (REF) wave-uniform: a batch held a reference-order record
     uint2 rg = ranges[t];
     rg.y &= ~kLongFlag;
     uint32_t skipped[kBlocks] = {0u, 0u, 0u, 0u}, unused[kBlocks];   // colour this block has left out so far (stage_records)
@@ -704,39 +718,48 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     // list not staged at all those trips ARE the tile's duration (188 batches x ~2.5 us on the clustered scene; the
     // compiler overlapped them in one build and not in the next, depending on its register allocation -- round 3).
     float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb4 = na, nc = na;      // records of the next batch
-    uint32_t idx2 = 0;                                                      // list entry of the batch after it
+    uint32_t idx2 = 0, idx1 = 0;                                            // list entry of the batch after it, of the next batch
     if (rg.x + (uint32_t)lane < rg.y) {
-        const Record *q = rec + vals[rg.x + lane];
+        idx1 = vals[rg.x + lane];
+        const Record *q = rec + idx1;
         na = q->a; nb4 = q->b; nc = q->c;
     }
     if (rg.x + 64u + (uint32_t)lane < rg.y) idx2 = vals[rg.x + 64u + lane];
     for (uint32_t base = rg.x; base < rg.y; base += 64) {
         uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
+#ifdef GSX_TEST_HOOKS
+        const unsigned long long probe_q0 = __builtin_readcyclecounter();
+#endif
         const float4 ra = na, rb = nb4, rc = nc;
+        const uint32_t idx0 = idx1;       // (this batch's list entry: the Gaussian's slot of the side array)
         if (base + 64u + (uint32_t)lane < rg.y) {
             const Record *q = rec + idx2;
             na = q->a; nb4 = q->b; nc = q->c;
+            idx1 = idx2;
         }
         if (base + 128u + (uint32_t)lane < rg.y) idx2 = vals[base + 128u + lane];
         unsigned long long ref_slots = 0ull;
-        float4 rq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (REF && (uint32_t)lane < nb && rc.z == kRefOrderFlag) rq = qraw[vals[base + lane]];     // (few lanes: the entry is in the cache)
         const int kind = stage_records<kStageOneBlock, REF>(ra, rb, rc, (uint32_t)lane < nb, nb, sh, lane, (float)(tx * 16),
-                                                            (float)(ty * 16), 16.0f, skipped, budget, quarter, unused, 0u, &ref_slots, rq);
+                                                            (float)(ty * 16), 16.0f, skipped, budget, quarter, unused, 0u, &ref_slots, qraw, idx0);
         cost += nb + kBatchCost;
 #ifdef GSX_TEST_HOOKS
         probe_staged += nb;
         if (checked && probe_checked_at == 0xFFFFFFu) probe_checked_at = probe_batch;
         ++probe_batch;
 #endif
-        if (!REF && kind == kBatchRefOrder) {       // (wave-uniform) not here: blend_redo_kernel composites this quarter
+        if (REF && kind >= kBatchRefOrder) saw_ref = true;
+        if (!REF && kind >= kBatchRefOrder) {       // (wave-uniform) not here: blend_redo_kernel composites this quarter
             if (lane == 0) {
                 push_redo(redo, t, (uint32_t)quarter + 1u);
-                if (redo_hint) redo_hint[t] = 1;    // (a long tile's byte is only ever set: its quarters do not agree on it)
+                if (redo_hint) atomicOr(redo_hint + t, kHintRedoFound << quarter);      // (not a mask bit yet: see kHintRedoMask)
             }
             return;
         }
         tile_sync<REF>();
+#ifdef GSX_TEST_HOOKS
+        unsigned long long probe_q1 = __builtin_readcyclecounter();
+        probe_qc[0] += (uint32_t)(probe_q1 - probe_q0);
+#endif
         // Whole trips of eight records (the batch is padded with null records, see kPad).  The alphas of a trip
         // are computed independently of each other and of T -- no branch between them --; then either the plain
         // chain T -> T - T alpha with ONE wave-level saturation test per trip, or -- from the first trip in which any
@@ -756,24 +779,19 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
             }
         } else {
             for (uint32_t k = 0; k < nb; k += kTrip) {
-                // a trip that holds a reference-order record (wave-uniform: a scalar branch, taken by few trips) goes one
-                // record at a time through the scalar form, which evaluates such a record by the reference's operations
-                // (composite<1>: the exact rule, valid anywhere; a pixel it stops has T = 0, which the next trip's test sees)
-                if (REF && __builtin_expect((uint32_t)(ref_slots >> k) & 0xFFu, 0)) {
-                    for (uint32_t u = 0; u < (uint32_t)kTrip; ++u) {
-                        const Splat s = read_splat(sh, k + u);
-                        const float e_p[1] = {cy};
-                        float T1[1] = {T}, a0[1] = {c0}, a1[1] = {c1}, a2[1] = {c2};
-                        composite<1, REF>(cx, e_p, s, T1, a0, a1, a2, 0, (float)(tx * 16), (float)(ty * 16));
-                        T = T1[0]; c0 = a0[0]; c1 = a1[0]; c2 = a2[0];
-                    }
-                    continue;
-                }
                 float alpha[kTrip];
 #pragma unroll
                 for (int u = 0; u < kTrip; ++u) {
                     const float4 A = sh.rec[0][k + u];
                     const float2 Bq = *reinterpret_cast<const float2 *>(&sh.rec[1][k + u]);   // (r11, log2 op)
+                    // (wave-uniform, a scalar branch few trips take) a reference-order record: (x, y, Q00, Q01) (Q10, op) (.., Q11),
+                    // the reference's operations at the pixel's FRAME coordinates.  Its alpha may exceed 1 by a rounding:
+                    // the chain below tests T after every record.  (Round 5 sent such a trip through the scalar form one
+                    // record at a time: 4 300 cycles against 1 400.)
+                    if (REF && ((uint32_t)(ref_slots >> k) >> u) & 1u) {
+                        alpha[u] = alpha_ref(A.x, A.y, A.z, A.w, Bq.x, sh.rec[2][k + u].y, Bq.y, (float)(tx * 16) + cx, (float)(ty * 16) + cy);
+                        continue;
+                    }
                     const float e_x = A.x - cx;
                     const float s0 = __builtin_fmaf(-(A.z * e_x), e_x, Bq.y);
                     const float w = __builtin_fmaf(-Bq.x, cy, __builtin_fmaf(-A.w, cx, A.y));
@@ -812,6 +830,14 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
                     c2 = __builtin_fmaf(ta[u], cb, c2);
                 }
                 T = Tt;
+#ifdef GSX_TEST_HOOKS
+                {
+                    const unsigned long long now = __builtin_readcyclecounter();
+                    probe_qc[1] += (uint32_t)(now - probe_q1);
+                    probe_q1 = now;
+                    ++probe_qtrips;
+                }
+#endif
             }
         }
         tile_sync<REF>();
@@ -819,10 +845,19 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     }
     // (the largest of the four quarters' costs = the records one wave would have walked until all 256 pixels are done)
     if (cost_out && lane == 0) atomicMax(cost_out, cost | 0x80000000u);
+    // for the next frame of the view: this quarter's bit of the tile's hint word (the four quarters are four waves)
+    if (REF && redo_hint && lane == 0) {
+        if (saw_ref)
+            atomicOr(redo_hint + t, 1u << quarter);
+        else
+            atomicAnd(redo_hint + t, ~((1u << quarter) | (kHintRedoFound << quarter)));
+    }
 #ifdef GSX_TEST_HOOKS
     if (g_blend_probe && lane == 0)
         g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t | 0x40000000u, rg.y - rg.x,
                                                probe_staged | (checked ? 0x80000000u : 0u));
+    if (g_blend_probe && lane == 2 && blockDim.x == 64u)
+        g_blend_probe[3 * kProbeSecond + 65536u + blockIdx.x] = make_uint4(probe_qc[0], probe_qc[1], probe_qc[2], probe_qref | (probe_qtrips << 12));
     if (g_blend_probe && lane == 1)
         g_blend_probe[kProbeSecond + blockIdx.x] =
             make_uint4(probe_checked_at, (uint32_t)wall_clock64(),
@@ -834,41 +869,46 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     o[2] = c2;
 }
 
-// Workgroup b of the hint-list workgroups of the first launch: the tiles 256 b .. 256 b + 255 whose hint byte is 1 go on the
-// redo list -- the same tiles blend_tile16<.., false> returns from early: not long, inside the part's span -- with one add
-// on the list's counter per workgroup.
-__device__ __forceinline__ void list_hinted_tiles(uint32_t b, int lane, const uint8_t *__restrict__ hint,
+// Workgroup b of the hint-list workgroups of the first launch: of the tiles 256 b .. 256 b + 255 those whose hint word says
+// so go on the redo list -- a tile on one wave (bit 0 .. 3, whichever: blend_tile16<.., false> returns early from exactly
+// these) as (tile, 0), a long tile's quarter q (bit q: its helper workgroup returns early) as (tile, 1 + q); inside the
+// part's span only -- with one add on the list's counter per workgroup.
+__device__ __forceinline__ void list_hinted_tiles(uint32_t b, int lane, const uint32_t *__restrict__ hint,
                                                   const uint2 *__restrict__ ranges, const TileGrid &g, const TileSpan &span,
-                                                  uint32_t *__restrict__ redo) {
+                                                  uint32_t *__restrict__ redo, bool split) {
     const uint32_t nt = (uint32_t)g.count(), t0 = (b * 64u + (uint32_t)lane) * 4u;
-    bool take[4];
-    unsigned long long m[4];
-    uint32_t total = 0;
+    uint32_t modes[4];          // bit m: entry (tile, m) goes on the list
+    uint32_t mine = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const uint32_t t = t0 + (uint32_t)e;
-        take[e] = false;
-        if (t < nt && hint[t] == 1 && !(ranges[t].y & kLongFlag)) {
+        modes[e] = 0u;
+        if (t < nt) {
+            const uint32_t bits = hint[t] & kHintRedoMask;
             const int lead = span.axis ? g.wy0 + (int)(t % (uint32_t)g.nwy()) : g.wx0 + (int)(t / (uint32_t)g.nwy());
-            take[e] = lead >= span.lo && lead < span.hi;
+            if (bits && lead >= span.lo && lead < span.hi) modes[e] = (split && (ranges[t].y & kLongFlag)) ? bits << 1 : 1u;
         }
-        m[e] = __ballot(take[e]);
-        total += (uint32_t)__popcll(m[e]);
+        mine += (uint32_t)__popc(modes[e]);
     }
+    uint32_t x = mine;          // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+        if (lane >= o) x += y;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)x, 63);
     if (total == 0u) return;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(redo, total);
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    uint32_t at = base;
+    uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + x - mine;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (take[e]) {
-            const uint32_t slot = at + (uint32_t)__popcll(m[e] & ((1ull << lane) - 1ull));
-            redo[kRedoHeader + 2 * slot] = t0 + (uint32_t)e;
-            redo[kRedoHeader + 1 + 2 * slot] = 0u;
-        }
-        at += (uint32_t)__popcll(m[e]);
-    }
+    for (int e = 0; e < 4; ++e)
+        for (uint32_t m = 0; m < 5u; ++m)
+            if ((modes[e] >> m) & 1u) {
+                redo[kRedoHeader + 2 * slot] = t0 + (uint32_t)e;
+                redo[kRedoHeader + 1 + 2 * slot] = m;
+                ++slot;
+            }
 }
 
 // One 16x16 tile on one wave, 4 pixels per lane (the body of blend_tile16_kernel; see there).  REF as in
@@ -884,6 +924,8 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
     const uint32_t probe_w0 = (uint32_t)wall_clock64();
     uint32_t probe_staged = 0, probe_batches = 0, probe_after = 0;
+    uint32_t probe_first_ref = 0xFFFu, probe_ref_batches = 0, probe_ref_records = 0;      // (REF: tools/attic/redo_probe.py)
+    uint32_t probe_cyc[4] = {0u, 0u, 0u, 0u}, probe_ent[3] = {0u, 0u, 0u};      // cycles: staging, compositing regular / wild / ref-order batches; entries walked
 #endif
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
     if ((span.axis ? ty : tx) < span.lo || (span.axis ? ty : tx) >= span.hi) return;      // another part's tile
@@ -929,7 +971,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
         }
     }
     if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
-    if (!REF && hints.redo_hint && hints.redo_hint[t] == 1) {
+    if (!REF && hints.redo_hint && (hints.redo_hint[t] & kHintRedoMask)) {
         // it met an ill-conditioned record last frame (GsxParams.hints): compositing up to that record here would be in
         // vain, and list_hinted_tiles has put it on the redo list.  (Not from here: a needle-ridden frame is 8 000 pushes
         // at once, which queue up on the list's counter at ~12 ns each -- 80 us, measured from here and from
@@ -955,11 +997,21 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
         if (base + 64u + (uint32_t)lane < rg.y) idx = vals[base + 64u + lane];
         uint32_t count[kBlocks];
         unsigned long long ref_slots = 0ull;     // (wave-uniform) the slots of this batch that hold a reference-order record
+#ifdef GSX_TEST_HOOKS
+        const unsigned long long probe_b0 = __builtin_readcyclecounter();
+#endif
         const int kind = stage_batch<kStageBlocks, (REF || VARIANT == 0)>(rec, qraw, vals, base, nb, sh, lane, (float)(tx * 16),
                                                                           (float)(ty * 16), 16.0f, skipped, count, budget, &idx_now, 0,
                                                                           dead, &ref_slots);
         const bool wild = kind != kBatchRegular;     // wave-uniform
-        if (REF && kind == kBatchRefOrder) saw_ref = true;
+        if (REF && kind >= kBatchRefOrder) saw_ref = true;
+#ifdef GSX_TEST_HOOKS
+        if (REF && kind >= kBatchRefOrder) {
+            if (probe_first_ref == 0xFFFu) probe_first_ref = probe_batches;
+            ++probe_ref_batches;
+            probe_ref_records += (uint32_t)__popcll(ref_slots);
+        }
+#endif
         // the wave walks as far as its LONGEST block list; the other blocks' lists are padded with a null record
         const uint32_t nl = max(max(count[0], count[1]), max(count[2], count[3]));
         cost += nl + kBatchCost;
@@ -969,16 +1021,20 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
         if (checked) probe_after += nl;           // (entries walked under the exact rule, whole batches)
 #endif
         tile_sync<REF>();
+#ifdef GSX_TEST_HOOKS
+        const unsigned long long probe_b1 = __builtin_readcyclecounter();
+        probe_cyc[0] += (uint32_t)(probe_b1 - probe_b0);
+#endif
         if (VARIANT == 0) {
             for (uint32_t k = 0; k < nb; ++k) {
                 const Splat s = read_splat(sh, k);
                 composite<4, (REF || VARIANT == 0)>(cx, cy, s, T, c0, c1, c2, blk, (float)(tx * 16), (float)(ty * 16));
             }
-        } else if (!REF && kind == kBatchRefOrder) {
+        } else if (!REF && kind >= kBatchRefOrder) {
             // (wave-uniform) an ill-conditioned footprint: not here -- blend_redo_kernel composites this tile
             if (lane == 0) {
                 push_redo(lt.redo, t, 0u);
-                if (hints.redo_hint) hints.redo_hint[t] = 2;      // (2: on the list; 1 would make blend_redo_kernel take it twice)
+                if (hints.redo_hint) hints.redo_hint[t] = kHintRedoListed;      // (not a mask bit: list_hinted_tiles would list it a second time)
             }
             return;
         } else if (kind == kBatchMono) {
@@ -1061,7 +1117,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
                 while (!checked && k + kTrip <= nl) checked = !trip(std::integral_constant<int, kTrip>());
                 while (!checked && k < nl) checked = !trip(std::integral_constant<int, 2>());   // what is left: trips of two (+ a null record)
             }
-            if (!REF || kind != kBatchRefOrder) {
+            if (!REF || kind < kBatchRefOrder) {
                 while (k < nl) exact_pair();
             } else {
                 // The batch holds an ill-conditioned footprint (kKindRefOrder; such a batch counts as wild).  A pair of
@@ -1071,11 +1127,24 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
                 // every record's alpha is what it is in any other batch.
                 const float fx_ = (float)(tx * 16) + cx;
                 const v2f fya = splat2((float)(ty * 16)) + cya, fyb = splat2((float)(ty * 16)) + cyb;
+                auto is_ref = [&](uint32_t s_) -> bool { return (s_ >> 4) < 64u && ((ref_slots >> (s_ >> 4)) & 1ull) != 0ull; };
                 while (k < nl) {
+                    // Nothing but regular records beside the flagged ones (kBatchRefOrder), no pixel saturated yet: four list
+                    // entries none of which -- in any block -- is flagged are a trip like in any regular batch (one flagged
+                    // record in 64 sent the whole batch through the exact rule pair by pair: 726 cycles per entry against
+                    // 466, a third of the heavy-tailed scene's compositing)
+                    if (kind == kBatchRefOrder && !checked && k + kTrip <= nl) {
+                        bool flagged = false;
+#pragma unroll
+                        for (int u = 0; u < kTrip; ++u) flagged |= is_ref(my_list[k + u]);
+                        if (!__any(flagged)) {
+                            checked = !trip(std::integral_constant<int, kTrip>());
+                            continue;
+                        }
+                    }
                     const uint32_t s0_ = my_list[k], s1_ = my_list[k + 1];
                     // (a list's padding names the null record's slot, which may be slot 64: no bit of the mask)
-                    const bool r0 = (s0_ >> 4) < 64u && ((ref_slots >> (s0_ >> 4)) & 1ull) != 0ull;
-                    const bool r1 = (s1_ >> 4) < 64u && ((ref_slots >> (s1_ >> 4)) & 1ull) != 0ull;
+                    const bool r0 = is_ref(s0_), r1 = is_ref(s1_);
                     if (!__any(r0 | r1)) {
                         exact_pair();
                         continue;
@@ -1097,6 +1166,13 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
             }
         }
         tile_sync<REF>();
+#ifdef GSX_TEST_HOOKS
+        {
+            const int pk = kind == kBatchRegular ? 0 : (kind >= kBatchRefOrder ? 2 : 1);
+            probe_cyc[1 + pk] += (uint32_t)(__builtin_readcyclecounter() - probe_b1);
+            probe_ent[pk] += nl;
+        }
+#endif
         bool live;
         if (VARIANT == 0)
             live = (T[0] > 0.0f) | (T[1] > 0.0f) | (T[2] > 0.0f) | (T[3] > 0.0f);
@@ -1141,12 +1217,22 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
 
     if (hints.lens && lane == 0) hints.lens[t] = cost;
     if (REF && hints.redo_hint && lane == 0) hints.redo_hint[t] = saw_ref ? 1 : 0;    // for the next frame of the view
+    if (REF && hints.in_place && saw_ref && lane == 0) atomicAdd(lt.redo, 1u);        // (no list: GsxFrameStats.n_redo is counted here)
 #ifdef GSX_TEST_HOOKS
-    if (g_blend_probe && lane == 0)
+    // REF (several waves per workgroup): by tile, behind the two records of the first launch's workgroups
+    if (REF && g_blend_probe && lane == 0)
+        g_blend_probe[2 * kProbeSecond + t] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0),
+                                                         probe_batches | (probe_first_ref << 12) | (checked ? 0x80000000u : 0u),
+                                                         probe_ref_batches | (probe_ref_records << 12), rg.y - rg.x);
+    if (REF && g_blend_probe && lane == 1) {
+        g_blend_probe[2 * kProbeSecond + 65536u + t] = make_uint4(probe_cyc[0], probe_cyc[1], probe_cyc[2], probe_cyc[3]);
+        g_blend_probe[3 * kProbeSecond + t] = make_uint4(probe_ent[0], probe_ent[1], probe_ent[2], 0u);
+    }
+    if (!REF && g_blend_probe && lane == 0)
         g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t, rg.y - rg.x,
                                                probe_staged | (checked ? 0x80000000u : 0u));
     // (where and when: HW_ID = register 4, XCC_ID = register 20; wall_clock64 ticks at 100 MHz on every XCD alike)
-    if (g_blend_probe && lane == 1)
+    if (!REF && g_blend_probe && lane == 1)
         g_blend_probe[kProbeSecond + blockIdx.x] =
             make_uint4(probe_batches | (probe_after << 12), (uint32_t)wall_clock64(),
                        (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16),
@@ -1178,13 +1264,14 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
 //                   contiguous bytes per store instruction.
 // VARIANT 0: scalar-form composite<4>; VARIANT 1: packed form, four (then two) records per saturation test;
 // VARIANT 2 (test library only): six per test.
-template <int VARIANT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))   // 64 VGPRs: every lost wave costs (DESIGN.md)
-    blend_tile16_kernel(const Record *__restrict__ rec, const float4 *__restrict__ qraw, const uint32_t *__restrict__ vals,
-                        const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
-                        uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints,
-                        uint32_t tile_blocks, uint32_t sched_cap_, TileSpan span) {
-    __shared__ Staged sh;
+// REF (blend_tile16_inplace_kernel): every workgroup evaluates reference-order records itself -- no redo list.
+template <int VARIANT, bool REF>
+__device__ __forceinline__ void blend_tile16_grid(const Record *__restrict__ rec, const float4 *__restrict__ qraw,
+                                                  const uint32_t *__restrict__ vals, const uint2 *__restrict__ ranges,
+                                                  const TileGrid &g, const OutDesc &out, const ClearPlan &cp, const LongTiles &lt,
+                                                  uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget,
+                                                  uint32_t quarters, const BlendHints &hints, uint32_t tile_blocks,
+                                                  uint32_t sched_cap_, const TileSpan &span, Staged &sh) {
     // block order: [spare workgroups: the next frame's splitters] [helpers of long tiles (dispatched first: they have
     // the most to do)] [tiles] [clears]
     // (hints.rank_last -- gsx_api.hip: a window whose tiles just about fill the chip once -- : the spare workgroups come
@@ -1200,10 +1287,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         return;
     }
     uint32_t block = hints.rank_last ? blockIdx.x : blockIdx.x - nrank;
-    if (!quarters && hints.redo_hint) {      // (the hint-list workgroups: in front of everything else, done in a microsecond)
+    if (!REF && !quarters && hints.redo_hint) {      // (the hint-list workgroups: in front of everything else, done in a microsecond)
         const uint32_t nlist = ((uint32_t)g.count() + 255u) >> 8;
         if (block < nlist) {
-            list_hinted_tiles(block, (int)threadIdx.x, hints.redo_hint, ranges, g, span, lt.redo);
+            list_hinted_tiles(block, (int)threadIdx.x, hints.redo_hint, ranges, g, span, lt.redo, nhelpers != 0u);
             return;
         }
         block -= nlist;
@@ -1224,8 +1311,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         const uint32_t per = nt >> 3, extra = nt & 7u, xcd = b & 7u, i = b >> 5;
         if (i >= per + (xcd < extra ? 1u : 0u)) return;
         (void)u;
-        blend_long_tile_quarter<false>(rec, qraw, vals, ranges, g, out, xcd_remap((i << 3) | xcd, nt), (int)((b >> 3) & 3u), sh, budget,
-                                       nullptr, lt.redo, hints.redo_hint);
+        blend_long_tile_quarter<REF>(rec, qraw, vals, ranges, g, out, xcd_remap((i << 3) | xcd, nt), (int)((b >> 3) & 3u), sh, budget,
+                                     nullptr, lt.redo, hints.redo_hint);
         return;
     }
     if (block < nhelpers) {
@@ -1238,8 +1325,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
             const int lead = span.axis ? g.wy0 + (int)(lt_tile % (uint32_t)g.nwy()) : g.wx0 + (int)(lt_tile / (uint32_t)g.nwy());
             if (lead < span.lo || lead >= span.hi) return;
         }
-        blend_long_tile_quarter<false>(rec, qraw, vals, ranges, g, out, lt_tile, quarter, sh, budget,
-                                       hints.lens ? hints.lens + lt_tile : nullptr, lt.redo, hints.redo_hint);
+        // (its hint bit: list_hinted_tiles has put this quarter on the redo list -- walking up to the record here would be in vain)
+        if (!REF && hints.redo_hint && ((hints.redo_hint[lt_tile] >> quarter) & 1u)) return;
+        blend_long_tile_quarter<REF>(rec, qraw, vals, ranges, g, out, lt_tile, quarter, sh, budget,
+                                     hints.lens ? hints.lens + lt_tile : nullptr, lt.redo, hints.redo_hint);
         return;
     }
     const uint32_t bid = block - nhelpers;
@@ -1250,8 +1339,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const uint32_t t = hints.xcd_sched ? xcd_scheduled_tile(bid, (uint32_t)g.count(), sched_cap_, sched, hints.header)
                                        : scheduled_tile(bid, (uint32_t)g.count(), sched);
     if (t >= (uint32_t)g.count()) return;
-    blend_tile16<VARIANT, false>(rec, qraw, vals, ranges, g, out, lt, budget, hints, span, t, sh);
+    blend_tile16<VARIANT, REF>(rec, qraw, vals, ranges, g, out, lt, budget, hints, span, t, sh);
 }
+
+template <int VARIANT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))   // 64 VGPRs: every lost wave costs (DESIGN.md)
+    blend_tile16_kernel(const Record *__restrict__ rec, const float4 *__restrict__ qraw, const uint32_t *__restrict__ vals,
+                        const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
+                        uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints,
+                        uint32_t tile_blocks, uint32_t sched_cap_, TileSpan span) {
+    __shared__ Staged sh;
+    blend_tile16_grid<VARIANT, false>(rec, qraw, vals, ranges, g, out, cp, lt, nhelpers, sched, budget, quarters, hints, tile_blocks,
+                                      sched_cap_, span, sh);
+}
+
+// The same grid with reference-order records evaluated where they turn up (REF): one launch, the schedule, the long
+// tiles' helpers and all, at the price of registers -- W waves per SIMD.  For views most of whose tiles hold such records.
+#define GSX_INPLACE_KERNEL(W)                                                                                                   \
+    __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, 8)))                                             \
+        blend_tile16_inplace_kernel_##W(const Record *__restrict__ rec, const float4 *__restrict__ qraw,                         \
+                                        const uint32_t *__restrict__ vals, const uint2 *__restrict__ ranges, TileGrid g,        \
+                                        OutDesc out, ClearPlan cp, LongTiles lt, uint32_t nhelpers,                              \
+                                        const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints, \
+                                        uint32_t tile_blocks, uint32_t sched_cap_, TileSpan span) {                             \
+        __shared__ Staged sh;                                                                                                   \
+        blend_tile16_grid<1, true>(rec, qraw, vals, ranges, g, out, cp, lt, nhelpers, sched, budget, quarters, hints,           \
+                                   tile_blocks, sched_cap_, span, sh);                                                          \
+    }
+GSX_INPLACE_KERNEL(4)
+GSX_INPLACE_KERNEL(5)
+GSX_INPLACE_KERNEL(6)
+GSX_INPLACE_KERNEL(8)
 
 // The tiles and long-tile quarters the launch above left in the redo list (push_redo), composited with reference-order
 // records evaluated by the reference's own operations.  Same staging, same rules, same pixel assignment as the first
@@ -1280,7 +1398,7 @@ __global__ void __launch_bounds__(64 * kRedoWavesPerBlock) __attribute__((amdgpu
             const int lead = span.axis ? g.wy0 + (int)(t % (uint32_t)g.nwy()) : g.wx0 + (int)(t / (uint32_t)g.nwy());
             if (lead >= span.lo && lead < span.hi)
                 blend_long_tile_quarter<true>(rec, qraw, vals, ranges, g, out, t, (int)mode - 1, sh, budget,
-                                              hints.lens ? hints.lens + t : nullptr, nullptr, nullptr);
+                                              hints.lens ? hints.lens + t : nullptr, nullptr, hints.redo_hint);
         }
         tile_sync<true>();
         uint32_t next = 0;
@@ -1695,6 +1813,8 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
         BlendHints bh = hints;
         if (quarters) bh.lens = nullptr;
         if (variant == 0 || !lt.redo) bh.redo_hint = nullptr;      // (no second launch: no tile may wait for it)
+        const int in_place = variant != 0 && lt.redo ? knob("GSX_REF_IN_PLACE", 0) : 0;      // (experiment: test library only)
+        bh.in_place = in_place ? 1u : 0u;
         // tile workgroups: one per tile, or -- per-XCD schedule from GsxParams.hints -- 8 x cap (gsx_schedule_device.h)
         const uint32_t cap = bh.xcd_sched ? sched_cap((uint32_t)nt, (uint32_t)grid.nwy()) : 0u;
         const unsigned tile_blocks = bh.xcd_sched ? kSchedXcds * cap : (unsigned)nt;
@@ -1705,9 +1825,17 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             grid_blocks = (unsigned)((nt + 7) / 8) * 32u + clear_blocks;
         }
         grid_blocks += bh.samples ? kRankGroups : 0u;
-        if (!quarters && bh.redo_hint) grid_blocks += (unsigned)((nt + 255) / 256);      // list_hinted_tiles
+        if (!quarters && bh.redo_hint && !in_place) grid_blocks += (unsigned)((nt + 255) / 256);      // list_hinted_tiles
         const uint32_t q = quarters ? 1u : 0u;
-        if (variant == 0)
+        if (in_place == 4)
+            blend_tile16_inplace_kernel_4<<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
+        else if (in_place == 5)
+            blend_tile16_inplace_kernel_5<<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
+        else if (in_place == 6)
+            blend_tile16_inplace_kernel_6<<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
+        else if (in_place)
+            blend_tile16_inplace_kernel_8<<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
+        else if (variant == 0)
             blend_tile16_kernel<0><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         else if (variant == 2)
             blend_tile16_kernel<2><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
@@ -1717,7 +1845,7 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             blend_tile16_kernel<1><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         // what the launch left for the second one: tiles that hold ill-conditioned footprints (see blend_redo_kernel;
         // VARIANT 0 -- test library -- evaluates every record kind in place and leaves nothing)
-        if (variant != 0 && lt.redo && !bh.skip_redo) {
+        if (variant != 0 && lt.redo && !bh.skip_redo && !in_place) {
             const hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
             const uint32_t capacity = (uint32_t)nt + 4u * kMaxLongTiles;

@@ -35,11 +35,13 @@ GSX_API int gsx_debug_depth_sort(uint32_t *keys, int64_t n, const void *rect, vo
                                  int32_t mode, uint32_t lds_cap, int64_t kept_hint, int64_t *counts_host,
                                  void *scratch, size_t scratch_bytes, void *stream);
 
-/* Who is the compositing launch waiting for, and where does it run?  device_buffer: 2^18 x 16 bytes, or NULL to switch
+/* Who is the compositing launch waiting for, and where does it run?  device_buffer: 4 x 2^17 x 16 bytes, or NULL to switch
  * the probe off.  While set, every workgroup of the tile-16 REF_CPU compositing kernel stores (cycles it ran, window-
  * local tile id | 1 << 30 for a long tile's helper, length of the tile's list, records staged | saturated << 31) at
  * index blockIdx.x and (batches staged | entries walked under the exact rule << 12, wall clock at its end [10 ns], HW_ID & 0xFFFF | XCC_ID << 16,
- * wall clock at its start) at index 2^17 + blockIdx.x (tools/attic/blend_probe.py, tools/attic/simd_balance.py). */
+ * wall clock at its start) at index 2^17 + blockIdx.x (tools/attic/blend_probe.py, tools/attic/simd_balance.py); the
+ * second launch (blend_redo_kernel) stores (cycles, batches | first batch with a reference-order record << 12 | saturated
+ * << 31, such batches | such records << 12, list length) per tile at 2^18 + tile (tools/attic/redo_probe.py). */
 GSX_API int gsx_debug_set_blend_probe(void *device_buffer);
 
 #ifdef __cplusplus

@@ -203,7 +203,8 @@ struct BlendHints {
     uint32_t skip_redo = 0;     // GSX_FLAG_SKIP_REDO: the second compositing launch is not issued
     // one byte per tile (GsxParams.hints): the tile met an ill-conditioned record last frame, so this frame's first
     // launch sends it to the redo list at once instead of compositing up to that record in vain (stale: time only)
-    uint8_t *redo_hint = nullptr;
+    uint32_t *redo_hint = nullptr;
+    uint32_t in_place = 0;      // the compositing launch evaluates reference-order records itself (blend_tile16_inplace_kernel)
 };
 hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
                               uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,

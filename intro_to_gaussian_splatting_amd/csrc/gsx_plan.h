@@ -149,7 +149,7 @@ inline HintsLayout hints_layout(int64_t max_tiles, int64_t /*max_axis*/) {
     h.lens = h.samples + (size_t)kSortSamples * 4;
     h.sched = h.lens + ((t * 4 + 255) & ~(size_t)255);
     h.redo = h.sched + ((hints_sched_entries(max_tiles) * 4 + 255) & ~(size_t)255);
-    h.total = h.redo + ((t + 255) & ~(size_t)255);          // one byte per tile (BlendHints.redo_hint)
+    h.total = h.redo + ((t * 4 + 255) & ~(size_t)255);      // one word per tile (BlendHints.redo_hint)
     return h;
 }
 

@@ -84,7 +84,7 @@ def test_argument_errors_do_not_need_a_gpu():
     assert 0 < small < big and big % 256 == 0
     assert lib.gsx_hints_bytes(0, 64, 16) == 0
     # header + 256 splitters + 2048 samples + list lengths (120 x 68 tiles at 1080p) + per-XCD schedule (tiles + tiles / 32 + 64) + redo hints
-    assert lib.gsx_hints_bytes(1920, 1080, 16) == 256 + 1024 + 8192 + 32768 + 34048 + 8192     # (+ one redo-hint byte per tile)
+    assert lib.gsx_hints_bytes(1920, 1080, 16) == 256 + 1024 + 8192 + 32768 + 34048 + 32768     # (+ one redo-hint word per tile)
     # (round 3 sized the schedule by the frame's LONGER axis and a frame of more than ~512 tiles along the shorter one
     # overran it; the bound itself is swept in tests/host/plan_sanitize.cpp)
     t = 625 * 625

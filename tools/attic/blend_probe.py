@@ -15,7 +15,7 @@ lib = _ffi.load()
 for _ in range(3):
     scene.render_image_hip(1)
 grid = 1 << 17                # gsx_blend.hip: kProbeSecond
-buf = torch.zeros((2 * grid, 4), dtype=torch.int32, device="cuda")
+buf = torch.zeros((4 * grid, 4), dtype=torch.int32, device="cuda")
 lib.gsx_debug_set_blend_probe(buf.data_ptr())
 st = {}
 scene.render_image_hip(1, stats=st, timing=True)

@@ -13,7 +13,7 @@ for _ in range(4):
     scene.render_image_hip(1)
 torch.cuda.synchronize()
 half = 1 << 17
-buf = torch.zeros((2 * half, 4), dtype=torch.int32, device="cuda")
+buf = torch.zeros((4 * half, 4), dtype=torch.int32, device="cuda")
 lib.gsx_debug_set_blend_probe(buf.data_ptr())
 st = {}
 scene.render_image_hip(1, stats=st, timing=True)

@@ -12,7 +12,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians  # noqa: E402
+from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians, _ffi  # noqa: E402
+if os.environ.get("GSX_FUZZ_TEST_LIB"):      # libgsx_test.so, so that its knobs (GSX_REF_IN_PLACE, ...) select what is fuzzed
+    _ffi.use_test_library()
 from intro_to_gaussian_splatting_amd.synthetic import make_scene, write_colmap_text  # noqa: E402
 from oracle import c_oracle, cpu_ref  # noqa: E402
 
