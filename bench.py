@@ -715,6 +715,9 @@ def main() -> None:
                          "workload's pose, one captured frame (movable camera) re-aimed before every replay, so that the "
                          "hints each frame finds are the previous pose's; plus the cold frame of a view (no hints at all). "
                          "'none' switches the leg off")
+    ap.add_argument("--plain-min-tiles", type=int, default=None,
+                    help="development: the window size from which a view without ill-conditioned footprints takes "
+                         "GSX_FLAG_PLAIN_FOOTPRINTS (the wrapper's default: 16384 tiles; 1 = always, a huge number = never)")
     ap.add_argument("--sync-frames", action="store_true",
                     help="read the instance count back inside every frame instead of speculating on it")
     args = ap.parse_args()
@@ -726,6 +729,9 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node == --gpus" % (args.gpus, world))
+    if args.plain_min_tiles is not None:
+        from intro_to_gaussian_splatting_amd import gaussian_scene as _wrapper
+        _wrapper._PLAIN_MIN_TILES = int(args.plain_min_tiles)
     if args.test_lib:
         from intro_to_gaussian_splatting_amd import _ffi
         _ffi.use_test_library()
@@ -1071,8 +1077,8 @@ def main() -> None:
             "value_frames_in_flight": None if inflight_ms is None else round(width * height / (inflight_ms * 1e-3) / 1e6, 2),
             "config": {"workload": desc, "n_gaussians": n, "width": width, "height": height, "tile": tile,
                        "semantics": sem, "layout": layout, "n_visible": nvis, "n_kept": int(stats.get("n_kept") or 0), "tile_instances": d,
-                       # tiles the compositing launch handed to its second launch (ill-conditioned footprints evaluated in the
-                       # reference's operation order); 0: later frames of the view do not issue that launch at all
+                       # tiles (and long-tile quarters) that held an ill-conditioned footprint, evaluated in the reference's
+                       # operation order; 0: a large window's later frames take GSX_FLAG_PLAIN_FOOTPRINTS
                        "tiles_redone": int(stats.get("n_redo") or 0),
                        "frames_in_flight": 1,
                        "launch": "one hipGraph replay per frame" if one is not None else "separate kernel launches",

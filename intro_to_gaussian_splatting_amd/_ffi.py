@@ -37,7 +37,7 @@ GSX_FLAG_NO_TILE_SCHEDULE = 64
 GSX_FLAG_HINTS_VALID = 128
 GSX_FLAG_SMALL_BATCH = 256
 GSX_FLAG_ONE_VISIBLE = 512
-GSX_FLAG_SKIP_REDO = 1024
+GSX_FLAG_PLAIN_FOOTPRINTS = 1024
 
 
 def visible_rows_flag(n: int, n_visible: int, flags: int) -> int:

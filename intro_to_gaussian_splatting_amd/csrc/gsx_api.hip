@@ -95,7 +95,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
     int64_t *dev2 = (int64_t *)(counters + 4);
     uint2 *ranges = (uint2 *)(ws + c.ranges);
     bool counts_on_device = false, counts_in_host = false;
-    bool redo_counted = false;      // the compositing launch ran with a redo list: its length is GsxFrameStats.n_redo
+    bool redo_counted = false;      // the compositing launch counts tiles with reference-order records: GsxFrameStats.n_redo
     bool parts_marked = false;      // GsxParams.substrip_events recorded (every path records them once, behind its last launch at the latest)
     // no Gaussians: every tile's list is empty -- GsxParams.tile_counts says so (an empty WINDOW has no entries)
     if (n == 0 && p.tile_counts && p.grid.count() > 0)
@@ -152,8 +152,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
             tm.mark();  // 4: tile sort (+ the compositing schedule)
             gsx::BlendHints bh = fh.blend;
             bh.xcd_sched = fh.sched ? 1u : 0u;
-            bh.skip_redo = p.skip_redo ? 1u : 0u;
-            if (p.skip_redo) bh.redo_hint = nullptr;      // (a tile left to a launch that is not issued would stay undone)
+            bh.plain = p.plain ? 1u : 0u;
             redo_counted = p.semantics == GSX_SEM_REF_CPU && p.grid.tile == 16 && !p.generic;
             // The 128 spare workgroups hold 16 wave slots of every XCD for ~15 us.  In front of the tiles that is free
             // -- unless the window's tiles fill the chip's 8 192 wave slots just about once (1080p: 7 973 tiles): then
@@ -402,7 +401,6 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
         sh = gsx::SortHints{hdr, (const uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.samples),
                             p.hints_valid && route == gsx::kDepth256};
         fh.blend = gsx::BlendHints{hdr, sh.samples, (uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.lens), 0u};
-        fh.blend.redo_hint = (uint32_t *)(p.hints + hl.redo);
         // the schedule costs nothing here (a spare workgroup of the projection launch): every window of more than two
         // tiles per SIMD gets one, unless told not to
         if (p.hints_valid && p.schedule != 0 && p.grid.count() > 2048) {

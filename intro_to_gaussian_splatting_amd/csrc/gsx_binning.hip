@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(kBlock)
         }
         *ec.d32 = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d;
         *ec.long_count = 0u;
-        for (uint32_t k = 0; k <= (uint32_t)kMaxSubstrips; ++k) ec.redo_count[k] = 0u;     // entries + the parts' queue heads
+        *ec.redo_count = 0u;
     }
 
     // ---- the chunk's pairs, in groups of 8 consecutive pairs aligned in the GLOBAL pair index (8 keys and 8 values

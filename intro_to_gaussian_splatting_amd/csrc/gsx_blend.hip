@@ -53,8 +53,8 @@
 // four float32 products cancel (needles from ~20:1) its own rounding moves alpha by 1e-4 .. 1e-3, and since the
 // restatement this kernel is held against executes the reference's operations in the reference's order, that rounding
 // is part of the result.  pack_record flags such records; on the tiles where the rounding can reach 2e-5 (stage_records:
-// a needle's ridge) they are evaluated by alpha_ref -- the reference's operations one for one -- in blend_redo_kernel,
-// a second launch with twice the registers that composites every tile the first one handed over (push_redo).
+// a needle's ridge) they are evaluated by alpha_ref -- the reference's operations one for one -- where they turn up
+// (blend_tile16_ref_kernel, the REF instances of the loops below).
 // T(1 - alpha) is evaluated as T - T alpha (1 ulp).
 // Coordinates are TILE-RELATIVE (round 3): the lane that stages a record subtracts the tile's origin from the mean
 // once (x' = x - x0, y' = y - y0; pixel offsets px', py' = 0 .. tile-1 are exact) and forms c0 = fma(r11, y', h x'),
@@ -73,7 +73,7 @@
 // Test library only (gsx_debug.h: gsx_debug_set_blend_probe): when set, every workgroup of blend_tile16_kernel leaves
 // (cycles, tile, list length, records staged | flags << 24) there, indexed by blockIdx.x -- who is the frame waiting for?
 __device__ uint4 *g_blend_probe = nullptr;
-constexpr uint32_t kProbeSecond = 1u << 17;     // a second record per workgroup starts here, the redo launch's per-tile records at twice this (the buffer holds 3 x 2^17)
+constexpr uint32_t kProbeSecond = 1u << 17;     // a second record per workgroup starts here, the REF instance's per-tile records at twice this (the buffer holds 3 x 2^17)
 #endif
 
 namespace gsx {
@@ -235,7 +235,7 @@ __device__ __forceinline__ float exponent_y(const Splat &g, float p, float s0, f
 // there: alpha = 0, which leaves T and the colour exactly as they are, like not visiting the record at all.
 // ox, oy: the tile's origin in the frame (a kKindRefOrder record is evaluated in frame coordinates, like the reference).
 // WITH_REF = false: the caller never meets a kKindRefOrder record (the first launch of the tile-16 kernel sends such
-// tiles to the redo list before it gets here) and does not carry the code for one.
+// tiles away before it gets here -- GSX_FLAG_PLAIN_FOOTPRINTS) and does not carry the code for one.
 template <int NPX, bool WITH_REF = true>
 __device__ __forceinline__ void composite(float px, const float (&e_p)[NPX], const Splat &g, float (&T)[NPX],
                                           float (&c0)[NPX], float (&c1)[NPX], float (&c2)[NPX], int blk, float ox, float oy) {
@@ -348,7 +348,7 @@ __device__ __forceinline__ float skip_threshold(float bound, uint32_t &skipped, 
 // Gaussian in nearly every batch, and fetched up front for all of them the side array was a dependent trip to memory per
 // batch, ~3 us for a long tile's lone wave, 188 batches long): such a
 // record is staged as (x, y, Q00, Q01) (Q10, op, r, g) (b, Q11, flag, bits) in FRAME coordinates; without it the record
-// keeps its completed-square form -- all the caller needs is the batch's kind, it sends the tile to the redo list.
+// keeps its completed-square form -- all the caller needs is the batch's kind: it leaves the tile undone and counts it.
 // Either way the skip bound is the completed square's, computed like any other record's.
 template <int MODE, bool WITH_REF = true>
 __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool have, uint32_t &nb, Staged &sh, int lane,
@@ -636,22 +636,19 @@ __device__ __forceinline__ void rank_samples(uint32_t group, int lane, const Ble
     }
 }
 
-// ---- the redo list.  The compositing launch proper keeps to the completed square and has no register to spare for
-// anything else (64 VGPRs, 8 waves per SIMD: DESIGN.md); a tile -- or a long tile's quarter -- that meets a reference-order
-// record in a batch stops there, leaves (tile, mode) in this list and writes nothing, and blend_redo_kernel, launched
-// behind it with twice the registers, composites those tiles from their first record with the same staging, the same
-// rules and the reference's operations on the flagged records.  redo[0] = entries, redo[1 + part] = queue head
-// of a part's redo launch (all zeroed by the emit kernel), entries from redo[kRedoHeader]: (tile, 0 = whole tile |
-// 1 + quarter).  A scene without ill-conditioned footprints leaves the list empty and the second launch 1024 idle
-// workgroups long (~4 us; GSX_FLAG_SKIP_REDO: not issued).
-// GsxParams.hints carry one byte per tile from frame to frame: 1 = the tile held such a record last frame -- the first
-// launch then leaves it alone, and a few workgroups of that launch put all such tiles on the list, 256 per workgroup and
-// ONE add on the list's counter for them (list_hinted_tiles); 2 = found and listed in this frame.
-// The barrier between staging a batch and compositing it.  The first launch's workgroups are one wave each: s_barrier.
-// blend_redo_kernel packs FOUR independent waves into a workgroup (a quarter of the dispatches: the launch is mostly
-// idle workgroups when a scene has no ill-conditioned footprint), each with a staging area of its own: all that is
-// needed there is that the wave's LDS reads follow its own LDS writes -- which the hardware guarantees (the DS
-// operations of one wave execute in issue order) once the compiler keeps them in program order.
+// ---- two instances of every tile-16 loop.  REF = true (blend_tile16_ref_kernel, what a frame runs): reference-order
+// records are evaluated where they turn up; 128 VGPRs, 4 waves per SIMD, nothing spilled.  REF = false
+// (blend_tile16_kernel, GSX_FLAG_PLAIN_FOOTPRINTS: the caller knows from an earlier frame of the view that no tile holds
+// such a record): the completed square only, 64 VGPRs, 8 waves per SIMD -- 6 % faster on a 4K frame of 5M Gaussians, no
+// faster at 1080p --; a tile or long tile's quarter that does meet a flagged record stops there, writes nothing and adds
+// one to *redo (GsxFrameStats.n_redo: the caller renders the frame again without the flag).  REF = true counts the tiles
+// and quarters that held one there, so that a caller learns when the flag is safe.
+// (Round 5 first ran REF = false for every frame with a SECOND launch behind it for the tiles it had left, fed by a list:
+// one launch waited for the other's longest tile, a needle-ridden frame took 0.77 ms where this takes 0.53.)
+// The barrier between staging a batch and compositing it: every workgroup is one wave, all that is needed is that the
+// wave's LDS reads follow its own LDS writes -- which the hardware guarantees (the DS operations of one wave execute in
+// issue order) once the compiler keeps them in program order (WAVE; the REF = false instances keep their s_barrier: a
+// change there moves the register allocation of a kernel that has none to spare).
 template <bool WAVE>
 __device__ __forceinline__ void tile_sync() {
     if (WAVE) {
@@ -663,16 +660,6 @@ __device__ __forceinline__ void tile_sync() {
     }
 }
 
-// GsxParams.hints, one word per tile (BlendHints.redo_hint): bits 0 .. 3 = the tile -- bit 0 -- or its quarter q -- bit q,
-// where four waves composite it -- met a reference-order record in the last frame of the view; kHintRedoListed (the tile)
-// / kHintRedoFound << q (a quarter) = found and listed in THIS frame, until the second launch has composited it and says which.
-constexpr uint32_t kHintRedoMask = 0x0Fu, kHintRedoFound = 0x10u, kHintRedoListed = 0x100u;
-__device__ __forceinline__ void push_redo(uint32_t *redo, uint32_t tile, uint32_t mode) {
-    const uint32_t slot = atomicAdd(redo, 1u);
-    redo[kRedoHeader + 2 * slot] = tile;
-    redo[kRedoHeader + 1 + 2 * slot] = mode;
-}
-
 // ---- long tiles: a quarter of the tile -- one of its four 8x8 blocks -- per wave, one pixel per lane, eight records per trip
 // Same per-(pixel, record) arithmetic as the kernels above (bit-identical frames, tested): what changes is
 // the shape of the loop.  A lone wave spends ~430 cycles per record in the two-records-per-trip loop (LDS
@@ -680,15 +667,14 @@ __device__ __forceinline__ void push_redo(uint32_t *redo, uint32_t tile, uint32_
 // and only the T / colour chains sequential, and four such waves per tile, a 20 000-entry tile takes about as
 // long as 700 entries did.  The four workgroups of a tile are placed on one XCD (block ids congruent mod 8),
 // so the records they all gather are fetched into that XCD's L2 once.
-// REF (see blend_redo_kernel): false -- the quarter does not composite reference-order records itself: the first batch
-// that holds one sends (tile, quarter) to the redo list and the workgroup ends; true -- it does.
+// REF (see above): false -- the quarter does not composite reference-order records itself: the first batch that holds
+// one ends the workgroup, counted in *redo; true -- it does.
 template <bool REF>
 __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict__ rec, const float4 *__restrict__ qraw,
                                                         const uint32_t *__restrict__ vals,
                                                         const uint2 *__restrict__ ranges, const TileGrid &g,
                                                         const OutDesc &out, uint32_t t, int quarter,
-                                                        Staged &sh, uint32_t budget, uint32_t *cost_out, uint32_t *redo,
-                                                        uint32_t *redo_hint) {
+                                                        Staged &sh, uint32_t budget, uint32_t *cost_out, uint32_t *redo) {
     const int lane = REF ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;      // (REF: four independent waves per workgroup)
 #ifdef GSX_TEST_HOOKS
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
@@ -748,11 +734,8 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
         ++probe_batch;
 #endif
         if (REF && kind >= kBatchRefOrder) saw_ref = true;
-        if (!REF && kind >= kBatchRefOrder) {       // (wave-uniform) not here: blend_redo_kernel composites this quarter
-            if (lane == 0) {
-                push_redo(redo, t, (uint32_t)quarter + 1u);
-                if (redo_hint) atomicOr(redo_hint + t, kHintRedoFound << quarter);      // (not a mask bit yet: see kHintRedoMask)
-            }
+        if (!REF && kind >= kBatchRefOrder) {       // (wave-uniform) not here: the quarter stays undone (GSX_FLAG_PLAIN_FOOTPRINTS)
+            if (lane == 0) atomicAdd(redo, 1u);
             return;
         }
         tile_sync<REF>();
@@ -845,13 +828,7 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     }
     // (the largest of the four quarters' costs = the records one wave would have walked until all 256 pixels are done)
     if (cost_out && lane == 0) atomicMax(cost_out, cost | 0x80000000u);
-    // for the next frame of the view: this quarter's bit of the tile's hint word (the four quarters are four waves)
-    if (REF && redo_hint && lane == 0) {
-        if (saw_ref)
-            atomicOr(redo_hint + t, 1u << quarter);
-        else
-            atomicAnd(redo_hint + t, ~((1u << quarter) | (kHintRedoFound << quarter)));
-    }
+    if (REF && saw_ref && lane == 0 && redo) atomicAdd(redo, 1u);      // (GsxFrameStats.n_redo)
 #ifdef GSX_TEST_HOOKS
     if (g_blend_probe && lane == 0)
         g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t | 0x40000000u, rg.y - rg.x,
@@ -869,50 +846,8 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
     o[2] = c2;
 }
 
-// Workgroup b of the hint-list workgroups of the first launch: of the tiles 256 b .. 256 b + 255 those whose hint word says
-// so go on the redo list -- a tile on one wave (bit 0 .. 3, whichever: blend_tile16<.., false> returns early from exactly
-// these) as (tile, 0), a long tile's quarter q (bit q: its helper workgroup returns early) as (tile, 1 + q); inside the
-// part's span only -- with one add on the list's counter per workgroup.
-__device__ __forceinline__ void list_hinted_tiles(uint32_t b, int lane, const uint32_t *__restrict__ hint,
-                                                  const uint2 *__restrict__ ranges, const TileGrid &g, const TileSpan &span,
-                                                  uint32_t *__restrict__ redo, bool split) {
-    const uint32_t nt = (uint32_t)g.count(), t0 = (b * 64u + (uint32_t)lane) * 4u;
-    uint32_t modes[4];          // bit m: entry (tile, m) goes on the list
-    uint32_t mine = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const uint32_t t = t0 + (uint32_t)e;
-        modes[e] = 0u;
-        if (t < nt) {
-            const uint32_t bits = hint[t] & kHintRedoMask;
-            const int lead = span.axis ? g.wy0 + (int)(t % (uint32_t)g.nwy()) : g.wx0 + (int)(t / (uint32_t)g.nwy());
-            if (bits && lead >= span.lo && lead < span.hi) modes[e] = (split && (ranges[t].y & kLongFlag)) ? bits << 1 : 1u;
-        }
-        mine += (uint32_t)__popc(modes[e]);
-    }
-    uint32_t x = mine;          // inclusive scan over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)x, o);
-        if (lane >= o) x += y;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)x, 63);
-    if (total == 0u) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(redo, total);
-    uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + x - mine;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-        for (uint32_t m = 0; m < 5u; ++m)
-            if ((modes[e] >> m) & 1u) {
-                redo[kRedoHeader + 2 * slot] = t0 + (uint32_t)e;
-                redo[kRedoHeader + 1 + 2 * slot] = m;
-                ++slot;
-            }
-}
-
 // One 16x16 tile on one wave, 4 pixels per lane (the body of blend_tile16_kernel; see there).  REF as in
-// blend_long_tile_quarter: false -- a batch that holds a reference-order record sends the tile to the redo list.
+// blend_long_tile_quarter: false -- a batch that holds a reference-order record ends the tile, counted in *lt.redo.
 template <int VARIANT, bool REF>
 __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, const float4 *__restrict__ qraw,
                                              const uint32_t *__restrict__ vals,
@@ -924,7 +859,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
     const unsigned long long probe_t0 = __builtin_readcyclecounter();
     const uint32_t probe_w0 = (uint32_t)wall_clock64();
     uint32_t probe_staged = 0, probe_batches = 0, probe_after = 0;
-    uint32_t probe_first_ref = 0xFFFu, probe_ref_batches = 0, probe_ref_records = 0;      // (REF: tools/attic/redo_probe.py)
+    uint32_t probe_first_ref = 0xFFFu, probe_ref_batches = 0, probe_ref_records = 0;      // (REF: tools/attic/ref_probe.py)
     uint32_t probe_cyc[4] = {0u, 0u, 0u, 0u}, probe_ent[3] = {0u, 0u, 0u};      // cycles: staging, compositing regular / wild / ref-order batches; entries walked
 #endif
     const int tx = g.wx0 + (int)(t / (uint32_t)g.nwy()), ty = g.wy0 + (int)(t % (uint32_t)g.nwy());
@@ -959,7 +894,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
     // records actually staged until the tile was done (a dense tile that saturates after a tenth of its list costs a
     // tenth; records that cannot matter are not staged) plus a few per batch for the staging itself -- stored when the
     // tile ends.  (A long tile's entry is the helpers': tile_ranges_kernel flagged it, they raise it.)
-    if (!REF && hints.lens && lane == 0 && t == 0) {
+    if (hints.lens && lane == 0 && t == 0) {
         const bool by_cost = hints.header[kHintLens] == (uint32_t)g.count() && hints.header[kHintSched] == (uint32_t)g.count();
         hints.header[kHintLens] = (uint32_t)g.count();
         // How many tiles qualified as long this frame steers the threshold of the next (gsx_plan.h: kHintLongPct).  A
@@ -971,13 +906,6 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
         }
     }
     if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
-    if (!REF && hints.redo_hint && (hints.redo_hint[t] & kHintRedoMask)) {
-        // it met an ill-conditioned record last frame (GsxParams.hints): compositing up to that record here would be in
-        // vain, and list_hinted_tiles has put it on the redo list.  (Not from here: a needle-ridden frame is 8 000 pushes
-        // at once, which queue up on the list's counter at ~12 ns each -- 80 us, measured from here and from
-        // tile_ranges_kernel alike.)  A stale byte costs nothing but the place: blend_redo_kernel composites any tile.
-        return;
-    }
     bool saw_ref = false;           // (REF) wave-uniform: a batch of this tile held a reference-order record
     uint32_t cost = 0;
     uint32_t skipped[kBlocks] = {0u, 0u, 0u, 0u};    // colour every block has left out so far (stage_records)
@@ -1031,11 +959,8 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
                 composite<4, (REF || VARIANT == 0)>(cx, cy, s, T, c0, c1, c2, blk, (float)(tx * 16), (float)(ty * 16));
             }
         } else if (!REF && kind >= kBatchRefOrder) {
-            // (wave-uniform) an ill-conditioned footprint: not here -- blend_redo_kernel composites this tile
-            if (lane == 0) {
-                push_redo(lt.redo, t, 0u);
-                if (hints.redo_hint) hints.redo_hint[t] = kHintRedoListed;      // (not a mask bit: list_hinted_tiles would list it a second time)
-            }
+            // (wave-uniform) an ill-conditioned footprint: not here -- the tile stays undone (GSX_FLAG_PLAIN_FOOTPRINTS)
+            if (lane == 0) atomicAdd(lt.redo, 1u);
             return;
         } else if (kind == kBatchMono) {
             // A record in the monomial fallback (caller-given inverse covariances on the stage-2 entry; a degenerate
@@ -1216,8 +1141,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
     }
 
     if (hints.lens && lane == 0) hints.lens[t] = cost;
-    if (REF && hints.redo_hint && lane == 0) hints.redo_hint[t] = saw_ref ? 1 : 0;    // for the next frame of the view
-    if (REF && hints.in_place && saw_ref && lane == 0) atomicAdd(lt.redo, 1u);        // (no list: GsxFrameStats.n_redo is counted here)
+    if (REF && saw_ref && lane == 0 && lt.redo) atomicAdd(lt.redo, 1u);        // (GsxFrameStats.n_redo)
 #ifdef GSX_TEST_HOOKS
     // REF (several waves per workgroup): by tile, behind the two records of the first launch's workgroups
     if (REF && g_blend_probe && lane == 0)
@@ -1228,11 +1152,11 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
         g_blend_probe[2 * kProbeSecond + 65536u + t] = make_uint4(probe_cyc[0], probe_cyc[1], probe_cyc[2], probe_cyc[3]);
         g_blend_probe[3 * kProbeSecond + t] = make_uint4(probe_ent[0], probe_ent[1], probe_ent[2], 0u);
     }
-    if (!REF && g_blend_probe && lane == 0)
+    if ((!REF || blockDim.x == 64u) && g_blend_probe && lane == 0)
         g_blend_probe[blockIdx.x] = make_uint4((uint32_t)(__builtin_readcyclecounter() - probe_t0), t, rg.y - rg.x,
                                                probe_staged | (checked ? 0x80000000u : 0u));
     // (where and when: HW_ID = register 4, XCC_ID = register 20; wall_clock64 ticks at 100 MHz on every XCD alike)
-    if (!REF && g_blend_probe && lane == 1)
+    if ((!REF || blockDim.x == 64u) && g_blend_probe && lane == 1)
         g_blend_probe[kProbeSecond + blockIdx.x] =
             make_uint4(probe_batches | (probe_after << 12), (uint32_t)wall_clock64(),
                        (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16),
@@ -1264,7 +1188,6 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
 //                   contiguous bytes per store instruction.
 // VARIANT 0: scalar-form composite<4>; VARIANT 1: packed form, four (then two) records per saturation test;
 // VARIANT 2 (test library only): six per test.
-// REF (blend_tile16_inplace_kernel): every workgroup evaluates reference-order records itself -- no redo list.
 template <int VARIANT, bool REF>
 __device__ __forceinline__ void blend_tile16_grid(const Record *__restrict__ rec, const float4 *__restrict__ qraw,
                                                   const uint32_t *__restrict__ vals, const uint2 *__restrict__ ranges,
@@ -1286,15 +1209,7 @@ __device__ __forceinline__ void blend_tile16_grid(const Record *__restrict__ rec
         if (span.first) rank_samples(blockIdx.x - rank0, (int)threadIdx.x, hints);
         return;
     }
-    uint32_t block = hints.rank_last ? blockIdx.x : blockIdx.x - nrank;
-    if (!REF && !quarters && hints.redo_hint) {      // (the hint-list workgroups: in front of everything else, done in a microsecond)
-        const uint32_t nlist = ((uint32_t)g.count() + 255u) >> 8;
-        if (block < nlist) {
-            list_hinted_tiles(block, (int)threadIdx.x, hints.redo_hint, ranges, g, span, lt.redo, nhelpers != 0u);
-            return;
-        }
-        block -= nlist;
-    }
+    const uint32_t block = hints.rank_last ? blockIdx.x : blockIdx.x - nrank;
     if (quarters) {
         // A window of few tiles (a rank's strip): EVERY tile on four waves, a quarter of its pixels each.  One wave per
         // tile would leave the SIMDs with one to four waves, and a wave with few neighbours needs up to 3.3x its own
@@ -1312,7 +1227,7 @@ __device__ __forceinline__ void blend_tile16_grid(const Record *__restrict__ rec
         if (i >= per + (xcd < extra ? 1u : 0u)) return;
         (void)u;
         blend_long_tile_quarter<REF>(rec, qraw, vals, ranges, g, out, xcd_remap((i << 3) | xcd, nt), (int)((b >> 3) & 3u), sh, budget,
-                                     nullptr, lt.redo, hints.redo_hint);
+                                     nullptr, lt.redo);
         return;
     }
     if (block < nhelpers) {
@@ -1325,10 +1240,8 @@ __device__ __forceinline__ void blend_tile16_grid(const Record *__restrict__ rec
             const int lead = span.axis ? g.wy0 + (int)(lt_tile % (uint32_t)g.nwy()) : g.wx0 + (int)(lt_tile / (uint32_t)g.nwy());
             if (lead < span.lo || lead >= span.hi) return;
         }
-        // (its hint bit: list_hinted_tiles has put this quarter on the redo list -- walking up to the record here would be in vain)
-        if (!REF && hints.redo_hint && ((hints.redo_hint[lt_tile] >> quarter) & 1u)) return;
         blend_long_tile_quarter<REF>(rec, qraw, vals, ranges, g, out, lt_tile, quarter, sh, budget,
-                                     hints.lens ? hints.lens + lt_tile : nullptr, lt.redo, hints.redo_hint);
+                                     hints.lens ? hints.lens + lt_tile : nullptr, lt.redo);
         return;
     }
     const uint32_t bid = block - nhelpers;
@@ -1353,58 +1266,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
                                       sched_cap_, span, sh);
 }
 
-// The same grid with reference-order records evaluated where they turn up (REF): one launch, the schedule, the long
-// tiles' helpers and all, at the price of registers -- W waves per SIMD.  For views most of whose tiles hold such records.
-#define GSX_INPLACE_KERNEL(W)                                                                                                   \
-    __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, 8)))                                             \
-        blend_tile16_inplace_kernel_##W(const Record *__restrict__ rec, const float4 *__restrict__ qraw,                         \
-                                        const uint32_t *__restrict__ vals, const uint2 *__restrict__ ranges, TileGrid g,        \
-                                        OutDesc out, ClearPlan cp, LongTiles lt, uint32_t nhelpers,                              \
-                                        const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints, \
-                                        uint32_t tile_blocks, uint32_t sched_cap_, TileSpan span) {                             \
-        __shared__ Staged sh;                                                                                                   \
-        blend_tile16_grid<1, true>(rec, qraw, vals, ranges, g, out, cp, lt, nhelpers, sched, budget, quarters, hints,           \
-                                   tile_blocks, sched_cap_, span, sh);                                                          \
-    }
-GSX_INPLACE_KERNEL(4)
-GSX_INPLACE_KERNEL(5)
-GSX_INPLACE_KERNEL(6)
-GSX_INPLACE_KERNEL(8)
-
-// The tiles and long-tile quarters the launch above left in the redo list (push_redo), composited with reference-order
-// records evaluated by the reference's own operations.  Same staging, same rules, same pixel assignment as the first
-// launch -- a tile is composited by exactly one of the two, from its first record.  128 VGPRs (4 waves per SIMD): the
-// extra evaluation and the record kinds side by side do not fit the first launch's 64.  A fixed, small grid walks the
-// list (its length exists only in device memory); with nothing in it the launch is ~1.5 us of the frame.
-constexpr unsigned kRedoWaves = 4096;       // workers (the chip holds 4096 waves of this kernel at a time) ...
-constexpr unsigned kRedoWavesPerBlock = 4;  // ... four to a workgroup: 1024 dispatches, ~1 us when there is nothing to do
-__global__ void __launch_bounds__(64 * kRedoWavesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
-    blend_redo_kernel(const Record *__restrict__ rec, const float4 *__restrict__ qraw, const uint32_t *__restrict__ vals,
-                      const uint2 *__restrict__ ranges,
-                      TileGrid g, OutDesc out, LongTiles lt, uint32_t budget, BlendHints hints, TileSpan span, uint32_t capacity) {
-    __shared__ Staged sh_all[kRedoWavesPerBlock];
-    Staged &sh = sh_all[threadIdx.x >> 6];
-    const uint32_t n = min(lt.redo[0], capacity);
-    const uint32_t workers = gridDim.x * kRedoWavesPerBlock, me = blockIdx.x * kRedoWavesPerBlock + (threadIdx.x >> 6);
-    // The waves PULL their entries (one atomic per tile on the part's queue head): tiles differ by orders
-    // of magnitude in length, a fixed stride would leave the launch waiting for whoever drew the long ones.  A wave's
-    // first entry is its own index -- an empty list costs no atomic at all --, the following ones come from the queue,
-    // which starts behind the last worker.
-    for (uint32_t i = me; i < n;) {
-        const uint32_t t = lt.redo[kRedoHeader + 2 * i], mode = lt.redo[kRedoHeader + 1 + 2 * i];
-        if (mode == 0u) {
-            blend_tile16<1, true>(rec, qraw, vals, ranges, g, out, lt, budget, hints, span, t, sh);
-        } else {
-            const int lead = span.axis ? g.wy0 + (int)(t % (uint32_t)g.nwy()) : g.wx0 + (int)(t / (uint32_t)g.nwy());
-            if (lead >= span.lo && lead < span.hi)
-                blend_long_tile_quarter<true>(rec, qraw, vals, ranges, g, out, t, (int)mode - 1, sh, budget,
-                                              hints.lens ? hints.lens + t : nullptr, nullptr, hints.redo_hint);
-        }
-        tile_sync<true>();
-        uint32_t next = 0;
-        if ((threadIdx.x & 63u) == 0u) next = workers + atomicAdd(lt.redo + 1 + span.index, 1u);
-        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-    }
+// The same grid with reference-order records evaluated where they turn up (REF, see above): what a frame runs.  128 VGPRs,
+// 4 waves per SIMD.  (5 and 6 waves -- 96 and 80 VGPRs, 130 and 206 of them spilled -- measured 1 .. 6 % slower on the
+// uniform and the heavy-tailed 1M-Gaussian frames alike, 8 waves -- 314 spilled -- 15 .. 20 %.)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+    blend_tile16_ref_kernel(const Record *__restrict__ rec, const float4 *__restrict__ qraw, const uint32_t *__restrict__ vals,
+                            const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
+                            uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters,
+                            BlendHints hints, uint32_t tile_blocks, uint32_t sched_cap_, TileSpan span) {
+    __shared__ Staged sh;
+    blend_tile16_grid<1, true>(rec, qraw, vals, ranges, g, out, cp, lt, nhelpers, sched, budget, quarters, hints, tile_blocks,
+                               sched_cap_, span, sh);
 }
 
 // Any tile size: one wave per tile, one pixel per lane, tile*tile/64 sweeps over the list.
@@ -1812,9 +1684,8 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
         const bool quarters = nt <= (int64_t)knob("GSX_QUARTERS_BELOW", kQuartersBelow);
         BlendHints bh = hints;
         if (quarters) bh.lens = nullptr;
-        if (variant == 0 || !lt.redo) bh.redo_hint = nullptr;      // (no second launch: no tile may wait for it)
-        const int in_place = variant != 0 && lt.redo ? knob("GSX_REF_IN_PLACE", 0) : 0;      // (experiment: test library only)
-        bh.in_place = in_place ? 1u : 0u;
+        // GSX_FLAG_PLAIN_FOOTPRINTS: the instance that does not evaluate reference-order records (see tile_sync)
+        const bool plain = bh.plain != 0u && lt.redo != nullptr;
         // tile workgroups: one per tile, or -- per-XCD schedule from GsxParams.hints -- 8 x cap (gsx_schedule_device.h)
         const uint32_t cap = bh.xcd_sched ? sched_cap((uint32_t)nt, (uint32_t)grid.nwy()) : 0u;
         const unsigned tile_blocks = bh.xcd_sched ? kSchedXcds * cap : (unsigned)nt;
@@ -1825,16 +1696,9 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             grid_blocks = (unsigned)((nt + 7) / 8) * 32u + clear_blocks;
         }
         grid_blocks += bh.samples ? kRankGroups : 0u;
-        if (!quarters && bh.redo_hint && !in_place) grid_blocks += (unsigned)((nt + 255) / 256);      // list_hinted_tiles
         const uint32_t q = quarters ? 1u : 0u;
-        if (in_place == 4)
-            blend_tile16_inplace_kernel_4<<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
-        else if (in_place == 5)
-            blend_tile16_inplace_kernel_5<<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
-        else if (in_place == 6)
-            blend_tile16_inplace_kernel_6<<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
-        else if (in_place)
-            blend_tile16_inplace_kernel_8<<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
+        if (variant == 1 && !plain)
+            blend_tile16_ref_kernel<<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         else if (variant == 0)
             blend_tile16_kernel<0><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         else if (variant == 2)
@@ -1843,16 +1707,6 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
             blend_tile16_kernel<3><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
         else
             blend_tile16_kernel<1><<<grid_blocks, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp, lt, nh, sched, budget, q, bh, tile_blocks, cap, span);
-        // what the launch left for the second one: tiles that hold ill-conditioned footprints (see blend_redo_kernel;
-        // VARIANT 0 -- test library -- evaluates every record kind in place and leaves nothing)
-        if (variant != 0 && lt.redo && !bh.skip_redo && !in_place) {
-            const hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return e;
-            const uint32_t capacity = (uint32_t)nt + 4u * kMaxLongTiles;
-            const int64_t want = (nt + 4 * (int64_t)kMaxLongTiles + kRedoWavesPerBlock - 1) / kRedoWavesPerBlock;
-            blend_redo_kernel<<<(unsigned)min((int64_t)(kRedoWaves / kRedoWavesPerBlock), want), 64 * kRedoWavesPerBlock, 0, s>>>(
-                rec, bbox, sorted_vals, ranges, grid, out, lt, budget, bh, span, capacity);
-        }
     } else {
         blend_generic_kernel<<<nb, 64, 0, s>>>(rec, bbox, sorted_vals, ranges, grid, out, cp);
     }

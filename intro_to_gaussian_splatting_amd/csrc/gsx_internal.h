@@ -35,7 +35,7 @@ constexpr uint32_t kEmptyKey = 0xFFFFFFFEu;   // visible, but it reaches no tile
 //     or, for an ILL-CONDITIONED footprint (pack_record in gsx_project.hip), the same completed square with c = (b,
 //     opacity factor, 2, -) and the raw float32 conic (Q00, Q01, Q10, Q11) in the Gaussian's slot of the per-Gaussian
 //     float4 side array (the workspace's `bbox`): the compositing kernels execute the reference's own operation order
-//     on such a record wherever its rounding can show (gsx_blend.hip: kKindRefOrder, blend_redo_kernel)
+//     on such a record wherever its rounding can show (gsx_blend.hip: kKindRefOrder, blend_tile16_ref_kernel)
 //   other semantics:
 //     a = (x_pix, y_pix, Q''00, Q''01 + Q''10)   b = (Q''11, log2(opacity factor) | opacity, r, g)   c = (b, depth, 0, -)
 struct __attribute__((aligned(16))) Record {
@@ -66,9 +66,8 @@ struct LongTiles {
     uint32_t *cost = nullptr;
     const uint32_t *header = nullptr;
     uint32_t cost_pct = 30;
-    // the redo list of the tile-16 REF_CPU compositing launch (gsx_blend.hip: push_redo / blend_redo_kernel): [0] = entries,
-    // [1 .. 16] = the queue heads of up to 16 part launches (all zeroed by the emit kernel), entries (tile, mode) from
-    // [kRedoHeader]; kRedoHeader + 2 (tiles + 4 kMaxLongTiles) words
+    // one word, zeroed by the emit kernel: tiles and long-tile quarters of the tile-16 REF_CPU compositing launch that met a
+    // reference-order record (GsxFrameStats.n_redo; with GSX_FLAG_PLAIN_FOOTPRINTS: that were left undone for it)
     uint32_t *redo = nullptr;
 };
 __host__ __device__ inline uint32_t long_tile_threshold(uint32_t pairs, uint32_t tiles) {
@@ -200,11 +199,7 @@ struct BlendHints {
     uint32_t xcd_sched;         // != 0: `sched` is hints.sched, the per-XCD schedule (gsx_schedule_device.h) -- trusted
                                 // only if header[kHintSched] == number of tiles; 0: tile_schedule_kernel's whole-frame order
     uint32_t rank_last = 0;     // the spare workgroups that rank the samples come last in the grid instead of first
-    uint32_t skip_redo = 0;     // GSX_FLAG_SKIP_REDO: the second compositing launch is not issued
-    // one byte per tile (GsxParams.hints): the tile met an ill-conditioned record last frame, so this frame's first
-    // launch sends it to the redo list at once instead of compositing up to that record in vain (stale: time only)
-    uint32_t *redo_hint = nullptr;
-    uint32_t in_place = 0;      // the compositing launch evaluates reference-order records itself (blend_tile16_inplace_kernel)
+    uint32_t plain = 0;         // GSX_FLAG_PLAIN_FOOTPRINTS: the compositing instance that cannot evaluate reference-order records
 };
 hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
                               uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,
@@ -229,7 +224,7 @@ bool blend_uses_schedule(const TileGrid &grid, int semantics, bool generic, int6
 struct TileSpan {
     int32_t axis, lo, hi;
     uint32_t first;
-    uint32_t index = 0;         // which part (0 .. 15): the redo launch of a part pulls from a queue head of its own
+    uint32_t index = 0;         // which part (0 .. 15)
 };
 // can this kernel family composite a window in parts?  (tile-16 REF_CPU kernel only; the others take one launch)
 bool blend_in_parts(const TileGrid &grid, int semantics, bool generic);

@@ -26,7 +26,6 @@ constexpr int kSortQuad = 4;           // chunks per count workgroup
 constexpr int kSortBins = 256;         // digit-table rows
 constexpr int kEmitChunk = 1024;       // depth ranks per workgroup of chunk_sums / emit (gsx_binning.hip)
 constexpr uint32_t kMaxLongTiles = 512;
-constexpr uint32_t kRedoHeader = 32;   // words in front of the redo list's entries (count, queue heads)
 constexpr int kMaxSubstrips = 16;      // GsxParams.n_substrips
 constexpr size_t kParamsBytesAbi300 = 104;   // sizeof(GsxParams) before struct_size existed: what struct_size == 0 means
 constexpr int kClearFloats = 6144;     // floats zeroed per clear workgroup (gsx_blend.hip)
@@ -131,7 +130,7 @@ GSX_HD inline uint32_t sched_cap(uint32_t nt, uint32_t /*nwy*/) {
     return (c.s + 1u) * c.k;
 }
 struct HintsLayout {
-    size_t splitters, samples, lens, sched, redo, total;   // byte offsets
+    size_t splitters, samples, lens, sched, total;   // byte offsets
 };
 // max_tiles: tiles of the frame (a window has at most as many).  The schedule region holds 8 x sched_cap(nt) entries for
 // the LARGEST number any window of up to max_tiles tiles needs: 8 k (s + 1) <= nt + 8 k <= nt + nt / 32 + 8, which
@@ -148,8 +147,7 @@ inline HintsLayout hints_layout(int64_t max_tiles, int64_t /*max_axis*/) {
     h.samples = h.splitters + (size_t)kSortBins * 4;
     h.lens = h.samples + (size_t)kSortSamples * 4;
     h.sched = h.lens + ((t * 4 + 255) & ~(size_t)255);
-    h.redo = h.sched + ((hints_sched_entries(max_tiles) * 4 + 255) & ~(size_t)255);
-    h.total = h.redo + ((t * 4 + 255) & ~(size_t)255);      // one word per tile (BlendHints.redo_hint)
+    h.total = h.sched + ((hints_sched_entries(max_tiles) * 4 + 255) & ~(size_t)255);
     return h;
 }
 
@@ -213,8 +211,8 @@ inline Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes)
     c.tkeys0 = take(cc * 4); c.tkeys1 = take(cc * 4); c.tvals0 = take(cc * 4); c.tvals1 = take(cc * 4);
     c.ranges = take((size_t)(max_tiles > 0 ? max_tiles : 1) * kRangeBytes);
     c.longs = take(kMaxLongTiles * sizeof(uint32_t));
-    // the compositing launch's redo list (gsx_blend.hip): a count + (tile, mode) for every tile and long-tile quarter
-    c.redo = take((kRedoHeader + 2 * ((size_t)(max_tiles > 0 ? max_tiles : 1) + 4 * kMaxLongTiles)) * sizeof(uint32_t));
+    // GsxFrameStats.n_redo on the device (LongTiles.redo)
+    c.redo = take(256);
     c.sched = take((size_t)(max_tiles > 0 ? max_tiles : 1) * sizeof(uint32_t));   // tiles by falling list length
     c.counters = take(64);
     c.temp = take(temp_bytes);
@@ -260,7 +258,7 @@ struct Plan {
     bool generic;  // GSX_FLAG_GENERIC_KERNELS
     bool tight;    // GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS
     bool split;    // long tiles on four waves (not GSX_FLAG_NO_LONG_TILE_SPLIT)
-    bool skip_redo;     // GSX_FLAG_SKIP_REDO
+    bool plain;         // GSX_FLAG_PLAIN_FOOTPRINTS
     int small_batch;    // 1: GSX_FLAG_ONE_VISIBLE, 2: GSX_FLAG_SMALL_BATCH, 0: neither
     int schedule;  // tiles handed out by list length: 1 GSX_FLAG_TILE_SCHEDULE, 0 GSX_FLAG_NO_TILE_SCHEDULE, -1 by size
     const GsxCamera *camera_device;
@@ -320,7 +318,7 @@ inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_ima
     p.generic = (d.flags & GSX_FLAG_GENERIC_KERNELS) != 0;
     p.tight = d.semantics == GSX_SEM_STD_3DGS && (d.flags & GSX_FLAG_PUBLISHED_RECTS) == 0;
     p.split = (d.flags & GSX_FLAG_NO_LONG_TILE_SPLIT) == 0;
-    p.skip_redo = (d.flags & GSX_FLAG_SKIP_REDO) != 0;
+    p.plain = (d.flags & GSX_FLAG_PLAIN_FOOTPRINTS) != 0;
     p.small_batch = (d.flags & GSX_FLAG_ONE_VISIBLE) ? 1 : ((d.flags & GSX_FLAG_SMALL_BATCH) ? 2 : 0);
     p.schedule = (d.flags & GSX_FLAG_NO_TILE_SCHEDULE) ? 0 : ((d.flags & GSX_FLAG_TILE_SCHEDULE) ? 1 : -1);
     TileGrid &g = p.grid;

@@ -81,6 +81,7 @@ class _Workspace:
 
 _WORKSPACE = _Workspace()
 _PINNED_SLOTS = 256
+_PLAIN_MIN_TILES = 16384  # windows from this many tiles take GSX_FLAG_PLAIN_FOOTPRINTS when the view allows it (render_image_hip)
 _HINT_VIEWS = 64          # GsxParams.hints buffers a scene keeps (83 KB each at 1080p, 300 KB at 4K): the most recent views
 _SEMANTICS = {"ref_cpu": _ffi.GSX_SEM_REF_CPU, "ref_cuda": _ffi.GSX_SEM_REF_CUDA,
               "std_3dgs": _ffi.GSX_SEM_STD_3DGS}
@@ -211,8 +212,8 @@ class CapturedFrame:
                                 % (st.reserved, st.n_instances))
         if getattr(self, "_skip_redo", False) and st.n_redo > 0:
             raise _ffi.GsxError(_ffi.GSX_ERR_UNSUPPORTED,
-                                "the frame was captured without the second compositing launch (GSX_FLAG_SKIP_REDO) and %d tiles "
-                                "now hold ill-conditioned footprints: capture it again" % st.n_redo)
+                                "the frame was captured with GSX_FLAG_PLAIN_FOOTPRINTS and %d tiles now hold ill-conditioned "
+                                "footprints: capture it again" % st.n_redo)
         return self.out
 
 
@@ -229,7 +230,7 @@ class GaussianScene:
         self._last_instances = 0      # instance count of the latest full frame
         self._cap_hints = {}          # (image, tile, window, semantics) -> pair capacity for the next frame
         self._kept_hints = {}         # same key -> Gaussians that reached a tile of the window (GsxParams.kept_hint)
-        self._redo_hints = {}         # same key -> tiles the last frame handed to the second compositing launch (n_redo)
+        self._redo_hints = {}         # same key -> tiles of the last frame that held an ill-conditioned footprint (n_redo)
         self._hints = _Lru(_HINT_VIEWS)   # (same key, stream) -> [GsxParams.hints buffer, a frame has run with it?]
         self._pending = []            # speculative frames awaiting confirm_frames()
         self._part_events = {}        # (stream, K) -> K HIP events the library records behind the parts of a frame
@@ -456,12 +457,16 @@ class GaussianScene:
             own["inputs"][:] = passed
         # how many Gaussians reached a tile of this window last time: picks the depth-sort route (a hint)
         params.kept_hint = int(own.get("kept", self._kept_hints.get(cap_key, 0)))
-        # GSX_FLAG_SKIP_REDO: the last frame of this view handed no tile to the second compositing launch (no ill-conditioned
-        # footprint in sight), so this one does not issue it; its own n_redo says whether that held (checked below / by
+        # GSX_FLAG_PLAIN_FOOTPRINTS: no tile of the last frame of this view held an ill-conditioned footprint, so this one runs
+        # the compositing instance that cannot evaluate them -- where that pays: from _PLAIN_MIN_TILES tiles (measured: 6 %
+        # of a 4K frame of 5M Gaussians, nothing at 1080p); its own n_redo says whether that held (checked below / by
         # confirm_frames / by CapturedFrame.confirm: a frame that was wrong about it is rendered again without the flag)
-        skip_redo = bool(own["skip_redo"]) if "skip_redo" in own else (self._redo_hints.get(cap_key) == 0)
+        n_window_tiles = (tile_window[1] - tile_window[0]) * (tile_window[3] - tile_window[2]) if tile_window is not None \
+            else (-(-width // tile_size) * -(-height // tile_size) if tile_size > 0 else 0)
+        skip_redo = bool(own["skip_redo"]) if "skip_redo" in own else \
+            (self._redo_hints.get(cap_key) == 0 and n_window_tiles >= _PLAIN_MIN_TILES)
         if skip_redo and semantics == "ref_cpu" and tile_size == 16 and not generic_kernels:
-            params.flags |= _ffi.GSX_FLAG_SKIP_REDO
+            params.flags |= _ffi.GSX_FLAG_PLAIN_FOOTPRINTS
         # GsxParams.hints: one buffer per view and stream (a captured frame owns its own), valid once a frame has filled it
         hint_slot = None
         if use_hints:
@@ -505,9 +510,9 @@ class GaussianScene:
                 rc = lib.gsx_render_forward(ctypes.byref(cam), *[_ptr(t) for t in tensors], n, tile_size, _ptr(out),
                                             ctypes.byref(params), st_ref, _ptr(ws), nbytes,
                                             _stream_handle(dev))
-                if rc == _ffi.GSX_OK and not speculative and params.flags & _ffi.GSX_FLAG_SKIP_REDO and int(st.n_redo) > 0:
-                    # the frame did need the second compositing launch after all: once more, with it
-                    params.flags &= ~_ffi.GSX_FLAG_SKIP_REDO
+                if rc == _ffi.GSX_OK and not speculative and params.flags & _ffi.GSX_FLAG_PLAIN_FOOTPRINTS and int(st.n_redo) > 0:
+                    # the view does hold ill-conditioned footprints after all: once more, with the instance that evaluates them
+                    params.flags &= ~_ffi.GSX_FLAG_PLAIN_FOOTPRINTS
                     continue
                 again = 0
                 if rc == _ffi.GSX_OK and not speculative and not own and semantics != "std_3dgs":
@@ -533,7 +538,7 @@ class GaussianScene:
             return out
         if speculative:
             # counts are still in flight: remember what has to be confirmed
-            self._pending.append((pinned, cap_key, bool(params.flags & _ffi.GSX_FLAG_SKIP_REDO), dict(
+            self._pending.append((pinned, cap_key, bool(params.flags & _ffi.GSX_FLAG_PLAIN_FOOTPRINTS), dict(
                 image_idx=image_idx, tile_size=tile_size, layout=layout, tile_window=tile_window, out=out,
                 out_origin=out_origin, semantics=semantics, background=background,
                 generic_kernels=generic_kernels, published_rects=published_rects, camera_buffer=camera_buffer,
@@ -624,10 +629,12 @@ class GaussianScene:
         nbytes = lib.gsx_workspace_bytes(n, cam.width, cam.height, tile_size, cap)
         if nbytes == 0:
             raise _ffi.GsxError(_ffi.GSX_ERR_INVALID_ARGUMENT, "gsx_workspace_bytes rejected the sizes")
-        # the graph bakes in whether the second compositing launch is issued: not for a fixed camera whose frame handed it
-        # nothing (confirm() checks every replay's n_redo); a movable camera may turn to ill-conditioned footprints
+        # the graph bakes in which compositing instance runs: the plain one (GSX_FLAG_PLAIN_FOOTPRINTS) only for a fixed camera
+        # whose frame held no ill-conditioned footprint, where it pays (confirm() checks every replay's n_redo); a movable
+        # camera may turn to such footprints
         private = dict(cap=cap, workspace=torch.empty(nbytes, dtype=torch.uint8, device=dev), kept=int(st["n_kept"]),
-                       skip_redo=(not movable_camera) and int(st.get("n_redo", 1)) == 0,
+                       skip_redo=(not movable_camera) and int(st.get("n_redo", 1)) == 0 and
+                       int(st.get("n_tiles", 0)) >= _PLAIN_MIN_TILES,
                        pinned=torch.zeros(ctypes.sizeof(_ffi.GsxFrameStats), dtype=torch.uint8).pin_memory(), inputs=[],
                        hints=[torch.zeros(lib.gsx_hints_bytes(cam.width, cam.height, tile_size), dtype=torch.uint8,
                                           device=dev), False])

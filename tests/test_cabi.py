@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), "libgsx.so does not export %s" % name
         assert name in _ffi.SIGNATURES, "ctypes binding lacks %s" % name
-    assert lib.gsx_version() == 303
+    assert lib.gsx_version() == 304
 
 
 def _exported(path):
@@ -83,8 +83,8 @@ def test_argument_errors_do_not_need_a_gpu():
     small, big = lib.gsx_workspace_bytes(1000, 256, 256, 16, 8000), lib.gsx_workspace_bytes(1_000_000, 1920, 1080, 16, 5_000_000)
     assert 0 < small < big and big % 256 == 0
     assert lib.gsx_hints_bytes(0, 64, 16) == 0
-    # header + 256 splitters + 2048 samples + list lengths (120 x 68 tiles at 1080p) + per-XCD schedule (tiles + tiles / 32 + 64) + redo hints
-    assert lib.gsx_hints_bytes(1920, 1080, 16) == 256 + 1024 + 8192 + 32768 + 34048 + 32768     # (+ one redo-hint word per tile)
+    # header + 256 splitters + 2048 samples + list lengths (120 x 68 tiles at 1080p) + per-XCD schedule (tiles + tiles / 32 + 64)
+    assert lib.gsx_hints_bytes(1920, 1080, 16) == 256 + 1024 + 8192 + 32768 + 34048
     # (round 3 sized the schedule by the frame's LONGER axis and a frame of more than ~512 tiles along the shorter one
     # overran it; the bound itself is swept in tests/host/plan_sanitize.cpp)
     t = 625 * 625

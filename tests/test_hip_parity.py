@@ -775,15 +775,17 @@ def test_needles_through_every_kernel_family(tmp_path):
     assert d.max() <= PIXEL_TOL
 
 
-def test_second_compositing_launch_is_skipped_only_where_nothing_needs_it(tmp_path):
-    """GsxFrameStats.n_redo / GSX_FLAG_SKIP_REDO: a view without ill-conditioned footprints reports n_redo = 0, its next
-    frame is issued without the second compositing launch and is the same frame; a view with needles reports n_redo > 0
-    and keeps the launch; a frame that wrongly skipped it reports the tiles it left undone and the wrapper renders it
-    again -- on the synchronising path at once, for enqueued frames in confirm_frames(), for a captured frame by
-    raising in confirm()."""
+def test_plain_footprints_instance_only_where_no_tile_needs_the_other(tmp_path, monkeypatch):
+    """GsxFrameStats.n_redo / GSX_FLAG_PLAIN_FOOTPRINTS: a view without ill-conditioned footprints reports n_redo = 0, its
+    next frame runs the compositing instance that cannot evaluate them (here also on a small window: the wrapper's size
+    threshold is lowered) and is the same frame; a view with needles reports n_redo > 0 and keeps the other instance; a
+    frame that wrongly took the plain one reports the tiles it left undone and the wrapper renders it again -- on the
+    synchronising path at once, for enqueued frames in confirm_frames(), for a captured frame by raising in confirm()."""
     _need_gpu()
     from intro_to_gaussian_splatting_amd import _ffi
     from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    from intro_to_gaussian_splatting_amd import gaussian_scene as wrapper
 
     w, h = 320, 192
     sc = make_scene(20_000, w, h, seed=9)
@@ -793,13 +795,15 @@ def test_second_compositing_launch_is_skipped_only_where_nothing_needs_it(tmp_pa
     assert st["n_redo"] == 0
     key = (1, 16, None, "ref_cpu")
     assert scene._redo_hints[key] == 0
+    assert not scene.capture_frame(1)._skip_redo        # (240 tiles: the plain instance pays from 16 384)
+    monkeypatch.setattr(wrapper, "_PLAIN_MIN_TILES", 1)
     st = {}
-    assert torch.equal(scene.render_image_hip(1, stats=st), a) and st["n_redo"] == 0        # (issued with GSX_FLAG_SKIP_REDO)
+    assert torch.equal(scene.render_image_hip(1, stats=st), a) and st["n_redo"] == 0        # (issued with GSX_FLAG_PLAIN_FOOTPRINTS)
     frame = scene.capture_frame(1, headroom=8.0)        # (room for the pairs of the needles grown below)
     assert frame._skip_redo
     frame.replay()
     assert torch.equal(frame.confirm(), a)
-    # needles: the launch is needed and kept
+    # needles: counted, and the view keeps the instance that evaluates them
     sc2 = dict(sc)
     sc2["scales"] = sc["scales"].copy()
     sc2["scales"][::8, 0] *= 80.0
@@ -810,7 +814,7 @@ def test_second_compositing_launch_is_skipped_only_where_nothing_needs_it(tmp_pa
     _, port, inst = _oracle_frame(needles, sc2)
     assert st["n_instances"] == inst and np.max(np.abs(b.cpu().numpy() - port)) <= PIXEL_TOL
     assert not needles.capture_frame(1)._skip_redo
-    # a frame that wrongly believes it can skip: the synchronising path notices and renders again ...
+    # a frame that wrongly takes the plain instance: the synchronising path notices and renders again ...
     needles._redo_hints[key] = 0
     st = {}
     assert torch.equal(needles.render_image_hip(1, stats=st), b) and st["n_redo"] > 0
@@ -822,7 +826,7 @@ def test_second_compositing_launch_is_skipped_only_where_nothing_needs_it(tmp_pa
     # ... and a frame captured for a scene that has since grown needles says so
     scene.gaussians.scales[::8, 0] *= 80.0
     frame.replay()
-    with pytest.raises(_ffi.GsxError, match="second compositing launch"):
+    with pytest.raises(_ffi.GsxError, match="GSX_FLAG_PLAIN_FOOTPRINTS"):
         frame.confirm()
 
 

@@ -1,6 +1,6 @@
-"""What does the second compositing launch (blend_redo_kernel) spend its time on?  One frame of a bench workload on
-libgsx_test.so with the blend probe on: per redone tile its batches walked, the first batch that held a reference-order
-record, how many batches / records did.   python tools/attic/redo_probe.py [workload]"""
+"""What does the compositing launch (blend_tile16_ref_kernel) spend its time on?  One frame of a bench workload on
+libgsx_test.so with the blend probe on: per tile its batches walked, the first batch that held a reference-order
+record, how many batches / records did.   python tools/attic/ref_probe.py [workload]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians, _ffi  # noqa: E402
-if os.environ.get("GSX_FUZZ_TEST_LIB"):      # libgsx_test.so, so that its knobs (GSX_REF_IN_PLACE, ...) select what is fuzzed
+if os.environ.get("GSX_FUZZ_TEST_LIB"):      # libgsx_test.so, so that its knobs (GSX_BLEND_VARIANT, GSX_DEPTH_SORT, ...) select what is fuzzed
     _ffi.use_test_library()
 from intro_to_gaussian_splatting_amd.synthetic import make_scene, write_colmap_text  # noqa: E402
 from oracle import c_oracle, cpu_ref  # noqa: E402
@@ -39,7 +39,7 @@ for seed in range(first, first + count):
     if rs.uniform() < 0.4 and n > 0:
         needles = True
         # needles: a share of the Gaussians stretched 20 .. 300-fold along one axis -- ill-conditioned footprints, which
-        # the compositing kernels hand to the redo launch (reference-order evaluation, gsx_blend.hip)
+        # the compositing kernels evaluate in the reference's operation order (gsx_blend.hip: kKindRefOrder)
         sc["scales"] = sc["scales"].copy()
         pick = rs.uniform(size=sc["scales"].shape[0]) < float(rs.choice([0.02, 0.2, 1.0]))
         sc["scales"][pick, rs.randint(0, 3)] *= np.float32(rs.uniform(20.0, 300.0))
@@ -71,7 +71,7 @@ for seed in range(first, first + count):
     d = float(np.abs(img - ref).max()) if img.size else 0.0
     assert d <= 1e-4, ("ref pixels", tag, d)
     worst_ref = max(worst_ref, d)
-    # the next frame of the view finds this one's hints (splitters, costs, redo bytes): same pixels
+    # the next frame of the view finds this one's hints (splitters, costs, schedule): same pixels
     again = scene.render_image_hip(1, tile_size=tile, layout=layout).cpu().numpy()
     assert np.array_equal(again.transpose(1, 0, 2) if layout == "hw3" else again, img), ("hinted frame differs", tag)
     # ---- a random tile window of the same frame (multi-GPU strips use these)
