@@ -1269,14 +1269,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 // The same grid with reference-order records evaluated where they turn up (REF, see above): what a frame runs.  128 VGPRs,
 // 4 waves per SIMD.  (5 and 6 waves -- 96 and 80 VGPRs, 130 and 206 of them spilled -- measured 1 .. 6 % slower on the
 // uniform and the heavy-tailed 1M-Gaussian frames alike, 8 waves -- 314 spilled -- 15 .. 20 %.)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+#ifndef GSX_REF_WAVES
+#define GSX_REF_WAVES 4      // (build-time knobs for A/B runs: tools/ab_bench.sh)
+#endif
+#ifndef GSX_REF_VARIANT
+#define GSX_REF_VARIANT 1    // (2: trips of six records)
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSX_REF_WAVES, 8)))
     blend_tile16_ref_kernel(const Record *__restrict__ rec, const float4 *__restrict__ qraw, const uint32_t *__restrict__ vals,
                             const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
                             uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters,
                             BlendHints hints, uint32_t tile_blocks, uint32_t sched_cap_, TileSpan span) {
     __shared__ Staged sh;
-    blend_tile16_grid<1, true>(rec, qraw, vals, ranges, g, out, cp, lt, nhelpers, sched, budget, quarters, hints, tile_blocks,
-                               sched_cap_, span, sh);
+    blend_tile16_grid<GSX_REF_VARIANT, true>(rec, qraw, vals, ranges, g, out, cp, lt, nhelpers, sched, budget, quarters, hints,
+                                             tile_blocks, sched_cap_, span, sh);
 }
 
 // Any tile size: one wave per tile, one pixel per lane, tile*tile/64 sweeps over the list.
