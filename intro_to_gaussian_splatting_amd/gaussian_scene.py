@@ -545,12 +545,14 @@ class GaussianScene:
                 tile_counts=tile_counts, split_long_tiles=split_long_tiles, tile_schedule=tile_schedule,
                 use_hints=use_hints)))
             if stats is not None:
-                stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True)
+                stats.update(n_visible=None, n_instances=None, n_tiles=st.n_tiles, speculative=True,
+                             plain_footprints=bool(params.flags & _ffi.GSX_FLAG_PLAIN_FOOTPRINTS))
             return out
         self._note_count(cap_key, int(st.n_instances), int(st.n_kept), int(st.n_redo))
         if stats is not None:
+            # (plain_footprints: the frame ran the compositing instance of GSX_FLAG_PLAIN_FOOTPRINTS)
             stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles, n_kept=st.n_kept,
-                         n_redo=int(st.n_redo))
+                         n_redo=int(st.n_redo), plain_footprints=bool(params.flags & _ffi.GSX_FLAG_PLAIN_FOOTPRINTS))
             if timing:
                 stats["stage_ms"] = {k: float(st.stage_ms[i]) for i, k in enumerate(_ffi.STAGE_NAMES)}
         return out

@@ -830,6 +830,53 @@ def test_plain_footprints_instance_only_where_no_tile_needs_the_other(tmp_path, 
         frame.confirm()
 
 
+def test_both_compositing_instances_render_the_same_frames(tmp_path, monkeypatch):
+    """The compositing launch has two instances (gsx_blend.hip: REF): the one every frame runs and the plain one of
+    GSX_FLAG_PLAIN_FOOTPRINTS, which the wrapper takes from 16 384 tiles.  With that threshold lowered the second frame
+    of a view without ill-conditioned footprints runs the plain instance: same frame bit for bit -- on reference-made
+    fixtures (whose images both are held against), on a heavy-tailed scene with long tiles on four waves, on a tile
+    window, in both layouts and through a captured frame."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import gaussian_scene as wrapper
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    cases = [(name, _scene_from_golden(tmp_path / name, load_golden(name)), load_golden(name))
+             for name in ("small_64x48_n300", "c1_256x256_n2000", "dense_48x48_n1500", "defaults_64x64_n800")]
+    sc = make_scene(150_000, 640, 400, seed=4, cluster_fraction=0.5, cluster_area=0.05, sigma_ln=1.0)
+    sc["scales"] = np.repeat(sc["scales"][:, :1], 3, axis=1)      # round footprints: heavy-tailed sizes, no needles
+    cases.append(("heavy-tailed", _scene_from_arrays(tmp_path / "heavy", sc), None))
+    first = {}
+    for name, scene, g in cases:
+        st = {}
+        tile = int(g["tile"]) if g is not None else 16
+        first[name] = scene.render_image_hip(1, tile_size=tile, stats=st).clone()
+        assert st["n_redo"] == 0 and not st["plain_footprints"], (name, st)
+    monkeypatch.setattr(wrapper, "_PLAIN_MIN_TILES", 1)
+    for name, scene, g in cases:
+        tile = int(g["tile"]) if g is not None else 16
+        st = {}
+        b = scene.render_image_hip(1, tile_size=tile, stats=st)
+        assert st["plain_footprints"] == (tile == 16) and st["n_redo"] == 0, (name, st)
+        assert torch.equal(b, first[name]), name
+        if g is not None:
+            assert np.max(np.abs(b.cpu().numpy() - g["image"])) <= PIXEL_TOL
+        if tile == 16:
+            st = {}
+            hw = scene.render_image_hip(1, layout="hw3", stats=st)
+            assert torch.equal(hw.permute(1, 0, 2), first[name]), name
+    scene = cases[-1][1]
+    st = {}
+    part = scene.render_image_hip(1, tile_window=(10, 30, 2, 20), stats=st)        # (first frame of that window: the other instance)
+    st = {}
+    again = scene.render_image_hip(1, tile_window=(10, 30, 2, 20), stats=st)
+    assert st["plain_footprints"] and torch.equal(again, part)
+    assert torch.equal(part[160:480, 32:320], first["heavy-tailed"][160:480, 32:320])
+    frame = scene.capture_frame(1)
+    assert frame._skip_redo
+    frame.replay()
+    assert torch.equal(frame.confirm(), first["heavy-tailed"])
+
+
 def test_orbit_of_eight_poses_through_one_captured_frame(tmp_path):
     """What bench.py --camera-path times, at a size the oracle renders whole: eight cameras 1 degree apart on an orbit
     (synthetic.orbit_poses), ONE frame captured with a movable camera and re-aimed before every replay.  Every replay

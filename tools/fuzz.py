@@ -1,6 +1,6 @@
 """Randomised parity fuzz on the GPU box: random frame sizes, tile sizes, populations, footprints,
 off-axis spread, cull shares, poses, layouts and tile windows; HIP path vs the C restatements.
-    python tools/fuzz.py [first_seed] [count]
+    python tools/fuzz.py [first_seed] [count] [big] [plain]
 ref_cpu: D and N_vis equal, max |dpixel| <= 1e-4.  std_3dgs: counts equal with the published
 rectangles, frames of both binnings bit-identical, pixels within 1e-4 up to 1/255-threshold flips."""
 import os
@@ -20,7 +20,10 @@ from oracle import c_oracle, cpu_ref  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-big = len(sys.argv) > 3 and sys.argv[3] == "big"     # larger frames (up to > 65 536 tiles) and populations
+big = "big" in sys.argv[3:]     # larger frames (up to > 65 536 tiles) and populations
+if "plain" in sys.argv[3:]:     # the second frame of every view takes GSX_FLAG_PLAIN_FOOTPRINTS where the first found it safe
+    from intro_to_gaussian_splatting_amd import gaussian_scene as _wrapper
+    _wrapper._PLAIN_MIN_TILES = 1
 worst_ref, worst_std, flips_total = 0.0, 0.0, 0
 for seed in range(first, first + count):
     rs = np.random.RandomState(77000 + seed)

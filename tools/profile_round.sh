@@ -12,7 +12,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 20 --warmup 3 --repeats 5 --no-cpu-baseline --streams 1 --camera-path none"
 P="python3 $R/bench.py --steps 5 --warmup 1 --repeats 1 --no-cpu-baseline --streams 1 --camera-path none"
-for w in c3 c2 c4 c3_clustered strip; do
+for w in c3 c2 c4 c3_clustered c3_trainedlike strip; do
   if [ $w = strip ]; then A="--workload c4 --strip-of 8"; else A="--workload $w"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o $w -- $B $A > $O/prof_$w.log 2>&1
   cp $(find $O/prof_$w -name "*kernel_stats.csv" | head -1) $O/${w}_kernel_stats.csv
