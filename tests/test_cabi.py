@@ -63,6 +63,24 @@ def test_shipping_library_reads_no_environment_variable():
     assert "getenv" in und_test
 
 
+def test_python_constants_equal_the_headers():
+    """Every GSX_ERR_* / GSX_SEM_* / GSX_LAYOUT_* / GSX_FLAG_* the ctypes binding spells out is the header's value, and the
+    binding knows every flag the header defines."""
+    import re
+    from intro_to_gaussian_splatting_amd import _ffi
+
+    text = open(HEADER).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+(GSX_[A-Z0-9_]+)\s+(-?(?:0x)?[0-9a-fA-F]+)\b", text, re.M)}
+    enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(GSX_(?:OK|ERR|SEM|LAYOUT)[A-Z0-9_]*)\s*=\s*(-?\d+)", text)}
+    known = {**defines, **enums}
+    mine = {k: v for k, v in vars(_ffi).items() if re.match(r"GSX_(OK|ERR|SEM|LAYOUT|FLAG)", k) and isinstance(v, int)}
+    assert mine, "no constants found in _ffi"
+    for k, v in mine.items():
+        assert k in known, "%s is not in include/gsx.h" % k
+        assert known[k] == v, (k, v, known[k])
+    assert {k for k in defines if k.startswith("GSX_FLAG_")} <= set(mine), sorted(set(defines) - set(mine))
+
+
 def test_struct_layouts():
     assert ctypes.sizeof(_ffi.GsxCamera) == 16 * 4 * 2 + 4 * 4 + 2 * 4 + 3 * 4
     assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16 + 8 + 8 + 24 and _ffi.GsxParams.kept_hint.offset == 88
