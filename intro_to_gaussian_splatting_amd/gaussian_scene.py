@@ -210,7 +210,7 @@ class CapturedFrame:
             raise _ffi.GsxError(_ffi.GSX_ERR_WORKSPACE_TOO_SMALL,
                                 "the captured frame holds %d pairs but the scene now produces %d: capture it again"
                                 % (st.reserved, st.n_instances))
-        if getattr(self, "_skip_redo", False) and st.n_redo > 0:
+        if getattr(self, "_plain_footprints", False) and st.n_redo > 0:
             raise _ffi.GsxError(_ffi.GSX_ERR_UNSUPPORTED,
                                 "the frame was captured with GSX_FLAG_PLAIN_FOOTPRINTS and %d tiles now hold ill-conditioned "
                                 "footprints: capture it again" % st.n_redo)
@@ -230,7 +230,7 @@ class GaussianScene:
         self._last_instances = 0      # instance count of the latest full frame
         self._cap_hints = {}          # (image, tile, window, semantics) -> pair capacity for the next frame
         self._kept_hints = {}         # same key -> Gaussians that reached a tile of the window (GsxParams.kept_hint)
-        self._redo_hints = {}         # same key -> tiles of the last frame that held an ill-conditioned footprint (n_redo)
+        self._n_redo_seen = {}         # same key -> tiles of the last frame that held an ill-conditioned footprint (n_redo)
         self._hints = _Lru(_HINT_VIEWS)   # (same key, stream) -> [GsxParams.hints buffer, a frame has run with it?]
         self._pending = []            # speculative frames awaiting confirm_frames()
         self._part_events = {}        # (stream, K) -> K HIP events the library records behind the parts of a frame
@@ -463,9 +463,9 @@ class GaussianScene:
         # confirm_frames / by CapturedFrame.confirm: a frame that was wrong about it is rendered again without the flag)
         n_window_tiles = (tile_window[1] - tile_window[0]) * (tile_window[3] - tile_window[2]) if tile_window is not None \
             else (-(-width // tile_size) * -(-height // tile_size) if tile_size > 0 else 0)
-        skip_redo = bool(own["skip_redo"]) if "skip_redo" in own else \
-            (self._redo_hints.get(cap_key) == 0 and n_window_tiles >= _PLAIN_MIN_TILES)
-        if skip_redo and semantics == "ref_cpu" and tile_size == 16 and not generic_kernels:
+        plain = bool(own["plain"]) if "plain" in own else \
+            (self._n_redo_seen.get(cap_key) == 0 and n_window_tiles >= _PLAIN_MIN_TILES)
+        if plain and semantics == "ref_cpu" and tile_size == 16 and not generic_kernels:
             params.flags |= _ffi.GSX_FLAG_PLAIN_FOOTPRINTS
         # GsxParams.hints: one buffer per view and stream (a captured frame owns its own), valid once a frame has filled it
         hint_slot = None
@@ -562,7 +562,7 @@ class GaussianScene:
         self._cap_hints[cap_key] = int(n_instances * 1.1) + 4096
         self._kept_hints[cap_key] = max(1, int(n_kept))
         if n_redo is not None:
-            self._redo_hints[cap_key] = int(n_redo)
+            self._n_redo_seen[cap_key] = int(n_redo)
         if cap_key[2] is None and cap_key[3] == "ref_cpu":
             self._last_instances = n_instances
 
@@ -589,11 +589,11 @@ class GaussianScene:
         torch.cuda.synchronize(self.gaussians.points.device)
         redone = 0
         pending, self._pending = self._pending, []
-        for pinned, cap_key, skipped_redo, call in pending:
+        for pinned, cap_key, ran_plain, call in pending:
             st = ctypes.cast(ctypes.c_void_p(pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents
             self._note_count(cap_key, int(st.n_instances), int(st.n_kept), int(st.n_redo))
             # more pairs than the workspace held (dropped), or tiles left to a second compositing launch that was not issued
-            if st.n_instances > st.reserved or (skipped_redo and st.n_redo > 0):
+            if st.n_instances > st.reserved or (ran_plain and st.n_redo > 0):
                 redone += 1
                 self.render_image_hip(**call)          # synchronising path, same output tensor
         return redone
@@ -635,7 +635,7 @@ class GaussianScene:
         # whose frame held no ill-conditioned footprint, where it pays (confirm() checks every replay's n_redo); a movable
         # camera may turn to such footprints
         private = dict(cap=cap, workspace=torch.empty(nbytes, dtype=torch.uint8, device=dev), kept=int(st["n_kept"]),
-                       skip_redo=(not movable_camera) and int(st.get("n_redo", 1)) == 0 and
+                       plain=(not movable_camera) and int(st.get("n_redo", 1)) == 0 and
                        int(st.get("n_tiles", 0)) >= _PLAIN_MIN_TILES,
                        pinned=torch.zeros(ctypes.sizeof(_ffi.GsxFrameStats), dtype=torch.uint8).pin_memory(), inputs=[],
                        hints=[torch.zeros(lib.gsx_hints_bytes(cam.width, cam.height, tile_size), dtype=torch.uint8,
@@ -651,7 +651,7 @@ class GaussianScene:
         frame = CapturedFrame(self, graph, out, private["pinned"], call, camera_buffer=cam_buf,
                               workspace=private["workspace"], capacity=cap, inputs=private["inputs"])
         frame._hints = private["hints"][0]     # the recorded kernels read and refresh this buffer on every replay
-        frame._skip_redo = bool(private["skip_redo"])
+        frame._plain_footprints = bool(private["plain"])
         return frame
 
     def render_image(self, image_idx: int, tile_size: int = 16) -> torch.Tensor:
@@ -686,10 +686,10 @@ class GaussianScene:
         def finish(k: int) -> torch.Tensor:
             copied[k].synchronize()
             if checks[k] is not None:
-                pinned, cap_key, skipped_redo, call = checks[k]
+                pinned, cap_key, ran_plain, call = checks[k]
                 st = ctypes.cast(ctypes.c_void_p(pinned.data_ptr()), ctypes.POINTER(_ffi.GsxFrameStats)).contents
                 self._note_count(cap_key, int(st.n_instances), int(st.n_kept), int(st.n_redo))
-                if st.n_instances > st.reserved or (skipped_redo and st.n_redo > 0):    # dropped pairs / tiles left undone: once more, synchronously
+                if st.n_instances > st.reserved or (ran_plain and st.n_redo > 0):    # dropped pairs / tiles left undone: once more, synchronously
                     self.render_image_hip(**call)
                     hosts[k].copy_(frames[k])
             return hosts[k]

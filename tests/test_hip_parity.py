@@ -794,13 +794,13 @@ def test_plain_footprints_instance_only_where_no_tile_needs_the_other(tmp_path, 
     a = scene.render_image_hip(1, stats=st).clone()
     assert st["n_redo"] == 0
     key = (1, 16, None, "ref_cpu")
-    assert scene._redo_hints[key] == 0
-    assert not scene.capture_frame(1)._skip_redo        # (240 tiles: the plain instance pays from 16 384)
+    assert scene._n_redo_seen[key] == 0
+    assert not scene.capture_frame(1)._plain_footprints        # (240 tiles: the plain instance pays from 16 384)
     monkeypatch.setattr(wrapper, "_PLAIN_MIN_TILES", 1)
     st = {}
     assert torch.equal(scene.render_image_hip(1, stats=st), a) and st["n_redo"] == 0        # (issued with GSX_FLAG_PLAIN_FOOTPRINTS)
     frame = scene.capture_frame(1, headroom=8.0)        # (room for the pairs of the needles grown below)
-    assert frame._skip_redo
+    assert frame._plain_footprints
     frame.replay()
     assert torch.equal(frame.confirm(), a)
     # needles: counted, and the view keeps the instance that evaluates them
@@ -810,16 +810,16 @@ def test_plain_footprints_instance_only_where_no_tile_needs_the_other(tmp_path, 
     needles = _scene_from_arrays(tmp_path / "needles", sc2)
     st = {}
     b = needles.render_image_hip(1, stats=st).clone()
-    assert st["n_redo"] > 0 and needles._redo_hints[key] > 0
+    assert st["n_redo"] > 0 and needles._n_redo_seen[key] > 0
     _, port, inst = _oracle_frame(needles, sc2)
     assert st["n_instances"] == inst and np.max(np.abs(b.cpu().numpy() - port)) <= PIXEL_TOL
-    assert not needles.capture_frame(1)._skip_redo
+    assert not needles.capture_frame(1)._plain_footprints
     # a frame that wrongly takes the plain instance: the synchronising path notices and renders again ...
-    needles._redo_hints[key] = 0
+    needles._n_redo_seen[key] = 0
     st = {}
     assert torch.equal(needles.render_image_hip(1, stats=st), b) and st["n_redo"] > 0
     # ... an enqueued frame is redone by confirm_frames() ...
-    needles._redo_hints[key] = 0
+    needles._n_redo_seen[key] = 0
     out = torch.empty_like(b)
     needles.render_image_hip(1, out=out, no_sync=True)
     assert needles.confirm_frames() == 1 and torch.equal(out, b)
@@ -872,7 +872,7 @@ def test_both_compositing_instances_render_the_same_frames(tmp_path, monkeypatch
     assert st["plain_footprints"] and torch.equal(again, part)
     assert torch.equal(part[160:480, 32:320], first["heavy-tailed"][160:480, 32:320])
     frame = scene.capture_frame(1)
-    assert frame._skip_redo
+    assert frame._plain_footprints
     frame.replay()
     assert torch.equal(frame.confirm(), first["heavy-tailed"])
 

@@ -22,4 +22,4 @@ for movable in (False, True):
             ts.append((e0, e1))
         torch.cuda.synchronize()
         print("%s movable=%s headroom=%.1f: median %.4f ms (plain instance: %s)" % (
-            wl, movable, headroom, float(np.median([a.elapsed_time(b) for a, b in ts])), frame._skip_redo))
+            wl, movable, headroom, float(np.median([a.elapsed_time(b) for a, b in ts])), frame._plain_footprints))
