@@ -1256,7 +1256,10 @@ __device__ __forceinline__ void blend_tile16_grid(const Record *__restrict__ rec
 }
 
 template <int VARIANT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))   // 64 VGPRs: every lost wave costs
+#ifndef GSX_PLAIN_WAVES
+#define GSX_PLAIN_WAVES 8    // (build-time knob for A/B runs: tools/ab_bench.sh)
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GSX_PLAIN_WAVES, 8)))   // 64 VGPRs: every lost wave costs
     blend_tile16_kernel(const Record *__restrict__ rec, const float4 *__restrict__ qraw, const uint32_t *__restrict__ vals,
                         const uint2 *__restrict__ ranges, TileGrid g, OutDesc out, ClearPlan cp, LongTiles lt,
                         uint32_t nhelpers, const uint32_t *__restrict__ sched, uint32_t budget, uint32_t quarters, BlendHints hints,

@@ -422,7 +422,8 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
         // the compositing kernels execute the reference's operations on it, one for one (alpha_ref in gsx_blend.hip).
         // (float32 and the approximate reciprocal square root are plenty for a threshold)
         const float cc = 0.5f * fabsf(q01 + q10) * __builtin_amdgcn_rsqf(q00 * q11);
-        const bool ref_order = ok && q00 > 0.0f && q11 > 0.0f && cc < 1.0f && 8.8e-8f * op * (1.0f + cc) > 3e-5f * (1.0f - cc);
+        // (c >= 1: the float32 conic is not even positive definite -- the right-hand side is <= 0 and the record is flagged)
+        const bool ref_order = ok && q00 > 0.0f && q11 > 0.0f && 8.8e-8f * op * (1.0f + cc) > 3e-5f * (1.0f - cc);
         if (ref_order && qraw) {
             // the completed square as for any record (the skip bounds of the compositing kernels are computed from it),
             // the opacity factor itself where the depth would be, and the raw conic in the Gaussian's side slot

@@ -775,6 +775,48 @@ def test_needles_through_every_kernel_family(tmp_path):
     assert d.max() <= PIXEL_TOL
 
 
+def test_conic_whose_float32_determinant_cancelled_takes_the_reference_order(tmp_path):
+    """Found by tools/fuzz.py (big profile, seed 301): a 290:1 needle 2 000 px long whose 2D covariance determinant cancels
+    in float32 -- the reference inverts it all the same (utils.py:383 floors the determinant), and the conic that comes
+    out, (16.61, -24.63; -24.63, 36.51), has c = |Q01 + Q10| / 2 sqrt(Q00 Q11) = 1 - 6.6e-8: in float32 exactly 1.0.  The
+    flag test of pack_record excluded c >= 1 and composited the MOST ill-conditioned record by the completed square:
+    0.058 off the reference's operations.  Through the stage-2 entry (the record as the reference's stage 1 made it),
+    alone and among regular footprints, on every kernel family."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import render_preprocessed
+    from oracle import c_oracle, cpu_ref
+
+    w, h = 1456, 1139
+    rs = np.random.RandomState(5)
+    m = 41
+    pts = np.stack([rs.uniform(600, 900, m), rs.uniform(550, 850, m)], axis=1).astype(np.float32)
+    inv = np.zeros((m, 2, 2), np.float32)
+    sig = rs.uniform(6.0, 30.0, m).astype(np.float32)
+    inv[:, 0, 0] = inv[:, 1, 1] = 1.0 / (sig * sig)
+    rad = np.ceil(3.0 * sig).astype(np.float32)
+    op = rs.uniform(0.05, 0.9, m).astype(np.float32)
+    k = 20       # the needle, in the middle of the depth order
+    pts[k] = (755.3137817382812, 699.432861328125)
+    inv[k] = [[16.614168167114258, -24.628461837768555], [-24.628463745117188, 36.50867462158203]]
+    rad[k] = 1980.0
+    op[k] = 0.011413033120334148
+    pre = cpu_ref.Preprocessed(points=pts, colors=rs.uniform(0.1, 1.0, (m, 3)).astype(np.float32), covariance_2d=np.zeros((m, 2, 2), np.float32),
+                               depths=np.arange(m, dtype=np.float32) + 1.0, inverse_covariance_2d=inv, radius=rad, points_xy=pts,
+                               min_x=pts[:, 0] - rad, min_y=pts[:, 1] - rad, max_x=pts[:, 0] + rad, max_y=pts[:, 1] + rad,
+                               sigmoid_opacity=op.reshape(-1, 1), order=np.arange(m))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    for name, sub in (("alone", pre._replace(**{f: np.asarray(getattr(pre, f))[k:k + 1] for f in pre._fields})), ("among others", pre)):
+        for tile in (16, 8):
+            ref, _, inst = c_oracle.render(sub, w, h, tile)
+            st = {}
+            img = render_preprocessed(h, w, tile, t(sub.points), t(sub.colors), t(sub.inverse_covariance_2d), t(sub.min_x), t(sub.max_x),
+                                      t(sub.min_y), t(sub.max_y), t(sub.sigmoid_opacity), stats=st).cpu().numpy()
+            assert st["n_instances"] == inst
+            d = float(np.abs(img - ref).max())
+            assert d <= PIXEL_TOL, (name, tile, d)
+        assert float(ref.max()) > 1e-3, name        # (the needle is in the picture)
+
+
 def test_plain_footprints_instance_only_where_no_tile_needs_the_other(tmp_path, monkeypatch):
     """GsxFrameStats.n_redo / GSX_FLAG_PLAIN_FOOTPRINTS: a view without ill-conditioned footprints reports n_redo = 0, its
     next frame runs the compositing instance that cannot evaluate them (here also on a small window: the wrapper's size
