@@ -817,6 +817,27 @@ def test_conic_whose_float32_determinant_cancelled_takes_the_reference_order(tmp
         assert float(ref.max()) > 1e-3, name        # (the needle is in the picture)
 
 
+@pytest.mark.parametrize("seed,big", [(30, False), (7, False), (2, True)])
+def test_corners_of_the_parameter_space(tmp_path, seed, big):
+    """tools/fuzz.py's `extreme` profile: needles to 3000:1, pancakes, specks of a hundredth of a pixel, opacity logits of
+    +-12, many centres on one spot.  Seeds 30 and (big) 2 were 0.56 / 0.80 off: a needle seen from 1 000 px has the
+    reference's own exponent off by more than one -- its alpha is the exact one times e^(+-delta), not plus a small
+    delta alpha --, and a flagged record was demoted / dropped from a block's list by the EXACT alpha there."""
+    _need_gpu()
+    from tools.fuzz_scene import fuzz_scene
+
+    _, sc, w, h, tile, n, _ = fuzz_scene(seed, big, True)
+    scene = _scene_from_arrays(tmp_path, sc)
+    _, ref, inst = _oracle_frame(scene, sc, tile)
+    st = {}
+    img = scene.render_image_hip(1, tile_size=tile, stats=st)
+    assert st["n_instances"] == inst
+    d = float(np.abs(img.cpu().numpy() - ref).max())
+    assert d <= PIXEL_TOL, (seed, big, d)
+    assert torch.equal(img, scene.render_image_hip(1, tile_size=tile, generic_kernels=True))
+    assert torch.equal(img, scene.render_image_hip(1, tile_size=tile, split_long_tiles=False))
+
+
 def test_plain_footprints_instance_only_where_no_tile_needs_the_other(tmp_path, monkeypatch):
     """GsxFrameStats.n_redo / GSX_FLAG_PLAIN_FOOTPRINTS: a view without ill-conditioned footprints reports n_redo = 0, its
     next frame runs the compositing instance that cannot evaluate them (here also on a small window: the wrapper's size

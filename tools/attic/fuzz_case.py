@@ -1,5 +1,5 @@
 """One seed of tools/fuzz.py's big profile through several kernel routes, to localise a mismatch.
-    python tools/attic/fuzz_case.py <seed>"""
+    python tools/attic/fuzz_case.py <seed> [big] [extreme]"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -9,23 +9,8 @@ if os.environ.get("GSX_TEST_LIB_PATH") or os.environ.get("GSX_FUZZ_TEST_LIB"):
 from intro_to_gaussian_splatting_amd.synthetic import make_scene, write_colmap_text
 from oracle import c_oracle, cpu_ref
 seed = int(sys.argv[1])
-rs = np.random.RandomState(77000 + seed)
-w, h = int(rs.randint(3, 400)), int(rs.randint(3, 300))
-tile = int(rs.choice([1, 2, 3, 4, 7, 8, 16, 16, 16, 16, 17, 32, 40]))
-n = int(rs.choice([0, 1, 2, 17, 300, 2500, 20000]))
-w, h = int(rs.randint(300, 2200)), int(rs.randint(200, 1300))
-tile = int(rs.choice([3, 4, 8, 16, 16, 16]))
-n = int(rs.choice([5000, 50000, 200000]))
-q = rs.normal(size=4)
-sc = make_scene(max(n, 1), w, h, seed=seed, behind_fraction=float(rs.choice([0.0, 0.0, 0.3, 1.0])),
-                qvec=tuple(q / np.linalg.norm(q)), tvec=tuple(rs.normal(size=3)),
-                spread=float(rs.choice([1.0, 1.0, 1.5, 3.0])), sigma_scale=float(rs.choice([0.05, 0.5, 1.0, 1.0, 3.0, 12.0])))
-needles = False
-if rs.uniform() < 0.4 and n > 0:
-    needles = True
-    sc["scales"] = sc["scales"].copy()
-    pick = rs.uniform(size=sc["scales"].shape[0]) < float(rs.choice([0.02, 0.2, 1.0]))
-    sc["scales"][pick, rs.randint(0, 3)] *= np.float32(rs.uniform(20.0, 300.0))
+from tools.fuzz_scene import fuzz_scene
+_, sc, w, h, tile, n, needles = fuzz_scene(seed, "big" in sys.argv[2:], "extreme" in sys.argv[2:])
 print("seed", seed, "w h tile n", w, h, tile, n, "needles", needles)
 with tempfile.TemporaryDirectory() as tmp:
     write_colmap_text(tmp, sc)

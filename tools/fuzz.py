@@ -1,6 +1,6 @@
 """Randomised parity fuzz on the GPU box: random frame sizes, tile sizes, populations, footprints,
 off-axis spread, cull shares, poses, layouts and tile windows; HIP path vs the C restatements.
-    python tools/fuzz.py [first_seed] [count] [big] [plain]
+    python tools/fuzz.py [first_seed] [count] [big] [plain] [extreme]
 ref_cpu: D and N_vis equal, max |dpixel| <= 1e-4.  std_3dgs: counts equal with the published
 rectangles, frames of both binnings bit-identical, pixels within 1e-4 up to 1/255-threshold flips."""
 import os
@@ -17,35 +17,18 @@ if os.environ.get("GSX_FUZZ_TEST_LIB"):      # libgsx_test.so, so that its knobs
     _ffi.use_test_library()
 from intro_to_gaussian_splatting_amd.synthetic import make_scene, write_colmap_text  # noqa: E402
 from oracle import c_oracle, cpu_ref  # noqa: E402
+from tools.fuzz_scene import fuzz_scene  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 big = "big" in sys.argv[3:]     # larger frames (up to > 65 536 tiles) and populations
+extreme = "extreme" in sys.argv[3:]     # needles to 3000:1, pancakes, specks, saturated opacities, coincident centres
 if "plain" in sys.argv[3:]:     # the second frame of every view takes GSX_FLAG_PLAIN_FOOTPRINTS where the first found it safe
     from intro_to_gaussian_splatting_amd import gaussian_scene as _wrapper
     _wrapper._PLAIN_MIN_TILES = 1
 worst_ref, worst_std, flips_total = 0.0, 0.0, 0
 for seed in range(first, first + count):
-    rs = np.random.RandomState(77000 + seed)
-    w, h = int(rs.randint(3, 400)), int(rs.randint(3, 300))
-    tile = int(rs.choice([1, 2, 3, 4, 7, 8, 16, 16, 16, 16, 17, 32, 40]))
-    n = int(rs.choice([0, 1, 2, 17, 300, 2500, 20000]))
-    if big:
-        w, h = int(rs.randint(300, 2200)), int(rs.randint(200, 1300))
-        tile = int(rs.choice([3, 4, 8, 16, 16, 16]))
-        n = int(rs.choice([5000, 50000, 200000]))
-    q = rs.normal(size=4)
-    sc = make_scene(max(n, 1), w, h, seed=seed, behind_fraction=float(rs.choice([0.0, 0.0, 0.3, 1.0])),
-                    qvec=tuple(q / np.linalg.norm(q)), tvec=tuple(rs.normal(size=3)),
-                    spread=float(rs.choice([1.0, 1.0, 1.5, 3.0])), sigma_scale=float(rs.choice([0.05, 0.5, 1.0, 1.0, 3.0, 12.0])))
-    needles = False
-    if rs.uniform() < 0.4 and n > 0:
-        needles = True
-        # needles: a share of the Gaussians stretched 20 .. 300-fold along one axis -- ill-conditioned footprints, which
-        # the compositing kernels evaluate in the reference's operation order (gsx_blend.hip: kKindRefOrder)
-        sc["scales"] = sc["scales"].copy()
-        pick = rs.uniform(size=sc["scales"].shape[0]) < float(rs.choice([0.02, 0.2, 1.0]))
-        sc["scales"][pick, rs.randint(0, 3)] *= np.float32(rs.uniform(20.0, 300.0))
+    rs, sc, w, h, tile, n, needles = fuzz_scene(seed, big, extreme)
     if n == 0:
         sc = {k: (v[:0] if isinstance(v, np.ndarray) and v.ndim == 2 else v) for k, v in sc.items()}
     with tempfile.TemporaryDirectory() as tmp:
