@@ -1,6 +1,6 @@
 """Randomised parity fuzz on the GPU box: random frame sizes, tile sizes, populations, footprints,
 off-axis spread, cull shares, poses, layouts and tile windows; HIP path vs the C restatements.
-    python tools/fuzz.py [first_seed] [count] [big] [plain] [extreme]
+    python tools/fuzz.py [first_seed] [count] [big] [plain] [extreme] [family=trained|needle|tie|few|mixed]
 ref_cpu: D and N_vis equal, max |dpixel| <= 1e-4.  std_3dgs: counts equal with the published
 rectangles, frames of both binnings bit-identical, pixels within 1e-4 up to 1/255-threshold flips."""
 import os
@@ -22,13 +22,14 @@ from tools.fuzz_scene import fuzz_scene  # noqa: E402
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 big = "big" in sys.argv[3:]     # larger frames (up to > 65 536 tiles) and populations
+family = ([a.split("=", 1)[1] for a in sys.argv[3:] if a.startswith("family=")] or [""])[0]     # trained / needle / tie / few / mixed
 extreme = "extreme" in sys.argv[3:]     # needles to 3000:1, pancakes, specks, saturated opacities, coincident centres
 if "plain" in sys.argv[3:]:     # the second frame of every view takes GSX_FLAG_PLAIN_FOOTPRINTS where the first found it safe
     from intro_to_gaussian_splatting_amd import gaussian_scene as _wrapper
     _wrapper._PLAIN_MIN_TILES = 1
 worst_ref, worst_std, flips_total = 0.0, 0.0, 0
 for seed in range(first, first + count):
-    rs, sc, w, h, tile, n, needles = fuzz_scene(seed, big, extreme)
+    rs, sc, w, h, tile, n, needles = fuzz_scene(seed, big, extreme, family)
     if n == 0:
         sc = {k: (v[:0] if isinstance(v, np.ndarray) and v.ndim == 2 else v) for k, v in sc.items()}
     with tempfile.TemporaryDirectory() as tmp:
