@@ -61,6 +61,17 @@ for seed in range(first, first + count):
     # the next frame of the view finds this one's hints (splitters, costs, schedule): same pixels
     again = scene.render_image_hip(1, tile_size=tile, layout=layout).cpu().numpy()
     assert np.array_equal(again.transpose(1, 0, 2) if layout == "hw3" else again, img), ("hinted frame differs", tag)
+    # ---- the compositing in parts along the leading axis (GsxParams.n_substrips: what a rank sends while it composites the next)
+    if tile == 16 and min(w, h) >= 32:
+        from intro_to_gaussian_splatting_amd import strips as _strips
+        n_lead = _strips.tiles_along(w if layout == "wh3" else h, tile)
+        parts = int(rs.randint(2, min(16, n_lead) + 1)) if n_lead >= 2 else 0
+        if parts:
+            evs = []
+            got = scene.render_image_hip(1, tile_size=tile, layout=layout, substrips=_strips.substrip_bounds(0, n_lead, parts),
+                                         substrip_events=evs).cpu().numpy()
+            torch.cuda.synchronize()
+            assert np.array_equal(got.transpose(1, 0, 2) if layout == "hw3" else got, img), ("substrips differ", tag, parts)
     # ---- a random tile window of the same frame (multi-GPU strips use these)
     from intro_to_gaussian_splatting_amd import strips
     ntx, nty = strips.tiles_along(w, tile), strips.tiles_along(h, tile)
