@@ -337,6 +337,72 @@ def stage1_vs_reference(workload: str, scene, device: str) -> dict:
             "d_ref": int(g["tile_instances"]), "d_hip": int(st["n_instances"])}
 
 
+TILE_FIXTURE_OF = {"c3": "tiles_c3_1080p_n1000000", "c3_clustered": "tiles_c3_clustered_1080p_n1000000",
+                   "c3_trainedlike": "tiles_c3_trainedlike_1080p_n1000000"}
+
+
+def pixels_vs_reference(workload: str, scene, frame: torch.Tensor, device, tile: int) -> dict:
+    """The frame's pixels against the REFERENCE ITSELF at this size: tests/golden/tiles_*.npz hold 16x16 blocks that the
+    reference's own render_tile (splat/gaussian_scene.py:173-198) composited from its own preprocess of this workload's
+    scene (oracle/capture_golden.py: capture_tiles; 7 - 60 s of the reference per tile, which is why it is tiles and not
+    the frame).  ``frame``: the frame the timed region produced.  The trained-like workload is timed with degree-3
+    spherical harmonics, which the reference does not have: its tiles are compared on a frame of the same Gaussians with
+    their base colours (rendered here, untimed)."""
+    from oracle import golden_check
+
+    name = TILE_FIXTURE_OF[workload]
+    g = golden_check.load(name)
+    sc = golden_check.tiles_scene(g)            # (checks that the generator still makes the scene the reference was given)
+    note = "the timed region's last frame"
+    if workload == "c3_trainedlike":
+        from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians
+        from intro_to_gaussian_splatting_amd.synthetic import write_colmap_text
+
+        tmp = tempfile.mkdtemp(prefix="gsx_bench_tiles_")
+        write_colmap_text(tmp, sc)
+        plain = GaussianScene(tmp, Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"],
+                                                         sc["opacity"], device=str(device)))
+        frame = plain.render_image_hip(1, tile_size=tile)
+        note = "a frame of the same Gaussians with their base colours (the reference has no spherical harmonics)"
+    rep = golden_check.compare_tiles_with_reference(g, frame.cpu().numpy())
+    return {"fixture": "tests/golden/%s.npz" % name,
+            "made_by": "the reference's own preprocess + render_tile (oracle/capture_golden.py: capture_tiles)",
+            "frame": note, "tiles": rep["tiles"], "max_abs": rep["max_abs"], "pixels_over_1e-4": rep["pixels_over_1e4"],
+            "pixels": rep["tiles"] * tile * tile, "longest_list": rep["longest_list"],
+            "tile_coordinates": [[int(a), int(b)] for a, b in g["tiles"]],
+            "per_tile_max_abs": [float("%.3g" % v) for v in rep["per_tile"]],
+            "ok": bool(rep["max_abs"] <= 1e-4)}
+
+
+def tie_order_effect(workload: str, sc, scene) -> dict:
+    """What the ONE thing this build does not take from the reference -- the order of Gaussians of EQUAL view depth -- does to
+    the picture at this size: the C restatement composites the frame twice, once in this build's order (ties by original
+    index) and once in the reference's (what torch.argsort, unstable, did inside every run of equal depths: recorded by
+    the stage-1 fixture), same stage-1 arrays.  c2 / c3 only (the workloads that have a stage-1 fixture)."""
+    from oracle import c_oracle, cpu_ref, golden_check
+
+    g = golden_check.load("stage1_c3_1080p_n1000000" if workload == "c3" else "stage1_c2_1080p_n100000")
+    golden_check.stage1_scene(g)
+    im = scene.images[1]
+    c = im.gsx_camera()
+    cam = cpu_ref.Camera(im.world2view.cpu().numpy(), im.full_proj_transform.cpu().numpy(), np.float32(c.tan_fovx),
+                         np.float32(c.tan_fovy), np.float32(c.fx), np.float32(c.fy), c.width, c.height)
+    t0 = time.perf_counter()
+    pre = c_oracle.preprocess(sc["points"], scene._colors(1).cpu().numpy(), sc["scales"], sc["quaternions"], sc["opacity"], cam)
+    rows = golden_check.rows_in_reference_order(pre.order, g)
+    theirs = cpu_ref.Preprocessed(*[np.ascontiguousarray(np.asarray(f)[rows]) for f in pre])
+    cores = os.cpu_count() or 1
+    a, _, inst_a = c_oracle.render(pre, c.width, c.height, 16, nthreads=cores)
+    b, _, inst_b = c_oracle.render(theirs, c.width, c.height, 16, nthreads=cores)
+    d = np.abs(a - b).max(axis=2)
+    return {"max_abs_dpixel": float(d.max()), "pixels_over_1e-4": int((d > 1e-4).sum()), "pixels_differing": int((d > 0).sum()),
+            "pixels": int(d.size), "sorted_positions_differing": int(np.count_nonzero(rows != np.arange(rows.size))),
+            "gaussians_with_equal_depths": int(g["tie_positions"].size), "instances_equal": bool(inst_a == inst_b),
+            "how": "oracle/raster_cpu.c, whole frame twice on %d threads: ties by original index (this build) vs the reference's "
+                   "torch.argsort order inside runs of equal depths (tests/golden/stage1_*.npz: tie_positions / tie_order)" % cores,
+            "seconds": round(time.perf_counter() - t0, 2)}
+
+
 def pmc_record(workload: str, world: int, strip_of: int = 0):
     """PMC measurements of the compositing launch, taken with rocprofv3 in separate passes (FETCH_SIZE,
     WRITE_SIZE, SQ_*; MI355X_MICROARCH.md: FETCH_SIZE doubled on gfx950) and committed under profiles/;
@@ -718,6 +784,11 @@ def main() -> None:
     ap.add_argument("--plain-min-tiles", type=int, default=None,
                     help="development: the window size from which a view without ill-conditioned footprints takes "
                          "GSX_FLAG_PLAIN_FOOTPRINTS (the wrapper's default: 16384 tiles; 1 = always, a huge number = never)")
+    ap.add_argument("--dist-preflight", action="store_true",
+                    help="--gpus 1 only: run the MULTI-GPU code path with a world of one rank -- "
+                         "dist.init_process_group('nccl') (RCCL accepts one rank per device), strips.render_overlapped / "
+                         "render_sharded / StripPipeline, barriers, reductions, the `distributed` block -- so that communicator "
+                         "creation, stream / event ordering and every collective call have met real RCCL before a node run")
     ap.add_argument("--sync-frames", action="store_true",
                     help="read the instance count back inside every frame instead of speculating on it")
     args = ap.parse_args()
@@ -729,6 +800,9 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node == --gpus" % (args.gpus, world))
+    if args.dist_preflight and world != 1:
+        raise SystemExit("--dist-preflight is the one-GPU rehearsal of the multi-GPU path")
+    multi = world > 1 or args.dist_preflight       # the strip path with its process group (a world of one under --dist-preflight)
     if args.plain_min_tiles is not None:
         from intro_to_gaussian_splatting_amd import gaussian_scene as _wrapper
         _wrapper._PLAIN_MIN_TILES = int(args.plain_min_tiles)
@@ -739,8 +813,12 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_preflight:
+            os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # ("nccl" is RCCL on ROCm; a collective that never completes -- a rank that died, a transport that does not come
         # up -- ends the run after three minutes instead of the default ten: the driver's clock is running)
         dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=180))
@@ -758,7 +836,7 @@ def main() -> None:
             os.path.basename(args.ply), n, scene.gaussians.sh_degree, width, height)
     else:
         n_orbit = 0
-        if args.camera_path != "none" and world == 1 and args.strip_of <= 1 and args.semantics == "ref_cpu":
+        if args.camera_path != "none" and not multi and args.strip_of <= 1 and args.semantics == "ref_cpu":
             kind, _, cnt = args.camera_path.partition(":")
             if kind != "orbit" or not (cnt or "61").isdigit() or int(cnt or 61) < 3:
                 raise SystemExit("--camera-path: orbit:N with N >= 3, or none")
@@ -779,7 +857,7 @@ def main() -> None:
     # N > 1: every rank renders the frame once (untimed), reads the per-tile list lengths the library reports
     # (GsxParams.tile_counts) and derives the same balanced strip plan from them -- no communication needed
     strip_plan = None
-    if world > 1 and args.balance:
+    if multi and args.balance:
         ntx, nty = strips.tiles_along(width, tile, sem), strips.tiles_along(height, tile, sem)
         counts = torch.zeros(max(1, ntx * nty), dtype=torch.int32, device=device)
         scene.render_image_hip(1, tile_size=tile, layout=layout, tile_counts=counts, semantics=sem)
@@ -814,7 +892,7 @@ def main() -> None:
         # 1 GPU: speculative frames (GSX_FLAG_NO_SYNC) -- the pair list is sized by the previous
         # frame's instance count, so nothing waits for the device inside a frame; the counts are
         # confirmed after the timed region (confirm_frames) and a miss invalidates the run.
-        if world == 1:
+        if not multi:
             if graphs:          # the whole frame (every launch, clear and count copy) is ONE graph launch
                 st = gstreams[step.count % len(gstreams)]
                 step.count += 1
@@ -831,19 +909,19 @@ def main() -> None:
         if pipeline is not None:
             return pipeline.submit()
         return strips.render_sharded(render_strip, width, height, tile, layout, device, cache=strip_cache,
-                                     semantics=sem, plan=strip_plan)
+                                     semantics=sem, plan=strip_plan, collective_with_one_rank=args.dist_preflight)
 
     step.count = 0
     strip_cache = {}
-    streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if (world == 1 and args.streams > 1) else []
+    streams = [torch.cuda.Stream(device) for _ in range(args.streams)] if (not multi and args.streams > 1) else []
     outs = {st: torch.empty((width, height, 3), dtype=torch.float32, device=device) for st in streams}
-    single_out = torch.empty((width, height, 3), dtype=torch.float32, device=device) if world == 1 else None
+    single_out = torch.empty((width, height, 3), dtype=torch.float32, device=device) if not multi else None
     # N > 1: strips of consecutive frames in flight on side streams, gathers in frame order on this stream
     pipeline = None
-    if world > 1 and args.streams > 1 and not args.sync_frames:
+    if multi and args.streams > 1 and not args.sync_frames:
         pipeline = strips.StripPipeline(render_strip, width, height, tile, layout, device, depth=args.streams,
                                         semantics=sem, plan=strip_plan)
-    use_graphs = world == 1 and not args.no_graphs and not args.sync_frames
+    use_graphs = not multi and not args.no_graphs and not args.sync_frames
     gstreams = (streams or [torch.cuda.Stream(device)]) if use_graphs else []
     graphs = {st: scene.capture_frame(1, tile_size=tile, layout=layout, semantics=sem) for st in gstreams}
     lat_stream = torch.cuda.Stream(device)
@@ -854,25 +932,25 @@ def main() -> None:
         if strip_window is not None:
             return scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=strip_window, out=strip_out,
                                           out_origin=(strip_window[0] * tile, 0), no_sync=not args.sync_frames, semantics=sem)
-        if world > 1 and overlapped["on"]:
+        if multi and overlapped["on"]:
             return strips.render_overlapped(render_strip, width, height, tile, layout, device, parts=args.substrips,
                                             cache=strip_cache, semantics=sem, plan=strip_plan)
-        if world > 1:
+        if multi:
             return strips.render_sharded(render_strip, width, height, tile, layout, device, cache=strip_cache,
-                                         semantics=sem, plan=strip_plan)
+                                         semantics=sem, plan=strip_plan, collective_with_one_rank=args.dist_preflight)
         if one is not None:
             return one.replay()
         return scene.render_image_hip(1, tile_size=tile, layout=layout, out=single_out, no_sync=not args.sync_frames,
                                       semantics=sem)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     # N > 1: the overlapped gather is new code on first contact with a multi-GPU node -- check one frame of it against the
     # single-GPU frame before anything is timed, and let the plain path take over if it does not hold
-    overlapped = {"on": world > 1 and args.substrips > 1, "why": None}
+    overlapped = {"on": multi and args.substrips > 1, "why": None}
     if overlapped["on"]:
         ok = torch.ones(1, dtype=torch.int32, device=device)
         try:
@@ -903,7 +981,7 @@ def main() -> None:
             single_frame()
         torch.cuda.synchronize()
         done = (time.perf_counter() - t_settle) * 1e3 >= args.settle_ms
-        if world > 1:   # every frame is a collective: the ranks must agree on when to stop, not each ask its own clock
+        if multi:   # every frame is a collective: the ranks must agree on when to stop, not each ask its own clock
             flag = torch.tensor([1 if done else 0], dtype=torch.int32, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             done = bool(flag.item())
@@ -926,7 +1004,7 @@ def main() -> None:
     respeculated = scene.confirm_frames()
     if one is not None:
         one.confirm()           # raises if a replay needed more pairs than the graph was captured with
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -946,7 +1024,7 @@ def main() -> None:
             respeculated += scene.confirm_frames()
             frame_ms += [e0.elapsed_time(e1) for e0, e1 in evs]
     frame_ms = np.sort(np.asarray(frame_ms, dtype=np.float64))
-    if world > 1:       # a frame is done when the slowest rank is: take every rank's median, report the largest
+    if multi:       # a frame is done when the slowest rank is: take every rank's median, report the largest
         t = torch.tensor([float(np.median(frame_ms))], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         median_ms = float(t.item())
@@ -958,7 +1036,7 @@ def main() -> None:
     # ---- for reference: several frames in flight (whole-job throughput of a stream of frames)
     inflight_ms = None
     launches_ms = None
-    if (world == 1 and (len(streams) > 1)) or pipeline is not None:
+    if (not multi and (len(streams) > 1)) or pipeline is not None:
         for _ in range(args.warmup):
             step()
         fence()
@@ -971,7 +1049,7 @@ def main() -> None:
         respeculated += scene.confirm_frames()
         for gf in graphs.values():
             gf.confirm()
-        if world > 1:
+        if multi:
             t = torch.tensor([inflight_ms], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             inflight_ms = float(t.item())
@@ -990,21 +1068,21 @@ def main() -> None:
         torch.cuda.synchronize()
         launches_ms = (time.perf_counter() - t1) / args.steps * 1e3
         scene.confirm_frames()
-    if world > 1:
+    if multi:
         flag = torch.tensor([respeculated], dtype=torch.int64, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         respeculated = int(flag.item())
     if respeculated:
         raise SystemExit("speculative frames missed their instance hint %d times: timing invalid" % respeculated)
 
-    moving = moving_camera_leg(args, scene, sc, tile, layout, sem, lat_stream) if (world == 1 and len(scene.images) > 3) else None
+    moving = moving_camera_leg(args, scene, sc, tile, layout, sem, lat_stream) if (not multi and len(scene.images) > 3) else None
 
     # per-stage HIP-event times of this rank's share (live, same process, separate loop)
     stage = {}
     stats = {}
     reps = max(3, min(args.steps, 10))
     window = strip_window
-    if world > 1:
+    if multi:
         plan = strip_plan or strips.strip_plan(strips.tiles_along(width, tile, sem), world)[1]
         window = (plan[rank][0], plan[rank][1], 0, strips.tiles_along(height, tile, sem))
     for _ in range(reps):
@@ -1016,7 +1094,7 @@ def main() -> None:
 
     # how long the tile lists are (GsxParams.tile_counts): the compositing kernel lasts as long as its longest
     tile_list = None
-    if world == 1 and strip_window is None:
+    if not multi and strip_window is None:
         ntx_, nty_ = strips.tiles_along(width, tile, sem), strips.tiles_along(height, tile, sem)
         if ntx_ * nty_ > 0:
             tc = torch.zeros(ntx_ * nty_, dtype=torch.int32, device=device)
@@ -1026,7 +1104,7 @@ def main() -> None:
                          "p99": float(tcs[int(0.99 * (len(tcs) - 1))]), "max": float(tcs[-1]), "tiles": int(len(tcs))}
 
     strips_ok = None
-    if world > 1:
+    if multi:
         # the gathered frame must equal the single-GPU frame bit for bit
         last = single_frame()
         torch.cuda.synchronize()
@@ -1037,7 +1115,7 @@ def main() -> None:
         dist.barrier()
     # what the process group actually was (the first multi-GPU run has to explain itself): every rank's device and strip
     dist_info = None
-    if world > 1:
+    if multi:
         mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(device),
                 "tile_columns": [int(window[0]), int(window[1])], "n_kept": int(stats.get("n_kept") or 0),
                 "tile_instances": int(stats.get("n_instances") or 0), "stage_ms_total": round(stage.get("total", 0.0), 4)}
@@ -1049,6 +1127,30 @@ def main() -> None:
                      else "plain: one point-to-point gather of whole strips behind the frame (strips.render_sharded)",
                      "gather_why": overlapped["why"] or ("--substrips %d" % args.substrips),
                      "frames_in_flight_path": None if pipeline is None else "strips.StripPipeline, depth %d" % pipeline.depth}
+        if args.dist_preflight:
+            # the calls a world of one never reaches by itself, made once against the real backend: the plain gather, and a
+            # grouped point-to-point pair with this rank as its own peer (ncclSend / ncclRecv under RCCL)
+            probes = {}
+            try:
+                got = strips.render_sharded(render_strip, width, height, tile, layout, device, cache={}, semantics=sem,
+                                            collective_with_one_rank=True)
+                torch.cuda.synchronize()
+                scene.confirm_frames()
+                probes["gather_one_rank"] = bool(torch.equal(got, scene.render_image_hip(1, tile_size=tile, layout=layout, semantics=sem)))
+            except Exception as exc:        # noqa: BLE001
+                probes["gather_one_rank"] = "%s: %s" % (type(exc).__name__, exc)
+            try:
+                src = torch.arange(1 << 20, dtype=torch.float32, device=device)
+                dst = torch.zeros_like(src)
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, 0), dist.P2POp(dist.irecv, dst, 0)]):
+                    req.wait()
+                torch.cuda.synchronize()
+                probes["send_recv_to_self"] = bool(torch.equal(src, dst))
+            except Exception as exc:        # noqa: BLE001
+                probes["send_recv_to_self"] = "%s: %s" % (type(exc).__name__, exc)
+            dist_info["preflight"] = dict(probes, note="world of ONE rank: communicator creation, barrier / all_reduce / broadcast / "
+                                          "all_gather_object, the gather and a grouped send / recv pair have executed against "
+                                          "the real backend; no data crossed a link")
     if rank == 0:
         d, nvis = int(stats["n_instances"]), int(stats["n_visible"])
         my_tiles = int(stats["n_tiles"])
@@ -1061,10 +1163,11 @@ def main() -> None:
         pairs = 256.0 * d
         valu = pairs * VALU_OPS_PER_PAIR / (blend_ms * 1e-3) / FP32_LANE_OPS_PER_S if blend_ms > 0 else 0.0
         ref_rules = sem == "ref_cpu"
-        from intro_to_gaussian_splatting_amd import gaussian_scene as _wrapper_mod
         # which instance of the compositing launch the timed frames ran (gaussian_scene.py: _PLAIN_MIN_TILES)
-        plain_instance = ref_rules and tile == 16 and int(stats.get("n_redo") or 0) == 0 and my_tiles >= _wrapper_mod._PLAIN_MIN_TILES and \
-            not args.strip_of
+        # (what the TIMED frames ran: the captured frame's baked-in instance; without graphs, the wrapper's choice for the
+        # stage-timing frames above, which take the same decision from the same view history)
+        plain_instance = ref_rules and tile == 16 and (bool(getattr(one, "_plain_footprints", False)) if one is not None
+                                                       else bool(stats.get("plain_footprints")))
         pmc_traffic, pmc_valu, pmc_file = pmc_record(args.workload, world, args.strip_of) if ref_rules else (None, None, None)
         out = {
             "metric": "Mpixels/sec forward raster (1M Gaussians, 1080p) + max |dpixel| vs CPU ref",
@@ -1076,7 +1179,7 @@ def main() -> None:
                          "max": round(float(frame_ms[-1]), 4), "p90": round(float(frame_ms[int(0.9 * (len(frame_ms) - 1))]), 4),
                          "frames": int(len(frame_ms)),
                          "how": "hipEvent pair around every frame, one frame in flight, %d x %d frames%s" % (
-                             args.repeats, args.steps, "; largest per-rank median" if world > 1 else "")},
+                             args.repeats, args.steps, "; largest per-rank median" if multi else "")},
             # whole-job rate with several frames in flight on separate HIP streams (not the contract's number)
             "value_frames_in_flight": None if inflight_ms is None else round(width * height / (inflight_ms * 1e-3) / 1e6, 2),
             "config": {"workload": desc, "n_gaussians": n, "width": width, "height": height, "tile": tile,
@@ -1087,14 +1190,14 @@ def main() -> None:
                        "frames_in_flight": 1,
                        "launch": "one hipGraph replay per frame" if one is not None else "separate kernel launches",
                        "ms_per_frame_in_flight": None if inflight_ms is None else round(inflight_ms, 4),
-                       "frames_in_flight_for_that": (max(1, len(streams)) if world == 1 else (pipeline.depth if pipeline else 1)),
+                       "frames_in_flight_for_that": (max(1, len(streams)) if not multi else (pipeline.depth if pipeline else 1)),
                        "ms_per_frame_separate_launches": None if launches_ms is None else round(launches_ms, 4),
                        "frame_sync": "host reads instance count every frame" if args.sync_frames
                        else "speculative (GSX_FLAG_NO_SYNC), counts confirmed after the timed region",
-                       "parallelism": "1 GPU" if world == 1 else "%d column strips + RCCL gather (%s)" % (
+                       "parallelism": "1 GPU" if not multi else "%d column strips + RCCL gather (%s)" % (
                            world, "sub-strips sent while the next is composited, %d parts" % args.substrips if overlapped["on"]
                            else "one gather behind the frame" + ("; overlapped path failed: %s" % overlapped["why"] if overlapped["why"] else "")),
-                       "strip_plan": None if world == 1 else (strip_plan or "equal")},
+                       "strip_plan": None if not multi else (strip_plan or "equal")},
             "fps": round(1e3 / median_ms, 2),
             "roofline": {"bound": "hbm", "kernel": ("blend_tile16_kernel<1> (GSX_FLAG_PLAIN_FOOTPRINTS)" if plain_instance else "blend_tile16_ref_kernel") if ref_rules
                          else "blend_rules_kernel",
@@ -1119,7 +1222,7 @@ def main() -> None:
             "stage_ms": {k: round(v, 4) for k, v in stage.items()},
             "tile_list_length": tile_list,
         }
-        if stage.get("project", 0.0) > 0.0 and world == 1:
+        if stage.get("project", 0.0) > 0.0 and not multi:
             # the HBM-bound stage: 56 B read + 60 B written per Gaussian that reaches a tile (record 48, key 4,
             # rectangle 8); the HIP-event bracket includes the launch, the kernel alone is ~3 us shorter (profiles/)
             pb = 116.0 * n
@@ -1129,11 +1232,15 @@ def main() -> None:
                                        "unit": "GB/s", "frac": round(pb / (stage["project"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if moving is not None:
             out.update(moving)
+            # the two numbers a VIEWER sees, beside `value` (a warm frame of one view replayed): the first frame of a view --
+            # no hints, separate launches -- and a camera that moves one degree per frame (stale hints), same units
+            out["value_cold_frame"] = round(width * height / (moving["cold_frame_ms"] * 1e-3) / 1e6, 2)
+            out["value_moving_camera"] = round(width * height / (moving["moving_camera"]["median_ms"] * 1e-3) / 1e6, 2)
         if strips_ok is not None:
             out["strips_equal_single_gpu"] = strips_ok
         if dist_info is not None:
             out["distributed"] = dist_info
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             base, err, inst, psnr = cpu_baseline(sc, scene, frame, semantics=sem)
             out["cpu_baseline"] = base
             out["max_abs_dpixel"] = err
@@ -1146,6 +1253,10 @@ def main() -> None:
                                      "path, pinned to reference-made fixtures)")
             if ref_rules and args.ply is None:
                 out["stage1_vs_reference"] = stage1_vs_reference(args.workload, scene, device)
+                if args.workload in TILE_FIXTURE_OF and strip_window is None:
+                    out["pixels_vs_reference"] = pixels_vs_reference(args.workload, scene, frame, device, tile)
+                if args.workload in ("c2", "c3"):
+                    out["tie_order_effect"] = tie_order_effect(args.workload, sc, scene)
             if ref_rules:
                 # THE bar: the same instance count and every pixel within 1e-4 of the float32 restatement of the
                 # reference (pinned to the reference's own outputs, tests/test_oracle_golden.py).  Where the frame
@@ -1163,7 +1274,7 @@ def main() -> None:
                                         base["threshold_flip_pixels"] <= 2 + 1e-5 * base["window_pixels"] and
                                         base["max_abs_dpixel_incl_flips"] < 0.006)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

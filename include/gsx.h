@@ -26,7 +26,12 @@
 extern "C" {
 #endif
 
-#define GSX_VERSION 304 /* major*10000 + minor*100 + patch.  304: one compositing launch; GSX_FLAG_SKIP_REDO (303) is now
+#define GSX_VERSION 305 /* major*10000 + minor*100 + patch.  305: GsxParams.stats_size (136 bytes): GsxFrameStats is written only as far
+                         * as the caller says its struct reaches (64 bytes -- the ABI-300 struct, no n_redo -- when params is NULL or ends
+                         * before the field); GSX_FLAG_PLAIN_FOOTPRINTS needs stats_size >= 72.  Binaries built against the 302 .. 304
+                         * headers must be REBUILT (their 128-byte GsxParams is still read, but their 72-byte GsxFrameStats gets no
+                         * n_redo, and a 302 binary that fills its struct through the exported function gsx_default_params has its
+                         * n_substrips fields ignored -- see there).  304: one compositing launch; GSX_FLAG_SKIP_REDO (303) is now
                          * GSX_FLAG_PLAIN_FOOTPRINTS, same value and contract; gsx_hints_bytes is smaller.  303: GsxFrameStats.n_redo (72 bytes);
                          * gsx_default_params_sized (gsx_default_params is a macro over
                          * it; the exported function of that name serves ABI 300 / 301 binaries), GSX_FLAG_SMALL_BATCH / _ONE_VISIBLE,
@@ -169,6 +174,13 @@ typedef struct GsxParams {
     int32_t substrip_axis;
     const int32_t *substrip_bounds;
     void *const *substrip_events;
+    /* sizeof(GsxFrameStats) as the CALLER compiled it (ABI 305); gsx_default_params() fills it in.  The render calls write
+     * `stats_host` only that far: 64 bytes (n_visible .. n_kept, the struct of ABI 300) or 72 (+ n_redo).  A caller whose
+     * GsxParams ends before this field, or who passes params == NULL, is taken to own the 64-byte struct and gets no n_redo
+     * (GsxFrameStats grew once, in ABI 303, with nothing to tell the two apart: INTEGRATION.md's stub was overrun by 8 bytes).
+     * Any other value is GSX_ERR_INVALID_ARGUMENT.  Every later field of GsxFrameStats will be reported the same way. */
+    int32_t stats_size;
+    int32_t reserved1; /* 0 */
 } GsxParams;
 
 /* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call
@@ -237,7 +249,9 @@ typedef struct GsxParams {
  * this flag the call runs the instance of that launch that CANNOT evaluate them -- half the registers, twice the waves
  * per SIMD, ~6 % faster on a 4K frame of 5M Gaussians, no faster at 1080p -- for a caller that knows from an earlier frame
  * of the same view that n_redo was 0.  The frame's own n_redo says whether that held: if it is > 0, that many tiles /
- * quarters were NOT composited (their pixels are unspecified) and the frame must be rendered again without the flag. */
+ * quarters were NOT composited (their pixels are unspecified) and the frame must be rendered again without the flag.
+ * A call that could not report n_redo -- stats_host NULL, or GsxParams.stats_size < 72 -- is refused with the flag set
+ * (GSX_ERR_INVALID_ARGUMENT): the caller MUST be able to read it. */
 #define GSX_FLAG_PLAIN_FOOTPRINTS 1024
 
 /* Indices into GsxFrameStats.stage_ms (milliseconds). */
@@ -260,8 +274,10 @@ typedef struct GsxFrameStats {
     int64_t n_kept;      /* Gaussians that reach a tile of the window (what the depth sort keeps): GsxParams.kept_hint
                           * of the next frame of this view                       */
     int64_t n_redo;      /* tiles (and long-tile quarters) that held an ill-conditioned footprint; see
-                          * GSX_FLAG_PLAIN_FOOTPRINTS (ABI 303: the struct has 72 bytes) */
+                          * GSX_FLAG_PLAIN_FOOTPRINTS (ABI 303: the struct has 72 bytes).  Written only when
+                          * GsxParams.stats_size >= 72 says the caller's struct has it */
 } GsxFrameStats;
+#define GSX_FRAME_STATS_BYTES_ABI300 64 /* n_visible .. n_kept: what a call writes when it is not told the struct's size */
 
 GSX_API int gsx_version(void);
 GSX_API const char *gsx_last_error(void);
@@ -269,7 +285,10 @@ GSX_API const char *gsx_last_error(void);
  * behaviour and states that size in GsxParams.struct_size.  Nothing behind those bytes is touched. */
 GSX_API void gsx_default_params_sized(GsxParams *params, size_t struct_size);
 /* What callers write: the size is this header's.  (The exported FUNCTION of this name exists for binaries built
- * against the ABI 300 / 301 headers, where the struct had 104 bytes: it fills those and states struct_size = 104.) */
+ * against the ABI 300 / 301 headers, where the struct had 104 bytes: it fills those and states struct_size = 104 -- so
+ * the fields appended since (n_substrips .., stats_size) are NOT read from a struct filled through it.  A binary built
+ * against the 302 header, the only one that had those fields AND called this function, must be rebuilt: its
+ * substrip_events would never be recorded.  Language bindings call gsx_default_params_sized.) */
 GSX_API void gsx_default_params(GsxParams *params);
 #define gsx_default_params(params) gsx_default_params_sized((params), sizeof(GsxParams))
 

@@ -43,11 +43,19 @@ GSX_FLAG_PLAIN_FOOTPRINTS = 1024
 def visible_rows_flag(n: int, n_visible: int, flags: int) -> int:
     """include/gsx.h, GSX_FLAG_SMALL_BATCH / GSX_FLAG_ONE_VISIBLE: the flag a call over ``n`` Gaussians has to carry when
     ``n_visible`` of them turned out visible and it was issued with ``flags`` -- 0 when it already assumed the right
-    number of rows (from four rows up, or n itself at most three and all of them visible)."""
+    number of rows (from four rows up, or n itself at most three and all of them visible); -1 when it carried one of the
+    two flags and four or more Gaussians are visible: issue it again with NEITHER."""
     cls = lambda k: GSX_FLAG_ONE_VISIBLE if k == 1 else (GSX_FLAG_SMALL_BATCH if k <= 3 else 0)  # noqa: E731
     assumed = (flags & (GSX_FLAG_ONE_VISIBLE | GSX_FLAG_SMALL_BATCH)) or cls(n)
     true = cls(n_visible) if n_visible > 0 else assumed
-    return 0 if true == assumed else true
+    if true == assumed:
+        return 0
+    return true if true else -1
+
+
+def with_rows_flag(flags: int, again: int) -> int:
+    """``flags`` with the row class ``visible_rows_flag`` asked for (-1: neither flag)."""
+    return (flags & ~(GSX_FLAG_SMALL_BATCH | GSX_FLAG_ONE_VISIBLE)) | max(int(again), 0)
 STAGE_NAMES = ("project", "depth_sort", "scan", "bin", "blend", "total")
 
 
@@ -65,7 +73,7 @@ class GsxParams(ctypes.Structure):
                 ("tile_counts", c_void_p), ("sh", c_void_p), ("sh_degree", c_int32), ("struct_size", c_int32),
                 ("kept_hint", c_int64), ("hints", c_void_p),
                 ("n_substrips", c_int32), ("substrip_axis", c_int32), ("substrip_bounds", POINTER(c_int32)),
-                ("substrip_events", POINTER(c_void_p))]
+                ("substrip_events", POINTER(c_void_p)), ("stats_size", c_int32), ("reserved1", c_int32)]
 
 
 class GsxFrameStats(ctypes.Structure):

@@ -96,6 +96,8 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
     uint2 *ranges = (uint2 *)(ws + c.ranges);
     bool counts_on_device = false, counts_in_host = false;
     bool redo_counted = false;      // the compositing launch counts tiles with reference-order records: GsxFrameStats.n_redo
+    const bool has_redo = p.stats_bytes >= offsetof(GsxFrameStats, n_redo) + sizeof(int64_t);
+    if (p.plain && !stats) return fail(GSX_ERR_INVALID_ARGUMENT, "GSX_FLAG_PLAIN_FOOTPRINTS needs stats_host: n_redo must reach the caller");
     bool parts_marked = false;      // GsxParams.substrip_events recorded (every path records them once, behind its last launch at the latest)
     // no Gaussians: every tile's list is empty -- GsxParams.tile_counts says so (an empty WINDOW has no entries)
     if (n == 0 && p.tile_counts && p.grid.count() > 0)
@@ -200,8 +202,10 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
                 GSX_HIP(hipMemcpyAsync(stats, dev2, 16, hipMemcpyDeviceToHost, s));
                 GSX_HIP(hipMemcpyAsync(&stats->n_kept, dev2 + 2, 8, hipMemcpyDeviceToHost, s));
             }
-            stats->n_redo = 0;      // (the upper half stays: the device count has 32 bits)
-            if (redo_counted) GSX_HIP(hipMemcpyAsync(&stats->n_redo, ws + c.redo, 4, hipMemcpyDeviceToHost, s));
+            if (has_redo) {             // GsxParams.stats_size: the caller's struct reaches n_redo
+                stats->n_redo = 0;      // (the upper half stays: the device count has 32 bits)
+                if (redo_counted) GSX_HIP(hipMemcpyAsync(&stats->n_redo, ws + c.redo, 4, hipMemcpyDeviceToHost, s));
+            }
             stats->n_tiles = p.grid.count();
             stats->reserved = cap;  // > 0: counts are delivered asynchronously; value = pair capacity used
         }
@@ -216,7 +220,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
         stats->n_visible = host2[0];
         stats->n_instances = host2[1];
         stats->n_kept = host2[2];
-        stats->n_redo = redo_host;
+        if (has_redo) stats->n_redo = redo_host;
         stats->n_tiles = p.grid.count();
         stats->reserved = 0;
     }

@@ -744,8 +744,9 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
         if (checked && probe_checked_at == 0xFFFFFFu) probe_checked_at = probe_batch;
         ++probe_batch;
 #endif
-        if (REF && kind >= kBatchRefOrder) saw_ref = true;
-        if (!REF && kind >= kBatchRefOrder) {       // (wave-uniform) not here: the quarter stays undone (GSX_FLAG_PLAIN_FOOTPRINTS)
+        // (ref_slots, not the batch's kind: a batch that also holds a monomial record is kBatchMono whatever else it holds)
+        if (REF && ref_slots != 0ull) saw_ref = true;
+        if (!REF && ref_slots != 0ull) {            // (wave-uniform) not here: the quarter stays undone (GSX_FLAG_PLAIN_FOOTPRINTS)
             if (lane == 0) atomicAdd(redo, 1u);
             return;
         }
@@ -943,7 +944,8 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
                                                                           (float)(ty * 16), 16.0f, skipped, count, budget, &idx_now, 0,
                                                                           dead, &ref_slots);
         const bool wild = kind != kBatchRegular;     // wave-uniform
-        if (REF && kind >= kBatchRefOrder) saw_ref = true;
+        // (ref_slots, not the batch's kind: a batch that also holds a monomial record is kBatchMono whatever else it holds)
+        if (REF && ref_slots != 0ull) saw_ref = true;
 #ifdef GSX_TEST_HOOKS
         if (REF && kind >= kBatchRefOrder) {
             if (probe_first_ref == 0xFFFu) probe_first_ref = probe_batches;
@@ -969,7 +971,7 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
                 const Splat s = read_splat(sh, k);
                 composite<4, (REF || VARIANT == 0)>(cx, cy, s, T, c0, c1, c2, blk, (float)(tx * 16), (float)(ty * 16));
             }
-        } else if (!REF && kind >= kBatchRefOrder) {
+        } else if (!REF && ref_slots != 0ull) {
             // (wave-uniform) an ill-conditioned footprint: not here -- the tile stays undone (GSX_FLAG_PLAIN_FOOTPRINTS)
             if (lane == 0) atomicAdd(lt.redo, 1u);
             return;
@@ -1134,8 +1136,14 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
         for (uint32_t base = rg.x; base < rg.y; base += 64) {
             uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
             uint32_t count[kBlocks];
+            unsigned long long ref_slots = 0ull;
             (void)stage_batch<kStageBlocks, (REF || VARIANT == 0)>(rec, qraw, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16),
-                                                                   16.0f, skipped, count, budget);
+                                                                   16.0f, skipped, count, budget, nullptr, 0, 0u, &ref_slots);
+            if (REF && ref_slots != 0ull) saw_ref = true;
+            if (!REF && ref_slots != 0ull) {        // (wave-uniform) a later batch holds an ill-conditioned footprint: the tile stays undone
+                if (lane == 0) atomicAdd(lt.redo, 1u);
+                return;
+            }
             cost += 4u * nb;
             tile_sync<REF>();
             for (uint32_t k = 0; k < nb; ++k) {         // every staged record, in order; a lane's block takes what it keeps

@@ -170,6 +170,7 @@ inline void default_params(GsxParams *params, size_t bytes = sizeof(GsxParams)) 
     d.layout = GSX_LAYOUT_WH3;
     d.tile_x1 = -1;
     d.tile_y1 = -1;
+    d.stats_size = (int32_t)sizeof(GsxFrameStats);      // (only a struct that reaches the field receives it)
     memcpy(params, &d, bytes);
 }
 
@@ -259,6 +260,7 @@ struct Plan {
     bool tight;    // GSX_SEM_STD_3DGS without GSX_FLAG_PUBLISHED_RECTS
     bool split;    // long tiles on four waves (not GSX_FLAG_NO_LONG_TILE_SPLIT)
     bool plain;         // GSX_FLAG_PLAIN_FOOTPRINTS
+    size_t stats_bytes; // how far GsxFrameStats is written: GsxParams.stats_size, 64 when the caller did not state it
     int small_batch;    // 1: GSX_FLAG_ONE_VISIBLE, 2: GSX_FLAG_SMALL_BATCH, 0: neither
     int schedule;  // tiles handed out by list length: 1 GSX_FLAG_TILE_SCHEDULE, 0 GSX_FLAG_NO_TILE_SCHEDULE, -1 by size
     const GsxCamera *camera_device;
@@ -286,6 +288,7 @@ inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_ima
     };
     GsxParams d;
     default_params(&d);
+    d.stats_size = GSX_FRAME_STATS_BYTES_ABI300;      // not stated (NULL params, a struct that ends before the field): the ABI-300 struct
     if (params) {
         // GsxParams.struct_size: only the bytes the caller's struct has are read; fields behind them keep their defaults
         // (include/gsx.h).  0 = the ABI-300 struct, which ends behind `hints`.
@@ -319,6 +322,14 @@ inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_ima
     p.tight = d.semantics == GSX_SEM_STD_3DGS && (d.flags & GSX_FLAG_PUBLISHED_RECTS) == 0;
     p.split = (d.flags & GSX_FLAG_NO_LONG_TILE_SPLIT) == 0;
     p.plain = (d.flags & GSX_FLAG_PLAIN_FOOTPRINTS) != 0;
+    if (d.stats_size == 0) d.stats_size = GSX_FRAME_STATS_BYTES_ABI300;     // (a zeroed struct: not stated)
+    if (d.stats_size != GSX_FRAME_STATS_BYTES_ABI300 && (d.stats_size < (int32_t)sizeof(GsxFrameStats) || (d.stats_size & 7) != 0))
+        return fail(GSX_ERR_INVALID_ARGUMENT, "GsxParams.stats_size %d is neither %d nor >= %zu", d.stats_size,
+                    GSX_FRAME_STATS_BYTES_ABI300, sizeof(GsxFrameStats));
+    p.stats_bytes = d.stats_size > (int32_t)sizeof(GsxFrameStats) ? sizeof(GsxFrameStats) : (size_t)d.stats_size;
+    if (p.plain && p.stats_bytes < offsetof(GsxFrameStats, n_redo) + sizeof(int64_t))
+        return fail(GSX_ERR_INVALID_ARGUMENT, "GSX_FLAG_PLAIN_FOOTPRINTS needs GsxParams.stats_size >= %zu: n_redo must reach the caller",
+                    offsetof(GsxFrameStats, n_redo) + sizeof(int64_t));
     p.small_batch = (d.flags & GSX_FLAG_ONE_VISIBLE) ? 1 : ((d.flags & GSX_FLAG_SMALL_BATCH) ? 2 : 0);
     p.schedule = (d.flags & GSX_FLAG_NO_TILE_SCHEDULE) ? 0 : ((d.flags & GSX_FLAG_TILE_SCHEDULE) ? 1 : -1);
     TileGrid &g = p.grid;

@@ -102,12 +102,13 @@ def render_preprocessed(height: int, width: int, tile_size: int, point_means: to
                         point_colors: torch.Tensor, inverse_covariance_2d: torch.Tensor, min_x: torch.Tensor,
                         max_x: torch.Tensor, min_y: torch.Tensor, max_y: torch.Tensor, opacity: torch.Tensor,
                         layout: str = "wh3", instances_hint: int = 0,
-                        stats: Optional[dict] = None, semantics: str = "ref_cpu") -> torch.Tensor:
+                        stats: Optional[dict] = None, semantics: str = "ref_cpu", flags: int = 0) -> torch.Tensor:
     """Stage 2 on depth-sorted stage-1 arrays: the reference's native entry point
     ``render_image(image_height, image_width, tile_size, point_means, point_colors,
     inverse_covariance_2d, min_x, max_x, min_y, max_y, opacity)`` (splat/c/render.cu:90-101) with the
     CPU path's compositing semantics (``semantics="ref_cuda"``: the CUDA kernel's own semantics,
-    SURVEY.md Appendix B).  Returns (W,H,3) for layout "wh3", (H,W,3) for "hw3"."""
+    SURVEY.md Appendix B).  Returns (W,H,3) for layout "wh3", (H,W,3) for "hw3".  ``flags``: GSX_FLAG_* of
+    include/gsx.h, as they are (a caller that sets GSX_FLAG_PLAIN_FOOTPRINTS reads ``stats["n_redo"]``)."""
     lib = _ffi.load()
     dev = point_means.device
     _require_gpu(dev)
@@ -119,6 +120,7 @@ def render_preprocessed(height: int, width: int, tile_size: int, point_means: to
     params = _ffi.default_params()
     params.layout = _ffi.GSX_LAYOUT_WH3 if layout == "wh3" else _ffi.GSX_LAYOUT_HW3
     params.semantics = _SEMANTICS[semantics]
+    params.flags |= int(flags)
     shape = (width, height, 3) if layout == "wh3" else (height, width, 3)
     out = torch.empty(shape, dtype=torch.float32, device=dev)
     st = _ffi.GsxFrameStats()
@@ -137,7 +139,7 @@ def render_preprocessed(height: int, width: int, tile_size: int, point_means: to
             cap = int(st.n_instances * 1.25) + 4096
     _ffi.check(rc)
     if stats is not None:
-        stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles)
+        stats.update(n_visible=st.n_visible, n_instances=st.n_instances, n_tiles=st.n_tiles, n_redo=int(st.n_redo))
     return out
 
 
@@ -316,7 +318,7 @@ class GaussianScene:
                 again = _ffi.visible_rows_flag(n, int(nvis.value), params.flags) if rc == _ffi.GSX_OK else 0
                 if not again:
                     break
-                params.flags = (params.flags & ~(_ffi.GSX_FLAG_SMALL_BATCH | _ffi.GSX_FLAG_ONE_VISIBLE)) | again
+                params.flags = _ffi.with_rows_flag(params.flags, again)
         _ffi.check(rc)
         m = nvis.value
         self.last_order = order[:m]
@@ -467,6 +469,9 @@ class GaussianScene:
             (self._n_redo_seen.get(cap_key) == 0 and n_window_tiles >= _PLAIN_MIN_TILES)
         if plain and semantics == "ref_cpu" and tile_size == 16 and not generic_kernels:
             params.flags |= _ffi.GSX_FLAG_PLAIN_FOOTPRINTS
+        # capture_frame: the row class (GSX_FLAG_SMALL_BATCH / _ONE_VISIBLE) the view's uncaptured frame ended up with is
+        # baked into the graph -- a captured call cannot be issued again when n_visible says it assumed wrongly
+        params.flags |= int(own.get("rows_flag", 0))
         # GsxParams.hints: one buffer per view and stream (a captured frame owns its own), valid once a frame has filled it
         hint_slot = None
         if use_hints:
@@ -521,7 +526,7 @@ class GaussianScene:
                     # at most three Gaussians pass the cull, fewer than the call assumed: the reference's BLAS then sums
                     # its products over the visible ones in another order (GSX_FLAG_SMALL_BATCH / _ONE_VISIBLE,
                     # include/gsx.h) -- once more, in that order
-                    params.flags = (params.flags & ~(_ffi.GSX_FLAG_SMALL_BATCH | _ffi.GSX_FLAG_ONE_VISIBLE)) | again
+                    params.flags = _ffi.with_rows_flag(params.flags, again)
                     continue
                 if rc != _ffi.GSX_ERR_WORKSPACE_TOO_SMALL or "cap" in own:
                     break
@@ -635,6 +640,7 @@ class GaussianScene:
         # whose frame held no ill-conditioned footprint, where it pays (confirm() checks every replay's n_redo); a movable
         # camera may turn to such footprints
         private = dict(cap=cap, workspace=torch.empty(nbytes, dtype=torch.uint8, device=dev), kept=int(st["n_kept"]),
+                       rows_flag=0 if semantics == "std_3dgs" else max(_ffi.visible_rows_flag(n, int(st["n_visible"]), 0), 0),
                        plain=(not movable_camera) and int(st.get("n_redo", 1)) == 0 and
                        int(st.get("n_tiles", 0)) >= _PLAIN_MIN_TILES,
                        pinned=torch.zeros(ctypes.sizeof(_ffi.GsxFrameStats), dtype=torch.uint8).pin_memory(), inputs=[],

@@ -128,7 +128,7 @@ def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor,
                    width: int, height: int, tile: int, layout: str, device: torch.device,
                    group: Optional[dist.ProcessGroup] = None, all_ranks: bool = False,
                    cache: Optional[dict] = None, semantics: str = "ref_cpu",
-                   plan: Optional[List[Tuple[int, int]]] = None) -> Optional[torch.Tensor]:
+                   plan: Optional[List[Tuple[int, int]]] = None, collective_with_one_rank: bool = False) -> Optional[torch.Tensor]:
     """Renders this rank's strip with ``render_fn(tile_window, out_strip, out_origin)`` and gathers
     the frame on rank 0 (or on every rank with ``all_ranks``).
 
@@ -142,6 +142,8 @@ def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor,
     ``plan`` ([(t0, t1) per rank], e.g. from ``balanced_plan``; the same on every rank) replaces the equal
     strips: each rank then renders straight into (a buffer the size of) its own rows and the strips travel
     point to point instead of through one equal-sized gather.
+    ``collective_with_one_rank``: a process group of ONE rank still issues the gather (bench.py --dist-preflight: the
+    collective call meets the real backend on a single GPU); by default a lone rank returns its strip as the frame.
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -176,7 +178,7 @@ def render_sharded(render_fn: Callable[[Tuple[int, int, int, int], torch.Tensor,
             frame[covered:].zero_()                    # never-rendered last tile row(s)
     strip = frame[rank * rows:(rank + 1) * rows] if is_dst else buffer("strip", (rows, other, 3))
     render_fn(window, strip, origin)
-    if world == 1:
+    if world == 1 and not (collective_with_one_rank and dist.is_initialized()):
         return frame[:lead]
     if all_ranks:
         dist.all_gather_into_tensor(frame[:covered], strip, group=group)

@@ -99,3 +99,57 @@ def compare_stage1_with_reference(g, fields, order, strict: bool = True, sigmoid
     report.update(tied=int(pos.size), order_diffs_inside_ties=int(np.count_nonzero(ours != ref_members)) if runs_match else -1,
                   order_diffs_outside_ties=0 if outside_ok else -1)
     return report
+
+
+# ----------------------------------------------------------------- reference-rendered tiles at the metric's configuration
+TILE_FIXTURE_NAMES = ("tiles_c3_1080p_n1000000", "tiles_c3_clustered_1080p_n1000000", "tiles_c3_trainedlike_1080p_n1000000")
+
+
+def tiles_scene(g):
+    """The inputs of a ``tiles_*`` fixture (oracle/capture_golden.py: capture_tiles), regenerated from its generator
+    arguments and checked against the hash of what the reference was given.  The reference has no spherical harmonics:
+    the trained-like scene is rendered with its base colours."""
+    from intro_to_gaussian_splatting_amd import synthetic
+
+    gen = {"scene": synthetic.make_scene, "trained": synthetic.make_trained_like_scene}[str(g["generator_name"])]
+    sc = gen(**dict(ast.literal_eval(str(g["generator"]))))
+    sc.pop("sh", None)
+    sc.pop("sh_degree", None)
+    got = sha256(np.concatenate([sc[k].reshape(-1) for k in ("points", "colors_0_255", "scales", "quaternions", "opacity")]))
+    assert got == str(g["inputs_sha256"]), "the synthetic generator no longer produces the scene the fixture was made from"
+    return sc
+
+
+def tile_lists(g):
+    """Per tile of a ``tiles_*`` fixture: ((tx, ty), original Gaussian indices in the REFERENCE's compositing order)."""
+    off = np.concatenate([[0], np.cumsum(g["list_len"])]).astype(np.int64)
+    return [((int(t[0]), int(t[1])), g["list_indices"][off[k]:off[k + 1]].astype(np.int64)) for k, t in enumerate(g["tiles"])]
+
+
+def compare_tiles_with_reference(g, image_whc) -> dict:
+    """``image_whc``: a frame (W, H, 3) indexed [x, y] of the fixture's scene.  Its 16x16 blocks at the fixture's tiles
+    against what the REFERENCE's own ``render_tile`` (splat/gaussian_scene.py:173-198) returned for them."""
+    t = int(g["tile"])
+    image_whc = np.asarray(image_whc)
+    per_tile = []
+    for k, (tx, ty) in enumerate(g["tiles"]):
+        blk = image_whc[tx * t:(tx + 1) * t, ty * t:(ty + 1) * t]
+        per_tile.append(float(np.abs(blk - g["blocks"][k]).max()))
+    return dict(tiles=int(len(per_tile)), max_abs=float(max(per_tile)), per_tile=per_tile,
+                pixels_over_1e4=int(sum(int((np.abs(image_whc[tx * t:(tx + 1) * t, ty * t:(ty + 1) * t] - g["blocks"][k]).max(axis=2) > 1e-4).sum())
+                                        for k, (tx, ty) in enumerate(g["tiles"]))),
+                longest_list=int(g["list_len"].max()), tie_swapped_entries=int(g["tie_swapped"].sum()))
+
+
+def rows_in_reference_order(pre_order, g):
+    """Rows of a depth-sorted stage 1 (``pre_order``: original index of each row; ties by index) rearranged into the
+    REFERENCE's permutation: a stage-1 fixture records what torch.argsort did inside every run of equal depths
+    (``tie_positions`` / ``tie_order``).  Returns the row numbers in the reference's compositing order."""
+    order = np.asarray(pre_order, np.int64)
+    patched = order.copy()
+    patched[g["tie_positions"].astype(np.int64)] = g["tie_order"].astype(np.int64)
+    inv = np.full(int(g["n"]), -1, np.int64)
+    inv[order] = np.arange(order.size)
+    rows = inv[patched]
+    assert (rows >= 0).all() and np.array_equal(np.sort(rows), np.arange(order.size))
+    return rows

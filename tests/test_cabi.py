@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), "libgsx.so does not export %s" % name
         assert name in _ffi.SIGNATURES, "ctypes binding lacks %s" % name
-    assert lib.gsx_version() == 304
+    assert lib.gsx_version() == 305
 
 
 def _exported(path):
@@ -83,7 +83,8 @@ def test_python_constants_equal_the_headers():
 
 def test_struct_layouts():
     assert ctypes.sizeof(_ffi.GsxCamera) == 16 * 4 * 2 + 4 * 4 + 2 * 4 + 3 * 4
-    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16 + 8 + 8 + 24 and _ffi.GsxParams.kept_hint.offset == 88
+    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16 + 8 + 8 + 24 + 8 and _ffi.GsxParams.kept_hint.offset == 88
+    assert _ffi.GsxParams.stats_size.offset == 128          # (128 = the struct of ABI 302 .. 304)
     assert _ffi.GsxParams.hints.offset == 96 and _ffi.GsxParams.n_substrips.offset == 104       # (104 = the ABI-300 struct)
     assert _ffi.GsxParams.substrip_bounds.offset == 112 and _ffi.GsxParams.substrip_events.offset == 120
     assert _ffi.GsxFrameStats.n_kept.offset == 56 and _ffi.GsxFrameStats.stage_ms.offset == 32
@@ -91,6 +92,35 @@ def test_struct_layouts():
     p = _ffi.default_params()
     assert p.semantics == _ffi.GSX_SEM_REF_CPU and p.layout == _ffi.GSX_LAYOUT_WH3
     assert p.tile_x1 == -1 and p.tile_y1 == -1 and p.out_w == 0
+    assert p.stats_size == ctypes.sizeof(_ffi.GsxFrameStats) == 72
+
+
+def test_stats_size_is_validated_and_plain_footprints_needs_n_redo():
+    """GsxParams.stats_size (ABI 305): 0 / 64 (the ABI-300 struct) and >= 72 are accepted, anything else is refused before
+    anything runs; GSX_FLAG_PLAIN_FOOTPRINTS is refused when n_redo could not reach the caller (a 64-byte struct, a
+    GsxParams that ends before the field).  (That the 64-byte struct is not overrun: test_hip_parity, with a canary.)"""
+    lib = _ffi.load()
+    cam = _ffi.GsxCamera()
+    cam.width, cam.height = 64, 64
+    out = ctypes.c_void_p(256)          # never dereferenced: the workspace check fails first
+    st = _ffi.GsxFrameStats()
+    args = lambda par: (ctypes.byref(cam), None, None, None, None, None, 0, 16, out, ctypes.byref(par), ctypes.byref(st),  # noqa: E731
+                        None, 0, None)
+    for size, ok in ((0, True), (64, True), (72, True), (80, True), (68, False), (56, False), (-8, False), (71, False)):
+        p = _ffi.default_params()
+        p.stats_size = size
+        rc = lib.gsx_render_forward(*args(p))
+        assert rc == _ffi.GSX_ERR_INVALID_ARGUMENT
+        assert (b"workspace" in lib.gsx_last_error()) == ok and (b"stats_size" in lib.gsx_last_error()) == (not ok), size
+    for shrink in ("stats_size", "struct_size"):
+        p = _ffi.default_params()
+        p.flags |= _ffi.GSX_FLAG_PLAIN_FOOTPRINTS
+        assert lib.gsx_render_forward(*args(p)) == _ffi.GSX_ERR_INVALID_ARGUMENT and b"workspace" in lib.gsx_last_error()
+        if shrink == "stats_size":
+            p.stats_size = 64
+        else:
+            p.struct_size = 128         # the struct of ABI 302 .. 304: no stats_size
+        assert lib.gsx_render_forward(*args(p)) == _ffi.GSX_ERR_INVALID_ARGUMENT and b"PLAIN_FOOTPRINTS" in lib.gsx_last_error()
 
 
 def test_argument_errors_do_not_need_a_gpu():

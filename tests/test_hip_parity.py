@@ -13,8 +13,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (ROOT, STAGE1_FIELDS, STAGE1_NAMES, assert_same_order_outside_ties, compare_stage1_with_reference,
-                      golden_preprocessed, load_golden, oracle_camera, rows_by_index, stage1_scene)
+from conftest import (ROOT, STAGE1_FIELDS, STAGE1_NAMES, TILE_FIXTURE_NAMES, assert_same_order_outside_ties,
+                      compare_stage1_with_reference, compare_tiles_with_reference, golden_preprocessed, load_golden,
+                      oracle_camera, rows_by_index, stage1_scene, tile_lists, tiles_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -124,6 +125,37 @@ def test_stage1_at_benchmark_size_equals_the_reference_bit_for_bit(tmp_path, nam
     assert np.array_equal(counts.cpu().numpy().reshape(ntx, nty).astype(np.uint32), g["tile_counts"])
 
 
+@pytest.mark.parametrize("name", TILE_FIXTURE_NAMES)
+def test_frames_of_the_1m_scenes_hold_the_references_own_pixels(tmp_path, name):
+    """The METRIC's configuration against the reference itself, pixels included: ``tiles_*`` hold 16x16 blocks that the
+    reference's own ``render_tile`` (splat/gaussian_scene.py:173-198) composited from its own ``preprocess`` of the C3,
+    clustered and trained-like 1M-Gaussian 1080p scenes -- the frame's longest list (642 / 12 061 / 10 298 entries), tiles
+    where the stop rule fires, tiles along the ridge of a 330:1 footprint (the kernel's reference-order records), seeded
+    random picks.  The HIP frame (whole path, one call, the kernels bench.py times) carries those pixels to 1e-4 (the
+    north-star tolerance; measured <= 1e-6), its tile lists have the reference's lengths, and so does a captured frame."""
+    _need_gpu()
+    g = load_golden(name)
+    sc = tiles_scene(g)
+    scene = _scene_from_arrays(tmp_path, sc)
+    w, h, t = int(g["width"]), int(g["height"]), int(g["tile"])
+    ntx, nty = (w - 1) // t, (h - 1) // t
+    counts = torch.zeros(ntx * nty, dtype=torch.int32, device="cuda:0")
+    st = {}
+    img = scene.render_image_hip(1, tile_size=t, tile_counts=counts, stats=st)
+    assert st["n_visible"] == int(g["n_visible"]) and st["n_instances"] == int(g["tile_instances"])
+    counts = counts.cpu().numpy().reshape(ntx, nty)
+    for k, (tx, ty) in enumerate(g["tiles"]):
+        assert counts[tx, ty] == g["list_len"][k]
+    rep = compare_tiles_with_reference(g, img.cpu().numpy())
+    print("%s: %r" % (name, rep))
+    assert rep["max_abs"] <= PIXEL_TOL and rep["tiles"] == len(g["tiles"])
+    assert rep["max_abs"] <= 2e-6           # measured; the tolerance the north star states is the line above
+    frame = scene.capture_frame(1, tile_size=t)
+    rep2 = compare_tiles_with_reference(g, frame.replay().cpu().numpy())
+    frame.confirm()
+    assert rep2["per_tile"] == rep["per_tile"]
+
+
 def test_equal_depths_follow_the_original_index_where_the_reference_follows_its_sort_library(tmp_path):
     """ties_64x64_n400 (367 of 400 Gaussians share their depth with another): the kernel's stage 1 equals the
     reference's Gaussian by Gaussian, its permutation differs from the reference's only inside runs of equal depths,
@@ -176,6 +208,52 @@ def test_blend_given_the_references_stage1_arrays(golden):
     assert stats["n_instances"] == inst
 
 
+@pytest.mark.parametrize("long_tile", [False, True])
+def test_a_monomial_record_beside_reference_order_records(long_tile):
+    """The stage-2 entry with a conic the completed square does not exist for (Q11 = 0: the monomial fallback) in the same
+    batches as the needles' reference-order records.  A batch's kind is then "monomial" whatever else it holds: the
+    launch a frame runs still counts its tiles in n_redo, and the plain instance (GSX_FLAG_PLAIN_FOOTPRINTS) still leaves
+    them undone and says so -- round 5 composited the flagged records by the completed square there and reported 0.
+    ``long_tile``: the lists repeated until the tiles are split over four waves (the quarter kernel)."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import _ffi, render_preprocessed
+    from oracle import c_oracle, cpu_ref
+
+    g = load_golden("needle_160x160_n110")
+    w, h = int(g["width"]), int(g["height"])
+    pre = {k: np.ascontiguousarray(g["pre_" + k]).copy() for k in ("points", "colors", "inverse_covariance_2d", "min_x",
+                                                                   "max_x", "min_y", "max_y", "sigmoid_opacity")}
+    n0 = pre["points"].shape[0]
+    for k in range(0, n0, 9):         # every ninth row: a vertical bar, weight exp(-q00 dx^2 / 2), in every tile of its columns
+        pre["inverse_covariance_2d"][k] = np.array([[0.02, 0.0], [0.0, 0.0]], np.float32)
+        pre["min_y"][k], pre["max_y"][k] = -1.0, float(h)
+    if long_tile:    # 23 fainter copies of everything, binned (by their caller-given boxes) into tile (4, 4) alone: a list of
+        # > 2 500 entries, > 4x the frame's average -- the tile is split over four waves
+        more = {k: np.concatenate([v] * 23) for k, v in pre.items()}
+        more["sigmoid_opacity"] = (more["sigmoid_opacity"] - 3.0).astype(np.float32)
+        for k in ("min_x", "min_y"):
+            more[k][:] = 65.0
+        for k in ("max_x", "max_y"):
+            more[k][:] = 79.0
+        pre = {k: np.concatenate([pre[k], more[k]]) for k in pre}
+    n = pre["points"].shape[0]
+    ref_pre = cpu_ref.Preprocessed(pre["points"], pre["colors"], np.zeros((n, 2, 2), np.float32), np.zeros(n, np.float32),
+                                   pre["inverse_covariance_2d"], np.zeros(n, np.float32), pre["points"], pre["min_x"],
+                                   pre["min_y"], pre["max_x"], pre["max_y"], pre["sigmoid_opacity"], np.arange(n))
+    ref, _, inst = c_oracle.render(ref_pre, w, h, 16)
+    t = {k: torch.from_numpy(v).to("cuda:0") for k, v in pre.items()}
+    args = (h, w, 16, t["points"], t["colors"], t["inverse_covariance_2d"], t["min_x"], t["max_x"], t["min_y"], t["max_y"],
+            t["sigmoid_opacity"])
+    st = {}
+    img = render_preprocessed(*args, stats=st)
+    assert st["n_instances"] == inst
+    assert np.max(np.abs(img.cpu().numpy() - ref)) <= 1e-5
+    assert st["n_redo"] > 0                         # tiles with reference-order records, counted although their batches are "monomial"
+    plain = {}
+    render_preprocessed(*args, stats=plain, flags=_ffi.GSX_FLAG_PLAIN_FOOTPRINTS)
+    assert plain["n_redo"] == st["n_redo"]          # the same tiles / quarters: left undone, and reported
+
+
 def test_full_path_matches_reference_image(tmp_path, golden):
     _need_gpu()
     g = golden
@@ -188,6 +266,24 @@ def test_full_path_matches_reference_image(tmp_path, golden):
     assert stats["n_visible"] == int(g["in_view"].sum())
     again = scene.render_image(1, tile_size=int(g["tile"]))
     assert again.device.type == "cpu" and torch.equal(img.cpu(), again)     # deterministic; host tensor like the reference
+
+
+@pytest.mark.parametrize("name", ["fewvisible_48x48_n9", "onevisible_48x48_n7", "three_48x48_n3", "c1_256x256_n2000"])
+def test_captured_frame_keeps_the_row_class_of_its_view(tmp_path, name):
+    """A captured call cannot be issued again when n_visible says it assumed the wrong row class (GSX_FLAG_SMALL_BATCH /
+    _ONE_VISIBLE): capture_frame bakes in the class the view's uncaptured frame ended up with -- the replay equals the
+    uncaptured frame bit for bit, and the reference's image to the usual tolerance."""
+    _need_gpu()
+    g = load_golden(name)
+    scene = _scene_from_golden(tmp_path, g)
+    direct = scene.render_image_hip(1, tile_size=int(g["tile"])).clone()
+    frame = scene.capture_frame(1, tile_size=int(g["tile"]))
+    for _ in range(2):
+        img = frame.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(img, direct)
+    assert np.max(np.abs(img.cpu().numpy() - g["image"])) <= PIXEL_TOL
+    frame.confirm()
 
 
 def test_tile_size_two_like_the_notebook(tmp_path):
@@ -1813,3 +1909,32 @@ def test_hinted_frames_equal_frames_rendered_from_scratch(tmp_path):
         frame.out.fill_(5.0)
         frame.replay()
         assert torch.equal(frame.confirm(), ref[cam][0]), cam
+
+
+def test_multi_gpu_path_meets_rccl_with_a_world_of_one():
+    """No multi-GPU node has been available to any round: every collective of the strip path had only ever run on gloo.
+    ``bench.py --gpus 1 --dist-preflight`` runs THAT code -- dist.init_process_group("nccl") (= RCCL), the overlapped
+    sub-strip gather (strips.render_overlapped), the plain gather, StripPipeline, the barriers / reductions / broadcast of
+    the timing protocol, the `distributed` block -- with a process group of one rank on this GPU: communicator creation,
+    stream / event ordering and every call have then executed against the real backend at least once."""
+    _need_gpu()
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist-preflight", "--workload", "c2",
+                          "--steps", "3", "--warmup", "1", "--repeats", "2", "--settle-ms", "10"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    d = line["distributed"]
+    print(json.dumps(d))
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and line["n_gpus"] == 1
+    assert line["strips_equal_single_gpu"] is True
+    assert d["gather"].startswith("overlapped"), d            # the overlapped path passed its self-check against the lone frame
+    assert d["preflight"]["gather_one_rank"] is True, d["preflight"]
+    assert d["preflight"]["send_recv_to_self"] is True, d["preflight"]
+    assert d["frames_in_flight_path"].startswith("strips.StripPipeline")

@@ -318,3 +318,20 @@ def test_orbit_poses_and_trained_like_generator():
     assert ratio.max() > 30.0 and ratio.max() <= 50.0 * 1.001 and np.median(ratio) > 3.0
     op = a["opacity"][:, 0]
     assert 0.35 < (op < 0.0).mean() < 0.65 and (op > 2.0).mean() > 0.3 and (op < -2.0).mean() > 0.3
+
+
+def test_visible_rows_flag_names_the_class_or_says_clear():
+    """_ffi.visible_rows_flag (GSX_FLAG_SMALL_BATCH / _ONE_VISIBLE, include/gsx.h): 0 = the call assumed the right row
+    class, a flag = issue it again with that flag, -1 = it carried a flag and four or more Gaussians are visible: issue
+    it again with NEITHER (round 5 returned 0 there: "nothing to do")."""
+    from intro_to_gaussian_splatting_amd import _ffi
+
+    one, few = _ffi.GSX_FLAG_ONE_VISIBLE, _ffi.GSX_FLAG_SMALL_BATCH
+    f = _ffi.visible_rows_flag
+    assert f(9, 9, 0) == 0 and f(9, 4, 0) == 0 and f(3, 3, 0) == 0 and f(1, 1, 0) == 0
+    assert f(9, 2, 0) == few and f(9, 3, 0) == few and f(9, 1, 0) == one and f(3, 1, 0) == one and f(3, 2, 0) == 0
+    assert f(9, 2, few) == 0 and f(9, 1, one) == 0 and f(9, 1, few) == one and f(9, 3, one) == few
+    assert f(9, 4, few) == -1 and f(9, 9, one) == -1
+    assert f(9, 0, 0) == 0 and f(9, 0, few) == 0                       # nothing visible: nothing was multiplied
+    assert _ffi.with_rows_flag(few | 1024, -1) == 1024 and _ffi.with_rows_flag(few | 2, one) == (one | 2)
+    assert _ffi.with_rows_flag(0, few) == few
