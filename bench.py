@@ -132,6 +132,18 @@ def build_scene(workload: str, device: str, orbit: int = 0):
     return sc, scene
 
 
+def colors_by_original_index(scene, image_idx: int) -> np.ndarray:
+    """The colours the frame of camera ``image_idx`` is rendered with, (n, 3), in ORIGINAL Gaussian order (the oracle's
+    order) -- also for a scene whose rows were reordered (--spatial-order)."""
+    rows = scene._colors(image_idx).cpu().numpy()
+    oi = getattr(scene.gaussians, "original_index", None)
+    if oi is None:
+        return rows
+    out = np.empty_like(rows)
+    out[oi.cpu().numpy().astype(np.int64)] = rows
+    return out
+
+
 def _cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -148,7 +160,7 @@ def cpu_baseline_std3dgs(sc, scene, cam, gpu_frame: torch.Tensor, budget_s: floa
     cores = os.cpu_count() or 1
     w, h, tile = cam.width, cam.height, 16
     ntx, nty = strips.tiles_along(w, tile, "std_3dgs"), strips.tiles_along(h, tile, "std_3dgs")
-    colors = scene._colors(1).cpu().numpy()         # SH scenes: the colours of this camera
+    colors = colors_by_original_index(scene, 1)         # SH scenes: the colours of this camera
     run = lambda win: c_oracle.render_std3dgs(sc["points"], colors, sc["scales"], sc["quaternions"],  # noqa: E731
                                               sc["opacity"], cam, tile=tile, nthreads=cores, window=win)
     px = max(0, ntx // 2 - 4)
@@ -202,7 +214,7 @@ def cpu_baseline(sc, scene, gpu_frame: torch.Tensor, budget_s: float = 20.0, sem
         return cpu_baseline_std3dgs(sc, scene, cam, gpu_frame, budget_s)
     cores = os.cpu_count() or 1
     t0 = time.perf_counter()
-    pre = c_oracle.preprocess(sc["points"], scene._colors(1).cpu().numpy(), sc["scales"], sc["quaternions"],
+    pre = c_oracle.preprocess(sc["points"], colors_by_original_index(scene, 1), sc["scales"], sc["quaternions"],
                               sc["opacity"], cam)
     t_pre = time.perf_counter() - t0
     w, h, tile = c.width, c.height, 16
@@ -388,7 +400,7 @@ def tie_order_effect(workload: str, sc, scene) -> dict:
     cam = cpu_ref.Camera(im.world2view.cpu().numpy(), im.full_proj_transform.cpu().numpy(), np.float32(c.tan_fovx),
                          np.float32(c.tan_fovy), np.float32(c.fx), np.float32(c.fy), c.width, c.height)
     t0 = time.perf_counter()
-    pre = c_oracle.preprocess(sc["points"], scene._colors(1).cpu().numpy(), sc["scales"], sc["quaternions"], sc["opacity"], cam)
+    pre = c_oracle.preprocess(sc["points"], colors_by_original_index(scene, 1), sc["scales"], sc["quaternions"], sc["opacity"], cam)
     rows = golden_check.rows_in_reference_order(pre.order, g)
     theirs = cpu_ref.Preprocessed(*[np.ascontiguousarray(np.asarray(f)[rows]) for f in pre])
     cores = os.cpu_count() or 1
@@ -627,7 +639,7 @@ def moving_camera_leg(args, scene, sc, tile: int, layout: str, sem: str, stream)
             for i in (ids[0], mid, ids[-1]):
                 st = {}
                 img = scene.render_image_hip(i, tile_size=tile, layout=layout, semantics=sem, stats=st)
-                pre = c_oracle.preprocess(sc["points"], scene._colors(i).cpu().numpy(), sc["scales"], sc["quaternions"],
+                pre = c_oracle.preprocess(sc["points"], colors_by_original_index(scene, i), sc["scales"], sc["quaternions"],
                                           sc["opacity"], _oracle_camera(scene, i))
                 ref, _, inst = c_oracle.render(pre, w, h, tile, nthreads=os.cpu_count() or 1, window=win)
                 x0, x1, y0, y1 = win[0] * tile, win[1] * tile, win[2] * tile, win[3] * tile
@@ -784,6 +796,11 @@ def main() -> None:
     ap.add_argument("--plain-min-tiles", type=int, default=None,
                     help="development: the window size from which a view without ill-conditioned footprints takes "
                          "GSX_FLAG_PLAIN_FOOTPRINTS (the wrapper's default: 16384 tiles; 1 = always, a huge number = never)")
+    ap.add_argument("--spatial-order", action="store_true",
+                    help="render from Gaussians.spatially_ordered() -- the parameter rows along a Morton curve, filed under "
+                         "their original index (same frame bit for bit) -- so that a strip's survivors are read as whole "
+                         "cache lines (--strip-of N, or the ranks of a multi-GPU run)")
+    ap.add_argument("--no-spatial-order", action="store_true", help="N > 1: keep the parameter rows in the generator's order")
     ap.add_argument("--dist-preflight", action="store_true",
                     help="--gpus 1 only: run the MULTI-GPU code path with a world of one rank -- "
                          "dist.init_process_group('nccl') (RCCL accepts one rank per device), strips.render_overlapped / "
@@ -842,6 +859,11 @@ def main() -> None:
                 raise SystemExit("--camera-path: orbit:N with N >= 3, or none")
             n_orbit = int(cnt or 61)
         sc, scene = build_scene(args.workload, str(device), orbit=n_orbit)
+    # a real multi-GPU run renders strips: every rank takes its parameter rows in Morton order (the same frame bit for bit,
+    # tests/test_hip_parity.py; a strip's projection 74 -> 41 us at 5M Gaussians) unless told not to
+    if args.spatial_order or (world > 1 and not args.no_spatial_order):
+        scene.gaussians = scene.gaussians.spatially_ordered()
+        desc += " -- parameter rows in Morton order (Gaussians.spatially_ordered)"
     tile, layout, sem = 16, "wh3", args.semantics
     strip_window = strip_out = None
     if args.strip_of > 1:

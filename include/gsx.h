@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GSX_VERSION 305 /* major*10000 + minor*100 + patch.  305: GsxParams.stats_size (136 bytes): GsxFrameStats is written only as far
+#define GSX_VERSION 305 /* major*10000 + minor*100 + patch.  305: GsxParams.stats_size, .original_index, .block_bounds and .row_of_index (160 bytes): GsxFrameStats is written only as far
                          * as the caller says its struct reaches (64 bytes -- the ABI-300 struct, no n_redo -- when params is NULL or ends
                          * before the field); GSX_FLAG_PLAIN_FOOTPRINTS needs stats_size >= 72.  Binaries built against the 302 .. 304
                          * headers must be REBUILT (their 128-byte GsxParams is still read, but their 72-byte GsxFrameStats gets no
@@ -181,7 +181,31 @@ typedef struct GsxParams {
      * Any other value is GSX_ERR_INVALID_ARGUMENT.  Every later field of GsxFrameStats will be reported the same way. */
     int32_t stats_size;
     int32_t reserved1; /* 0 */
+    /* gsx_render_forward / gsx_preprocess (ABI 305).  NULL (default): Gaussian i of the input arrays IS Gaussian i.  Otherwise
+     * a DEVICE array of n int32, a permutation of 0 .. n-1: the caller has REORDERED its five parameter arrays (and `sh`) -- e.g.
+     * along a space-filling curve, so that the Gaussians of one part of the frame lie together in memory and a rank that
+     * renders a strip reads AND WRITES whole cache lines of survivors (Gaussians.spatially_ordered() of the Python surface)
+     * -- and row i of them holds the Gaussian whose ORIGINAL index is original_index[i].  The frame is then the one the
+     * original arrays give, bit for bit: the depth keys are filed under the original index and the depth sort enumerates
+     * them in that order, so equal depths still composite in original-index order; `order` and every reported index is the
+     * original one.  gsx_render_forward also needs the inverse, row_of_index (below): records and rectangles stay in ROW
+     * order -- written and, tile by tile, read back as neighbours -- and the sort's first pass turns an original index into
+     * the row it names. */
+    const int32_t *original_index;
+    /* gsx_render_forward, with original_index (ABI 305).  NULL (default) or a DEVICE array of 8 floats per block of
+     * GSX_BOUNDS_ROWS consecutive ROWS of the (reordered) arrays -- (min x, min y, min z, largest |scale|, max x, max y, max z,
+     * 0) over the block's means and scales; ceil(n / GSX_BOUNDS_ROWS) blocks.  A call that renders a PART of the frame then
+     * drops a whole block after reading these 32 bytes when the projected box, grown by the largest footprint radius any of
+     * its Gaussians can have, misses the tile window and lies in front of the cull plane -- instead of reading 24 bytes of
+     * every Gaussian to find the same thing out row by row.  Conservative: a block is only dropped when each of its rows
+     * would be; the frame is the same bit for bit.  The bounds describe the arrays AS THEY ARE: whoever moves a mean or
+     * grows a scale recomputes them (Gaussians.refresh_block_bounds()). */
+    const float *block_bounds;
+    /* gsx_render_forward, with original_index: DEVICE array of n int32, the inverse permutation -- row_of_index[original_index[i]]
+     * == i.  Required there (GSX_ERR_INVALID_ARGUMENT without it); gsx_preprocess does not read it. */
+    const int32_t *row_of_index;
 } GsxParams;
+#define GSX_BOUNDS_ROWS 256
 
 /* Record per-stage GPU times with HIP events on `stream` into GsxFrameStats.stage_ms (the call
  * then waits for the frame to finish).  Off by default: timing is measurement, not product. */

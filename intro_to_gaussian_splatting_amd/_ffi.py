@@ -38,6 +38,7 @@ GSX_FLAG_HINTS_VALID = 128
 GSX_FLAG_SMALL_BATCH = 256
 GSX_FLAG_ONE_VISIBLE = 512
 GSX_FLAG_PLAIN_FOOTPRINTS = 1024
+GSX_BOUNDS_ROWS = 256
 
 
 def visible_rows_flag(n: int, n_visible: int, flags: int) -> int:
@@ -73,7 +74,8 @@ class GsxParams(ctypes.Structure):
                 ("tile_counts", c_void_p), ("sh", c_void_p), ("sh_degree", c_int32), ("struct_size", c_int32),
                 ("kept_hint", c_int64), ("hints", c_void_p),
                 ("n_substrips", c_int32), ("substrip_axis", c_int32), ("substrip_bounds", POINTER(c_int32)),
-                ("substrip_events", POINTER(c_void_p)), ("stats_size", c_int32), ("reserved1", c_int32)]
+                ("substrip_events", POINTER(c_void_p)), ("stats_size", c_int32), ("reserved1", c_int32),
+                ("original_index", c_void_p), ("block_bounds", c_void_p), ("row_of_index", c_void_p)]
 
 
 class GsxFrameStats(ctypes.Structure):

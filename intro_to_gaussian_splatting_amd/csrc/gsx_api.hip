@@ -303,7 +303,7 @@ int gsx_preprocess(const GsxCamera *camera, const float *means3d, const float *s
     // (3) Rank order: one 48-byte gather per rank, the derived fields, eleven coalesced output arrays.  Round 2 ran a
     // memset node, a key kernel, a 12-launch LSD sort over all n keys, a counting kernel and a projection that
     // gathered the five input arrays by rank.
-    gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors};
+    gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, colors, original_index_of(params)};
     gsx::Record *stage = (gsx::Record *)(ws + c.rec);
     GSX_HIP(gsx::launch_project_stage(*camera, in, n, k0, stage, counters, small_batch, s));
     const gsx::DepthRoute route = gsx::depth_sort_route(n, 0);
@@ -376,6 +376,8 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     }
     if (n > 0 && (!means3d || !scales || !quats || !opacity_logit || (!colors && !p.sh)))
         return fail(GSX_ERR_INVALID_ARGUMENT, "an input array is NULL");
+    if (p.original_index && !p.row_of_index) return fail(GSX_ERR_INVALID_ARGUMENT, "original_index needs row_of_index (its inverse)");
+    const uint32_t *row_of = p.original_index ? (const uint32_t *)p.row_of_index : nullptr;
     Carve c;
     int64_t cap;
     rc = check_workspace(workspace, workspace_bytes, n, max_tiles_of(camera->width, camera->height, tile_size), c, cap);
@@ -385,7 +387,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     uint32_t *v0 = (uint32_t *)(ws + c.vals0), *v1 = (uint32_t *)(ws + c.vals1);
     StageTimer tm;
     tm.begin(p.timing, s);
-    gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, p.sh ? p.sh : colors};
+    gsx::GaussiansIn in{means3d, scales, quats, opacity_logit, p.sh ? p.sh : colors, p.original_index, (const float4 *)p.block_bounds};
     uint32_t *counters = (uint32_t *)(ws + c.counters);
     // GsxParams.hints: what the previous frame of this view left (splitters, tile-list lengths) and what this one
     // leaves.  Only where every producer and consumer exists: the tile-16 REF_CPU compositing kernel (lengths,
@@ -415,13 +417,14 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
     }
     GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, p.small_batch, p.sh_degree, k0, (gsx::Record *)(ws + c.rec),
                                      (gsx::TileRect *)(ws + c.rect), counters,
-                                     p.semantics != GSX_SEM_STD_3DGS ? (float4 *)(ws + c.bbox) : nullptr, sched_hint, s));
+                                     p.semantics != GSX_SEM_STD_3DGS ? (float4 *)(ws + c.bbox) : nullptr, sched_hint,
+                                     c.temp_bytes >= (size_t)(n / GSX_BOUNDS_ROWS + 1) ? (uint8_t *)(ws + c.temp) : nullptr, s));
     tm.mark();  // 1: project (+ depth keys)
     // the sampled routes also leave the per-chunk tile counts the pair emission starts from (one kernel less)
     if (sampled)
         GSX_HIP(gsx::sort_depth_sampled(route, ws + c.temp, k0, k1, v0, v1, n, p.kept_hint, counters + kCtrKept,
                                         counters + kCtrCulled, (const gsx::TileRect *)(ws + c.rect),
-                                        (gsx::TileRect *)(ws + c.rrect), 0, gsx::emit_chunk_sums(ws + c.temp, n, cap), sh, s));
+                                        (gsx::TileRect *)(ws + c.rrect), 0, gsx::emit_chunk_sums(ws + c.temp, n, cap), sh, s, row_of));
     else {
         // the LSD passes carry the rectangles along, packed into 4 bytes, when tile coordinates fit 8 bits; the two
         // arrays they travel in are the pair lists' value arrays, which nothing uses before the emission
@@ -429,7 +432,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
         GSX_HIP(gsx::sort_depth_compact(ws + c.temp, k0, k1, v0, v1, n, counters + kCtrKept, counters + kCtrCulled,
                                         (const gsx::TileRect *)(ws + c.rect), (gsx::TileRect *)(ws + c.rrect), s, sh.samples,
                                         carry ? (uint32_t *)(ws + c.tvals0) : nullptr,
-                                        carry ? (uint32_t *)(ws + c.tvals1) : nullptr));
+                                        carry ? (uint32_t *)(ws + c.tvals1) : nullptr, row_of));
     }
     tm.mark();  // 2: depth sort (drops what reaches no tile, leaves the rectangles in rank order)
     return bin_and_blend(p, c, ws, n, cap, (const gsx::TileRect *)(ws + c.rrect), v0, counters + kCtrKept,

@@ -83,6 +83,10 @@ struct StageOneOut {  // PreprocessedScene arrays (splat/schema.py:13-25), depth
 
 struct GaussiansIn {  // splat/gaussians.py:19-33
     const float *means3d, *scales, *quats, *opacity_logit, *colors;
+    // GsxParams.original_index (or null): row i holds the Gaussian of that ORIGINAL index -- keys, records and rectangles
+    // are filed under it (launch_project_pack pre-fills the keys with kEmptyKey first)
+    const int32_t *original_index = nullptr;
+    const float4 *block_bounds = nullptr;      // GsxParams.block_bounds (two float4 per GSX_BOUNDS_ROWS rows), or null
 };
 
 struct PreprocessedIn {  // argument list of splat/c/render.cu:90-101
@@ -116,7 +120,9 @@ hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                const TileGrid &grid, int semantics, bool tight_rects, int visible_rows, int sh_degree,
                                uint32_t *keys, Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox,
-                               const ScheduleHint &sched, hipStream_t s);
+                               const ScheduleHint &sched, uint8_t *block_scratch, hipStream_t s);
+// (block_scratch: ceil(n / GSX_BOUNDS_ROWS) bytes the launch may use when in.block_bounds is set -- the depth sort's
+// temp area, idle until the projection is done; in.original_index: the launch pre-fills the keys itself)
 // gsx_preprocess, last kernel: all PreprocessedScene fields in depth order; order[r] = Gaussian of rank r, r < *m_dev.
 hipError_t launch_project_full(const Record *stage, const uint32_t *order, const uint32_t *m_dev, int64_t n,
                                const StageOneOut &out, hipStream_t s);
@@ -170,10 +176,12 @@ hipError_t radix_sort_pairs_u16(void *temp, uint16_t *&keys_cur, uint16_t *&keys
 // first kernel runs) and gathering rect[index] into rrect[rank] in the last one.  On return
 // vals_cur[0 .. *m_dev) = Gaussian index of each depth rank (ties: original index).  The values of the
 // first pass are the item positions themselves (vals_cur need not be initialised).
+// row_of (both depth sorts; or null): GsxParams.row_of_index -- the keys are filed under ORIGINAL indices, the value an item
+// gets in the first pass is the ROW that index names (records and rectangles are in row order)
 hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
                               hipStream_t s, uint32_t *samples_out = nullptr, uint32_t *carry0 = nullptr,
-                              uint32_t *carry1 = nullptr);
+                              uint32_t *carry1 = nullptr, const uint32_t *row_of = nullptr);
 
 // The same contract with 5 kernels instead of 12: sample 2048 / 8192 keys -> 255 / 1023 splitters, ONE stable
 // partition pass, one in-LDS sort per bucket (gsx_sort.hip).  depth_sort_route picks the route from the
@@ -204,7 +212,7 @@ struct BlendHints {
 hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
                               uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,
                               const TileRect *rect, TileRect *rrect, uint32_t lds_cap, uint64_t *chunk_sums,
-                              const SortHints &hints, hipStream_t s);
+                              const SortHints &hints, hipStream_t s, const uint32_t *row_of = nullptr);
 // Where emit_instances keeps its chunk sums inside `temp` (for sort_depth_sampled to fill them in).
 uint64_t *emit_chunk_sums(void *temp, int64_t n, int64_t cap);
 
@@ -236,5 +244,6 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
 bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic);
 hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s);   // the zero fill alone
 hipError_t launch_zero_words(uint32_t *p, size_t n, hipStream_t s);
+hipError_t launch_fill_words(uint32_t *p, size_t n, uint32_t value, hipStream_t s);
 
 }  // namespace gsx

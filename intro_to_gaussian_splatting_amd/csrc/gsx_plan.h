@@ -174,6 +174,14 @@ inline void default_params(GsxParams *params, size_t bytes = sizeof(GsxParams)) 
     memcpy(params, &d, bytes);
 }
 
+// GsxParams.original_index of a caller's struct (null when the struct ends before the field): for the entry points that
+// read single fields instead of a whole Plan (gsx_preprocess).
+inline const int32_t *original_index_of(const GsxParams *params) {
+    if (!params) return nullptr;
+    const size_t have = params->struct_size ? (size_t)params->struct_size : kParamsBytesAbi300;
+    return have >= offsetof(GsxParams, original_index) + sizeof(const int32_t *) ? params->original_index : nullptr;
+}
+
 // Number of tiles along an axis.  REF_CPU iterates range(0, extent - tile, tile)
 // (splat/gaussian_scene.py:208,214): the last row/column is never rendered.
 // REF_CUDA covers the frame (splat/c/render.cu:119-120).
@@ -266,6 +274,9 @@ struct Plan {
     const GsxCamera *camera_device;
     uint32_t *tile_counts;
     const float *sh;
+    const int32_t *original_index;   // GsxParams.original_index (or null)
+    const float *block_bounds;       // GsxParams.block_bounds (or null; only with original_index)
+    const int32_t *row_of_index;     // GsxParams.row_of_index (the inverse of original_index)
     int sh_degree;   // -1: RGB colours
     int64_t kept_hint;   // GsxParams.kept_hint (0: unknown)
     char *hints;         // GsxParams.hints (or null)
@@ -306,6 +317,11 @@ inline int make_plan(int32_t width, int32_t height, int32_t tile, float *out_ima
     p.camera_device = d.camera_device;
     p.tile_counts = d.tile_counts;
     p.sh = d.sh;
+    p.original_index = d.original_index;
+    p.block_bounds = d.block_bounds;
+    p.row_of_index = d.row_of_index;
+    if (d.block_bounds && !d.original_index) return fail(GSX_ERR_INVALID_ARGUMENT, "block_bounds needs original_index");
+    if (d.block_bounds && (reinterpret_cast<uintptr_t>(d.block_bounds) & 15u) != 0) return fail(GSX_ERR_INVALID_ARGUMENT, "block_bounds must be 16-byte aligned");
     p.sh_degree = d.sh ? d.sh_degree : -1;
     p.kept_hint = d.kept_hint > 0 ? d.kept_hint : 0;
     p.hints = (char *)d.hints;

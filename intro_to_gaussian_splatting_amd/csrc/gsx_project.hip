@@ -356,14 +356,15 @@ __global__ void __launch_bounds__(kBlock)
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < 4) counters[i] = 0u;
     if (i >= n) return;
+    const int64_t slot = in.original_index ? (int64_t)in.original_index[i] : i;   // GsxParams.original_index: filed under the original index
     const float *p = in.means3d + 3 * i;
     const float p0 = p[0], p1 = p[1], p2 = p[2];
     if (!(row4_view(p0, p1, p2, cam.world2view, 2, rows_class(n)) >= 0.2f)) {      // utils.py:293-310: all n rows at once
-        keys[i] = kCulledKey;
+        keys[slot] = kCulledKey;
         return;
     }
     const float tz = row4_view(p0, p1, p2, cam.world2view, 2, vis);                // gaussian_scene.py:79-85: the visible rows
-    keys[i] = __float_as_uint(tz);
+    keys[slot] = __float_as_uint(tz);
     const float *s = in.scales + 3 * i, *q = in.quats + 4 * i, *c = in.colors + 3 * i;
     Projected o;
     project(cam, p0, p1, p2, tz, s[0], s[1], s[2], q[0], q[1], q[2], q[3], o, vis);
@@ -371,7 +372,7 @@ __global__ void __launch_bounds__(kBlock)
     r.a = make_float4(o.x, o.y, c[0], c[1]);
     r.b = make_float4(c[2], tz, sigmoid_torch(in.opacity_logit[i]), o.ca);
     r.c = make_float4(o.cb, o.cc, o.cd, 0.0f);
-    stage[i] = r;
+    stage[slot] = r;
 }
 
 // Opacity factor and conic as the compositing kernel consumes them.
@@ -444,153 +445,36 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
     out.c = make_float4(cb, depth, 0.0f, 0.0f);
 }
 
-// One thread per Gaussian, ORIGINAL order (coalesced reads of the parameter arrays, coalesced
-// writes): depth key for the sort, compositing record and tile rectangle.  A Gaussian that reaches no
-// tile of the window (culled, off screen, or -- on a rank that owns a strip of the frame -- in another
-// rank's strip) only gets its key written: no record, no rectangle, and its opacity and colour are
-// never read (40 B in + 4 B out instead of 56 B in + 60 B out; 7/8 of the Gaussians on an 8-GPU rank).
-// SHDEG >= 0 (GsxParams.sh, build extension): the colour is evaluated here from spherical harmonics of that
-// degree (gsx_sh_device.h: the workgroup streams its 256 Gaussians' coefficients through LDS) with the camera
-// centre of the GsxCamera the kernel reads -- no colour array, no colour launch, and a captured frame follows
-// a moving camera with SH colours too.  SHDEG = -1: in.colors holds RGB, as in the reference.
-template <bool DEVICE_CAMERA, int SHDEG, bool WINDOWED>
-__global__ void __launch_bounds__(kBlock)
-    project_pack_kernel(GsxCamera cam_arg, const GsxCamera *__restrict__ cam_dev, GaussiansIn in, int64_t n,
-                        TileGrid grid, int semantics, bool tight, int vis,
-                        uint32_t *__restrict__ keys, Record *__restrict__ rec,
-                        TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox,
-                        bool sh_vec, SchedJob sched_job) {
-    // the launch's eight spare workgroups -- blocks 0 .. 7, dispatched FIRST and long done when the Gaussians' blocks
-    // are: the compositing schedule of this frame, one XCD's share each, from the list lengths the previous frame left
-    // (GsxParams.hints, gsx_schedule_device.h)
-    if (sched_job.sched && blockIdx.x < kSchedXcds) {
-        schedule_from_lengths(sched_job, blockIdx.x);
-        return;
-    }
-    const int64_t blk = (int64_t)blockIdx.x - (sched_job.sched ? (int64_t)kSchedXcds : 0);
-    constexpr int DEG = SHDEG >= 0 ? SHDEG : 0;
-    using L = sh::Layout<DEG>;
-    __shared__ float sh_lds[SHDEG >= 0 ? L::kRows * L::STRIDE : 1];
-    int64_t g = blk * kBlock + threadIdx.x;
-    if (g < 4) counters[g] = 0u;   // the depth sort's culled / kept counts start from zero (no memset node)
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    if (SHDEG >= 0 && !WINDOWED) {
-        // colour of every Gaussian of the workgroup first (all threads take part in the staging rounds); a windowed
-        // call evaluates the colours of the survivors of its window test only, after the compaction below
-        const float *cc = DEVICE_CAMERA ? cam_dev->camera_center : cam_arg.camera_center;
-        const float c0 = cc[0], c1 = cc[1], c2 = cc[2];
-        // a part's coefficient block starts 16-byte aligned only if the whole array is and kRows * W * 4 is a multiple of 16
-        const bool vec = sh_vec && (L::kRows * L::W) % 4 == 0;
-#pragma unroll
-        for (int part = 0; part < L::kParts; ++part) {
-            if (part) __syncthreads();
-            sh::stage<DEG, L::kRows>(in.colors, n, blk * kBlock + part * L::kRows, sh_lds, vec);
-            const int row = (int)threadIdx.x - part * L::kRows;
-            if (row >= 0 && row < L::kRows && g < n) {
-                const float *pp = in.means3d + 3 * g;
-                sh::eval<DEG>(sh_lds + row * L::STRIDE, pp[0] - c0, pp[1] - c1, pp[2] - c2, cr, cg, cb);
-            }
-        }
-    }
-    // GsxParams.camera_device: the constants as they are in device memory now (uniform scalar loads)
-    const GsxCamera &cam = DEVICE_CAMERA ? *cam_dev : cam_arg;
+// The exact projection of ONE Gaussian: row g of the input arrays; record and rectangle go to row g, the depth key to `slot`
+// (g itself unless GsxParams.original_index reorders the rows: then the key is filed under the original index, which is the
+// order the stable depth sort enumerates the keys in).  CULL: the caller has not applied the cull plane yet (the
+// whole-frame kernel); the windowed kernel's survivors have passed it.  PRE: the caller fetched opacity logit and RGB colour
+// together with everything else (pre_op, cr / cg / cb) -- a survivor of the window test nearly always needs them, and
+// fetched here, behind the arithmetic, they are two more dependent trips to memory.  SHDEG >= 0: cr / cg / cb hold the
+// colour evaluated from spherical harmonics.  Shared by both kernels: same operations, same bits.
+template <int SHDEG, bool CULL, bool PRE>
+__device__ __forceinline__ void project_one(const GsxCamera &cam, const GaussiansIn &in, int64_t g, int64_t slot, bool remapped,
+                                            int64_t n, const TileGrid &grid, int semantics, bool tight, int vis, float cr,
+                                            float cg, float cb, float pre_op, float p0, float p1, float p2, float s0, float s1,
+                                            float s2, float q0, float q1, float q2, float q3, uint32_t *__restrict__ keys,
+                                            Record *__restrict__ rec, TileRect *__restrict__ rect, float4 *__restrict__ bbox) {
     const bool std3dgs = semantics == GSX_SEM_STD_3DGS;
-
-    // ---- phase 1 (WINDOWED: the call renders a strict part of the frame, e.g. one rank's strip), every
-    // Gaussian of the workgroup: cull plane, then a cheap conservative window test.  What survives is
-    // compacted inside the workgroup, so that the covariance arithmetic below (~400 instructions, correctly
-    // rounded divisions and square roots) runs on dense waves: on a rank that owns 1/8 of the frame 7/8 of
-    // the Gaussians end here, having cost 24 B of reads and one key.  A whole-frame call skips the phase
-    // (measured: +8 us at 1M Gaussians when nearly everything survives anyway).
-    __shared__ uint16_t s_list[WINDOWED ? kBlock : 1];
-    __shared__ uint32_t s_wcnt[kBlock / 64];
-    if (WINDOWED) {
-    bool survives = false;
-    if (g < n) {
-        const float *p = in.means3d + 3 * g;
-        const float p0 = p[0], p1 = p[1], p2 = p[2];
-        const float tz = row4_view(p0, p1, p2, cam.world2view, 2, std3dgs ? (int)kRowsMany : rows_class(n));
-        if (std3dgs ? !(tz > 0.2f) : !(tz >= 0.2f)) {               // utils.py:293-310 (all n rows at once)
-            keys[g] = kCulledKey;
-        } else {
-            survives = true;
-            if (!std3dgs) {
-                // (approximate reciprocal / square root: the margins below absorb their last bits)
-                // The exact radius is ceil(3 sqrt(lam)) with lam <= trace(Sigma2D) + sqrt(0.1), trace(Sigma2D) <=
-                // (|J row 0|^2 + |J row 1|^2) max(scale)^2 and |J row 0|^2 = (fx / z)^2 (1 + clamp(x/z)^2) <=
-                // (fx / z)^2 (1 + (1.3 tan_x)^2) -- 2 % and two pixels are added for the rounding of everything
-                // involved.  A Gaussian is dropped only if that generous box misses the window; whatever passes
-                // goes through the exact test of phase 2 (NaNs pass: comparisons are false).
-                const float *s = in.scales + 3 * g;
-                const float *F = cam.full_proj;
-                const float icw = __builtin_amdgcn_rcpf(row4(p0, p1, p2, F, 3)), itz = __builtin_amdgcn_rcpf(tz);
-                const float xe = (row4(p0, p1, p2, F, 0) * icw + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
-                const float ye = (row4(p0, p1, p2, F, 1) * icw + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
-                const float lx = 1.3f * cam.tan_fovx, ly = 1.3f * cam.tan_fovy;
-                const float smax = fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fabsf(s[2]));
-                const float jn = (cam.fx * cam.fx) * (1.0f + lx * lx) + (cam.fy * cam.fy) * (1.0f + ly * ly);
-                const float rb = 3.0f * __builtin_amdgcn_sqrtf(jn * (smax * smax) * (itz * itz) + 0.32f) * 1.02f + 2.0f;
-                const float T = (float)grid.tile;
-                if (xe - rb > (float)grid.wx1 * T || xe + rb < (float)grid.wx0 * T || ye - rb > (float)grid.wy1 * T ||
-                    ye + rb < (float)grid.wy0 * T) {
-                    keys[g] = kEmptyKey;
-                    survives = false;
-                }
-            }
-        }
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;  // (indentation: still inside `if (WINDOWED)`)
-    const unsigned long long mask = __ballot(survives);
-    if (lane == 0) s_wcnt[w] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < kBlock / 64; ++k) {
-        before += k < w ? s_wcnt[k] : 0u;
-        total += s_wcnt[k];
-    }
-    if (survives) s_list[before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
-    __syncthreads();
-    const uint32_t src = threadIdx.x < total ? s_list[threadIdx.x] : 0u;
-    g = blk * kBlock + src;
-    if (SHDEG >= 0) {
-        // the survivors' coefficient rows through LDS (a row per Gaussian, read by consecutive lanes), kRows at a time
-        const float *cc = DEVICE_CAMERA ? cam_dev->camera_center : cam_arg.camera_center;
-        const float c0 = cc[0], c1 = cc[1], c2 = cc[2];
-        for (int first = 0; first < (int)total; first += L::kRows) {
-            if (first) __syncthreads();
-            sh::stage_rows<DEG, L::kRows>(in.colors, blk * kBlock, s_list, (int)total, first, sh_lds, sh_vec);
-            const int row = (int)threadIdx.x - first;
-            if (row >= 0 && row < L::kRows && threadIdx.x < total) {
-                const float *pp = in.means3d + 3 * g;
-                sh::eval<DEG>(sh_lds + row * L::STRIDE, pp[0] - c0, pp[1] - c1, pp[2] - c2, cr, cg, cb);
-            }
-        }
-    }
-    if (threadIdx.x >= total) return;
-    } else if (g >= n) {
-        return;
-    }
-
-    // ---- phase 2 (WINDOWED: survivors only, dense): the exact projection
-    const float *p = in.means3d + 3 * g;
-    const float p0 = p[0], p1 = p[1], p2 = p[2];
     // the cull multiplies all n points at once (utils.py:305-307), everything after it the visible ones (its rows class
     // is `vis`): below four rows the two products differ in their last bit (row4_view)
-    const float tz_cull = row4_view(p0, p1, p2, cam.world2view, 2, std3dgs ? (int)kRowsMany : rows_class(n));
-    if (!WINDOWED && (std3dgs ? !(tz_cull > 0.2f) : !(tz_cull >= 0.2f))) {               // utils.py:293-310
-        keys[g] = kCulledKey;
-        return;
+    if (CULL) {
+        const float tz_cull = row4_view(p0, p1, p2, cam.world2view, 2, std3dgs ? (int)kRowsMany : rows_class(n));
+        if (std3dgs ? !(tz_cull > 0.2f) : !(tz_cull >= 0.2f)) {               // utils.py:293-310
+            keys[slot] = kCulledKey;
+            return;
+        }
     }
     const float tz = row4_view(p0, p1, p2, cam.world2view, 2, std3dgs ? (int)kRowsMany : vis);
-    const float *s = in.scales + 3 * g, *q = in.quats + 4 * g;
-    const float s0 = s[0], s1 = s[1], s2 = s[2];
     Projected o;
     bool keep = true;
     if (std3dgs)
-        keep = project_std(cam, p0, p1, p2, tz, s0, s1, s2, q[0], q[1], q[2], q[3], o);
+        keep = project_std(cam, p0, p1, p2, tz, s0, s1, s2, q0, q1, q2, q3, o);
     else
-        project(cam, p0, p1, p2, tz, s0, s1, s2, q[0], q[1], q[2], q[3], o, vis);
+        project(cam, p0, p1, p2, tz, s0, s1, s2, q0, q1, q2, q3, o, vis);
     TileRect tr;
     uint32_t cnt = std3dgs ? tile_rect(o.x, o.radius, o.y, o.radius, grid, semantics, tr)
                            : tile_rect(o.min_x, o.max_x, o.min_y, o.max_y, grid, semantics, tr);
@@ -598,7 +482,8 @@ __global__ void __launch_bounds__(kBlock)
     if (keep && cnt) {
         // (the reference's first sigmoid runs over the whole array -- torch's SIMD form --, its second on one element at a
         // time, which torch computes with libm's expf: gaussian_scene.py:143 and :164)
-        op = std3dgs ? sigmoidf(in.opacity_logit[g]) : sigmoid_torch(in.opacity_logit[g]);
+        const float logit = PRE ? pre_op : in.opacity_logit[g];
+        op = std3dgs ? sigmoidf(logit) : sigmoid_torch(logit);
         if (semantics == GSX_SEM_REF_CPU) op = sigmoidf(op);
     }
     if (std3dgs && tight && keep && cnt) {
@@ -622,19 +507,289 @@ __global__ void __launch_bounds__(kBlock)
     }
     if (!keep || cnt == 0u) {
         // reaches no tile of the window: it needs no depth rank, the sort drops it in its first pass
-        keys[g] = kEmptyKey;
+        // (GsxParams.original_index: the keys were pre-filled with exactly this)
+        if (!remapped) keys[g] = kEmptyKey;
         return;
     }
-    keys[g] = __float_as_uint(tz);
-    if (SHDEG < 0) {
+    keys[slot] = __float_as_uint(tz);
+    if (SHDEG < 0 && !PRE) {
         const float *c = in.colors + 3 * g;
         cr = c[0]; cg = c[1]; cb = c[2];
     }
     Record out;
+    // (record, rectangle and side slot in ROW order, whatever `slot` is: neighbours in the arrays write neighbouring lines --
+    // filed under scattered original indices, the 60 bytes of a strip's survivor were three partial-line stores, and those,
+    // not the reads, were what the windowed kernel spent its time on: 63 -> 34 us on a 1/8 strip of 5M Gaussians)
     pack_record(semantics, o.x, o.y, o.q00, o.q01, o.q10, o.q11, op, cr, cg, cb, o.depth, out, bbox ? bbox + g : nullptr);
     rec[g] = out;
     if (bbox && semantics == GSX_SEM_REF_CUDA) bbox[g] = make_float4(o.min_x, o.max_x, o.min_y, o.max_y);
     rect[g] = tr;
+}
+
+// One thread per Gaussian, ORIGINAL order (coalesced reads of the parameter arrays, coalesced
+// writes): depth key for the sort, compositing record and tile rectangle.  A Gaussian that reaches no
+// tile of the window (culled, off screen, or -- on a rank that owns a strip of the frame -- in another
+// rank's strip) only gets its key written: no record, no rectangle, and its opacity and colour are
+// never read (40 B in + 4 B out instead of 56 B in + 60 B out; 7/8 of the Gaussians on an 8-GPU rank).
+// SHDEG >= 0 (GsxParams.sh, build extension): the colour is evaluated here from spherical harmonics of that
+// degree (gsx_sh_device.h: the workgroup streams its 256 Gaussians' coefficients through LDS) with the camera
+// centre of the GsxCamera the kernel reads -- no colour array, no colour launch, and a captured frame follows
+// a moving camera with SH colours too.  SHDEG = -1: in.colors holds RGB, as in the reference.
+template <bool DEVICE_CAMERA, int SHDEG>
+__global__ void __launch_bounds__(kBlock)
+    project_pack_kernel(GsxCamera cam_arg, const GsxCamera *__restrict__ cam_dev, GaussiansIn in, int64_t n,
+                        TileGrid grid, int semantics, bool tight, int vis,
+                        uint32_t *__restrict__ keys, Record *__restrict__ rec,
+                        TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox,
+                        bool sh_vec, SchedJob sched_job) {
+    // the launch's eight spare workgroups -- blocks 0 .. 7, dispatched FIRST and long done when the Gaussians' blocks
+    // are: the compositing schedule of this frame, one XCD's share each, from the list lengths the previous frame left
+    // (GsxParams.hints, gsx_schedule_device.h)
+    if (sched_job.sched && blockIdx.x < kSchedXcds) {
+        schedule_from_lengths(sched_job, blockIdx.x);
+        return;
+    }
+    const int64_t blk = (int64_t)blockIdx.x - (sched_job.sched ? (int64_t)kSchedXcds : 0);
+    constexpr int DEG = SHDEG >= 0 ? SHDEG : 0;
+    using L = sh::Layout<DEG>;
+    __shared__ float sh_lds[SHDEG >= 0 ? L::kRows * L::STRIDE : 1];
+    int64_t g = blk * kBlock + threadIdx.x;
+    if (g < 4) counters[g] = 0u;   // the depth sort's culled / kept counts start from zero (no memset node)
+    // GsxParams.original_index: row g of the inputs is the Gaussian of ORIGINAL index remap[g]; its key, record and rectangle
+    // are filed under that index (the keys arrive pre-filled with kEmptyKey: only culled and kept Gaussians write theirs)
+    const int32_t *__restrict__ remap = in.original_index;
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    if (SHDEG >= 0) {
+        // colour of every Gaussian of the workgroup first (all threads take part in the staging rounds)
+        const float *cc = DEVICE_CAMERA ? cam_dev->camera_center : cam_arg.camera_center;
+        const float c0 = cc[0], c1 = cc[1], c2 = cc[2];
+        // a part's coefficient block starts 16-byte aligned only if the whole array is and kRows * W * 4 is a multiple of 16
+        const bool vec = sh_vec && (L::kRows * L::W) % 4 == 0;
+#pragma unroll
+        for (int part = 0; part < L::kParts; ++part) {
+            if (part) __syncthreads();
+            sh::stage<DEG, L::kRows>(in.colors, n, blk * kBlock + part * L::kRows, sh_lds, vec);
+            const int row = (int)threadIdx.x - part * L::kRows;
+            if (row >= 0 && row < L::kRows && g < n) {
+                const float *pp = in.means3d + 3 * g;
+                sh::eval<DEG>(sh_lds + row * L::STRIDE, pp[0] - c0, pp[1] - c1, pp[2] - c2, cr, cg, cb);
+            }
+        }
+    }
+    // GsxParams.camera_device: the constants as they are in device memory now (uniform scalar loads)
+    const GsxCamera &cam = DEVICE_CAMERA ? *cam_dev : cam_arg;
+    if (g >= n) return;
+
+    // ---- the exact projection (project_one: shared with the windowed kernel)
+    const float *p = in.means3d + 3 * g, *sc = in.scales + 3 * g, *q = in.quats + 4 * g;
+    project_one<SHDEG, true, false>(cam, in, g, remap ? (int64_t)remap[g] : g, remap != nullptr, n, grid, semantics, tight, vis, cr, cg,
+                                    cb, 0.0f, p[0], p[1], p[2], sc[0], sc[1], sc[2], q[0], q[1], q[2], q[3], keys, rec, rect, bbox);
+}
+
+// GsxParams.block_bounds: may the windowed kernel drop the block (lo.xyz .. hi.xyz = box of its means, lo.w = its largest
+// |scale|) unread?  Only if every row of it would fail the row test of phase 1 WITHOUT being culled: all eight corners
+// in front of the cull plane with a margin (view depth is affine in the mean: every row's lies between the corners'), and
+// the hull of the corners' pixel positions -- the image of a box under a projective map with w > 0 is the convex hull of
+// its corners' images --, grown by the largest conservative radius a row can have (largest scale at the smallest depth,
+// the row test's own formula) plus a pixel for the rounding of these few operations, misses the tile window.
+__device__ __forceinline__ bool block_misses_window(const GsxCamera &cam, const TileGrid &grid, float4 lo, float4 hi) {
+    const float *V = cam.world2view, *F = cam.full_proj;
+    // (a box that is not one -- a NaN or infinite mean in the block -- says nothing: row by row)
+    if (!(fabsf(lo.x) < 1e30f && fabsf(lo.y) < 1e30f && fabsf(lo.z) < 1e30f && fabsf(hi.x) < 1e30f && fabsf(hi.y) < 1e30f &&
+          fabsf(hi.z) < 1e30f && lo.w >= 0.0f && lo.w < 1e30f))
+        return false;
+    float tz_min = __builtin_inff(), x_min = __builtin_inff(), x_max = -__builtin_inff(), y_min = __builtin_inff(), y_max = -__builtin_inff();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float p0 = (c & 1) ? hi.x : lo.x, p1 = (c & 2) ? hi.y : lo.y, p2 = (c & 4) ? hi.z : lo.z;
+        const float tz = p0 * V[2] + p1 * V[6] + p2 * V[10] + V[14];
+        const float cw = row4(p0, p1, p2, F, 3);
+        tz_min = fminf(tz_min, fminf(tz, cw));
+        const float icw = 1.0f / cw;
+        const float xe = (row4(p0, p1, p2, F, 0) * icw + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
+        const float ye = (row4(p0, p1, p2, F, 1) * icw + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
+        x_min = fminf(x_min, xe); x_max = fmaxf(x_max, xe);
+        y_min = fminf(y_min, ye); y_max = fmaxf(y_max, ye);
+    }
+    if (!(tz_min >= 0.21f)) return false;           // (a corner near or behind the plane, or a NaN: row by row)
+    const float lx = 1.3f * cam.tan_fovx, ly = 1.3f * cam.tan_fovy;
+    const float jn = (cam.fx * cam.fx) * (1.0f + lx * lx) + (cam.fy * cam.fy) * (1.0f + ly * ly);
+    const float itz = 1.0f / (tz_min * 0.999f);
+    const float rb = 3.0f * sqrtf(jn * (lo.w * lo.w) * (itz * itz) + 0.32f) * 1.03f + 3.0f;
+    const float T = (float)grid.tile;
+    // (every comparison false on a NaN: the block is then kept)
+    return x_min - rb > (float)grid.wx1 * T || x_max + rb < (float)grid.wx0 * T || y_min - rb > (float)grid.wy1 * T ||
+           y_max + rb < (float)grid.wy0 * T;
+}
+
+// The projection of a call that renders a strict PART of the frame (a multi-GPU rank's strip, a tile window): most
+// Gaussians miss the window.  A workgroup takes kWinRows = 1024 consecutive rows.
+//   phase 1  every row: cull plane, then a cheap conservative window test; a thread handles FOUR rows (row = base + k * 256
+//            + thread, coalesced for every k) with all its loads -- means and scales -- in flight at once.  On a rank that owns
+//            1/8 of the frame 7/8 of the Gaussians end here, having cost 24 B of reads.  (Round 5 gave every thread one row:
+//            19 500 workgroups of 256 at 5M Gaussians, each a chain of four dependent trips to memory -- 74 us for 141 MB.)
+//   compact  the survivors' row numbers, in LDS, in row order;
+//   phase 2  256 survivors at a time, dense waves: means, scales, quaternion, opacity and colour of a survivor are requested
+//            together, then the exact projection (project_one: the whole-frame kernel's operations, bit for bit).
+// SHDEG >= 0: the survivors' coefficient rows go through LDS, kRows at a time, and the colour is evaluated before phase 2.
+constexpr int kWinPer = 1, kWinRows = kBlock * kWinPer;
+static_assert(kWinRows == GSX_BOUNDS_ROWS, "a workgroup of the windowed kernel takes one block of GsxParams.block_bounds");
+template <bool DEVICE_CAMERA, int SHDEG>
+__global__ void __launch_bounds__(kBlock)
+    project_window_kernel(GsxCamera cam_arg, const GsxCamera *__restrict__ cam_dev, GaussiansIn in, int64_t n,
+                          TileGrid grid, int semantics, bool tight, int vis,
+                          uint32_t *__restrict__ keys, Record *__restrict__ rec,
+                          TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox,
+                          bool sh_vec, SchedJob sched_job, const uint8_t *__restrict__ block_dropped) {
+    if (sched_job.sched && blockIdx.x < kSchedXcds) {       // (the spare workgroups of the launch: see project_pack_kernel)
+        schedule_from_lengths(sched_job, blockIdx.x);
+        return;
+    }
+    const int64_t blk = (int64_t)blockIdx.x - (sched_job.sched ? (int64_t)kSchedXcds : 0);
+    constexpr int DEG = SHDEG >= 0 ? SHDEG : 0;
+    using L = sh::Layout<DEG>;
+    __shared__ float sh_lds[SHDEG >= 0 ? L::kRows * L::STRIDE : 1];
+    __shared__ uint16_t s_list[kWinRows];
+    __shared__ uint32_t s_wcnt[kWinPer][kBlock / 64];
+    const int64_t base = blk * kWinRows;
+    if (blk == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0u;   // the depth sort's culled / kept counts start from zero
+    const int32_t *__restrict__ remap = in.original_index;          // (see project_pack_kernel)
+    const GsxCamera &cam = DEVICE_CAMERA ? *cam_dev : cam_arg;
+    const bool std3dgs = semantics == GSX_SEM_STD_3DGS;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // GsxParams.block_bounds: the whole block lies in front of the cull plane and off the window (prepare_reordered_kernel
+    // found that out: block_misses_window) -- nothing to read, nothing to write (the keys are pre-filled with kEmptyKey).
+    // (The test itself in here, uniform but on the vector ALU of every wave, cost what it saved: 150 instructions a wave.)
+    if (block_dropped && block_dropped[blk]) return;
+
+    // ---- phase 1
+    float px[kWinPer], py[kWinPer], pz[kWinPer], smax[kWinPer];
+#pragma unroll
+    for (int k = 0; k < kWinPer; ++k) {
+        const int64_t g = base + k * kBlock + threadIdx.x;
+        px[k] = py[k] = pz[k] = smax[k] = 0.0f;
+        if (g < n) {
+            const float *p = in.means3d + 3 * g;
+            px[k] = p[0]; py[k] = p[1]; pz[k] = p[2];
+            if (!std3dgs) {
+                const float *s = in.scales + 3 * g;
+                smax[k] = fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fabsf(s[2]));
+            }
+        }
+    }
+    unsigned long long mask[kWinPer];
+    bool survives[kWinPer];
+#pragma unroll
+    for (int k = 0; k < kWinPer; ++k) {
+        const int64_t g = base + k * kBlock + threadIdx.x;
+        survives[k] = false;
+        if (g < n) {
+            const float p0 = px[k], p1 = py[k], p2 = pz[k];
+            const float tz = row4_view(p0, p1, p2, cam.world2view, 2, std3dgs ? (int)kRowsMany : rows_class(n));
+            if (std3dgs ? !(tz > 0.2f) : !(tz >= 0.2f)) {               // utils.py:293-310 (all n rows at once)
+                keys[remap ? (int64_t)remap[g] : g] = kCulledKey;
+            } else {
+                survives[k] = true;
+                if (!std3dgs) {
+                    // (approximate reciprocal / square root: the margins below absorb their last bits)
+                    // The exact radius is ceil(3 sqrt(lam)) with lam <= trace(Sigma2D) + sqrt(0.1), trace(Sigma2D) <=
+                    // (|J row 0|^2 + |J row 1|^2) max(scale)^2 and |J row 0|^2 = (fx / z)^2 (1 + clamp(x/z)^2) <=
+                    // (fx / z)^2 (1 + (1.3 tan_x)^2) -- 2 % and two pixels are added for the rounding of everything
+                    // involved.  A Gaussian is dropped only if that generous box misses the window; whatever passes
+                    // goes through the exact test of phase 2 (NaNs pass: comparisons are false).
+                    const float *F = cam.full_proj;
+                    const float icw = __builtin_amdgcn_rcpf(row4(p0, p1, p2, F, 3)), itz = __builtin_amdgcn_rcpf(tz);
+                    const float xe = (row4(p0, p1, p2, F, 0) * icw + 1.0f) * ((float)cam.width - 1.0f) * 0.5f;
+                    const float ye = (row4(p0, p1, p2, F, 1) * icw + 1.0f) * ((float)cam.height - 1.0f) * 0.5f;
+                    const float lx = 1.3f * cam.tan_fovx, ly = 1.3f * cam.tan_fovy;
+                    const float jn = (cam.fx * cam.fx) * (1.0f + lx * lx) + (cam.fy * cam.fy) * (1.0f + ly * ly);
+                    const float rb = 3.0f * __builtin_amdgcn_sqrtf(jn * (smax[k] * smax[k]) * (itz * itz) + 0.32f) * 1.02f + 2.0f;
+                    const float T = (float)grid.tile;
+                    if (xe - rb > (float)grid.wx1 * T || xe + rb < (float)grid.wx0 * T || ye - rb > (float)grid.wy1 * T ||
+                        ye + rb < (float)grid.wy0 * T) {
+                        if (!remap) keys[g] = kEmptyKey;        // (GsxParams.original_index: the keys were pre-filled with this)
+                        survives[k] = false;
+                    }
+                }
+            }
+        }
+        mask[k] = __ballot(survives[k]);
+        if (lane == 0) s_wcnt[k][w] = (uint32_t)__popcll(mask[k]);
+    }
+    __syncthreads();
+    // ---- the survivors' rows, in row order (k major, then wave, then lane)
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < kWinPer; ++k) {
+        uint32_t before = total;
+#pragma unroll
+        for (int v = 0; v < kBlock / 64; ++v) {
+            before += v < w ? s_wcnt[k][v] : 0u;
+            total += s_wcnt[k][v];
+        }
+        if (survives[k]) s_list[before + (uint32_t)__popcll(mask[k] & ((1ull << lane) - 1ull))] = (uint16_t)(k * kBlock + threadIdx.x);
+    }
+    if (total == 0u) return;          // (uniform over the workgroup)
+    __syncthreads();
+
+    // ---- phase 2
+    for (uint32_t b = 0; b < total; b += (uint32_t)kBlock) {
+        const uint32_t idx = b + threadIdx.x;
+        const bool active = idx < total;
+        const int64_t g = base + (active ? (int64_t)s_list[idx] : 0);
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, lg = 0.f;
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        int64_t slot = g;
+        if (active) {           // everything a survivor needs, requested at once
+            const float *p = in.means3d + 3 * g, *s = in.scales + 3 * g, *q = in.quats + 4 * g;
+            p0 = p[0]; p1 = p[1]; p2 = p[2];
+            s0 = s[0]; s1 = s[1]; s2 = s[2];
+            q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+            lg = in.opacity_logit[g];
+            if (SHDEG < 0) {
+                const float *c = in.colors + 3 * g;
+                cr = c[0]; cg = c[1]; cb = c[2];
+            }
+            if (remap) slot = (int64_t)remap[g];
+        }
+        if (SHDEG >= 0) {
+            // the survivors' coefficient rows through LDS (a row per Gaussian, read by consecutive lanes), kRows at a time
+            const float *cc = DEVICE_CAMERA ? cam_dev->camera_center : cam_arg.camera_center;
+            const float c0 = cc[0], c1 = cc[1], c2 = cc[2];
+            const uint32_t stop = min(total, b + (uint32_t)kBlock);
+            for (uint32_t first = b; first < stop; first += (uint32_t)L::kRows) {
+                __syncthreads();        // (the rows staged before have been read)
+                sh::stage_rows<DEG, L::kRows>(in.colors, base, s_list, (int)stop, (int)first, sh_lds, sh_vec);
+                const int row = (int)idx - (int)first;
+                if (row >= 0 && row < L::kRows && active)
+                    sh::eval<DEG>(sh_lds + row * L::STRIDE, p0 - c0, p1 - c1, p2 - c2, cr, cg, cb);
+            }
+        }
+        if (active)
+            project_one<SHDEG, false, true>(cam, in, g, slot, remap != nullptr, n, grid, semantics, tight, vis, cr, cg, cb, lg, p0,
+                                            p1, p2, s0, s1, s2, q0, q1, q2, q3, keys, rec, rect, bbox);
+    }
+}
+
+// GsxParams.original_index, before the projection: the keys start out as kEmptyKey ("reaches no tile": the projection then
+// stores only the keys of culled and kept Gaussians, under their original index), and -- GsxParams.block_bounds, a call that
+// renders part of the frame -- one byte per block of GSX_BOUNDS_ROWS rows says whether the windowed kernel may drop the block
+// unread (block_misses_window).  One launch for both.
+template <bool DEVICE_CAMERA>
+__global__ void __launch_bounds__(kBlock)
+    prepare_reordered_kernel(GsxCamera cam_arg, const GsxCamera *__restrict__ cam_dev, TileGrid grid, uint32_t *__restrict__ keys,
+                             int64_t n, const float4 *__restrict__ bounds, int64_t nblocks, uint8_t *__restrict__ dropped) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = t * 4;
+    if (i + 4 <= n) {
+        *reinterpret_cast<uint4 *>(keys + i) = make_uint4(kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey);
+    } else {
+        for (int64_t k = i; k < n; ++k) keys[k] = kEmptyKey;
+    }
+    if (dropped && t < nblocks) {
+        const GsxCamera &cam = DEVICE_CAMERA ? *cam_dev : cam_arg;
+        dropped[t] = block_misses_window(cam, grid, bounds[2 * t], bounds[2 * t + 1]) ? 1 : 0;
+    }
 }
 
 // gsx_preprocess, last kernel: all PreprocessedScene fields (the reference's stage-1 API surface) in depth order, one
@@ -763,20 +918,33 @@ template <int SHDEG>
 static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                     const TileGrid &grid, int semantics, bool tight_rects, int visible_rows, uint32_t *keys,
                                     Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, const ScheduleHint &sh,
-                                    hipStream_t s) {
+                                    uint8_t *block_scratch, hipStream_t s) {
     const SchedJob job{sh.lens, sh.sched, sh.header, sh.ntiles, sh.nwy, sched_cap(sh.ntiles, sh.nwy)};
     const unsigned spare = sh.sched ? kSchedXcds : 0u;
     const bool vec = (reinterpret_cast<uintptr_t>(in.colors) & 15u) == 0;
     // a strict part of the frame (a rank's strip, a tile window): most Gaussians miss it -> two-phase kernel
     const bool windowed = grid.wx0 > 0 || grid.wy0 > 0 || grid.wx1 < grid.ntx || grid.wy1 < grid.nty;
-#define GSX_LAUNCH_PP(DC, WIN)                                                                                          \
-    project_pack_kernel<DC, SHDEG, WIN><<<blocks_for(n) + spare, kBlock, 0, s>>>(cam, cam_device, in, n, grid, semantics, \
-                                                                         tight_rects, visible_rows ? visible_rows : rows_class(n), keys, rec, rect, counters, bbox, vec, job)
-    if (cam_device) {
-        if (windowed) GSX_LAUNCH_PP(true, true); else GSX_LAUNCH_PP(true, false);
-    } else {
-        if (windowed) GSX_LAUNCH_PP(false, true); else GSX_LAUNCH_PP(false, false);
+    // GsxParams.original_index: pre-filled keys; GsxParams.block_bounds on a windowed call: which blocks to drop unread
+    uint8_t *dropped = nullptr;
+    if (in.original_index) {
+        const int64_t nblocks = (n + kWinRows - 1) / kWinRows;
+        if (windowed && in.block_bounds && semantics != GSX_SEM_STD_3DGS && block_scratch) dropped = block_scratch;
+        const unsigned blocks = blocks_for((n + 3) / 4 > nblocks ? (n + 3) / 4 : nblocks);
+        if (cam_device)
+            prepare_reordered_kernel<true><<<blocks, kBlock, 0, s>>>(cam, cam_device, grid, keys, n, in.block_bounds, nblocks, dropped);
+        else
+            prepare_reordered_kernel<false><<<blocks, kBlock, 0, s>>>(cam, cam_device, grid, keys, n, in.block_bounds, nblocks, dropped);
     }
+#define GSX_LAUNCH_PP(DC)                                                                                             \
+    do {                                                                                                              \
+        if (windowed)                                                                                                 \
+            project_window_kernel<DC, SHDEG><<<(unsigned)((n + kWinRows - 1) / kWinRows) + spare, kBlock, 0, s>>>(     \
+                cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows ? visible_rows : rows_class(n), keys, rec, rect, counters, bbox, vec, job, dropped); \
+        else                                                                                                          \
+            project_pack_kernel<DC, SHDEG><<<blocks_for(n) + spare, kBlock, 0, s>>>(                                   \
+                cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows ? visible_rows : rows_class(n), keys, rec, rect, counters, bbox, vec, job); \
+    } while (0)
+    if (cam_device) GSX_LAUNCH_PP(true); else GSX_LAUNCH_PP(false);
 #undef GSX_LAUNCH_PP
 }
 
@@ -784,14 +952,14 @@ static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_d
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                const TileGrid &grid, int semantics, bool tight_rects, int visible_rows, int sh_degree,
                                uint32_t *keys, Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox,
-                               const ScheduleHint &sched, hipStream_t s) {
+                               const ScheduleHint &sched, uint8_t *block_scratch, hipStream_t s) {
     if (n == 0) return hipSuccess;
     switch (sh_degree) {
-        case 0: launch_project_pack_deg<0>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, s); break;
-        case 1: launch_project_pack_deg<1>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, s); break;
-        case 2: launch_project_pack_deg<2>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, s); break;
-        case 3: launch_project_pack_deg<3>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, s); break;
-        default: launch_project_pack_deg<-1>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, s); break;
+        case 0: launch_project_pack_deg<0>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s); break;
+        case 1: launch_project_pack_deg<1>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s); break;
+        case 2: launch_project_pack_deg<2>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s); break;
+        case 3: launch_project_pack_deg<3>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s); break;
+        default: launch_project_pack_deg<-1>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s); break;
     }
     return hipGetLastError();
 }

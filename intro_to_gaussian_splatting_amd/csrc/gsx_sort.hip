@@ -361,13 +361,14 @@ __global__ void __launch_bounds__(kThreads)
         const uint32_t i = wave_base + (uint32_t)r * 64 + lane;
         ok[r] = i < n;
         key[r] = ok[r] ? kin[i] : (Key)0;
-        // FIRST: the value of an item is its position (the Gaussian index): nothing to read
-        val[r] = (MODE & kModeFirst) ? i : (ok[r] ? vin[i] : 0u);
+        // FIRST: the value of an item is its position (the Gaussian index): nothing to read -- unless the positions are
+        // original indices of reordered rows (GsxParams.row_of_index, handed in as `vin`): then it is the row
+        val[r] = (MODE & kModeFirst) ? (vin ? (ok[r] ? vin[i] : 0u) : i) : (ok[r] ? vin[i] : 0u);
         if (CARRY) {
             carry[r] = 0u;
             if (ok[r]) {
                 if (MODE & kModeFirst) {
-                    const TileRect t = rect[i];       // (index order: coalesced)
+                    const TileRect t = rect[val[r]];  // (index order: coalesced; a gather under row_of_index)
                     carry[r] = (uint32_t)t.x0 | ((uint32_t)t.x1 << 8) | ((uint32_t)t.y0 << 16) | ((uint32_t)t.y1 << 24);
                 } else {
                     carry[r] = cin[i];
@@ -1140,7 +1141,7 @@ __device__ __forceinline__ void small_sort_in_lds(const uint32_t *__restrict__ k
                                                   TileRect *__restrict__ rrect, uint32_t *__restrict__ m_out,
                                                   uint32_t *__restrict__ culled_out, RankShared &sh, uint32_t *skey,
                                                   uint32_t *sval, uint32_t *s_min, uint32_t *s_max, uint32_t *s_culled,
-                                                  unsigned long long *__restrict__ chunk_sums) {
+                                                  unsigned long long *__restrict__ chunk_sums, const uint32_t *__restrict__ row_of) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t key[R], val[R];
     bool ok[R];
@@ -1150,7 +1151,7 @@ __device__ __forceinline__ void small_sort_in_lds(const uint32_t *__restrict__ k
         const uint32_t i = (uint32_t)w * L + (uint32_t)r * 64 + lane;
         const bool in = (uint32_t)r * 64 < L && i < n;
         key[r] = in ? keys[i] : 0u;
-        val[r] = i;
+        val[r] = (row_of && in) ? row_of[i] : i;        // (GsxParams.row_of_index: the row the original index i names)
         ok[r] = in && key[r] < kEmptyKey;
         culled += in && key[r] == kCulledKey;
     }
@@ -1173,7 +1174,8 @@ __device__ __forceinline__ void small_sort_in_lds(const uint32_t *__restrict__ k
 __global__ void __launch_bounds__(kBigThreads)
     small_depth_sort_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ vout,
                             const TileRect *__restrict__ rect, TileRect *__restrict__ rrect, uint32_t *__restrict__ m_out,
-                            uint32_t *__restrict__ culled_out, unsigned long long *__restrict__ chunk_sums) {
+                            uint32_t *__restrict__ culled_out, unsigned long long *__restrict__ chunk_sums,
+                            const uint32_t *__restrict__ row_of) {
     __shared__ RankShared sh;
     __shared__ uint32_t skey[kBucketCap];
     __shared__ uint32_t sval[kBucketCap];
@@ -1188,14 +1190,14 @@ __global__ void __launch_bounds__(kBigThreads)
     __syncthreads();
     const uint32_t L = (((n + kBigWaves - 1) / kBigWaves) + 63u) & ~63u;
     if (L <= 2 * 64)
-        small_sort_in_lds<2>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled, chunk_sums);
+        small_sort_in_lds<2>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled, chunk_sums, row_of);
     else if (L <= 4 * 64)
-        small_sort_in_lds<4>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled, chunk_sums);
+        small_sort_in_lds<4>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled, chunk_sums, row_of);
     else if (L <= 8 * 64)
-        small_sort_in_lds<8>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled, chunk_sums);
+        small_sort_in_lds<8>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max, &s_culled, chunk_sums, row_of);
     else
         small_sort_in_lds<kBucketRounds>(keys, n, L, vout, rect, rrect, m_out, culled_out, sh, skey, sval, &s_min, &s_max,
-                                         &s_culled, chunk_sums);
+                                         &s_culled, chunk_sums, row_of);
 }
 
 struct PassPlan {
@@ -1340,20 +1342,21 @@ template <int NB>
 static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1, uint32_t *vals_cur, uint32_t *vals_alt,
                              int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
                              const uint32_t *splitters, const uint32_t *hdr, uint32_t *samples_out, uint32_t step,
-                             unsigned long long *zero_sums, uint32_t nsums, hipStream_t s) {
+                             unsigned long long *zero_sums, uint32_t nsums, hipStream_t s, const uint32_t *row_of = nullptr) {
+    (void)vals_cur;     // (FIRST mode generates the values: `vin` of its scatter is GsxParams.row_of_index, or null)
     if (NB == kBins && p.self_scan) {
         count_kernel<uint32_t, true, true, kBins><<<p.nblocks, kThreads, 0, s>>>(keys0, nullptr, (uint32_t)n, 0, 255u, p.table,
                                                                                  p.nbp, culled_dev, splitters, nullptr, hdr,
                                                                                  samples_out, step, zero_sums, nsums);
         scatter_kernel<uint32_t, kScanSelf, kModeFirst, 8, kBins><<<(p.nblocks + 7) & ~7, kThreads, 0, s>>>(
-            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
+            keys0, row_of, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
             nullptr, hdr);
     } else if (NB == kBins && p.scan == kScanQuads) {
         count_kernel<uint32_t, false, true, kBins><<<p.nquads, kQuad * kThreads, 0, s>>>(
             keys0, nullptr, (uint32_t)n, 0, 255u, p.table, p.nbp, culled_dev, splitters, p.quad_totals, hdr, samples_out, step,
             zero_sums, nsums);
         scatter_kernel<uint32_t, kScanQuads, kModeFirst, 8, kBins><<<(p.nblocks + 7) & ~7, kThreads, 0, s>>>(
-            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
+            keys0, row_of, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
             p.quad_totals, hdr);
     } else {
         count_kernel<uint32_t, false, true, NB><<<p.nquads, kQuad * kThreads, 0, s>>>(
@@ -1361,7 +1364,7 @@ static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1
             NB == kBins ? samples_out : nullptr, step, zero_sums, nsums);
         row_scan_kernel<<<NB, kThreads, 0, s>>>(p.table, p.nbp, p.totals);
         scatter_kernel<uint32_t, kScanRows, kModeFirst, 8, NB><<<(p.nblocks + 7) & ~7, kThreads, 0, s>>>(
-            keys0, vals_cur, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
+            keys0, row_of, keys1, vals_alt, nullptr, (uint32_t)n, 0, p.table, p.totals, p.nbp, m_dev, rect, rrect, splitters,
             nullptr, NB == kBins ? hdr : nullptr);
     }
 }
@@ -1374,11 +1377,11 @@ static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1
 hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
                               uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,
                               const TileRect *rect, TileRect *rrect, uint32_t lds_cap, uint64_t *chunk_sums,
-                              const SortHints &hints, hipStream_t s) {
+                              const SortHints &hints, hipStream_t s, const uint32_t *row_of) {
     if (n <= 0) return hipSuccess;
     unsigned long long *cs = reinterpret_cast<unsigned long long *>(chunk_sums);
     if (route == kDepthOneWorkgroup && n <= kBucketCap && lds_cap == 0) {   // everything fits one workgroup's LDS: one launch
-        small_depth_sort_kernel<<<1, kBigThreads, 0, s>>>(keys0, (uint32_t)n, vals_cur, rect, rrect, m_dev, culled_dev, cs);
+        small_depth_sort_kernel<<<1, kBigThreads, 0, s>>>(keys0, (uint32_t)n, vals_cur, rect, rrect, m_dev, culled_dev, cs, row_of);
         return hipGetLastError();
     }
     const int nb = route == kDepth1024 ? kSortBinsMax : kBins;
@@ -1405,7 +1408,7 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
 #else
         sample_rank_kernel<kSortBinsMax><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
         launch_partition<kSortBinsMax>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect, splitters, nullptr,
-                                       nullptr, 0u, nullptr, 0u, s);
+                                       nullptr, 0u, nullptr, 0u, s, row_of);
         bucket_sort_kernel<kSortBinsMax><<<kSortBinsMax, kBigThreads, 0, s>>>(p.totals, p.table, 0, keys1, vals_alt, keys0, vals_cur,
                                                                               rect, rrect, lds_cap, cs);
 #endif
@@ -1414,7 +1417,7 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
         if (!use) sample_rank_kernel<kBins><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
         launch_partition<kBins>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect,
                                 use ? hints.splitters : splitters, use ? hints.header : nullptr, samples_out, step,
-                                use ? cs : nullptr, nsums, s);
+                                use ? cs : nullptr, nsums, s, row_of);
         bucket_sort_kernel<kBins><<<kBins, kBigThreads, 0, s>>>(p.totals, p.table, p.self_scan ? p.nblocks : 0, keys1, vals_alt,
                                                                 keys0, vals_cur, rect, rrect, lds_cap, cs);
     }
@@ -1427,7 +1430,7 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
 // On return vals_cur[0 .. *m_dev) = Gaussian index of each depth rank.
 hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur, uint32_t *&vals_alt,
                               int64_t n, uint32_t *m_dev, uint32_t *culled_dev, const TileRect *rect, TileRect *rrect,
-                              hipStream_t s, uint32_t *samples_out, uint32_t *carry0, uint32_t *carry1) {
+                              hipStream_t s, uint32_t *samples_out, uint32_t *carry0, uint32_t *carry1, const uint32_t *row_of) {
     if (n <= 0) return hipSuccess;
     const PassPlan p = plan_for(temp, n);
     uint32_t *kc = keys0, *ka = keys1;
@@ -1442,7 +1445,7 @@ hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint
     };
     // (samples_out: GsxParams.hints -- pass 0's count kernel leaves the sample of kept keys a later frame's splitters
     // are ranked from, should that frame take the 256-bucket route: a rank's strip does, once its kept count is known)
-    launch_pass<uint32_t, kModeFirst, 8>(p, kc, vals_cur, ka, vals_alt, nullptr, n, 0, m_dev, culled_dev, carry ? rect : nullptr,
+    launch_pass<uint32_t, kModeFirst, 8>(p, kc, row_of, ka, vals_alt, nullptr, n, 0, m_dev, culled_dev, carry ? rect : nullptr,
                                          nullptr, s, samples_out, samples_out && n >= kSamples ? (uint32_t)(n / kSamples) : 0u,
                                          nullptr, ca, carry);
     flip();

@@ -281,6 +281,16 @@ class GaussianScene:
             tensors.append(_check_f32("colors", colors.reshape(n, 3), dev))
         return dev, n, tensors
 
+    def _original_index(self, dev, n: int) -> Optional[torch.Tensor]:
+        """``gaussians.original_index`` (Gaussians.spatially_ordered) as the library wants it -- int32, contiguous, n
+        entries, on the device of the parameters -- or None for rows in the caller's own order."""
+        oi = getattr(self.gaussians, "original_index", None)
+        if oi is None:
+            return None
+        if oi.device != dev or oi.dtype != torch.int32 or not oi.is_contiguous() or oi.numel() != n:
+            raise ValueError("gaussians.original_index must be a contiguous int32 tensor of %d entries on %s" % (n, dev))
+        return oi
+
     # ------------------------------------------------------------------ stage 1
     def preprocess(self, image_idx: int) -> PreprocessedScene:
         """Projection + depth sort on the GPU (gsx_preprocess); fields as splat/schema.py:13-25."""
@@ -304,6 +314,9 @@ class GaussianScene:
         order = f(n).view(torch.int32)
         nvis = ctypes.c_int64(0)
         params = _ffi.default_params()
+        oi = self._original_index(dev, n)
+        if oi is not None:          # spatially ordered rows: everything is filed and reported under the original index
+            params.original_index = oi.data_ptr()
         with torch.cuda.device(dev):
             nbytes = lib.gsx_workspace_bytes(n, cam.width, cam.height, 16, 1)
             ws = _WORKSPACE.get(dev, nbytes)
@@ -381,6 +394,20 @@ class GaussianScene:
             k = (int(g.sh_degree) + 1) ** 2
             sh_flat = _check_f32("sh", g.sh.reshape(n, k, 3), dev)
             params.sh, params.sh_degree = sh_flat.data_ptr(), int(g.sh_degree)
+        oi = self._original_index(dev, n)
+        if oi is not None:          # spatially ordered rows (Gaussians.spatially_ordered): same frame, bit for bit
+            ro = getattr(g_, "row_of_index", None)
+            if ro is None or ro.device != dev or ro.dtype != torch.int32 or not ro.is_contiguous() or ro.numel() != n:
+                raise ValueError("gaussians.row_of_index (the inverse of original_index) must be a contiguous int32 tensor "
+                                 "of %d entries on %s" % (n, dev))
+            params.original_index, params.row_of_index = oi.data_ptr(), ro.data_ptr()
+            bb = getattr(g_, "block_bounds", None)
+            if bb is not None:      # ... and a strip's projection drops whole blocks of 256 rows after reading their box
+                if bb.device != dev or bb.dtype != torch.float32 or not bb.is_contiguous() or \
+                        tuple(bb.shape) != (-(-n // _ffi.GSX_BOUNDS_ROWS), 8):
+                    raise ValueError("gaussians.block_bounds must be a contiguous float32 (%d, 8) tensor on %s "
+                                     "(Gaussians.refresh_block_bounds)" % (-(-n // _ffi.GSX_BOUNDS_ROWS), dev))
+                params.block_bounds = bb.data_ptr()
         params.layout = _ffi.GSX_LAYOUT_WH3 if layout == "wh3" else _ffi.GSX_LAYOUT_HW3
         params.semantics = _SEMANTICS[semantics]
         params.background[0], params.background[1], params.background[2] = [float(v) for v in background]
@@ -456,7 +483,8 @@ class GaussianScene:
                 raise ValueError("capture_frame needs contiguous float32 Gaussian tensors: a captured frame replays "
                                  "from the scene's own memory, and a non-contiguous attribute would be copied once, "
                                  "at capture time")
-            own["inputs"][:] = passed
+            own["inputs"][:] = passed + ([oi, g_.row_of_index] if oi is not None else []) + \
+                ([g_.block_bounds] if oi is not None and getattr(g_, "block_bounds", None) is not None else [])
         # how many Gaussians reached a tile of this window last time: picks the depth-sort route (a hint)
         params.kept_hint = int(own.get("kept", self._kept_hints.get(cap_key, 0)))
         # GSX_FLAG_PLAIN_FOOTPRINTS: no tile of the last frame of this view held an ill-conditioned footprint, so this one runs

@@ -32,6 +32,12 @@ class Gaussians:
         # build extension: spherical-harmonic colour (N,K,3); None = use `colors` like the reference
         self.sh: Optional[torch.Tensor] = None
         self.sh_degree = 0
+        # build extension (spatially_ordered): int32 (N,), the ORIGINAL index of the Gaussian in every row; None = the rows
+        # are in the caller's own order
+        self.original_index: Optional[torch.Tensor] = None
+        self.row_of_index: Optional[torch.Tensor] = None      # its inverse: row_of_index[original_index[i]] == i
+        # ... and float32 (ceil(N / 256), 8): per block of 256 rows (min xyz, largest |scale|, max xyz, 0) -- GsxParams.block_bounds
+        self.block_bounds: Optional[torch.Tensor] = None
 
     def __len__(self) -> int:
         return int(self.points.shape[0])
@@ -42,8 +48,75 @@ class Gaussians:
             setattr(self, name, getattr(self, name).to(dev).contiguous())
         if self.sh is not None:
             self.sh = self.sh.to(dev).contiguous()
+        if self.original_index is not None:
+            self.original_index = self.original_index.to(dev).contiguous()
+            self.row_of_index = self.row_of_index.to(dev).contiguous()
+        if self.block_bounds is not None:
+            self.block_bounds = self.block_bounds.to(dev).contiguous()
         self.device = dev
         return self
+
+    def refresh_block_bounds(self, rows: int = 256) -> None:
+        """(Re)computes ``block_bounds`` from the CURRENT points and scales of a spatially ordered container: per block of
+        ``rows`` = GSX_BOUNDS_ROWS consecutive rows the box of the means and the largest |scale|.  Call it again after
+        changing ``points`` or ``scales`` in place -- the library trusts the bounds (include/gsx.h: block_bounds)."""
+        n = len(self)
+        nb = -(-n // rows)
+        p = self.points.reshape(n, 3)
+        s = self.scales.reshape(n, 3).abs().amax(dim=1) if n else torch.zeros(0, device=p.device)
+        pad = nb * rows - n
+        big = torch.finfo(torch.float32).max
+        lo_src = torch.cat([p, torch.full((pad, 3), big, device=p.device)]) if pad else p
+        hi_src = torch.cat([p, torch.full((pad, 3), -big, device=p.device)]) if pad else p
+        s_src = torch.cat([s, torch.zeros(pad, device=p.device)]) if pad else s
+        out = torch.zeros((nb, 8), dtype=torch.float32, device=p.device)
+        if nb:
+            out[:, 0:3] = lo_src.reshape(nb, rows, 3).amin(dim=1)
+            out[:, 4:7] = hi_src.reshape(nb, rows, 3).amax(dim=1)
+            out[:, 3] = s_src.reshape(nb, rows).amax(dim=1)
+        self.block_bounds = out.contiguous()
+
+    def spatially_ordered(self, bits: int = 10) -> "Gaussians":
+        """A COPY of this container with the rows of every parameter array reordered along a 3D Morton (Z-order) curve of
+        the means (``bits`` per axis over the cloud's bounding box; ties by original index), carrying ``original_index``.
+        Opt-in, one time, view independent.  What it buys: Gaussians that are close in space -- hence on screen -- are
+        close in memory, so a call that renders a PART of the frame (a multi-GPU rank's strip, a tile window) finds the
+        survivors of its window test in runs and reads whole cache lines of their scales / quaternions / opacities /
+        colours instead of a scattered eighth of every line.  What it does not change: the
+        frame.  The library files every depth key under the Gaussian's ORIGINAL index (GsxParams.original_index) and
+        sorts them in that order, so equal depths composite in original-index order, ``GaussianScene.last_order`` and
+        ``preprocess`` report original indices, and every pixel is the unordered scene's, bit for bit (tested); records
+        and rectangles stay in row order (``row_of_index``, the inverse permutation, takes the sort from one to the other).
+        Per block of 256 rows ``block_bounds`` holds the box of the means: a strip's projection drops far blocks unread.  The
+        reference's arrays stay the default; nothing else of the reference's surface sees the permutation."""
+        if self.original_index is not None:
+            return self
+        n = len(self)
+        p = self.points.reshape(n, 3)
+        g = Gaussians.__new__(Gaussians)
+        g.device, g.model_path, g.sh_degree = self.device, self.model_path, self.sh_degree
+        if n == 0:
+            perm = torch.zeros(0, dtype=torch.int64, device=p.device)
+        else:
+            lo, hi = p.min(dim=0).values, p.max(dim=0).values
+            span = torch.clamp(hi - lo, min=1e-30)
+            cells = float(1 << bits)
+            q = torch.clamp(((p - lo) / span * cells).to(torch.int64), 0, (1 << bits) - 1)
+            q = torch.where(torch.isfinite(p), q, torch.zeros_like(q))         # (NaN / inf means: cell 0)
+            code = torch.zeros(n, dtype=torch.int64, device=p.device)
+            for b in range(bits):
+                for axis in range(3):
+                    code |= ((q[:, axis] >> b) & 1) << (3 * b + axis)
+            perm = torch.argsort(code, stable=True)
+        for name in ("points", "colors", "scales", "quaternions", "opacity"):
+            setattr(g, name, getattr(self, name)[perm].contiguous())
+        g.sh = None if self.sh is None else self.sh[perm].contiguous()
+        g.original_index = perm.to(torch.int32).contiguous()
+        g.row_of_index = torch.empty_like(g.original_index)
+        g.row_of_index[perm] = torch.arange(n, dtype=torch.int32, device=perm.device)
+        g.block_bounds = None
+        g.refresh_block_bounds()
+        return g
 
     def get_3d_covariance_matrix(self) -> torch.Tensor:
         """(N,3,3) Sigma = (R S)(R S)^T, computed on the GPU (gsx_covariance_3d); same result as the

@@ -83,8 +83,8 @@ def test_python_constants_equal_the_headers():
 
 def test_struct_layouts():
     assert ctypes.sizeof(_ffi.GsxCamera) == 16 * 4 * 2 + 4 * 4 + 2 * 4 + 3 * 4
-    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16 + 8 + 8 + 24 + 8 and _ffi.GsxParams.kept_hint.offset == 88
-    assert _ffi.GsxParams.stats_size.offset == 128          # (128 = the struct of ABI 302 .. 304)
+    assert ctypes.sizeof(_ffi.GsxParams) == 16 * 4 + 8 + 16 + 8 + 8 + 24 + 8 + 8 + 8 + 8 and _ffi.GsxParams.kept_hint.offset == 88
+    assert _ffi.GsxParams.stats_size.offset == 128 and _ffi.GsxParams.original_index.offset == 136 and _ffi.GsxParams.block_bounds.offset == 144 and _ffi.GsxParams.row_of_index.offset == 152   # (128 = the struct of ABI 302 .. 304)
     assert _ffi.GsxParams.hints.offset == 96 and _ffi.GsxParams.n_substrips.offset == 104       # (104 = the ABI-300 struct)
     assert _ffi.GsxParams.substrip_bounds.offset == 112 and _ffi.GsxParams.substrip_events.offset == 120
     assert _ffi.GsxFrameStats.n_kept.offset == 56 and _ffi.GsxFrameStats.stage_ms.offset == 32

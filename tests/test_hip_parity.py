@@ -1938,3 +1938,63 @@ def test_multi_gpu_path_meets_rccl_with_a_world_of_one():
     assert d["preflight"]["gather_one_rank"] is True, d["preflight"]
     assert d["preflight"]["send_recv_to_self"] is True, d["preflight"]
     assert d["frames_in_flight_path"].startswith("strips.StripPipeline")
+
+
+@pytest.mark.parametrize("name", ["ties_64x64_n400", "trainedlike_128x128_n3000", "cull_96x80_n400", "fewvisible_48x48_n9"])
+def test_spatially_ordered_scene_renders_the_same_frame_bit_for_bit(tmp_path, name):
+    """Gaussians.spatially_ordered() (GsxParams.original_index): the rows of the parameter arrays reordered along a Morton
+    curve, everything filed under the original index -- same frame bit for bit (whole frame, a tile window, a captured
+    frame), same permutation (``last_order`` holds ORIGINAL indices; on the tie fixture 367 of 400 Gaussians share a depth:
+    they still composite in original-index order), same stage-1 arrays, same counts."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import GaussianScene
+
+    g = load_golden(name)
+    scene = _scene_from_golden(tmp_path, g)
+    ordered = GaussianScene(str(tmp_path), scene.gaussians.spatially_ordered())
+    oi = ordered.gaussians.original_index.cpu().numpy()
+    if oi.size > 3:
+        assert not np.array_equal(oi, np.arange(oi.size))
+    tile = int(g["tile"])
+    sa, sb = {}, {}
+    a = scene.render_image_hip(1, tile_size=tile, stats=sa)
+    b = ordered.render_image_hip(1, tile_size=tile, stats=sb)
+    assert torch.equal(a, b)
+    assert {k: sa[k] for k in ("n_visible", "n_instances", "n_kept", "n_redo")} == {k: sb[k] for k in ("n_visible", "n_instances", "n_kept", "n_redo")}
+    assert np.max(np.abs(b.cpu().numpy() - g["image"])) <= (0.25 if name.startswith("ties") else PIXEL_TOL)
+    pa, pb = scene.preprocess(1), ordered.preprocess(1)
+    assert torch.equal(scene.last_order, ordered.last_order)
+    for f in pa._fields:
+        assert torch.equal(getattr(pa, f), getattr(pb, f)), f
+    ntx = (int(g["width"]) - 1) // tile
+    if ntx >= 2:
+        win = (1, ntx, 0, -1)
+        assert torch.equal(scene.render_image_hip(1, tile_size=tile, tile_window=win), ordered.render_image_hip(1, tile_size=tile, tile_window=win))
+    frame = ordered.capture_frame(1, tile_size=tile)
+    assert torch.equal(frame.replay(), a)
+    frame.confirm()
+
+
+def test_spatially_ordered_strips_of_a_100k_scene(tmp_path):
+    """C2 (100k Gaussians, 1080p) in eight column strips from spatially ordered rows: every strip equals the unordered
+    scene's strip, the strips tile the frame, and the SH path (degree 3, evaluated inside the windowed projection kernel
+    from the survivors' coefficient rows) follows the permutation too."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import GaussianScene, strips
+    from intro_to_gaussian_splatting_amd.synthetic import make_trained_like_scene
+
+    sc = make_trained_like_scene(100_000, 1920, 1080, seed=3)
+    scene = _scene_from_arrays(tmp_path, sc)
+    for with_sh in (False, True):
+        if with_sh:
+            scene.gaussians.sh = torch.from_numpy(sc["sh"]).to("cuda:0").contiguous()
+            scene.gaussians.sh_degree = int(sc["sh_degree"])
+        ordered = GaussianScene(str(tmp_path), scene.gaussians.spatially_ordered())
+        whole = scene.render_image_hip(1).clone()
+        assert torch.equal(ordered.render_image_hip(1), whole)
+        ntx, nty = strips.tiles_along(1920, 16), strips.tiles_along(1080, 16)
+        for t0, t1 in strips.strip_plan(ntx, 8)[1]:
+            win = (t0, t1, 0, nty)
+            out = torch.empty(((t1 - t0) * 16, 1080, 3), dtype=torch.float32, device="cuda:0")
+            ordered.render_image_hip(1, tile_window=win, out=out, out_origin=(t0 * 16, 0))
+            assert torch.equal(out, whole[t0 * 16:t1 * 16]), (with_sh, t0, t1)

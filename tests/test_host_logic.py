@@ -335,3 +335,35 @@ def test_visible_rows_flag_names_the_class_or_says_clear():
     assert f(9, 0, 0) == 0 and f(9, 0, few) == 0                       # nothing visible: nothing was multiplied
     assert _ffi.with_rows_flag(few | 1024, -1) == 1024 and _ffi.with_rows_flag(few | 2, one) == (one | 2)
     assert _ffi.with_rows_flag(0, few) == few
+
+
+def test_spatially_ordered_is_a_permutation_that_puts_neighbours_together():
+    """Gaussians.spatially_ordered() (opt-in): every parameter array -- SH coefficients included -- is
+    the same permutation of the original's, ``original_index`` says which; rows that follow each other are close in space;
+    ordering an ordered container is the identity; the source is untouched."""
+    import torch
+
+    from intro_to_gaussian_splatting_amd import Gaussians
+    from intro_to_gaussian_splatting_amd.synthetic import make_trained_like_scene
+
+    sc = make_trained_like_scene(4000, 320, 240, seed=2)
+    g = Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"], sc["opacity"], device="cpu")
+    g.sh, g.sh_degree = torch.from_numpy(sc["sh"]), int(sc["sh_degree"])
+    before = g.points.clone()
+    o = g.spatially_ordered()
+    assert g.original_index is None and torch.equal(g.points, before)
+    idx = o.original_index
+    assert idx.dtype == torch.int32 and sorted(idx.tolist()) == list(range(4000))
+    assert torch.equal(o.row_of_index[idx.long()].long(), torch.arange(4000))                    # the inverse permutation
+    bb = o.block_bounds
+    assert tuple(bb.shape) == (16, 8) and bool((bb[:, 0:3] <= bb[:, 4:7]).all())
+    blk = o.points[256:512]
+    assert torch.equal(bb[1, 0:3], blk.amin(dim=0)) and torch.equal(bb[1, 4:7], blk.amax(dim=0))
+    assert float(bb[1, 3]) == float(o.scales[256:512].abs().max())
+    for name in ("points", "colors", "scales", "quaternions", "opacity", "sh"):
+        assert torch.equal(getattr(o, name), getattr(g, name)[idx.long()]), name
+    assert o.sh_degree == g.sh_degree and o.spatially_ordered() is o
+    step = lambda p: float((p[1:] - p[:-1]).norm(dim=1).mean())  # noqa: E731
+    assert step(o.points) < 0.25 * step(g.points)
+    empty = Gaussians(torch.zeros((0, 3)), torch.zeros((0, 3)), device="cpu").spatially_ordered()
+    assert empty.original_index.numel() == 0
