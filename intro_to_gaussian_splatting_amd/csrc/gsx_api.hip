@@ -415,16 +415,21 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
             fh.sched = sched_hint.sched;
         }
     }
+    // no splitters on file (a view's first frame, a caller without a hints buffer): the projection launch ranks a sample itself
+    gsx::SampleHint presample;
+    if (sampled && !sh.use && gsx::knob("GSX_PRESAMPLE", 1) != 0)
+        presample = gsx::depth_presample(route, ws + c.temp, n, gsx::emit_chunk_sums(ws + c.temp, n, cap), row_of);
     GSX_HIP(gsx::launch_project_pack(*camera, p.camera_device, in, n, p.grid, p.semantics, p.tight, p.small_batch, p.sh_degree, k0, (gsx::Record *)(ws + c.rec),
                                      (gsx::TileRect *)(ws + c.rect), counters,
                                      p.semantics != GSX_SEM_STD_3DGS ? (float4 *)(ws + c.bbox) : nullptr, sched_hint,
-                                     c.temp_bytes >= (size_t)(n / GSX_BOUNDS_ROWS + 1) ? (uint8_t *)(ws + c.temp) : nullptr, s));
+                                     c.temp_bytes >= (size_t)(n / GSX_BOUNDS_ROWS + 1) ? (uint8_t *)(ws + c.temp) : nullptr, s, presample));
     tm.mark();  // 1: project (+ depth keys)
     // the sampled routes also leave the per-chunk tile counts the pair emission starts from (one kernel less)
     if (sampled)
         GSX_HIP(gsx::sort_depth_sampled(route, ws + c.temp, k0, k1, v0, v1, n, p.kept_hint, counters + kCtrKept,
                                         counters + kCtrCulled, (const gsx::TileRect *)(ws + c.rect),
-                                        (gsx::TileRect *)(ws + c.rrect), 0, gsx::emit_chunk_sums(ws + c.temp, n, cap), sh, s, row_of));
+                                        (gsx::TileRect *)(ws + c.rrect), 0, gsx::emit_chunk_sums(ws + c.temp, n, cap), sh, s, row_of,
+                                        presample.splitters != nullptr));
     else {
         // the LSD passes carry the rectangles along, packed into 4 bytes, when tile coordinates fit 8 bits; the two
         // arrays they travel in are the pair lists' value arrays, which nothing uses before the emission

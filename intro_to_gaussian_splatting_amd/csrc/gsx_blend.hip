@@ -1629,27 +1629,11 @@ __global__ void __launch_bounds__(256) zero_words_kernel(uint32_t *__restrict__ 
     if (i < n) p[i] = 0u;
 }
 
-// (the buffer is a workspace array: 256-byte aligned; four words per thread, the tail word by word)
-__global__ void __launch_bounds__(256) fill_words_kernel(uint32_t *__restrict__ p, size_t n, uint32_t value) {
-    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i + 4 <= n) {
-        *reinterpret_cast<uint4 *>(p + i) = make_uint4(value, value, value, value);
-    } else {
-        for (size_t k = i; k < n; ++k) p[k] = value;
-    }
-}
-
 }  // namespace
 
 hipError_t launch_zero_words(uint32_t *p, size_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     zero_words_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p, n);
-    return hipGetLastError();
-}
-
-hipError_t launch_fill_words(uint32_t *p, size_t n, uint32_t value, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    fill_words_kernel<<<(unsigned)((n + 1023) / 1024), 256, 0, s>>>(p, n, value);
     return hipGetLastError();
 }
 

@@ -117,10 +117,20 @@ hipError_t launch_project_stage(const GsxCamera &cam, const GaussiansIn &in, int
 // cam_device (may be null): GsxParams.camera_device, read by the kernel instead of `cam`.
 // sh_degree >= 0: in.colors holds spherical-harmonics coefficients, evaluated inline (GsxParams.sh).
 // counters: 4 words this kernel zeroes for the depth sort (culled count, kept count, ...).
+// A frame without splitters from an earlier frame of its view: `wgs` spare workgroups of the projection launch rank a sample
+// of `ns` keys they compute themselves (gsx_sample_device.h) into the partition pass' splitters and zero its chunk sums --
+// what sample_rank_kernel would do BEHIND the projection.  splitters == nullptr: not wanted.  (depth_presample, below: gsx_sort.hip)
+struct SampleHint {
+    uint32_t *splitters = nullptr;
+    unsigned long long *chunk_sums = nullptr;
+    uint32_t nsums = 0, ns = 0;
+    const uint32_t *row_of = nullptr;      // GsxParams.row_of_index: sample index (an original index) -> row
+};
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                const TileGrid &grid, int semantics, bool tight_rects, int visible_rows, int sh_degree,
                                uint32_t *keys, Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox,
-                               const ScheduleHint &sched, uint8_t *block_scratch, hipStream_t s);
+                               const ScheduleHint &sched, uint8_t *block_scratch, hipStream_t s,
+                               const SampleHint &sample = SampleHint());
 // (block_scratch: ceil(n / GSX_BOUNDS_ROWS) bytes the launch may use when in.block_bounds is set -- the depth sort's
 // temp area, idle until the projection is done; in.original_index: the launch pre-fills the keys itself)
 // gsx_preprocess, last kernel: all PreprocessedScene fields in depth order; order[r] = Gaussian of rank r, r < *m_dev.
@@ -189,6 +199,7 @@ hipError_t sort_depth_compact(void *temp, uint32_t *keys0, uint32_t *keys1, uint
 // lds_cap: 0 = the bucket kernel's capacity; tests pass a small value to drive buckets through its global-memory path.
 enum DepthRoute { kDepthLsd = 0, kDepth256 = 1, kDepth1024 = 2, kDepthOneWorkgroup = 3 };
 DepthRoute depth_sort_route(int64_t n, int64_t kept_hint);
+SampleHint depth_presample(DepthRoute route, void *temp, int64_t n, uint64_t *chunk_sums, const uint32_t *row_of);
 // The depth sort's share of GsxParams.hints (gsx_plan.h: hints_layout); header == nullptr: no hints buffer.
 struct SortHints {
     uint32_t *header;           // kHintSplitters says whether `splitters` are there, kHintLens / kHintSched how many tiles
@@ -212,7 +223,7 @@ struct BlendHints {
 hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
                               uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,
                               const TileRect *rect, TileRect *rrect, uint32_t lds_cap, uint64_t *chunk_sums,
-                              const SortHints &hints, hipStream_t s, const uint32_t *row_of = nullptr);
+                              const SortHints &hints, hipStream_t s, const uint32_t *row_of = nullptr, bool presampled = false);
 // Where emit_instances keeps its chunk sums inside `temp` (for sort_depth_sampled to fill them in).
 uint64_t *emit_chunk_sums(void *temp, int64_t n, int64_t cap);
 
@@ -244,6 +255,5 @@ hipError_t launch_blend(const Record *rec, const float4 *bbox, const uint32_t *s
 bool blend_splits_long_tiles(const TileGrid &grid, int semantics, bool generic);
 hipError_t launch_clear(const ClearPlan &cp, float *base, hipStream_t s);   // the zero fill alone
 hipError_t launch_zero_words(uint32_t *p, size_t n, hipStream_t s);
-hipError_t launch_fill_words(uint32_t *p, size_t n, uint32_t value, hipStream_t s);
 
 }  // namespace gsx

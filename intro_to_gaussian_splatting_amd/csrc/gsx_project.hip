@@ -20,6 +20,7 @@
 //   splat/utils.py:409-423          r = ceil(3 sqrt(lambda_max)), discriminant floored at 0.1
 //   splat/gaussian_scene.py:209-217 tile membership test (min <= x0 + T and max >= x0)
 #include "gsx_internal.h"
+#include "gsx_sample_device.h"
 #include "gsx_schedule_device.h"
 #include "gsx_sh_device.h"
 
@@ -445,6 +446,29 @@ __device__ __forceinline__ void pack_record(int semantics, float x, float y, flo
     out.c = make_float4(cb, depth, 0.0f, 0.0f);
 }
 
+// A spare workgroup of the projection launch ranking its share of the depth sort's sample (SampleHint, gsx_sample_device.h):
+// the key of sample index j is computed here -- the cull plane and the view depth of that Gaussian; whether it reaches a
+// tile of the window is not known yet, and need not be: any monotone set of splitters sorts correctly, these divide the
+// frustum's depths evenly.  lds: ns + 4 words.
+struct SampleJob {
+    uint32_t *splitters;
+    unsigned long long *chunk_sums;
+    uint32_t nsums, ns, wgs;
+    const uint32_t *row_of;
+};
+__device__ __forceinline__ void presample_depths(const GsxCamera &cam, const GaussiansIn &in, int64_t n, int semantics,
+                                                 const SampleJob &job, uint32_t wg, uint32_t *lds) {
+    const bool std3dgs = semantics == GSX_SEM_STD_3DGS;
+    sample_rank_body<kSortBins>(
+        [&](uint32_t j) -> uint32_t {
+            const int64_t row = job.row_of ? (int64_t)job.row_of[j] : (int64_t)j;
+            const float *p = in.means3d + 3 * row;
+            const float tz = row4(p[0], p[1], p[2], cam.world2view, 2);
+            return (std3dgs ? !(tz > 0.2f) : !(tz >= 0.2f)) ? kCulledKey : __float_as_uint(tz);
+        },
+        (uint32_t)n, job.ns, job.splitters, job.chunk_sums, job.nsums, wg, job.wgs, lds, lds + job.ns);
+}
+
 // The exact projection of ONE Gaussian: row g of the input arrays; record and rectangle go to row g, the depth key to `slot`
 // (g itself unless GsxParams.original_index reorders the rows: then the key is filed under the original index, which is the
 // order the stable depth sort enumerates the keys in).  CULL: the caller has not applied the cull plane yet (the
@@ -541,18 +565,27 @@ __global__ void __launch_bounds__(kBlock)
                         TileGrid grid, int semantics, bool tight, int vis,
                         uint32_t *__restrict__ keys, Record *__restrict__ rec,
                         TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox,
-                        bool sh_vec, SchedJob sched_job) {
-    // the launch's eight spare workgroups -- blocks 0 .. 7, dispatched FIRST and long done when the Gaussians' blocks
-    // are: the compositing schedule of this frame, one XCD's share each, from the list lengths the previous frame left
-    // (GsxParams.hints, gsx_schedule_device.h)
-    if (sched_job.sched && blockIdx.x < kSchedXcds) {
+                        bool sh_vec, SchedJob sched_job, SampleJob sample_job) {
+    constexpr int DEG = SHDEG >= 0 ? SHDEG : 0;
+    using L = sh::Layout<DEG>;
+    // (the spare workgroups' sample lives where the others stage spherical harmonics: kSortSamples + 4 words at least)
+    constexpr int kShWords = SHDEG >= 0 ? L::kRows * L::STRIDE : 1;
+    __shared__ float sh_lds[kShWords > kSortSamples + 4 ? kShWords : kSortSamples + 4];
+    // the launch's spare workgroups -- the first blocks, dispatched FIRST and long done when the Gaussians' blocks are:
+    //   eight put the compositing schedule of this frame together, one XCD's share each, from the list lengths the previous
+    //   frame left (GsxParams.hints, gsx_schedule_device.h);
+    //   on a frame without splitters 128 rank the depth sort's sample (presample_depths)
+    const uint32_t nsched = sched_job.sched ? kSchedXcds : 0u;
+    if (blockIdx.x < nsched) {
         schedule_from_lengths(sched_job, blockIdx.x);
         return;
     }
-    const int64_t blk = (int64_t)blockIdx.x - (sched_job.sched ? (int64_t)kSchedXcds : 0);
-    constexpr int DEG = SHDEG >= 0 ? SHDEG : 0;
-    using L = sh::Layout<DEG>;
-    __shared__ float sh_lds[SHDEG >= 0 ? L::kRows * L::STRIDE : 1];
+    const uint32_t nspare = nsched + (sample_job.splitters ? sample_job.wgs : 0u);
+    if (blockIdx.x < nspare) {
+        presample_depths(DEVICE_CAMERA ? *cam_dev : cam_arg, in, n, semantics, sample_job, blockIdx.x - nsched, reinterpret_cast<uint32_t *>(sh_lds));
+        return;
+    }
+    const int64_t blk = (int64_t)blockIdx.x - (int64_t)nspare;
     int64_t g = blk * kBlock + threadIdx.x;
     if (g < 4) counters[g] = 0u;   // the depth sort's culled / kept counts start from zero (no memset node)
     // GsxParams.original_index: row g of the inputs is the Gaussian of ORIGINAL index remap[g]; its key, record and rectangle
@@ -640,15 +673,22 @@ __global__ void __launch_bounds__(kBlock)
                           TileGrid grid, int semantics, bool tight, int vis,
                           uint32_t *__restrict__ keys, Record *__restrict__ rec,
                           TileRect *__restrict__ rect, uint32_t *__restrict__ counters, float4 *__restrict__ bbox,
-                          bool sh_vec, SchedJob sched_job, const uint8_t *__restrict__ block_dropped) {
-    if (sched_job.sched && blockIdx.x < kSchedXcds) {       // (the spare workgroups of the launch: see project_pack_kernel)
+                          bool sh_vec, SchedJob sched_job, const uint8_t *__restrict__ block_dropped, SampleJob sample_job) {
+    constexpr int DEG = SHDEG >= 0 ? SHDEG : 0;
+    using L = sh::Layout<DEG>;
+    constexpr int kShWords = SHDEG >= 0 ? L::kRows * L::STRIDE : 1;
+    __shared__ float sh_lds[kShWords > kSortSamples + 4 ? kShWords : kSortSamples + 4];
+    const uint32_t nsched = sched_job.sched ? kSchedXcds : 0u;       // (the spare workgroups of the launch: see project_pack_kernel)
+    if (blockIdx.x < nsched) {
         schedule_from_lengths(sched_job, blockIdx.x);
         return;
     }
-    const int64_t blk = (int64_t)blockIdx.x - (sched_job.sched ? (int64_t)kSchedXcds : 0);
-    constexpr int DEG = SHDEG >= 0 ? SHDEG : 0;
-    using L = sh::Layout<DEG>;
-    __shared__ float sh_lds[SHDEG >= 0 ? L::kRows * L::STRIDE : 1];
+    const uint32_t nspare = nsched + (sample_job.splitters ? sample_job.wgs : 0u);
+    if (blockIdx.x < nspare) {
+        presample_depths(DEVICE_CAMERA ? *cam_dev : cam_arg, in, n, semantics, sample_job, blockIdx.x - nsched, reinterpret_cast<uint32_t *>(sh_lds));
+        return;
+    }
+    const int64_t blk = (int64_t)blockIdx.x - (int64_t)nspare;
     __shared__ uint16_t s_list[kWinRows];
     __shared__ uint32_t s_wcnt[kWinPer][kBlock / 64];
     const int64_t base = blk * kWinRows;
@@ -918,9 +958,11 @@ template <int SHDEG>
 static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                     const TileGrid &grid, int semantics, bool tight_rects, int visible_rows, uint32_t *keys,
                                     Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox, const ScheduleHint &sh,
-                                    uint8_t *block_scratch, hipStream_t s) {
+                                    uint8_t *block_scratch, hipStream_t s, const SampleHint &sample) {
     const SchedJob job{sh.lens, sh.sched, sh.header, sh.ntiles, sh.nwy, sched_cap(sh.ntiles, sh.nwy)};
-    const unsigned spare = sh.sched ? kSchedXcds : 0u;
+    const SampleJob sjob{sample.splitters, sample.chunk_sums, sample.nsums, sample.ns,
+                         sample.splitters ? sample_rank_workgroups(sample.ns) : 0u, sample.row_of};
+    const unsigned spare = (sh.sched ? kSchedXcds : 0u) + sjob.wgs;
     const bool vec = (reinterpret_cast<uintptr_t>(in.colors) & 15u) == 0;
     // a strict part of the frame (a rank's strip, a tile window): most Gaussians miss it -> two-phase kernel
     const bool windowed = grid.wx0 > 0 || grid.wy0 > 0 || grid.wx1 < grid.ntx || grid.wy1 < grid.nty;
@@ -939,10 +981,10 @@ static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_d
     do {                                                                                                              \
         if (windowed)                                                                                                 \
             project_window_kernel<DC, SHDEG><<<(unsigned)((n + kWinRows - 1) / kWinRows) + spare, kBlock, 0, s>>>(     \
-                cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows ? visible_rows : rows_class(n), keys, rec, rect, counters, bbox, vec, job, dropped); \
+                cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows ? visible_rows : rows_class(n), keys, rec, rect, counters, bbox, vec, job, dropped, sjob); \
         else                                                                                                          \
             project_pack_kernel<DC, SHDEG><<<blocks_for(n) + spare, kBlock, 0, s>>>(                                   \
-                cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows ? visible_rows : rows_class(n), keys, rec, rect, counters, bbox, vec, job); \
+                cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows ? visible_rows : rows_class(n), keys, rec, rect, counters, bbox, vec, job, sjob); \
     } while (0)
     if (cam_device) GSX_LAUNCH_PP(true); else GSX_LAUNCH_PP(false);
 #undef GSX_LAUNCH_PP
@@ -952,14 +994,14 @@ static void launch_project_pack_deg(const GsxCamera &cam, const GsxCamera *cam_d
 hipError_t launch_project_pack(const GsxCamera &cam, const GsxCamera *cam_device, const GaussiansIn &in, int64_t n,
                                const TileGrid &grid, int semantics, bool tight_rects, int visible_rows, int sh_degree,
                                uint32_t *keys, Record *rec, TileRect *rect, uint32_t *counters, float4 *bbox,
-                               const ScheduleHint &sched, uint8_t *block_scratch, hipStream_t s) {
+                               const ScheduleHint &sched, uint8_t *block_scratch, hipStream_t s, const SampleHint &sample) {
     if (n == 0) return hipSuccess;
     switch (sh_degree) {
-        case 0: launch_project_pack_deg<0>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s); break;
-        case 1: launch_project_pack_deg<1>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s); break;
-        case 2: launch_project_pack_deg<2>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s); break;
-        case 3: launch_project_pack_deg<3>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s); break;
-        default: launch_project_pack_deg<-1>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s); break;
+        case 0: launch_project_pack_deg<0>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s, sample); break;
+        case 1: launch_project_pack_deg<1>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s, sample); break;
+        case 2: launch_project_pack_deg<2>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s, sample); break;
+        case 3: launch_project_pack_deg<3>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s, sample); break;
+        default: launch_project_pack_deg<-1>(cam, cam_device, in, n, grid, semantics, tight_rects, visible_rows, keys, rec, rect, counters, bbox, sched, block_scratch, s, sample); break;
     }
     return hipGetLastError();
 }

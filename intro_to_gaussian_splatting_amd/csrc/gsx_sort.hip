@@ -39,6 +39,7 @@
 #include <type_traits>
 
 #include "gsx_internal.h"
+#include "gsx_sample_device.h"
 
 namespace gsx {
 namespace {
@@ -920,77 +921,15 @@ __device__ __forceinline__ void bucket_in_lds(uint32_t start, uint32_t size, uin
     }
 }
 
-// The NB - 1 splitters of the partition pass: regular quantiles of the VALID ones among `ns` regularly spaced keys
-// (key at index i n / ns; a key >= kEmptyKey is dropped by the sort and says nothing about where the kept keys
-// lie -- on a rank that owns 1/8 of the frame 7 of 8 samples are of that kind, which is why such a frame takes
-// 8192 samples instead of 2048): splitters[j] = the valid sample of rank floor(j V / NB), V = number of valid
-// samples, splitters[0] = 0.  A single workgroup sorting the samples took 41 us (one CU doing 4 LDS radix
-// passes); here every workgroup packs the valid samples into LDS in index order (a thread owns ns / 256
-// consecutive samples, all loads in flight at once) and every sample's rank is counted directly --
-// #{j : s[j] < s[i]} + #{j < i : s[j] == s[i]} -- by 16 lanes that share the V comparisons, 16 samples per
-// workgroup; the sample that finds itself on a quantile writes the splitter(s) it is.
-constexpr int kRankLanes = 16, kRankPerGroup = kThreads / kRankLanes;   // 16 samples per 256-thread workgroup
-constexpr int kSamplesMax = kSortSamplesMax, kSamplesPerThreadMax = kSamplesMax / kThreads;
+// (the ranking itself: gsx_sample_device.h -- shared with the projection launch, whose spare workgroups rank a sample of
+// keys they compute themselves on a frame that has no splitters yet)
 template <int NB>
 __global__ void __launch_bounds__(kThreads)
     sample_rank_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t ns, uint32_t *__restrict__ splitters,
                        unsigned long long *__restrict__ chunk_sums, uint32_t nsums) {
     __shared__ uint32_t sm[kSamplesMax];
     __shared__ uint32_t s_wave[kThreads / 64];
-    // the chunk sums the bucket kernel adds to start from zero (the first kernel of the sort has threads to spare)
-    for (uint32_t k = blockIdx.x * (uint32_t)kThreads + threadIdx.x; chunk_sums && k < nsums; k += gridDim.x * (uint32_t)kThreads)
-        chunk_sums[k] = 0ull;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t per = ns / (uint32_t)kThreads;           // 8 or 32 (ns = 2048 / 8192)
-    uint32_t v[kSamplesPerThreadMax];
-    uint32_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < kSamplesPerThreadMax; ++k) {
-        v[k] = kCulledKey;
-        if ((uint32_t)k < per) v[k] = keys[(uint32_t)(((uint64_t)(threadIdx.x * per + (uint32_t)k) * n) / ns)];
-        mine += v[k] < kEmptyKey;
-    }
-    uint32_t x = mine;   // inclusive scan over the wave, then over the workgroup
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)x, o);
-        if (lane >= o) x += y;
-    }
-    if (lane == 63) s_wave[w] = x;
-    __syncthreads();
-    uint32_t at = x - mine, valid = 0;
-#pragma unroll
-    for (int k = 0; k < kThreads / 64; ++k) {
-        at += k < w ? s_wave[k] : 0u;
-        valid += s_wave[k];
-    }
-#pragma unroll
-    for (int k = 0; k < kSamplesPerThreadMax; ++k)
-        if (v[k] < kEmptyKey) sm[at++] = v[k];
-    __syncthreads();
-    if (valid == 0) {       // nothing reaches a tile: every key goes to bucket 0 (and is dropped there)
-        if (blockIdx.x == 0)
-            for (int k = threadIdx.x; k < NB; k += kThreads) splitters[k] = 0u;
-        return;
-    }
-    const uint32_t i = blockIdx.x * (uint32_t)kRankPerGroup + (threadIdx.x / kRankLanes);
-    const uint32_t part = threadIdx.x % kRankLanes;
-    if (blockIdx.x == 0 && threadIdx.x == 0) splitters[0] = 0u;
-    if (blockIdx.x * (uint32_t)kRankPerGroup >= valid) return;
-    const uint32_t mykey = i < valid ? sm[i] : 0u;
-    uint32_t c = 0;
-    // lane `part` compares against samples part, part + 16, part + 32, ... (conflict-free across the 16 lanes)
-    for (uint32_t j = part; j < valid; j += kRankLanes) {
-        const uint32_t y = sm[j];
-        c += (y < mykey) | ((y == mykey) & (j < i));
-    }
-#pragma unroll
-    for (int o = kRankLanes / 2; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
-    if (part == 0 && i < valid) {
-        // the quantiles j with floor(j valid / NB) == c (none, one, or several when valid < NB)
-        for (uint32_t j = (c * (uint32_t)NB + valid - 1u) / valid; j < (uint32_t)NB && (j * valid) / NB == c; ++j)
-            if (j) splitters[j] = mykey;
-    }
+    sample_rank_body<NB>([&](uint32_t i) { return keys[i]; }, n, ns, splitters, chunk_sums, nsums, blockIdx.x, gridDim.x, sm, s_wave);
 }
 
 // One workgroup per bucket of the partition pass.  in: (kin, vin) partitioned by bucket, bucket sizes = the
@@ -1369,6 +1308,20 @@ static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1
     }
 }
 
+// What the projection launch needs to rank the sample itself (SampleHint): where sort_depth_sampled(route, temp, .., n, ..)
+// will look for its splitters and which chunk sums it adds to.  Only the 256-bucket route of a frame of >= 8 192 Gaussians.
+SampleHint depth_presample(DepthRoute route, void *temp, int64_t n, uint64_t *chunk_sums, const uint32_t *row_of) {
+    SampleHint h;
+    if (route != kDepth256 || n < kSamplesMax || n >= ((int64_t)1 << 32)) return h;
+    const PassPlan p = plan_for(temp, n, kBins);
+    h.splitters = p.totals + kBins;
+    h.chunk_sums = reinterpret_cast<unsigned long long *>(chunk_sums);
+    h.nsums = (uint32_t)((n + kEmitChunk - 1) / kEmitChunk) + 1u;
+    h.ns = (uint32_t)kSamples;
+    h.row_of = row_of;
+    return h;
+}
+
 // Same contract as sort_depth_compact.  keys0 / keys1 / vals: n words each; on return vals_cur[0 .. *m_dev)
 // = Gaussian index of each depth rank, rrect[rank] = rect[index].  route: kDepthOneWorkgroup / kDepth256 /
 // kDepth1024.  kept_hint: see depth_sort_route (here it only sizes the sample).  lds_cap: bucket size above which
@@ -1377,7 +1330,7 @@ static void launch_partition(const PassPlan &p, uint32_t *keys0, uint32_t *keys1
 hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uint32_t *keys1, uint32_t *&vals_cur,
                               uint32_t *&vals_alt, int64_t n, int64_t kept_hint, uint32_t *m_dev, uint32_t *culled_dev,
                               const TileRect *rect, TileRect *rrect, uint32_t lds_cap, uint64_t *chunk_sums,
-                              const SortHints &hints, hipStream_t s, const uint32_t *row_of) {
+                              const SortHints &hints, hipStream_t s, const uint32_t *row_of, bool presampled) {
     if (n <= 0) return hipSuccess;
     unsigned long long *cs = reinterpret_cast<unsigned long long *>(chunk_sums);
     if (route == kDepthOneWorkgroup && n <= kBucketCap && lds_cap == 0) {   // everything fits one workgroup's LDS: one launch
@@ -1414,7 +1367,9 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
 #endif
     } else {
         const bool use = hinted && hints.use;
-        if (!use) sample_rank_kernel<kBins><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
+        // (presampled: spare workgroups of the projection launch have ranked a sample into `splitters` and zeroed the chunk
+        // sums already: depth_presample)
+        if (!use && !presampled) sample_rank_kernel<kBins><<<ns / kRankPerGroup, kThreads, 0, s>>>(keys0, (uint32_t)n, ns, splitters, cs, nsums);
         launch_partition<kBins>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect,
                                 use ? hints.splitters : splitters, use ? hints.header : nullptr, samples_out, step,
                                 use ? cs : nullptr, nsums, s, row_of);
