@@ -86,7 +86,7 @@ FP32_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 
 VALU_OPS_PER_PAIR = 11.25
 # PMC passes of the same command, committed under profiles/ (tools/profile_round.sh; the newest round that has the file)
 def _pmc_file(name: str):
-    for tag in ("r5", "r4", "r3"):
+    for tag in ("r6", "r5", "r4", "r3"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (tag, name))
         if os.path.exists(path):
             return path
@@ -415,13 +415,14 @@ def tie_order_effect(workload: str, sc, scene) -> dict:
             "seconds": round(time.perf_counter() - t0, 2)}
 
 
-def pmc_record(workload: str, world: int, strip_of: int = 0):
+def pmc_record(workload: str, world: int, strip_of: int = 0, spatial: bool = False):
     """PMC measurements of the compositing launch, taken with rocprofv3 in separate passes (FETCH_SIZE,
     WRITE_SIZE, SQ_*; MI355X_MICROARCH.md: FETCH_SIZE doubled on gfx950) and committed under profiles/;
     recorded for C2, C3 and C4 on 1 GPU (tools/profile_round.sh).  Returns (HBM-side bytes per launch, VALU busy
     fraction, file) or (None, None, None)."""
     # (a --strip-of run replays the STRIP's passes -- recorded for c4 / 8 --, never the whole frame's)
-    path = (_pmc_file("strip") if (workload == "c4" and strip_of == 8) else None) if strip_of > 1 else _pmc_file(workload)
+    path = (_pmc_file("strip_spatial" if spatial else "strip") if (workload == "c4" and strip_of == 8) else None) if strip_of > 1 \
+        else (None if spatial else _pmc_file(workload))
     if world != 1 or path is None:
         return None, None, None
     with open(path) as f:
@@ -1190,7 +1191,7 @@ def main() -> None:
         # stage-timing frames above, which take the same decision from the same view history)
         plain_instance = ref_rules and tile == 16 and (bool(getattr(one, "_plain_footprints", False)) if one is not None
                                                        else bool(stats.get("plain_footprints")))
-        pmc_traffic, pmc_valu, pmc_file = pmc_record(args.workload, world, args.strip_of) if ref_rules else (None, None, None)
+        pmc_traffic, pmc_valu, pmc_file = pmc_record(args.workload, world, args.strip_of, args.spatial_order) if ref_rules else (None, None, None)
         out = {
             "metric": "Mpixels/sec forward raster (1M Gaussians, 1080p) + max |dpixel| vs CPU ref",
             # W*H over the MEDIAN of hipEvent-bracketed single frames, one frame in flight

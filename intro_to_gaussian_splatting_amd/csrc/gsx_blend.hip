@@ -316,7 +316,7 @@ __device__ __forceinline__ void composite(float px, const float (&e_p)[NPX], con
 // so every kernel arrives at the same ones and the kernel families stay bit-identical to each other.
 constexpr uint32_t kSkipBudget = 1u << 23;   // 2^-17 of colour per block and channel, in units of 2^-40 (colours are < 1)
 // (kBatchRefOrder: kKindRefOrder records among regular ones; kBatchRefWild: and a D1 < 0 record as well; neither holds a monomial one)
-enum { kBatchRegular = 0, kBatchWild = 1, kBatchMono = 2, kBatchRefOrder = 3, kBatchRefWild = 4 };
+enum { kBatchRegular = 0, kBatchWild = 1, kBatchMono = 2, kBatchRefOrder = 3, kBatchRefWild = 4, kBatchKindMask = 7, kBatchHasRef = 8 };
 enum { kStageWhole = 0, kStageBlocks = 1, kStageOneBlock = 2 };
 
 // Which of the three classes of far-away records does this batch still skip in one block?  bound: the lane's record's
@@ -498,9 +498,17 @@ __device__ __forceinline__ int stage_records(float4 a, float4 b, float4 c, bool 
         in_slots |= 1ull << __popcll(mask & ((1ull << l) - 1ull));
     }
     if (ref_slots) *ref_slots = in_slots;
-    return __any(mono && keep) ? kBatchMono
-                               : (in_slots ? ((WITH_REF && __any(irregular && !refo && keep)) ? kBatchRefWild : kBatchRefOrder)
-                                           : (__any(irregular && keep) ? kBatchWild : kBatchRegular));
+    // (kBatchHasRef: the batch holds a reference-order record WHATEVER its kind -- one that also holds a monomial record is
+    // kBatchMono --: what n_redo counts and what the plain instance must not composite.  A bit of the return value, not
+    // a test of *ref_slots at the call site: that kept the 64-bit word live in the 64-VGPR instance and cost it 32 bytes
+    // more scratch per lane, 925 -> 1 060 us on the 4K frame.)
+    // (an instance that cannot evaluate reference-order records -- !WITH_REF -- is told about them FIRST: every such caller
+    // leaves the tile undone on kBatchRefOrder, also when the batch holds a monomial record beside it)
+    const int kind = (__any(mono && keep) && (WITH_REF || !in_slots))
+                         ? kBatchMono
+                         : (in_slots ? ((WITH_REF && __any(irregular && !refo && keep)) ? kBatchRefWild : kBatchRefOrder)
+                                     : (__any(irregular && keep) ? kBatchWild : kBatchRegular));
+    return kind | ((WITH_REF && in_slots) ? kBatchHasRef : 0);
 }
 
 // Gather + staging of one batch.  idx: this lane's entry of the tile's list (vals[base + lane]) when the caller has
@@ -736,17 +744,20 @@ __device__ __forceinline__ void blend_long_tile_quarter(const Record *__restrict
         }
         if (base + 128u + (uint32_t)lane < rg.y) idx2 = vals[base + 128u + lane];
         unsigned long long ref_slots = 0ull;
-        const int kind = stage_records<kStageOneBlock, REF>(ra, rb, rc, (uint32_t)lane < nb, nb, sh, lane, (float)(tx * 16),
-                                                            (float)(ty * 16), 16.0f, skipped, budget, quarter, unused, 0u, &ref_slots, qraw, idx0);
+        const int kind_all = stage_records<kStageOneBlock, REF>(ra, rb, rc, (uint32_t)lane < nb, nb, sh, lane, (float)(tx * 16),
+                                                                (float)(ty * 16), 16.0f, skipped, budget, quarter, unused, 0u, &ref_slots, qraw, idx0);
+        const int kind = kind_all & kBatchKindMask;
         cost += nb + kBatchCost;
 #ifdef GSX_TEST_HOOKS
         probe_staged += nb;
         if (checked && probe_checked_at == 0xFFFFFFu) probe_checked_at = probe_batch;
         ++probe_batch;
 #endif
-        // (ref_slots, not the batch's kind: a batch that also holds a monomial record is kBatchMono whatever else it holds)
-        if (REF && ref_slots != 0ull) saw_ref = true;
-        if (!REF && ref_slots != 0ull) {            // (wave-uniform) not here: the quarter stays undone (GSX_FLAG_PLAIN_FOOTPRINTS)
+        // (kBatchHasRef, not the batch's kind: a batch that also holds a monomial record is kBatchMono whatever else it holds)
+        if (REF && (kind_all & kBatchHasRef)) saw_ref = true;
+        // (the plain instance also leaves a batch with a MONOMIAL record -- stage-2 entry, degenerate conics -- to the other one:
+        // such a batch may hold a reference-order record as well, and its kind does not say)
+        if (!REF && kind >= kBatchRefOrder) {       // (wave-uniform) not here: the quarter stays undone (GSX_FLAG_PLAIN_FOOTPRINTS)
             if (lane == 0) atomicAdd(redo, 1u);
             return;
         }
@@ -940,12 +951,13 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
 #ifdef GSX_TEST_HOOKS
         const unsigned long long probe_b0 = __builtin_readcyclecounter();
 #endif
-        const int kind = stage_batch<kStageBlocks, (REF || VARIANT == 0)>(rec, qraw, vals, base, nb, sh, lane, (float)(tx * 16),
-                                                                          (float)(ty * 16), 16.0f, skipped, count, budget, &idx_now, 0,
-                                                                          dead, &ref_slots);
+        const int kind_all = stage_batch<kStageBlocks, (REF || VARIANT == 0)>(rec, qraw, vals, base, nb, sh, lane, (float)(tx * 16),
+                                                                              (float)(ty * 16), 16.0f, skipped, count, budget, &idx_now, 0,
+                                                                              dead, &ref_slots);
+        const int kind = kind_all & kBatchKindMask;
         const bool wild = kind != kBatchRegular;     // wave-uniform
-        // (ref_slots, not the batch's kind: a batch that also holds a monomial record is kBatchMono whatever else it holds)
-        if (REF && ref_slots != 0ull) saw_ref = true;
+        // (kBatchHasRef, not the batch's kind: a batch that also holds a monomial record is kBatchMono whatever else it holds)
+        if (REF && (kind_all & kBatchHasRef)) saw_ref = true;
 #ifdef GSX_TEST_HOOKS
         if (REF && kind >= kBatchRefOrder) {
             if (probe_first_ref == 0xFFFu) probe_first_ref = probe_batches;
@@ -971,8 +983,10 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
                 const Splat s = read_splat(sh, k);
                 composite<4, (REF || VARIANT == 0)>(cx, cy, s, T, c0, c1, c2, blk, (float)(tx * 16), (float)(ty * 16));
             }
-        } else if (!REF && ref_slots != 0ull) {
-            // (wave-uniform) an ill-conditioned footprint: not here -- the tile stays undone (GSX_FLAG_PLAIN_FOOTPRINTS)
+        } else if (!REF && kind >= kBatchRefOrder) {
+            // (wave-uniform) an ill-conditioned footprint -- or a record in the monomial fallback (stage-2 entry, degenerate
+            // conics), whose batch may hold one without its kind saying so: not here -- the tile stays undone
+            // (GSX_FLAG_PLAIN_FOOTPRINTS; the instance that evaluates both composites it when the frame is rendered again)
             if (lane == 0) atomicAdd(lt.redo, 1u);
             return;
         } else if (kind == kBatchMono) {
@@ -1136,11 +1150,10 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
         for (uint32_t base = rg.x; base < rg.y; base += 64) {
             uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, rg.y - base));
             uint32_t count[kBlocks];
-            unsigned long long ref_slots = 0ull;
-            (void)stage_batch<kStageBlocks, (REF || VARIANT == 0)>(rec, qraw, vals, base, nb, sh, lane, (float)(tx * 16), (float)(ty * 16),
-                                                                   16.0f, skipped, count, budget, nullptr, 0, 0u, &ref_slots);
-            if (REF && ref_slots != 0ull) saw_ref = true;
-            if (!REF && ref_slots != 0ull) {        // (wave-uniform) a later batch holds an ill-conditioned footprint: the tile stays undone
+            const int later = stage_batch<kStageBlocks, (REF || VARIANT == 0)>(rec, qraw, vals, base, nb, sh, lane, (float)(tx * 16),
+                                                                               (float)(ty * 16), 16.0f, skipped, count, budget);
+            if (REF && (later & kBatchHasRef)) saw_ref = true;
+            if (!REF && (later & kBatchKindMask) >= kBatchRefOrder) {   // (wave-uniform) a later batch holds one: the tile stays undone
                 if (lane == 0) atomicAdd(lt.redo, 1u);
                 return;
             }

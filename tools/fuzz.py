@@ -37,6 +37,7 @@ for seed in range(first, first + count):
         g = Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"], sc["opacity"],
                                   device="cuda:0")
         scene = GaussianScene(tmp, g)
+        ordered = GaussianScene(tmp, g.spatially_ordered())     # the same Gaussians, rows along a Morton curve (GsxParams.original_index)
     im = scene.images[1]
     c = im.gsx_camera()
     cam = cpu_ref.Camera(im.world2view.cpu().numpy(), im.full_proj_transform.cpu().numpy(), np.float32(c.tan_fovx),
@@ -61,6 +62,11 @@ for seed in range(first, first + count):
     # the next frame of the view finds this one's hints (splitters, costs, schedule): same pixels
     again = scene.render_image_hip(1, tile_size=tile, layout=layout).cpu().numpy()
     assert np.array_equal(again.transpose(1, 0, 2) if layout == "hw3" else again, img), ("hinted frame differs", tag)
+    # ---- spatially ordered rows, everything filed under the original index: the same frame bit for bit, equal depths included
+    so = {}
+    oimg = ordered.render_image_hip(1, tile_size=tile, layout=layout, stats=so).cpu().numpy()
+    assert np.array_equal(oimg.transpose(1, 0, 2) if layout == "hw3" else oimg, img), ("spatially ordered frame differs", tag)
+    assert so["n_instances"] == inst and so["n_visible"] == len(pre.depths), ("spatially ordered counts", tag, so)
     # ---- the compositing in parts along the leading axis (GsxParams.n_substrips: what a rank sends while it composites the next)
     if tile == 16 and min(w, h) >= 32:
         from intro_to_gaussian_splatting_amd import strips as _strips
@@ -87,6 +93,9 @@ for seed in range(first, first + count):
         assert float(np.abs(wimg - wref).max()) <= 1e-4, ("window pixels", tag, win)
         # the oracle counts instances over all tiles; inside the window the GPU count is the sum of its lists
         assert st["n_instances"] <= inst, ("window count", tag, win)
+        so = {}
+        owimg = ordered.render_image_hip(1, tile_size=tile, layout="wh3", tile_window=win, stats=so).cpu().numpy()
+        assert np.array_equal(owimg, wimg) and so["n_instances"] == st["n_instances"], ("spatially ordered window differs", tag, win)
     if needles:
         # the other rule sets are restatements nothing pins (their source kernels cannot run here); on ill-conditioned
         # footprints kernel and restatement are two float32 evaluations of the same formula, a few 1e-4 apart

@@ -12,12 +12,13 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
 src = "gpurun_out/%s" % tag
 LABELS = {"c3": "C3: 1M Gaussians, 1920x1080", "c2": "C2: 100k Gaussians, 1920x1080", "c4": "C4: 5M Gaussians, 3840x2160",
           "c3_clustered": "clustered: 1M Gaussians, half of them in 5 % of the frame",
           "c3_trainedlike": "trained-like: 1M Gaussians, log-normal anisotropic scales, degree-3 SH",
-          "strip": "strip 4 of 8 of C4 (tile columns [120,150) of the 4K frame): one rank's share of BASELINE config 5"}
+          "strip": "strip 4 of 8 of C4 (tile columns [120,150) of the 4K frame): one rank's share of BASELINE config 5",
+          "strip_spatial": "the same strip from spatially ordered rows (Gaussians.spatially_ordered: Morton order, block bounds)"}
 
 
 def short(name):
@@ -45,7 +46,7 @@ def kernel_table(path, label):
 
 
 lines = []
-for w in ("c3", "c2", "c4", "c3_clustered", "c3_trainedlike", "strip"):
+for w in ("c3", "c2", "c4", "c3_clustered", "c3_trainedlike", "strip", "strip_spatial"):
     p = "%s/%s_kernel_stats.csv" % (src, w)
     if os.path.exists(p):
         shutil.copy(p, "profiles/%s_%s_kernel_stats_1stream.csv" % (tag, w))
@@ -57,7 +58,9 @@ def k2(n):
     if "blend_tile16_ref_kernel" in n:      # (round 5: the instance a frame runs; the tables below keep one key for both)
         BLEND["name"] = "blend_tile16_ref_kernel"
         return "blend_tile16_kernel"
-    for key in ("blend_tile16_kernel", "project_pack_kernel", "emit_kernel", "tile_ranges_kernel", "chunk_sums_kernel",
+    if "project_window_kernel" in n:        # (round 6: the windowed projection is a kernel of its own; one key for both)
+        return "project_pack_kernel"
+    for key in ("blend_tile16_kernel", "project_pack_kernel", "prepare_reordered_kernel", "emit_kernel", "tile_ranges_kernel", "chunk_sums_kernel",
                 "row_scan_kernel", "sample_rank_kernel", "bucket_sort_kernel", "small_depth_sort_kernel",
                 "tile_schedule_kernel", "scan_sums_kernel"):
         if key in n:
@@ -81,6 +84,7 @@ def algorithmic(N, M, D, npix, windowed):
     pin = (24 * N + 32 * M) if windowed else 56 * N
     return {
         "project_pack_kernel": (pin, 4 * N + 56 * M),
+        "prepare_reordered_kernel": (0, 4 * N),
         "count_kernel<u32,split>": (4 * N, 0.5e6),
         "count_kernel<u32,first>": (4 * N, 0.5e6),
         "count_kernel<u32>": (4 * M, 0.5e6),
@@ -185,7 +189,7 @@ def pmc_summary(w):
 CORR = {}
 BLEND = {"name": "blend_tile16_kernel"}
 GATHER_CORR = 1.0       # profiles/r4_fetch_calibration.json: 0.92 .. 1.0 for isolated 48-byte records (an upper bound is kept)
-for w in ("c3", "c2", "c4", "strip"):
+for w in ("c3", "c2", "c4", "strip", "strip_spatial"):
     tl = pmc_summary(w)
     if tl:
         lines += tl
@@ -193,7 +197,7 @@ for w in ("c3", "c2", "c4", "strip"):
 lines.append("\n## Bench lines (profiles/%s_bench_*.json)\n" % tag)
 lines.append("| workload | Mpixel/s (value: median single frame) | ms/frame median [min, max] | ms/frame, 3 in flight | blend ms | "
              "max abs dpixel vs CPU port | parity_ok | CPU port Mpix/s |\n|---|---|---|---|---|---|---|---|")
-for w in ("c1", "c2", "c3", "c4", "c3_clustered", "c3_trainedlike", "c3_1m2", "strip", "c3_std3dgs", "c3_sh3"):
+for w in ("c1", "c2", "c3", "c4", "c3_clustered", "c3_trainedlike", "c3_1m2", "strip", "strip_spatial", "c3_std3dgs", "c3_sh3"):
     p = "%s/bench_%s.json" % (src, w)
     if not os.path.exists(p) or os.path.getsize(p) == 0:
         continue
