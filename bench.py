@@ -1258,7 +1258,10 @@ def main() -> None:
             # the two numbers a VIEWER sees, beside `value` (a warm frame of one view replayed): the first frame of a view --
             # no hints, separate launches -- and a camera that moves one degree per frame (stale hints), same units
             out["value_cold_frame"] = round(width * height / (moving["cold_frame_ms"] * 1e-3) / 1e6, 2)
-            out["value_moving_camera"] = round(width * height / (moving["moving_camera"]["median_ms"] * 1e-3) / 1e6, 2)
+            # (the frames within two degrees of the workload's own pose: they see what `value` sees -- further along the orbit
+            # part of the scene leaves the frustum, up to 20 % fewer pairs, and the orbit's median is FASTER than the view at rest)
+            out["value_moving_camera"] = round(width * height / (moving["moving_camera"]["near_middle_pose_median_ms"] * 1e-3) / 1e6, 2)
+            out["value_moving_camera_whole_orbit"] = round(width * height / (moving["moving_camera"]["median_ms"] * 1e-3) / 1e6, 2)
         if strips_ok is not None:
             out["strips_equal_single_gpu"] = strips_ok
         if dist_info is not None:
