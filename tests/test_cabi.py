@@ -195,3 +195,45 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "libgsx.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _ffi.load()
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_a_c99_client_links_and_runs(tmp_path):
+    """include/gsx.h is plain C: a C99 client (tests/host/cabi_smoke.c, -Wall -Wextra -pedantic) compiles against it, links
+    libgsx.so and exercises what needs no GPU -- the version, the defaults at the sizes IT compiled (canary behind the
+    struct), the size arithmetic and two argument errors -- the way a maintainer's C / C++ viewer would."""
+    exe = str(tmp_path / "cabi_smoke")
+    lib_dir = os.path.dirname(_ffi.LIB_PATH)
+    build = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "host", "cabi_smoke.c"), "-o", exe, _ffi.LIB_PATH,
+                            "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "GsxParams %d bytes, GsxFrameStats %d bytes" % (ctypes.sizeof(_ffi.GsxParams), ctypes.sizeof(_ffi.GsxFrameStats)) in run.stdout
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_the_c_snippets_of_the_integration_document_compile(tmp_path):
+    """The two C loops of INTEGRATION.md (a viewer's frame loop with the hand-over between frames and the n_redo check; a
+    multi-GPU rank compositing its strip in parts) are type-checked against include/gsx.h: every field, flag and call they
+    use exists with that type.  (HIP's own names are declared by a five-line prelude: the snippets are about gsx.)"""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```c\n(.*?)```", text, flags=re.S)
+    assert len(blocks) == 2
+    prelude = """
+#include <stdlib.h>
+#include "gsx.h"
+typedef void *hipEvent_t; typedef void *hipStream_t;
+enum { hipEventDisableTiming = 2 };
+int hipMalloc(void **p, size_t n); int hipMemsetAsync(void *p, int v, size_t n, hipStream_t s);
+int hipEventCreateWithFlags(hipEvent_t *e, unsigned flags); int hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+extern GsxCamera cam; extern const float *means, *scales, *quats, *opacity, *colors; extern int64_t n; extern float *image, *strip;
+extern void *ws; extern size_t ws_bytes; extern hipStream_t stream, comm_stream; extern int32_t col0, col1;
+"""
+    src = prelude + "void viewer(void) {\n" + blocks[0] + "\n}\nvoid rank(void) {\nGsxParams prm; GsxFrameStats st; gsx_default_params(&prm);\n" + blocks[1] + "\n(void)st;\n}\n"
+    path = tmp_path / "snippets.c"
+    path.write_text(src)
+    out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wno-unused-variable", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(path)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
