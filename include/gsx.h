@@ -199,7 +199,8 @@ typedef struct GsxParams {
      * its Gaussians can have, misses the tile window and lies in front of the cull plane -- instead of reading 24 bytes of
      * every Gaussian to find the same thing out row by row.  Conservative: a block is only dropped when each of its rows
      * would be; the frame is the same bit for bit.  The bounds describe the arrays AS THEY ARE: whoever moves a mean or
-     * grows a scale recomputes them (Gaussians.refresh_block_bounds()). */
+     * grows a scale recomputes them (the Python surface does, from torch's in-place version counters:
+     * Gaussians.current_block_bounds()). */
     const float *block_bounds;
     /* gsx_render_forward, with original_index: DEVICE array of n int32, the inverse permutation -- row_of_index[original_index[i]]
      * == i.  Required there (GSX_ERR_INVALID_ARGUMENT without it); gsx_preprocess does not read it. */

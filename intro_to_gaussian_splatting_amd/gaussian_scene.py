@@ -194,6 +194,11 @@ class CapturedFrame:
         self._camera_buffer.copy_(torch.frombuffer(bytearray(bytes(cam)), dtype=torch.uint8))
 
     def replay(self) -> torch.Tensor:
+        # (spatially ordered rows: the boxes a strip's projection trusts follow points / scales -- refreshed IN PLACE, at the
+        # address the graph holds, when those were modified since; a comparison of six integers otherwise)
+        g = self.scene.gaussians
+        if getattr(g, "original_index", None) is not None:
+            g.current_block_bounds()
         self.graph.replay()
         return self.out
 
@@ -401,8 +406,10 @@ class GaussianScene:
                 raise ValueError("gaussians.row_of_index (the inverse of original_index) must be a contiguous int32 tensor "
                                  "of %d entries on %s" % (n, dev))
             params.original_index, params.row_of_index = oi.data_ptr(), ro.data_ptr()
-            bb = getattr(g_, "block_bounds", None)
-            if bb is not None:      # ... and a strip's projection drops whole blocks of 256 rows after reading their box
+            # ... and a strip's projection drops whole blocks of 256 rows after reading their box (recomputed here when
+            # points / scales were modified since: Gaussians.current_block_bounds)
+            bb = g_.current_block_bounds() if hasattr(g_, "current_block_bounds") else getattr(g_, "block_bounds", None)
+            if bb is not None:
                 if bb.device != dev or bb.dtype != torch.float32 or not bb.is_contiguous() or \
                         tuple(bb.shape) != (-(-n // _ffi.GSX_BOUNDS_ROWS), 8):
                     raise ValueError("gaussians.block_bounds must be a contiguous float32 (%d, 8) tensor on %s "
@@ -484,7 +491,7 @@ class GaussianScene:
                                  "from the scene's own memory, and a non-contiguous attribute would be copied once, "
                                  "at capture time")
             own["inputs"][:] = passed + ([oi, g_.row_of_index] if oi is not None else []) + \
-                ([g_.block_bounds] if oi is not None and getattr(g_, "block_bounds", None) is not None else [])
+                ([bb] if oi is not None and bb is not None else [])
         # how many Gaussians reached a tile of this window last time: picks the depth-sort route (a hint)
         params.kept_hint = int(own.get("kept", self._kept_hints.get(cap_key, 0)))
         # GSX_FLAG_PLAIN_FOOTPRINTS: no tile of the last frame of this view held an ill-conditioned footprint, so this one runs

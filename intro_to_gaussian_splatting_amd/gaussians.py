@@ -74,7 +74,28 @@ class Gaussians:
             out[:, 0:3] = lo_src.reshape(nb, rows, 3).amin(dim=1)
             out[:, 4:7] = hi_src.reshape(nb, rows, 3).amax(dim=1)
             out[:, 3] = s_src.reshape(nb, rows).amax(dim=1)
-        self.block_bounds = out.contiguous()
+        old = self.block_bounds
+        if old is not None and old.shape == out.shape and old.device == out.device and old.is_contiguous():
+            old.copy_(out)          # in place: a captured frame (hipGraph) has this tensor's address baked in
+        else:
+            self.block_bounds = out.contiguous()
+        self._bounds_of = self._bounds_stamp()
+
+    def _bounds_stamp(self):
+        """What ``block_bounds`` was computed from: the identity and in-place version of ``points`` and ``scales`` (torch
+        counts in-place modifications of a tensor: ``_version``)."""
+        return (self.points.data_ptr(), self.points._version, tuple(self.points.shape),
+                self.scales.data_ptr(), self.scales._version, tuple(self.scales.shape))
+
+    def current_block_bounds(self) -> Optional[torch.Tensor]:
+        """``block_bounds`` for the arrays AS THEY ARE NOW: recomputed first when ``points`` or ``scales`` were replaced or
+        modified in place since (an optimiser step, an edit) -- stale boxes would make a strip's projection drop Gaussians
+        that have moved into its window.  None for a container whose rows are in the caller's own order."""
+        if self.original_index is None:
+            return None
+        if self.block_bounds is None or getattr(self, "_bounds_of", None) != self._bounds_stamp():
+            self.refresh_block_bounds()
+        return self.block_bounds
 
     def spatially_ordered(self, bits: int = 10) -> "Gaussians":
         """A COPY of this container with the rows of every parameter array reordered along a 3D Morton (Z-order) curve of

@@ -1998,3 +1998,15 @@ def test_spatially_ordered_strips_of_a_100k_scene(tmp_path):
             out = torch.empty(((t1 - t0) * 16, 1080, 3), dtype=torch.float32, device="cuda:0")
             ordered.render_image_hip(1, tile_window=win, out=out, out_origin=(t0 * 16, 0))
             assert torch.equal(out, whole[t0 * 16:t1 * 16]), (with_sh, t0, t1)
+    # the Gaussians MOVE (in place, as an optimiser step or an edit would): the boxes the strip's projection drops blocks by
+    # follow (Gaussians.current_block_bounds) -- a third of the scene shifted sideways by a quarter of the frame's width
+    og = ordered.gaussians
+    moved = torch.arange(0, 100_000, 3, device="cuda:0")
+    shift = torch.tensor([1.5, 0.0, 0.0], device="cuda:0")
+    scene.gaussians.points[moved] += shift
+    og.points[og.row_of_index[moved].long()] += shift
+    whole = scene.render_image_hip(1).clone()
+    for t0, t1 in strips.strip_plan(ntx, 8)[1]:
+        out = torch.empty(((t1 - t0) * 16, 1080, 3), dtype=torch.float32, device="cuda:0")
+        ordered.render_image_hip(1, tile_window=(t0, t1, 0, nty), out=out, out_origin=(t0 * 16, 0))
+        assert torch.equal(out, whole[t0 * 16:t1 * 16]), ("moved", t0, t1)

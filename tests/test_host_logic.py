@@ -367,3 +367,23 @@ def test_spatially_ordered_is_a_permutation_that_puts_neighbours_together():
     assert step(o.points) < 0.25 * step(g.points)
     empty = Gaussians(torch.zeros((0, 3)), torch.zeros((0, 3)), device="cpu").spatially_ordered()
     assert empty.original_index.numel() == 0
+
+
+def test_block_bounds_follow_points_and_scales():
+    """Gaussians.current_block_bounds(): the boxes a strip's projection trusts (GsxParams.block_bounds) are recomputed -- in
+    place, at the address a captured frame holds -- when ``points`` / ``scales`` were modified in place or replaced since."""
+    import torch
+
+    from intro_to_gaussian_splatting_amd import Gaussians
+
+    g = Gaussians(torch.rand(1000, 3), torch.rand(1000, 3) * 255, device="cpu").spatially_ordered()
+    first = g.current_block_bounds()
+    before, addr = first.clone(), first.data_ptr()
+    assert g.current_block_bounds() is first and torch.equal(first, before)          # nothing changed: nothing recomputed
+    g.points[5] += 100.0
+    after = g.current_block_bounds()
+    assert after.data_ptr() == addr and not torch.equal(after, before) and float(after[0, 4:7].max()) > 50.0
+    g.scales = g.scales * 2
+    assert float(g.current_block_bounds()[0, 3]) == float(g.scales[:256].abs().max()) and g.block_bounds.data_ptr() == addr
+    plain = Gaussians(torch.rand(10, 3), torch.rand(10, 3), device="cpu")
+    assert plain.current_block_bounds() is None
