@@ -349,8 +349,8 @@ def stage1_vs_reference(workload: str, scene, device: str) -> dict:
             "d_ref": int(g["tile_instances"]), "d_hip": int(st["n_instances"])}
 
 
-TILE_FIXTURE_OF = {"c3": "tiles_c3_1080p_n1000000", "c3_clustered": "tiles_c3_clustered_1080p_n1000000",
-                   "c3_trainedlike": "tiles_c3_trainedlike_1080p_n1000000"}
+TILE_FIXTURE_OF = {"c2": "tiles_c2_1080p_n100000", "c3": "tiles_c3_1080p_n1000000", "c4": "tiles_c4_4k_n5000000",
+                   "c3_clustered": "tiles_c3_clustered_1080p_n1000000", "c3_trainedlike": "tiles_c3_trainedlike_1080p_n1000000"}
 
 
 def pixels_vs_reference(workload: str, scene, frame: torch.Tensor, device, tile: int) -> dict:

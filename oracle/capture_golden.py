@@ -83,6 +83,12 @@ TILE_FIXTURES = {
     "tiles_c3_1080p_n1000000": dict(generator=None, args=dict(n=1_000_000, width=1920, height=1080, seed=0), tile=16,
                                     picks=("longest", "shortest", "first", "last", "most_tie_swaps", "most_saturated",
                                            "random", "random", "random", "random", "random", "random")),
+    # BASELINE configs 2 and 4 (100k at 1080p; 5M at 4K, the "HBM-roofline stress run"): the same, so that every synthetic
+    # configuration of BASELINE.json has pixels the reference itself composited
+    "tiles_c2_1080p_n100000": dict(generator=None, args=dict(n=100_000, width=1920, height=1080, seed=0), tile=16,
+                                   picks=("longest", "shortest", "first", "last", "most_tie_swaps", "most_saturated") + ("random",) * 10),
+    "tiles_c4_4k_n5000000": dict(generator=None, args=dict(n=5_000_000, width=3840, height=2160, seed=0), tile=16,
+                                 picks=("longest", "first", "last", "most_tie_swaps", "most_saturated", "random", "random")),
     "tiles_c3_clustered_1080p_n1000000": dict(generator=None, tile=16,
                                               args=dict(n=1_000_000, width=1920, height=1080, seed=0, cluster_fraction=0.5,
                                                         cluster_area=0.05, sigma_ln=1.0),

@@ -102,7 +102,8 @@ def compare_stage1_with_reference(g, fields, order, strict: bool = True, sigmoid
 
 
 # ----------------------------------------------------------------- reference-rendered tiles at the metric's configuration
-TILE_FIXTURE_NAMES = ("tiles_c3_1080p_n1000000", "tiles_c3_clustered_1080p_n1000000", "tiles_c3_trainedlike_1080p_n1000000")
+TILE_FIXTURE_NAMES = ("tiles_c2_1080p_n100000", "tiles_c3_1080p_n1000000", "tiles_c4_4k_n5000000", "tiles_c3_clustered_1080p_n1000000",
+                      "tiles_c3_trainedlike_1080p_n1000000")
 
 
 def tiles_scene(g):

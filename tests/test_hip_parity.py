@@ -127,9 +127,10 @@ def test_stage1_at_benchmark_size_equals_the_reference_bit_for_bit(tmp_path, nam
 
 @pytest.mark.parametrize("name", TILE_FIXTURE_NAMES)
 def test_frames_of_the_1m_scenes_hold_the_references_own_pixels(tmp_path, name):
-    """The METRIC's configuration against the reference itself, pixels included: ``tiles_*`` hold 16x16 blocks that the
-    reference's own ``render_tile`` (splat/gaussian_scene.py:173-198) composited from its own ``preprocess`` of the C3,
-    clustered and trained-like 1M-Gaussian 1080p scenes -- the frame's longest list (642 / 12 061 / 10 298 entries), tiles
+    """BASELINE's synthetic configurations (C2 100k / 1080p, C3 1M / 1080p -- the metric's --, C4 5M / 4K) and the two 1M stress
+    scenes against the reference itself, pixels included: ``tiles_*`` hold 16x16 blocks that the reference's own
+    ``render_tile`` (splat/gaussian_scene.py:173-198) composited from its own ``preprocess`` of those scenes -- the frame's
+    longest list (85 / 642 / 809 / 12 061 / 10 298 entries), tiles
     where the stop rule fires, tiles along the ridge of a 330:1 footprint (the kernel's reference-order records), seeded
     random picks.  The HIP frame (whole path, one call, the kernels bench.py times) carries those pixels to 1e-4 (the
     north-star tolerance; measured <= 1e-6), its tile lists have the reference's lengths, and so does a captured frame."""
