@@ -656,15 +656,17 @@ __device__ __forceinline__ bool block_misses_window(const GsxCamera &cam, const 
 }
 
 // The projection of a call that renders a strict PART of the frame (a multi-GPU rank's strip, a tile window): most
-// Gaussians miss the window.  A workgroup takes kWinRows = 1024 consecutive rows.
-//   phase 1  every row: cull plane, then a cheap conservative window test; a thread handles FOUR rows (row = base + k * 256
-//            + thread, coalesced for every k) with all its loads -- means and scales -- in flight at once.  On a rank that owns
-//            1/8 of the frame 7/8 of the Gaussians end here, having cost 24 B of reads.  (Round 5 gave every thread one row:
-//            19 500 workgroups of 256 at 5M Gaussians, each a chain of four dependent trips to memory -- 74 us for 141 MB.)
+// Gaussians miss the window.  A workgroup takes kWinRows consecutive rows (= one block of GsxParams.block_bounds).
+//   dropped  reordered rows with block boxes: prepare_reordered_kernel has marked the blocks that miss the window -- such a
+//            workgroup reads one byte and is done;
+//   phase 1  every row: cull plane, then a cheap conservative window test (means and scales requested together).  On a rank
+//            that owns 1/8 of the frame 7/8 of the Gaussians end here, having cost 24 B of reads;
 //   compact  the survivors' row numbers, in LDS, in row order;
-//   phase 2  256 survivors at a time, dense waves: means, scales, quaternion, opacity and colour of a survivor are requested
-//            together, then the exact projection (project_one: the whole-frame kernel's operations, bit for bit).
+//   phase 2  the survivors on dense waves: means, scales, quaternion, opacity and colour of a survivor are requested together,
+//            then the exact projection (project_one: the whole-frame kernel's operations, bit for bit).
 // SHDEG >= 0: the survivors' coefficient rows go through LDS, kRows at a time, and the colour is evaluated before phase 2.
+// (kWinPer rows per thread: 4 -- fewer, fatter workgroups with all loads in flight -- measured SLOWER, 81 -> 94 us on a 1/8
+// strip of 5M Gaussians, 73 VGPRs: the kernel never waited for its loads but for its partial-line stores)
 constexpr int kWinPer = 1, kWinRows = kBlock * kWinPer;
 static_assert(kWinRows == GSX_BOUNDS_ROWS, "a workgroup of the windowed kernel takes one block of GsxParams.block_bounds");
 template <bool DEVICE_CAMERA, int SHDEG>
