@@ -85,6 +85,7 @@ int make_plan_or_fail(int32_t width, int32_t height, int32_t tile, float *out_im
 struct FrameHints {
     gsx::BlendHints blend = gsx::BlendHints{nullptr, nullptr, nullptr, nullptr, 0u};
     const uint32_t *sched = nullptr;   // hints.sched, put together from the previous frame's list lengths, or null
+    uint32_t *sched_region = nullptr;  // the hints buffer's schedule region (whether or not it holds a schedule yet), or null
 };
 
 int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t cap, const gsx::TileRect *rrect,
@@ -147,13 +148,27 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
                                         (uint32_t *)(ws + c.tvals1), ranges, counters + kCtrPairs, lt, &sorted_vals, s));
             if (p.tile_counts) GSX_HIP(gsx::launch_tile_counts(ranges, p.grid.count(), p.tile_counts, s));
             const uint32_t *sched = fh.sched;      // handed over by the previous frame (GsxParams.hints): no kernel
-            if (!sched && cap > 0 && gsx::blend_uses_schedule(p.grid, p.semantics, p.generic, n, p.schedule)) {
-                sched = (uint32_t *)(ws + c.sched);
-                GSX_HIP(gsx::launch_tile_schedule(ranges, p.grid.count(), (uint32_t *)(ws + c.sched), s));
-            }
-            tm.mark();  // 4: tile sort (+ the compositing schedule)
             gsx::BlendHints bh = fh.blend;
             bh.xcd_sched = fh.sched ? 1u : 0u;
+            if (!sched && cap > 0 && gsx::blend_uses_schedule(p.grid, p.semantics, p.generic, n, p.schedule)) {
+                if (p.semantics == GSX_SEM_REF_CPU && gsx::knob("GSX_COLD_XCD_SCHED", 1) != 0) {
+                    // no schedule on file (a view's first frame, a caller without a hints buffer): the same per-XCD schedule
+                    // from THIS frame's list lengths, into the hints buffer's region when there is one (its header then says so)
+                    uint32_t *hdr = bh.header ? bh.header : (uint32_t *)(ws + c.sched_header);
+                    uint32_t *region = (bh.header && fh.sched_region) ? fh.sched_region : (uint32_t *)(ws + c.sched);
+                    if (!(bh.header && !fh.sched_region)) {
+                        GSX_HIP(gsx::launch_tile_schedule_xcd(ranges, p.grid.count(), p.grid.nwy(), region, hdr, s));
+                        sched = region;
+                        bh.header = hdr;
+                        bh.xcd_sched = 1u;
+                    }
+                }
+                if (!sched) {       // (the other rule sets: one workgroup ranks the whole frame)
+                    sched = (uint32_t *)(ws + c.sched);
+                    GSX_HIP(gsx::launch_tile_schedule(ranges, p.grid.count(), (uint32_t *)(ws + c.sched), s));
+                }
+            }
+            tm.mark();  // 4: tile sort (+ the compositing schedule)
             bh.plain = p.plain ? 1u : 0u;
             redo_counted = p.semantics == GSX_SEM_REF_CPU && p.grid.tile == 16 && !p.generic;
             // The 128 spare workgroups hold 16 wave slots of every XCD for ~15 us.  In front of the tiles that is free
@@ -407,6 +422,7 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
         sh = gsx::SortHints{hdr, (const uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.samples),
                             p.hints_valid && route == gsx::kDepth256};
         fh.blend = gsx::BlendHints{hdr, sh.samples, (uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.lens), 0u};
+        fh.sched_region = (uint32_t *)(p.hints + hl.sched);
         // the schedule costs nothing here (a spare workgroup of the projection launch): every window of more than two
         // tiles per SIMD gets one, unless told not to
         if (p.hints_valid && p.schedule != 0 && p.grid.count() > 2048) {

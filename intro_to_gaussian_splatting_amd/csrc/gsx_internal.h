@@ -172,6 +172,8 @@ hipError_t sort_instances(void *temp, int64_t cap, const TileGrid &grid, void *k
 hipError_t launch_tile_counts(const uint2 *ranges, int64_t nt, uint32_t *counts, hipStream_t s);
 // sched[k] = tile with the k-th longest list (1024 length classes), for launch_blend's balanced hand-out.
 hipError_t launch_tile_schedule(const uint2 *ranges, int64_t nt, uint32_t *sched, hipStream_t s);
+// the per-XCD schedule of THIS frame's list lengths (REF_CPU tile 16; header: kHintHeaderWords words, sched: hints_sched_entries)
+hipError_t launch_tile_schedule_xcd(const uint2 *ranges, int64_t nt, int64_t nwy, uint32_t *sched, uint32_t *header, hipStream_t s);
 // ---- gsx_sort.hip: stable LSD radix sort, up to 8 bits per pass, key bits [0, key_bits).  The element
 // count is min(*n_dev, bound) (n_dev == nullptr: bound); grids are sized by `bound`.  Buffers
 // ping-pong; on return keys_cur / vals_cur point at the sorted data.  temp: radix_temp_bytes(bound).

@@ -194,7 +194,7 @@ struct Carve {
     size_t keys0, keys1, vals0, vals1;      // n x u32: depth keys / original indices (ping-pong)
     size_t rec, rect, rrect, bbox;          // per Gaussian: record, tile rectangle by index / by depth rank
     size_t tkeys0, tkeys1, tvals0, tvals1;  // cap x u32: tile ids / Gaussian indices (ping-pong)
-    size_t ranges, longs, redo, sched, counters, temp, temp_bytes, total;
+    size_t ranges, longs, redo, sched_header, sched, counters, temp, temp_bytes, total;
 };
 
 // The 64-byte `counters` block: what the kernels of one frame hand to each other on the device.
@@ -222,7 +222,10 @@ inline Carve carve(int64_t n, int64_t cap, int64_t max_tiles, size_t temp_bytes)
     c.longs = take(kMaxLongTiles * sizeof(uint32_t));
     // GsxFrameStats.n_redo on the device (LongTiles.redo)
     c.redo = take(256);
-    c.sched = take((size_t)(max_tiles > 0 ? max_tiles : 1) * sizeof(uint32_t));   // tiles by falling list length
+    // a frame's own compositing schedule (no hints to take it from): per XCD, tiles by falling list length -- the layout of
+    // the hints' schedule region (hints_sched_entries) with a header of its own in front (kHintHeaderWords words)
+    c.sched_header = take(kHintHeaderWords * sizeof(uint32_t));
+    c.sched = take(hints_sched_entries(max_tiles) * sizeof(uint32_t));
     c.counters = take(64);
     c.temp = take(temp_bytes);
     c.temp_bytes = temp_bytes;

@@ -56,8 +56,10 @@ __host__ __device__ inline uint32_t sched_tile_of(uint32_t j, uint32_t x, const 
     return ch * c.s + (ch < c.rem ? ch : c.rem) + r;
 }
 
-// All 256 threads of spare workgroup x (0 .. 7) call this.
-__device__ __forceinline__ void schedule_from_lengths(const SchedJob &job, uint32_t x) {
+// All 256 threads of workgroup x (0 .. 7) call this.  raw_cost(tile): the tile's cost, bit 31 set when it runs as a long tile
+// on helper workgroups (to the hand-out it is empty, to the XCD's total it counts).
+template <typename RawCost>
+__device__ __forceinline__ void schedule_xcd(const SchedJob &job, uint32_t x, RawCost raw_cost) {
     constexpr uint32_t kClasses = 256;
     __shared__ uint32_t hist[kClasses];
     __shared__ uint32_t s_lo, s_hi, s_total, s_wsum[4];
@@ -65,20 +67,14 @@ __device__ __forceinline__ void schedule_from_lengths(const SchedJob &job, uint3
     const int lane = tid & 63, w = tid >> 6;
     const uint32_t nt = job.nt;
     const SchedCut cut = sched_cut(nt);
-    if (job.header[kHintLens] != nt) {          // nothing usable on file: the compositing launch falls back to index order
-        if (x == 0 && tid == 0) job.header[kHintSched] = 0u;
-        return;
-    }
     const uint32_t mine_n = sched_count(nt, job.nwy, x);
-    // (a tile's entry is its COST, gsx_plan.h; bit 31: it ran as a long tile on helper workgroups and will again -- to
-    // the hand-out it is empty, to the XCD's total it counts)
     auto cost_of = [&](uint32_t j) -> uint32_t {
-        const uint32_t l = job.lens[sched_tile_of(j, x, cut)];
+        const uint32_t l = raw_cost(sched_tile_of(j, x, cut));
         return (l >> 31) ? 0u : l;
     };
     uint32_t mn = 0xFFFFFFFFu, mx = 0u, total = 0u;
     for (uint32_t j = tid; j < mine_n; j += nthreads) {
-        const uint32_t raw = job.lens[sched_tile_of(j, x, cut)], l = (raw >> 31) ? 0u : raw;
+        const uint32_t raw = raw_cost(sched_tile_of(j, x, cut)), l = (raw >> 31) ? 0u : raw;
         mn = min(mn, l);
         mx = max(mx, l);
         total += min(raw & 0x7FFFFFFFu, 1u << 20);
@@ -132,6 +128,16 @@ __device__ __forceinline__ void schedule_from_lengths(const SchedJob &job, uint3
         job.header[kHintXcdCost + x] = s_total;
         if (x == 0) job.header[kHintSched] = nt;
     }
+}
+
+// The projection launch's spare workgroups: the schedule from the tiles' COSTS in the previous frame (GsxParams.hints:
+// records staged until the tile was done, gsx_plan.h).
+__device__ __forceinline__ void schedule_from_lengths(const SchedJob &job, uint32_t x) {
+    if (job.header[kHintLens] != job.nt) {      // nothing usable on file: the compositing launch falls back to index order
+        if (x == 0 && threadIdx.x == 0) job.header[kHintSched] = 0u;
+        return;
+    }
+    schedule_xcd(job, x, [&](uint32_t t) -> uint32_t { return job.lens[t]; });
 }
 
 }  // namespace gsx
