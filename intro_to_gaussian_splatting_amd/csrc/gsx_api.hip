@@ -421,7 +421,11 @@ int gsx_render_forward(const GsxCamera *camera, const float *means3d, const floa
         // frame of the view may take the 256-bucket route -- a rank's strip does once its kept count is known)
         sh = gsx::SortHints{hdr, (const uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.samples),
                             p.hints_valid && route == gsx::kDepth256};
-        fh.blend = gsx::BlendHints{hdr, sh.samples, (uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.lens), 0u};
+        // the 256-bucket route leaves the next frame's splitters itself -- the exact quantiles of this frame's keys (bucket_sort_kernel)
+        // -- and the compositing launch has no sample to rank; the LSD route still leaves a sample for it
+        const bool exact = route == gsx::kDepth256 && gsx::knob("GSX_EXACT_SPLITTERS", 1) != 0;
+        if (exact) sh.next_splitters = (uint32_t *)(p.hints + hl.splitters);
+        fh.blend = gsx::BlendHints{hdr, exact ? nullptr : sh.samples, (uint32_t *)(p.hints + hl.splitters), (uint32_t *)(p.hints + hl.lens), 0u};
         fh.sched_region = (uint32_t *)(p.hints + hl.sched);
         // the schedule costs nothing here (a spare workgroup of the projection launch): every window of more than two
         // tiles per SIMD gets one, unless told not to

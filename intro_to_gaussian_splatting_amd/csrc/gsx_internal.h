@@ -208,6 +208,10 @@ struct SortHints {
     const uint32_t *splitters;  // 256 words left by the previous frame
     uint32_t *samples;          // kSortSamples words this frame's count kernel fills for the next frame
     bool use;                   // GSX_FLAG_HINTS_VALID: partition with `splitters`, no sample kernel
+    // the 256-bucket route (round 6): the bucket kernel knows every kept key's rank and leaves the NEXT frame's splitters
+    // itself -- the EXACT 256-quantiles of this frame's keys, in place of the hints' splitters (every reader of the current
+    // ones has finished) -- instead of a sample for the compositing launch's spare workgroups to rank; null: not wanted
+    uint32_t *next_splitters = nullptr;
 };
 
 // The compositing launch's share: spare workgroups rank the samples into the next frame's splitters, every tile

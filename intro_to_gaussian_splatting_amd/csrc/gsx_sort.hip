@@ -824,6 +824,21 @@ __device__ __forceinline__ void key_span(const uint32_t (&key)[R], const bool (&
     __syncthreads();
 }
 
+// SortHints.next_splitters: the key of depth rank g is the next frame's splitter j for every j with floor(j M / 256) == g
+// (none, one, or several when fewer than 256 keys are kept) -- M = number of kept keys.  Every j in 1 .. 255 names exactly one
+// rank, every rank lies in exactly one non-empty bucket, and both bucket paths call this for their ranks [start, start + size):
+// all 255 are written, from one sorted sequence -- a monotone set by construction.  ONE thread of the workgroup calls it:
+// a bucket holds one quantile or two (key_at(i) = the key of the bucket's i-th rank).
+template <typename KeyAt>
+__device__ __forceinline__ void leave_splitters(uint32_t start, uint32_t size, uint32_t M, KeyAt key_at, uint32_t *__restrict__ spl) {
+    uint32_t j = (uint32_t)(((unsigned long long)start * (uint32_t)kBins + M - 1u) / M);
+    for (; j < (uint32_t)kBins; ++j) {
+        const uint32_t g = (uint32_t)(((unsigned long long)j * M) / (uint32_t)kBins);
+        if (g >= start + size) break;
+        if (j) spl[j] = key_at(g - start);
+    }
+}
+
 // A bucket that fits the LDS: load, sort over the bits of (key - smallest key), stream out.  (All 1024 threads.)
 // The offset from the smallest key, not the bits in which keys differ: a bucket holds 1/256 of the keys, a span
 // of 2^15 .. 2^18 float-depth codes at 1M Gaussians = two 9-bit passes, where one bucket that straddles a
@@ -838,7 +853,7 @@ template <int R>
 __device__ __forceinline__ void bucket_in_lds(uint32_t start, uint32_t size, uint32_t L, const uint32_t *kin,
                                               const uint32_t *vin, uint32_t *vout, TileRect *rrect, RankShared &sh,
                                               uint32_t *items, uint32_t *s_min, uint32_t *s_max,
-                                              unsigned long long *chunk_sums) {
+                                              unsigned long long *chunk_sums, uint32_t *next_spl, uint32_t kept) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t key[R], val[R];
     bool ok[R];
@@ -871,6 +886,10 @@ __device__ __forceinline__ void bucket_in_lds(uint32_t start, uint32_t size, uin
 #pragma unroll
     for (int r = 0; r < R; ++r) key[r] -= kmin;
     lds_passes<R, false>(key, val, ok, L, 0, span ? 32 - __clz((int)span) : 0, sh, items, items + kBucketCap);
+    // (the last pass left the sorted keys, minus kmin, in `items` -- unless no bit varies: then every key is kmin)
+    if (next_spl && threadIdx.x == 0)
+        leave_splitters(start, size, kept, [&](uint32_t i) -> uint32_t { return span ? items[i] + kmin : kmin; }, next_spl);
+    if (next_spl) __syncthreads();        // (uniform; `items` is reused below)
     // val[r] = position in the bucket of the item of rank (w, r, lane).  Thread-strided staging: item j = r * 1024 + tid.
     const bool together = size * 3u <= 2u * (uint32_t)kBucketCap;   // 12 bytes per item fit the buffer at once
     uint32_t *lval = together ? items + 2 * size : items;
@@ -940,7 +959,8 @@ __global__ void __launch_bounds__(kBigThreads)
     bucket_sort_kernel(const uint32_t *__restrict__ totals, const uint32_t *__restrict__ table_cm, int nblocks_cm,
                        uint32_t *kin, uint32_t *vin, uint32_t *kalt, uint32_t *vout,
                        const TileRect *__restrict__ rect, TileRect *rrect, uint32_t lds_cap,
-                       unsigned long long *__restrict__ chunk_sums) {
+                       unsigned long long *__restrict__ chunk_sums, uint32_t *next_spl, uint32_t *next_hdr,
+                       const uint32_t *__restrict__ m_dev) {
     __shared__ RankShared sh;
     __shared__ __attribute__((aligned(16))) uint32_t sitems[2 * kBucketCap];
     uint32_t *skey = sitems;
@@ -982,18 +1002,23 @@ __global__ void __launch_bounds__(kBigThreads)
     }
     __syncthreads();
     const uint32_t start = s_start, size = s_tot[blockIdx.x];
-    if (size == 0) return;
+    const uint32_t kept = next_spl ? *m_dev : 0u;      // (written by the partition pass: every kept key, all buckets)
+    if (next_spl && blockIdx.x == 0 && threadIdx.x == 0) {
+        next_spl[0] = 0u;
+        next_hdr[kHintSplitters] = kept ? (uint32_t)kBins : 0u;     // nothing kept: the next frame takes its stand-in splitters
+    }
+    if (size == 0 || (next_spl && kept == 0u)) return;
     if (size <= lds_cap) {
         // ---- in LDS: items wave-striped, L per wave, as few rounds of 64 per wave as hold them
         const uint32_t L = (((size + kBigWaves - 1) / kBigWaves) + 63u) & ~63u;
         if (L <= 2 * 64)
-            bucket_in_lds<2>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums);
+            bucket_in_lds<2>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums, next_spl, kept);
         else if (L <= 4 * 64)
-            bucket_in_lds<4>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums);
+            bucket_in_lds<4>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums, next_spl, kept);
         else if (L <= 8 * 64)
-            bucket_in_lds<8>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums);
+            bucket_in_lds<8>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums, next_spl, kept);
         else
-            bucket_in_lds<kBucketRounds>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums);
+            bucket_in_lds<kBucketRounds>(start, size, L, kin, vin, vout, rrect, sh, sitems, &s_min, &s_max, chunk_sums, next_spl, kept);
         return;
     }
     // ---- through global memory (a bucket that does not fit): LSD passes over the varying bytes, tile by tile
@@ -1069,6 +1094,8 @@ __global__ void __launch_bounds__(kBigThreads)
         }
         if (chunk_sums) tally.flush(chunk_sums);
     }
+    if (next_spl && threadIdx.x == 0)       // (sk: the sorted keys of the last pass, or the bucket as it came when no byte varies)
+        leave_splitters(start, size, kept, [&](uint32_t i) -> uint32_t { return sk[i]; }, next_spl);
 }
 
 // Up to kBucketCap keys (the reference's own scenes: 2 000 .. 52 000 Gaussians fit or nearly fit) ONE workgroup
@@ -1350,7 +1377,8 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
     // splitters, and with GSX_FLAG_HINTS_VALID the splitters of THIS frame are the ones the previous frame left --
     // no sample kernel on the frame's critical path
     const bool hinted = nb == kBins && hints.header != nullptr;
-    uint32_t *samples_out = hinted ? hints.samples : nullptr;
+    // (the bucket kernel leaves the next frame's splitters itself: no sample for the compositing launch to rank)
+    uint32_t *samples_out = hinted && !hints.next_splitters ? hints.samples : nullptr;
     const uint32_t step = hinted && n >= kSamples ? (uint32_t)(n / kSamples) : 0u;
     if (nb > kBins) {
 #ifndef GSX_TEST_HOOKS
@@ -1363,7 +1391,7 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
         launch_partition<kSortBinsMax>(p, keys0, keys1, vals_cur, vals_alt, n, m_dev, culled_dev, rect, rrect, splitters, nullptr,
                                        nullptr, 0u, nullptr, 0u, s, row_of);
         bucket_sort_kernel<kSortBinsMax><<<kSortBinsMax, kBigThreads, 0, s>>>(p.totals, p.table, 0, keys1, vals_alt, keys0, vals_cur,
-                                                                              rect, rrect, lds_cap, cs);
+                                                                              rect, rrect, lds_cap, cs, nullptr, nullptr, m_dev);
 #endif
     } else {
         const bool use = hinted && hints.use;
@@ -1374,7 +1402,8 @@ hipError_t sort_depth_sampled(DepthRoute route, void *temp, uint32_t *keys0, uin
                                 use ? hints.splitters : splitters, use ? hints.header : nullptr, samples_out, step,
                                 use ? cs : nullptr, nsums, s, row_of);
         bucket_sort_kernel<kBins><<<kBins, kBigThreads, 0, s>>>(p.totals, p.table, p.self_scan ? p.nblocks : 0, keys1, vals_alt,
-                                                                keys0, vals_cur, rect, rrect, lds_cap, cs);
+                                                                keys0, vals_cur, rect, rrect, lds_cap, cs,
+                                                                hinted ? hints.next_splitters : nullptr, hints.header, m_dev);
     }
     return hipGetLastError();
 }

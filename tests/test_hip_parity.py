@@ -2011,3 +2011,32 @@ def test_spatially_ordered_strips_of_a_100k_scene(tmp_path):
         out = torch.empty(((t1 - t0) * 16, 1080, 3), dtype=torch.float32, device="cuda:0")
         ordered.render_image_hip(1, tile_window=(t0, t1, 0, nty), out=out, out_origin=(t0 * 16, 0))
         assert torch.equal(out, whole[t0 * 16:t1 * 16]), ("moved", t0, t1)
+
+
+def test_a_frame_leaves_the_exact_depth_quantiles_as_the_next_frames_splitters(tmp_path):
+    """The 256-bucket depth sort knows every kept key's rank: its bucket kernel leaves the NEXT frame's splitters in the hints
+    buffer itself -- splitters[j] = the key of rank floor(j M / 256), the exact quantiles (round 6; before, 2 048 sampled keys
+    were ranked by spare workgroups of the compositing launch: buckets of 0.5 .. 2x the mean, and the largest bucket is the
+    bucket kernel's duration).  Read back here: 256 words, ascending, equal to the quantiles of the sorted depth keys -- and
+    the frame that uses them is the same bit for bit."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    sc = make_scene(60_000, 800, 608, seed=9)
+    scene = _scene_from_arrays(tmp_path, sc)
+    st = {}
+    first = scene.render_image_hip(1, stats=st).clone()
+    torch.cuda.synchronize()
+    slots = [v for v in scene._hints._d.values()] if hasattr(scene._hints, "_d") else list(scene._hints.values())
+    assert len(slots) == 1
+    words = slots[0][0].view(torch.int32).cpu().numpy().view(np.uint32)
+    assert words[0] == 256                                         # header[kHintSplitters]
+    spl = words[64:64 + 256].astype(np.int64)
+    assert spl[0] == 0 and np.all(np.diff(spl[1:]) >= 0)
+    pre = scene.preprocess(1)
+    depths = np.sort(pre.depths.cpu().numpy().view(np.uint32).astype(np.int64))
+    m = int(st["n_kept"])
+    if m == depths.size:                                            # (every visible Gaussian reaches a tile of this frame)
+        want = depths[(np.arange(1, 256) * m) // 256]
+        assert np.array_equal(spl[1:], want)
+    assert torch.equal(scene.render_image_hip(1), first)
