@@ -142,6 +142,7 @@ int bin_and_blend(const Plan &p, const Carve &c, char *ws, int64_t n, int64_t ca
                 lt.cost = fh.blend.lens;
                 lt.header = fh.blend.header;
                 lt.cost_pct = (uint32_t)gsx::knob("GSX_LONG_COST_PCT", 30);      // (test library only)
+                lt.stay_pct = (uint32_t)gsx::knob("GSX_LONG_STAY_PCT", 75);
                 if (!fh.sched || lt.cost_pct == 0) lt.header = nullptr;
             }
             GSX_HIP(gsx::sort_instances(temp, cap, p.grid, ws + c.tkeys0, ws + c.tkeys1, (uint32_t *)(ws + c.tvals0),

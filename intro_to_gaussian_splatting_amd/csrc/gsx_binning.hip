@@ -420,9 +420,12 @@ __global__ void __launch_bounds__(kBlock)
                 // a tile above a third of that share is still running when everything else has finished.  (By length,
                 // 4x the mean: the heavy-tailed test scene ended with ~100 single waves of 1 500 .. 2 500 records each
                 // running alone for 150 us; lowering the length threshold instead put 500 tiles on four waves, most
-                // of them cheap, and cost 50 %.)  A long tile's cost is the largest of its four helpers' -- what one
-                // wave would have walked --, so a tile does not change sides from frame to frame.
-                is_long = (lt.cost[cur] & 0x7FFFFFFFu) >= cost_thr && j >= 127u && keys[j - 127u] == cur;     // (and 128 entries now)
+                // of them cheap, and cost 50 %.)  A long tile's cost is the largest of its four helpers' -- about what one
+                // wave would have walked; a tile that was long stays long down to lt.stay_pct % of the threshold, so that
+                // a tile does not change sides from frame to frame (LongTiles in gsx_internal.h).
+                const uint32_t was = lt.cost[cur];
+                const uint32_t thr_now = (was >> 31) ? (uint32_t)(((uint64_t)cost_thr * lt.stay_pct) / 100u) : cost_thr;
+                is_long = (was & 0x7FFFFFFFu) >= thr_now && j >= 127u && keys[j - 127u] == cur;     // (and 128 entries now)
             }
             if (is_long) {
                 const uint32_t slot = atomicAdd(lt.count, 1u);

@@ -924,8 +924,8 @@ __device__ __forceinline__ void blend_tile16(const Record *__restrict__ rec, con
         // split tile is staged four times over, so splitting hundreds costs more than it saves (512 split tiles of the
         // heavy-tailed test scene: 0.60 ms of compositing against 0.38 for none and 0.31 for the 176 most expensive).
         if (lt.max && by_cost) {       // (a frame that chose by list length says nothing about the threshold)
-            const uint32_t found = *lt.count, pct = max(hints.header[kHintLongPct], 30u);
-            hints.header[kHintLongPct] = found > 192u ? min(pct + pct / 4u, 1000u) : (found < 64u ? max(pct - pct / 8u, 30u) : pct);
+            const uint32_t found = *lt.count, pct = max(hints.header[kHintLongPct], lt.cost_pct);
+            hints.header[kHintLongPct] = found > 192u ? min(pct + pct / 4u, 1000u) : (found < 64u ? max(pct - pct / 8u, lt.cost_pct) : pct);
         }
     }
     if (rg.y & kLongFlag) return;   // a long tile: four helper workgroups composite it
