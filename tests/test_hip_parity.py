@@ -529,6 +529,35 @@ def test_4k_5m_stress_properties(tmp_path):
     assert strip_ms["total"] <= 0.30 * full_ms["total"]
 
 
+def test_twenty_million_gaussians_through_the_same_path(tmp_path):
+    """Sizes beyond the BASELINE configurations (a 288 GB part holds scenes of hundreds of millions of Gaussians; tools/big_scene.py
+    ran 150M / 293M pairs against the whole C frame, profiles/r6_big_scenes.txt): 20M Gaussians at 1080p -- 19.8M kept, the
+    4-pass route of the depth sort far above its 1.5M threshold, 50M+ pairs -- with the counts of the C restatement, pixel
+    parity on a window it renders in seconds, and eight strips that assemble to the frame bit for bit."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+    from oracle import c_oracle
+
+    n, w, h = 20_000_000, 1920, 1080
+    sc = make_scene(n, w, h, seed=3, sigma_scale=0.45)
+    scene = _scene_from_arrays(tmp_path, sc)
+    st = {}
+    a = scene.render_image_hip(1, stats=st)
+    pre = c_oracle.preprocess(sc["points"], scene.gaussians.colors.cpu().numpy(), sc["scales"], sc["quaternions"], sc["opacity"],
+                              _oracle_cam(scene))
+    win, _, inst = c_oracle.render(pre, w, h, 16, window=(40, 48, 20, 28))
+    print("20M: visible %d, kept %d, pairs %d" % (st["n_visible"], st["n_kept"], st["n_instances"]))
+    assert st["n_visible"] == pre.points.shape[0] and st["n_instances"] == inst and inst > n
+    got = a[640:768, 320:448].cpu().numpy()
+    assert np.max(np.abs(got - win[640:768, 320:448])) <= PIXEL_TOL
+    ntx, nty = (w + 15) // 16, (h + 15) // 16
+    parts = torch.full_like(a, 3.0)
+    for k in range(8):
+        c0, c1 = ntx * k // 8, ntx * (k + 1) // 8
+        scene.render_image_hip(1, tile_window=(c0, c1, 0, nty), out=parts[c0 * 16:min(c1 * 16, w)], out_origin=(c0 * 16, 0))
+    assert torch.equal(parts, a)
+
+
 def test_long_tiles_on_four_waves_equal_the_single_wave_path(tmp_path):
     """Heavy-tailed scene (half of the Gaussians inside 5 % of the frame, footprint sigma_ln 1.0): the longest
     tile lists are ~20x the mean.  Tiles above long_tile_threshold are composited by four waves, one pixel per
