@@ -258,7 +258,12 @@ def extent_radius(c2: np.ndarray) -> np.ndarray:
 
 
 def sigmoid(x: np.ndarray) -> np.ndarray:
+    """``torch.sigmoid`` on ONE element at a time (splat/gaussian_scene.py:164: the reference's second sigmoid) -- torch's
+    scalar path, libm's ``expf``.  Arrays of up to 2^16 elements (a tile's list) go through libm itself; longer ones
+    through numpy's float32 exp, which is a last bit off here and there (nothing on the pinned paths is that long)."""
     x = np.asarray(x, dtype=f32)
+    if 0 < x.size <= 65536:
+        return (f32(1.0) / (f32(1.0) + _libm_expf(f32(0.0) - x).reshape(x.shape))).astype(f32)
     return (f32(1.0) / (f32(1.0) + np.exp(-x))).astype(f32)
 
 
@@ -280,6 +285,22 @@ def _vexp(d: np.ndarray) -> np.ndarray:
     return np.where(d > f32(100.0), f32(np.inf), u).astype(f32)
 
 
+_LIBM = None
+
+
+def _libm_expf(v: np.ndarray) -> np.ndarray:
+    """glibc's ``expf`` on every element (what torch's scalar tail loop calls; oracle/raster_cpu.c links the same one)."""
+    global _LIBM
+    if _LIBM is None:
+        import ctypes
+        import ctypes.util
+
+        _LIBM = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        _LIBM.expf.restype = ctypes.c_float
+        _LIBM.expf.argtypes = [ctypes.c_float]
+    return np.array([_LIBM.expf(float(t)) for t in np.asarray(v, f32).reshape(-1)], dtype=f32)
+
+
 def sigmoid_torch(x: np.ndarray, threads: int = 8) -> np.ndarray:
     """``torch.sigmoid`` on a contiguous float32 array as torch 2.10 executes it on an AVX-512 host
     (splat/gaussian_scene.py:143; probed: the reference's bits): ``1 / (1 + e)`` with ``e`` the SIMD exponential on
@@ -297,9 +318,11 @@ def sigmoid_torch(x: np.ndarray, threads: int = 8) -> np.ndarray:
         begin = (i // chunk) * chunk
         length = np.minimum(n - begin, chunk)
         tail = (i - begin) >= length - length % 32
-        # (libm's expf is correctly rounded for all practical purposes: the float64 exponential rounded once stands in
-        # for it; numpy's own float32 exp is another SIMD routine, a last bit off here and there)
-        out[tail] = f32(1.0) / (f32(1.0) + np.exp(-flat[tail].astype(np.float64)).astype(f32))
+        # libm's expf ITSELF, element by element (at most 31 per chunk): the float64 exponential rounded once stood in
+        # for it through round 5 -- glibc's expf is within 0.502 ulp, not correctly rounded, and a 200-case run of
+        # oracle/fuzz_vs_reference.py (round 6) met two elements in ~50 000 tails where the two differ by a bit;
+        # numpy's own float32 exp is another SIMD routine again
+        out[tail] = f32(1.0) / (f32(1.0) + _libm_expf(f32(0.0) - flat[tail]))
     return out.reshape(x.shape)
 
 
@@ -387,7 +410,7 @@ def render_pixel_scalar(px: int, py: int, means, colors, sig_op, inv) -> np.ndar
         e1 = means[k, 1] - fy_
         power = f32(t0 * e0 + t1 * e1)
         w = np.exp(power, dtype=f32)
-        o2 = f32(1.0) / (f32(1.0) + np.exp(-sig_op[k], dtype=f32))
+        o2 = f32(1.0) / (f32(1.0) + _libm_expf(f32(0.0) - sig_op[k:k + 1])[0])
         alpha = f32(w * o2)
         test = f32(T * (f32(1.0) - alpha))
         if test < STOP_T:

@@ -145,22 +145,23 @@ def run_case(seed: int, render: bool, GaussianScene, Gaussians, numpy_too: bool)
     return out
 
 
-def fuzz(cases: int = 24, renders: int = 6, seed: int = 0, verbose: bool = True) -> dict:
-    """Runs the cases; returns a summary with ``ok``.  Needs /root/reference."""
+def fuzz(cases: int = 24, renders: int = 6, seed: int = 0, verbose: bool = True, also=()) -> dict:
+    """Runs the cases (``also``: further stage-1 seeds, both restatements); returns a summary with ``ok``.  Needs /root/reference."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import capture_golden
 
     GaussianScene, Gaussians = capture_golden._import_reference()
     results = []
-    for k in range(cases + renders):
-        render = k >= cases
-        r = run_case(seed + k, render, GaussianScene, Gaussians, numpy_too=render or k % 4 == 0)
+    plan = [(seed + k, k >= cases, k >= cases or k % 4 == 0) for k in range(cases + renders)] + [(int(a), False, True) for a in also]
+    for case_seed, render, numpy_too in plan:
+        r = run_case(case_seed, render, GaussianScene, Gaussians, numpy_too=numpy_too)
         results.append(r)
         if verbose:
             print("case %4d %-9s n=%7d visible=%7d %4dx%-4d tied=%5d  diffs=%s order_outside_ties=%d%s" % (
                 r["seed"], r["kind"], r["n"], r["n_visible"], r["frame"][0], r["frame"][1], r["tied"], r["diffs"] or 0,
                 r["order_diffs_outside_ties"], ("  image %.2e (tile %d)" % (r["image_max_abs"], r["tile"])) if render else ""), flush=True)
     bad = [r for r in results if r["diffs"] or r["order_diffs_outside_ties"] or r.get("image_max_abs", 0.0) > 2e-6]
+    cases += len(tuple(also))
     summary = dict(cases=cases, renders=renders, seed=seed, gaussians=int(sum(r["n"] for r in results)),
                    arrays_compared=len(FIELDS) * sum(1 for _ in results), failing=[r["seed"] for r in bad],
                    worst_image=max([r.get("image_max_abs", 0.0) for r in results] + [0.0]), ok=not bad)
@@ -176,11 +177,13 @@ def main() -> int:
     ap.add_argument("--cases", type=int, default=24)
     ap.add_argument("--renders", type=int, default=6)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--also", default="", help="comma-separated further stage-1 seeds, each through BOTH restatements "
+                    "(1016,1152: the two cases of round 6's 200-case run in which the numpy port's stand-in for libm's expf was a bit off)")
     a = ap.parse_args()
     if not os.path.isdir(REFERENCE):
         print("fuzz_vs_reference: skipped (%s is not here: build container only)" % REFERENCE)
         return 0
-    return 0 if fuzz(a.cases, a.renders, a.seed)["ok"] else 1
+    return 0 if fuzz(a.cases, a.renders, a.seed, also=[int(v) for v in a.also.split(",") if v])["ok"] else 1
 
 
 if __name__ == "__main__":

@@ -344,8 +344,10 @@ def test_fuzz_against_the_reference_itself():
     import sys
 
     # (a child process: importing the reference stubs an absent third-party module and extends sys.path)
-    seed = 7000 + (os.getpid() % 500) * 10
-    run = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "fuzz_vs_reference.py"), "--cases", "8", "--renders", "0",
-                          "--seed", str(seed)], capture_output=True, text=True, timeout=900)
+    # (fixed seeds: the suite is the same run every time; `python oracle/fuzz_vs_reference.py --seed N` is where new ones are
+    # tried.  1016 / 1152: of 200 cases run in round 6 the two in which the NUMPY port stood one bit off the reference -- its
+    # float64 stand-in for libm's expf on the tail of a torch thread's chunk -- and the C port did not)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "fuzz_vs_reference.py"), "--cases", "6", "--renders", "0",
+                          "--seed", "7000", "--also", "1016,1152"], capture_output=True, text=True, timeout=900)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-2000:]
     assert "0 differing bits outside equal depths" in run.stdout, run.stdout[-3000:]
