@@ -10,6 +10,8 @@ the scenes somebody chose; this pins it on scenes nobody chose.
 Bar: every stage-1 array (depth, pixel position, 2D covariance, its inverse, radius, the four bounding-box arrays,
 sigmoid_opacity, colours) bit for bit, Gaussian by Gaussian; the permutation equal outside runs of equal depths; images
 within 2e-6 given the reference's order (the restatement's own order differs only where equal depths overlap).
+sigmoid_opacity is position dependent (torch's SIMD / scalar-tail split runs over the SORTED array): a Gaussian that a tie
+puts at another position is compared by count only (``sigmoid_differs_where_a_tie_moved_it``).
 
     python oracle/fuzz_vs_reference.py                 # 24 stage-1 cases (1e3 .. 8e5 Gaussians) + 6 rendered frames, ~2 min
     python oracle/fuzz_vs_reference.py --cases 200 --seed 1000
@@ -134,7 +136,20 @@ def run_case(seed: int, render: bool, GaussianScene, Gaussians, numpy_too: bool)
             b = np.zeros_like(a)
             a[ref_order] = ra
             b[mine.order] = np.asarray(getattr(mine, f), np.float32).reshape(ra.shape)
-            cnt = int(np.count_nonzero(bits(a) != bits(b)))
+            differs = bits(a) != bits(b)
+            if f == "sigmoid_opacity":
+                # torch.sigmoid runs on the SORTED array and its value depends on the element's POSITION (SIMD exponential on
+                # whole groups of 32, libm's expf on the tail of every thread's chunk: cpu_ref.sigmoid_torch).  Inside a run of
+                # equal depths the reference's unstable argsort and the restatements' index order put a Gaussian at different
+                # positions -- one of which may be a tail: not a difference of the arithmetic (seed 2131: one element, 2 ulp).
+                # Compared where the position is the same; the others are counted for the record.
+                same_place = np.zeros(n, bool)
+                same_place[ref_order[mine.order == ref_order]] = True
+                moved = int(np.count_nonzero(differs.reshape(n, -1).any(axis=1) & ~same_place))
+                if moved:
+                    out["sigmoid_differs_where_a_tie_moved_it"] = out.get("sigmoid_differs_where_a_tie_moved_it", 0) + moved
+                differs = differs.reshape(n, -1).any(axis=1) & same_place
+            cnt = int(np.count_nonzero(differs))
             if cnt:
                 out["diffs"]["%s:%s" % (label, f)] = cnt
     if render:
@@ -159,7 +174,8 @@ def fuzz(cases: int = 24, renders: int = 6, seed: int = 0, verbose: bool = True,
         if verbose:
             print("case %4d %-9s n=%7d visible=%7d %4dx%-4d tied=%5d  diffs=%s order_outside_ties=%d%s" % (
                 r["seed"], r["kind"], r["n"], r["n_visible"], r["frame"][0], r["frame"][1], r["tied"], r["diffs"] or 0,
-                r["order_diffs_outside_ties"], ("  image %.2e (tile %d)" % (r["image_max_abs"], r["tile"])) if render else ""), flush=True)
+                r["order_diffs_outside_ties"], (("  image %.2e (tile %d)" % (r["image_max_abs"], r["tile"])) if render else "") +
+                (("  [sigmoid at a tie-moved position: %d]" % r["sigmoid_differs_where_a_tie_moved_it"]) if r.get("sigmoid_differs_where_a_tie_moved_it") else "")), flush=True)
     bad = [r for r in results if r["diffs"] or r["order_diffs_outside_ties"] or r.get("image_max_abs", 0.0) > 2e-6]
     cases += len(tuple(also))
     summary = dict(cases=cases, renders=renders, seed=seed, gaussians=int(sum(r["n"] for r in results)),
