@@ -11,6 +11,7 @@ the absent third-party ``plyfile`` module (only used for an IO side effect of th
     python oracle/capture_golden.py            # all fixtures (~15 min: c1_256x256 3 min, needle 3 min, trainedlike 5 min)
     python oracle/capture_golden.py small      # only those whose name contains "small"
     python oracle/capture_golden.py tiles_     # the reference-rendered tiles of the 1M-Gaussian 1080p scenes (~10 min)
+    python oracle/capture_golden.py fuzz_tiles # reference-rendered tiles of 24 random scenes (~8 min)
 """
 from __future__ import annotations
 
@@ -417,6 +418,34 @@ def capture_tiles(name: str, spec: dict, GaussianScene, Gaussians) -> None:
         name, len(chosen), int(counts.sum()), sum(secs), time.time() - t_all, path, os.path.getsize(path) / 1024))
 
 
+# Random scenes, pixels by the reference: oracle/fuzz_vs_reference.py's "tiles" cases (scenes of 3e3 .. 6e4 Gaussians from seven
+# generators, random pose and frame; per scene the longest list the reference composites in ~10 s and a random one, through its
+# own render_tile) for these seeds.  The scene is regenerated from the seed where the fixture is used
+# (fuzz_vs_reference.random_case(seed, "tiles")): the fixture holds the reference's blocks and counts only.
+FUZZ_TILE_FIXTURES = {"fuzz_tiles_seeds_8000": list(range(8000, 8024))}
+
+
+def capture_fuzz_tiles(name: str, seeds, GaussianScene, Gaussians) -> None:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fuzz_vs_reference
+
+    rows, blocks = [], []
+    for seed in seeds:
+        r = fuzz_vs_reference.run_case(int(seed), "tiles", GaussianScene, Gaussians, numpy_too=False)
+        assert not r["diffs"] and r["order_diffs_outside_ties"] == 0 and r["image_max_abs"] <= 2e-6, r
+        for tx, ty, length, blk in r["blocks"]:
+            rows.append((int(seed), r["n"], r["n_visible"], r["frame"][0], r["frame"][1], r["tile_instances"], tx, ty, length, r["tied"]))
+            blocks.append(blk.astype(np.float32))
+        print("  %s seed %d %-9s n=%6d %4dx%-4d D=%8d: %d tiles, lists to %d, C port (reference's order) %.1e" % (
+            name, seed, r["kind"], r["n"], r["frame"][0], r["frame"][1], r["tile_instances"], len(r["blocks"]), r["longest_list"],
+            r["image_max_abs"]), flush=True)
+    out = dict(columns=np.array("seed n n_visible width height tile_instances tx ty list_len tied".split()),
+               rows=np.array(rows, dtype=np.int64), blocks=np.stack(blocks), tile=np.int64(16))
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s (%d tiles of %d scenes, %.0f KB)" % (path, len(blocks), len(seeds), os.path.getsize(path) / 1024), flush=True)
+
+
 def capture(name: str, spec: dict, GaussianScene, Gaussians) -> None:
     import torch
 
@@ -575,6 +604,9 @@ def main() -> None:
     for name, spec in TILE_FIXTURES.items():
         if only in name:
             capture_tiles(name, spec, GaussianScene, Gaussians)
+    for name, seeds in FUZZ_TILE_FIXTURES.items():
+        if only in name:
+            capture_fuzz_tiles(name, seeds, GaussianScene, Gaussians)
 
 
 if __name__ == "__main__":

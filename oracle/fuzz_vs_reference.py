@@ -15,6 +15,7 @@ puts at another position is compared by count only (``sigmoid_differs_where_a_ti
 
     python oracle/fuzz_vs_reference.py                 # 24 stage-1 cases (1e3 .. 8e5 Gaussians) + 6 rendered frames, ~2 min
     python oracle/fuzz_vs_reference.py --cases 200 --seed 1000
+    python oracle/fuzz_vs_reference.py --cases 0 --renders 0 --tiles 40      # lists of hundreds through the reference's render_tile, ~20 s each
 """
 from __future__ import annotations
 
@@ -42,7 +43,10 @@ def random_case(seed: int, render: bool) -> dict:
     from intro_to_gaussian_splatting_amd import synthetic
 
     rs = np.random.RandomState(seed)
-    if render:
+    if render == "tiles":       # denser scenes than a whole reference-rendered frame can afford: lists of hundreds, two tiles each
+        n = int(np.exp(rs.uniform(np.log(3e3), np.log(6e4))))
+        w, h = [(320, 240), (640, 480), (256, 256), (400, 304)][rs.randint(4)]
+    elif render:
         n = int(rs.randint(20, 400))
         w, h = int(rs.randint(40, 97)), int(rs.randint(40, 97))
     else:
@@ -72,13 +76,13 @@ def random_case(seed: int, render: bool) -> dict:
         args.update(sigma_scale=float(rs.uniform(0.03, 0.3)))
     if gen is synthetic.make_scene and rs.uniform() < 0.4:
         args["behind_fraction"] = float(rs.uniform(0.05, 0.5))
-    if render and rs.uniform() < 0.3:
+    if render is True and rs.uniform() < 0.3:
         # at most three Gaussians pass the cull: the reference's BLAS sums its few-row products in other orders
         # (oracle/probe_torch_order.py; GSX_FLAG_SMALL_BATCH / _ONE_VISIBLE in include/gsx.h)
         kind, gen = "few", synthetic.make_few_visible_scene
         vis = int(rs.randint(1, 4))
         args = dict(n=int(rs.randint(vis, 13)), width=w, height=h, seed=args["seed"], visible=vis)
-    return dict(kind=kind, gen=gen, args=args, tile=int([16, 16, 16, 8, 5][rs.randint(5)]) if render else 16)
+    return dict(kind=kind, gen=gen, args=args, tile=int([16, 16, 16, 8, 5][rs.randint(5)]) if render is True else 16, rs=rs)
 
 
 def bits(a):
@@ -115,7 +119,26 @@ def run_case(seed: int, render: bool, GaussianScene, Gaussians, numpy_too: bool)
         perm = torch.argsort((hom @ cam.world2view)[:, 2])
         assert torch.equal((hom @ cam.world2view)[:, 2][perm], pre.depths)
         ref_order = np.nonzero(in_view.numpy())[0][perm.numpy()].astype(np.int64)
-        image = scene.render_image(1, tile_size=case["tile"]).numpy() if render else None
+        image = scene.render_image(1, tile_size=case["tile"]).numpy() if render is True else None
+        blocks = []
+        if render == "tiles":
+            # the reference's own list (mask expressions of splat/gaussian_scene.py:209-226) and its own render_tile (:173-198)
+            t, W, H = 16, int(cam.width.item()), int(cam.height.item())
+            xin = torch.stack([(pre.min_x <= x0 + t) & (pre.max_x >= x0) for x0 in range(0, W - t, t)])
+            yin = torch.stack([(pre.min_y <= y0 + t) & (pre.max_y >= y0) for y0 in range(0, H - t, t)])
+            counts = (xin.float() @ yin.float().T).round().to(torch.int64).numpy()
+            # the longest list the reference composites in about ten seconds (75 us per pixel and entry), and a random one
+            affordable = np.where(counts <= 700, counts, -1)
+            picks = [np.unravel_index(int(np.argmax(affordable)), counts.shape)]
+            nz = np.argwhere((counts > 0) & (counts <= 700))
+            if len(nz):
+                picks.append(tuple(nz[case["rs"].randint(len(nz))]))
+            for tx, ty in picks:
+                inside = xin[tx] & yin[ty]
+                blk = scene.render_tile(x_min=int(tx) * t, y_min=int(ty) * t, points_in_tile_mean=pre.points[inside], colors=pre.colors[inside],
+                                        opacities=pre.sigmoid_opacity[inside], inverse_covariance=pre.inverse_covariance_2d[inside], tile_size=t)
+                blocks.append((int(tx), int(ty), int(inside.sum()), blk.numpy().copy()))
+            tile_instances = int(counts.sum())
         colors = g.colors.numpy()
     ocam = cpu_ref.Camera(cam.world2view.numpy(), cam.full_proj_transform.numpy(), cam.tan_fovX.numpy()[0], cam.tan_fovY.numpy()[0],
                           cam.f_x.numpy()[0], cam.f_y.numpy()[0], int(cam.width.item()), int(cam.height.item()))
@@ -152,29 +175,39 @@ def run_case(seed: int, render: bool, GaussianScene, Gaussians, numpy_too: bool)
             cnt = int(np.count_nonzero(differs))
             if cnt:
                 out["diffs"]["%s:%s" % (label, f)] = cnt
-    if render:
+    if render is True:
         given = cpu_ref.preprocess(sc["points"], colors, sc["scales"], sc["quaternions"], sc["opacity"], ocam, order=ref_order)
         img, _, _ = c_oracle.render(given, ocam.width, ocam.height, case["tile"])
         out["image_max_abs"] = float(np.abs(img - image).max()) if image.size else 0.0
         out["tile"] = case["tile"]
+    elif render == "tiles":
+        given = cpu_ref.preprocess(sc["points"], colors, sc["scales"], sc["quaternions"], sc["opacity"], ocam, order=ref_order)
+        worst, longest = 0.0, 0
+        for tx, ty, length, blk in blocks:
+            img, _, _ = c_oracle.render(given, ocam.width, ocam.height, 16, window=(tx, tx + 1, ty, ty + 1))
+            worst = max(worst, float(np.abs(img[tx * 16:(tx + 1) * 16, ty * 16:(ty + 1) * 16] - blk).max()))
+            longest = max(longest, length)
+        out["image_max_abs"], out["tile"], out["longest_list"] = worst, 16, longest
+        out["blocks"], out["tile_instances"] = blocks, tile_instances        # (oracle/capture_golden.py: fuzz_tiles_* fixtures)
     return out
 
 
-def fuzz(cases: int = 24, renders: int = 6, seed: int = 0, verbose: bool = True, also=()) -> dict:
+def fuzz(cases: int = 24, renders: int = 6, seed: int = 0, verbose: bool = True, also=(), tiles: int = 0) -> dict:
     """Runs the cases (``also``: further stage-1 seeds, both restatements); returns a summary with ``ok``.  Needs /root/reference."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import capture_golden
 
     GaussianScene, Gaussians = capture_golden._import_reference()
     results = []
-    plan = [(seed + k, k >= cases, k >= cases or k % 4 == 0) for k in range(cases + renders)] + [(int(a), False, True) for a in also]
+    plan = [(seed + k, k >= cases, k >= cases or k % 4 == 0) for k in range(cases + renders)] + [(int(a), False, True) for a in also] + \
+        [(seed + cases + renders + k, "tiles", True) for k in range(tiles)]
     for case_seed, render, numpy_too in plan:
         r = run_case(case_seed, render, GaussianScene, Gaussians, numpy_too=numpy_too)
         results.append(r)
         if verbose:
             print("case %4d %-9s n=%7d visible=%7d %4dx%-4d tied=%5d  diffs=%s order_outside_ties=%d%s" % (
                 r["seed"], r["kind"], r["n"], r["n_visible"], r["frame"][0], r["frame"][1], r["tied"], r["diffs"] or 0,
-                r["order_diffs_outside_ties"], (("  image %.2e (tile %d)" % (r["image_max_abs"], r["tile"])) if render else "") +
+                r["order_diffs_outside_ties"], (("  image %.2e (tile %d%s)" % (r["image_max_abs"], r["tile"], ", reference-rendered tiles, lists to %d" % r["longest_list"] if "longest_list" in r else "")) if render else "") +
                 (("  [sigmoid at a tie-moved position: %d]" % r["sigmoid_differs_where_a_tie_moved_it"]) if r.get("sigmoid_differs_where_a_tie_moved_it") else "")), flush=True)
     bad = [r for r in results if r["diffs"] or r["order_diffs_outside_ties"] or r.get("image_max_abs", 0.0) > 2e-6]
     cases += len(tuple(also))
@@ -182,8 +215,8 @@ def fuzz(cases: int = 24, renders: int = 6, seed: int = 0, verbose: bool = True,
                    arrays_compared=len(FIELDS) * sum(1 for _ in results), failing=[r["seed"] for r in bad],
                    worst_image=max([r.get("image_max_abs", 0.0) for r in results] + [0.0]), ok=not bad)
     if verbose:
-        print("fuzz_vs_reference: %d stage-1 cases + %d rendered frames, %d Gaussians: %s" % (
-            cases, renders, summary["gaussians"], "0 differing bits outside equal depths, images <= %.1e" % summary["worst_image"]
+        print("fuzz_vs_reference: %d stage-1 cases + %d rendered frames%s, %d Gaussians: %s" % (
+            cases, renders, " + %d scenes with reference-rendered tiles" % tiles if tiles else "", summary["gaussians"], "0 differing bits outside equal depths, images <= %.1e" % summary["worst_image"]
             if summary["ok"] else "FAILING seeds %r" % summary["failing"]))
     return summary
 
@@ -193,13 +226,15 @@ def main() -> int:
     ap.add_argument("--cases", type=int, default=24)
     ap.add_argument("--renders", type=int, default=6)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--tiles", type=int, default=0, help="further cases: scenes of 3e3 .. 6e4 Gaussians, two tiles each composited by the "
+                    "reference's own render_tile (the longest affordable list and a random one) against the C port on that window")
     ap.add_argument("--also", default="", help="comma-separated further stage-1 seeds, each through BOTH restatements "
                     "(1016,1152: the two cases of round 6's 200-case run in which the numpy port's stand-in for libm's expf was a bit off)")
     a = ap.parse_args()
     if not os.path.isdir(REFERENCE):
         print("fuzz_vs_reference: skipped (%s is not here: build container only)" % REFERENCE)
         return 0
-    return 0 if fuzz(a.cases, a.renders, a.seed, also=[int(v) for v in a.also.split(",") if v])["ok"] else 1
+    return 0 if fuzz(a.cases, a.renders, a.seed, also=[int(v) for v in a.also.split(",") if v], tiles=a.tiles)["ok"] else 1
 
 
 if __name__ == "__main__":

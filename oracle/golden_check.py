@@ -154,3 +154,23 @@ def rows_in_reference_order(pre_order, g):
     rows = inv[patched]
     assert (rows >= 0).all() and np.array_equal(np.sort(rows), np.arange(order.size))
     return rows
+
+
+FUZZ_TILE_FIXTURE_NAMES = ["fuzz_tiles_seeds_8000"]
+
+
+def fuzz_tiles_cases(g):
+    """Per scene of a ``fuzz_tiles_*`` fixture (oracle/capture_golden.py: capture_fuzz_tiles -- random scenes whose tiles the REFERENCE's
+    own ``render_tile`` composited): (seed, the scene's arrays regenerated from the seed, its row dict, [(tx, ty, list length, block)])."""
+    from oracle import fuzz_vs_reference
+
+    cols = [str(c) for c in g["columns"]]
+    rows = [dict(zip(cols, (int(v) for v in r))) for r in g["rows"]]
+    for seed in sorted({r["seed"] for r in rows}):
+        case = fuzz_vs_reference.random_case(seed, "tiles")
+        sc = case["gen"](**case["args"])
+        sc.pop("sh", None)
+        sc.pop("sh_degree", None)
+        mine = [(k, r) for k, r in enumerate(rows) if r["seed"] == seed]
+        yield seed, sc, mine[0][1], [(r["tx"], r["ty"], r["list_len"], g["blocks"][k]) for k, r in mine]
+

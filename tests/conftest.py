@@ -59,9 +59,9 @@ def golden(request):
     return load_golden(request.param)
 
 
-from oracle.golden_check import (STAGE1_FIELDS, TILE_FIXTURE_NAMES, compare_stage1_with_reference,  # noqa: E402,F401
-                                 compare_tiles_with_reference, rows_in_reference_order, sha256, stage1_scene,
-                                 tile_lists, tiles_scene)
+from oracle.golden_check import (FUZZ_TILE_FIXTURE_NAMES, STAGE1_FIELDS, TILE_FIXTURE_NAMES,  # noqa: E402,F401
+                                 compare_stage1_with_reference, compare_tiles_with_reference, fuzz_tiles_cases,
+                                 rows_in_reference_order, sha256, stage1_scene, tile_lists, tiles_scene)
 
 
 def tie_mask(depths_sorted) -> np.ndarray:

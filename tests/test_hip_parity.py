@@ -13,8 +13,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (ROOT, STAGE1_FIELDS, STAGE1_NAMES, TILE_FIXTURE_NAMES, assert_same_order_outside_ties,
-                      compare_stage1_with_reference, compare_tiles_with_reference, golden_preprocessed, load_golden,
+from conftest import (FUZZ_TILE_FIXTURE_NAMES, ROOT, STAGE1_FIELDS, STAGE1_NAMES, TILE_FIXTURE_NAMES,
+                      assert_same_order_outside_ties, compare_stage1_with_reference, compare_tiles_with_reference,
+                      fuzz_tiles_cases, golden_preprocessed, load_golden,
                       oracle_camera, rows_by_index, stage1_scene, tile_lists, tiles_scene)
 
 pytestmark = pytest.mark.gpu
@@ -527,6 +528,26 @@ def test_4k_5m_stress_properties(tmp_path):
     # median of event-bracketed frames by `bench.py --workload c4 --strip-of 8` (0.386 ms); the per-stage times printed
     # here are taken with a host synchronisation per stage mark and add up to more
     assert strip_ms["total"] <= 0.30 * full_ms["total"]
+
+
+@pytest.mark.parametrize("name", FUZZ_TILE_FIXTURE_NAMES)
+def test_reference_rendered_tiles_of_random_scenes_on_the_gpu(name, tmp_path):
+    """tests/golden/fuzz_tiles_* (24 random scenes from seven generators, 47 tiles composited by the REFERENCE's own render_tile,
+    lists to 1 291 entries; oracle/capture_golden.py: capture_fuzz_tiles): the HIP frame of every scene -- whole path, one call --
+    carries the reference's counts and its pixels (bar 1e-4; expected 1e-6 and below)."""
+    _need_gpu()
+    g = load_golden(name)
+    worst, tiles = 0.0, 0
+    for seed, sc, row, blocks in fuzz_tiles_cases(g):
+        scene = _scene_from_arrays(tmp_path / str(seed), sc)
+        st = {}
+        img = scene.render_image_hip(1, stats=st).cpu().numpy()
+        assert st["n_visible"] == row["n_visible"] and st["n_instances"] == row["tile_instances"], (seed, st, row)
+        for tx, ty, length, blk in blocks:
+            d = float(np.abs(img[tx * 16:(tx + 1) * 16, ty * 16:(ty + 1) * 16] - blk).max())
+            worst, tiles = max(worst, d), tiles + 1
+            assert d <= PIXEL_TOL, (seed, tx, ty, length, d)
+    print("%s: %d reference-rendered tiles of %d scenes, HIP max |dpixel| %.2e" % (name, tiles, len(set(g["rows"][:, 0])), worst))
 
 
 def test_twenty_million_gaussians_through_the_same_path(tmp_path):

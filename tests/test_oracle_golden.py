@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import (ROOT, STAGE1_FIELDS, STAGE1_NAMES, TILE_FIXTURE_NAMES, assert_same_order_outside_ties, sha256,
+from conftest import (FUZZ_TILE_FIXTURE_NAMES, ROOT, STAGE1_FIELDS, STAGE1_NAMES, TILE_FIXTURE_NAMES, fuzz_tiles_cases, assert_same_order_outside_ties, sha256,
                       compare_stage1_with_reference, golden_preprocessed, load_golden, oracle_camera, rows_by_index,
                       stage1_scene, tile_lists, tiles_scene)
 from oracle import c_oracle, cpu_ref
@@ -335,6 +335,36 @@ def test_tie_order_effect_at_the_benchmark_sizes(name):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="build container only: imports the reference from /root/reference")
+@pytest.mark.parametrize("name", FUZZ_TILE_FIXTURE_NAMES)
+def test_reference_rendered_tiles_of_random_scenes(name, tmp_path):
+    """tests/golden/fuzz_tiles_*: 24 scenes nobody chose (oracle/fuzz_vs_reference.py's generators: uniform, clustered, trained-like,
+    needles, wide, tiny; 3e3 .. 6e4 Gaussians, random pose and frame), two tiles each composited by the REFERENCE's own render_tile
+    -- lists to 1 291 entries.  The C restatement, from the seed alone (its own stage 1, its own depth order): the reference's counts,
+    every block within 1e-4 (equal depths aside it carries the reference's bits: 1e-7)."""
+    from intro_to_gaussian_splatting_amd import GaussianScene, Gaussians
+    from intro_to_gaussian_splatting_amd.synthetic import write_colmap_text
+
+    g = load_golden(name)
+    worst, tiles = 0.0, 0
+    for seed, sc, row, blocks in fuzz_tiles_cases(g):
+        d_ = tmp_path / str(seed)
+        write_colmap_text(str(d_), sc)
+        ga = Gaussians.from_arrays(sc["points"], sc["colors_0_255"], sc["scales"], sc["quaternions"], sc["opacity"], device="cpu")
+        im = GaussianScene(str(d_), ga).images[1]            # (camera constants exactly as the scene computes them)
+        c = im.gsx_camera()
+        cam = cpu_ref.Camera(im.world2view.numpy(), im.full_proj_transform.numpy(), np.float32(c.tan_fovx), np.float32(c.tan_fovy),
+                             np.float32(c.fx), np.float32(c.fy), c.width, c.height)
+        pre = c_oracle.preprocess(sc["points"], ga.colors.numpy(), sc["scales"], sc["quaternions"], sc["opacity"], cam)
+        assert pre.points.shape[0] == row["n_visible"], seed
+        for tx, ty, length, blk in blocks:
+            img, _, inst = c_oracle.render(pre, row["width"], row["height"], 16, window=(tx, tx + 1, ty, ty + 1))
+            assert inst == row["tile_instances"], seed
+            d = float(np.abs(img[tx * 16:(tx + 1) * 16, ty * 16:(ty + 1) * 16] - blk).max())
+            worst, tiles = max(worst, d), tiles + 1
+            assert d <= 1e-4, (seed, tx, ty, length, d)
+    print("%s: %d reference-rendered tiles, C port max |dpixel| %.2e" % (name, tiles, worst))
+
+
 def test_fuzz_against_the_reference_itself():
     """oracle/fuzz_vs_reference.py on a few seeds nobody looked at before (random generator, size, pose, frame): every
     stage-1 array of the C restatement (and of the numpy one on every fourth case) carries the reference's bits, the

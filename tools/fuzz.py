@@ -106,8 +106,10 @@ for seed in range(first, first + count):
         cimg = scene.render_image_hip(1, tile_size=tile, layout="hw3", semantics="ref_cuda").cpu().numpy()
         dc = np.abs(cimg.astype(np.float64) - cref).max(axis=-1) if cimg.size else np.zeros(1)
         # stop rule at T(1-alpha) < 1e-3: a pixel whose test sits within an ulp of the threshold may stop one
-        # Gaussian earlier or later on one side (<= 1e-3 of colour); everything else agrees to 1e-4
-        assert int((dc > 1e-4).sum()) <= 2 + 1e-5 * dc.size and dc.max() < 2e-3, ("ref_cuda pixels", tag, float(dc.max()))
+        # Gaussian earlier or later on one side, which moves it by T alpha colour = 1e-3 alpha / (1 - alpha) colour -- up to
+        # 0.099 at the rule's own alpha <= 0.99 (seed 204401 of round 6's campaign: test = 0.00100000075, alpha 0.84, 3.9e-3;
+        # tools/attic/refcuda_flip.py walks such a pixel); everything else agrees to 1e-4
+        assert int((dc > 1e-4).sum()) <= 2 + 1e-5 * dc.size and dc.max() < 0.1, ("ref_cuda pixels", tag, float(dc.max()))
     # ---- the stage-2 entry point on stage-1 arrays that no projection would produce: NaN / infinite /
     #      inverted bounding boxes, asymmetric inverse covariances (render.cu:90-101 takes them as given)
     if len(pre.depths) > 0:
