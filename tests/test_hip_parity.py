@@ -550,6 +550,71 @@ def test_reference_rendered_tiles_of_random_scenes_on_the_gpu(name, tmp_path):
     print("%s: %d reference-rendered tiles of %d scenes, HIP max |dpixel| %.2e" % (name, tiles, len(set(g["rows"][:, 0])), worst))
 
 
+def test_kernels_stay_inside_the_buffers_they_are_given(tmp_path):
+    """No GPU address sanitizer runs on this pool, so the bounds are checked the old way: workspace, hints buffer and output frame
+    are handed over as the MIDDLE of larger allocations whose margins hold a pattern, the workspace at exactly the size
+    gsx_workspace_bytes() names for the pair capacity -- the capacity the frame needs to the pair, one pair more, half of it
+    (GSX_ERR_WORKSPACE_TOO_SMALL: pairs are dropped, nothing may be written behind the end), a single pair -- over every depth-sort
+    route (one workgroup / 256 buckets / four LSD passes), long tiles on helper waves, other tile sizes, a tile window, both
+    layouts, frames with and without hints.  After every frame the margins still hold the pattern."""
+    _need_gpu()
+    from intro_to_gaussian_splatting_amd import _ffi
+    from intro_to_gaussian_splatting_amd.synthetic import make_scene
+
+    lib = _ffi.load()
+    margin = 1 << 20
+
+    def guarded(nbytes, fill=0):
+        big = torch.full((margin + nbytes + margin,), 0xA5, dtype=torch.uint8, device="cuda:0")
+        big[margin:margin + nbytes] = fill
+        return big, big[margin:margin + nbytes]
+
+    def intact(big, nbytes):
+        return bool((big[:margin] == 0xA5).all().item()) and bool((big[margin + nbytes:] == 0xA5).all().item())
+
+    cases = [  # (scene arguments, frame, tile, layout, window)
+        (dict(n=9_000, seed=31), (320, 240), 16, "wh3", None),                                    # one-workgroup depth sort
+        (dict(n=200_000, seed=32), (1280, 720), 16, "hw3", None),                                 # 256 buckets
+        (dict(n=200_000, seed=32), (1280, 720), 16, "wh3", (7, 41, 3, 29)),                       # ... on a tile window
+        (dict(n=150_000, seed=33, cluster_fraction=0.5, cluster_area=0.05, sigma_ln=1.0), (1920, 1080), 16, "wh3", None),   # long tiles
+        (dict(n=2_000_000, seed=34, sigma_scale=0.5), (1920, 1080), 16, "wh3", None),             # four LSD passes (> 1.5M kept)
+        (dict(n=60_000, seed=35), (640, 480), 8, "wh3", None),                                    # the any-tile-size kernels
+        (dict(n=60_000, seed=35), (333, 777), 5, "hw3", None),
+    ]
+    checked = 0
+    for k, (args, (w, h), tile, layout, window) in enumerate(cases):
+        sc = make_scene(width=w, height=h, **args)
+        scene = _scene_from_arrays(tmp_path / str(k), sc)
+        n = sc["points"].shape[0]
+        st = {}
+        want = scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=window, stats=st).clone()
+        d = int(st["n_instances"])
+        hbytes = lib.gsx_hints_bytes(w, h, tile)
+        frame_bytes = want.numel() * 4
+        for cap in (d, d + 1, max(d // 2, 1), 1):
+            nbytes = lib.gsx_workspace_bytes(n, w, h, tile, cap)
+            assert nbytes > 0
+            ws_big, ws = guarded(nbytes, fill=0x5A)
+            hints_big, hints = guarded(hbytes)
+            out_big, out_bytes = guarded(frame_bytes)
+            out = out_bytes.view(torch.float32).view(want.shape)
+            for rep in range(3):            # the first frame fills the hints buffer, the next ones use it
+                private = dict(cap=cap, workspace=ws, hints=[hints, rep > 0])
+                try:
+                    got = scene.render_image_hip(1, tile_size=tile, layout=layout, tile_window=window, out=out, _private=private)
+                    torch.cuda.synchronize()
+                    assert cap >= d, ("a workspace for %d pairs took %d without an error" % (cap, d), k)
+                    assert torch.equal(got, want), (k, cap, rep)
+                except _ffi.GsxError as exc:
+                    torch.cuda.synchronize()
+                    assert cap < d and exc.code == _ffi.GSX_ERR_WORKSPACE_TOO_SMALL, (k, cap, d, str(exc))
+                assert intact(ws_big, nbytes), ("workspace margins overwritten", k, cap, rep)
+                assert intact(hints_big, hbytes), ("hints margins overwritten", k, cap, rep)
+                assert intact(out_big, frame_bytes), ("frame margins overwritten", k, cap, rep)
+                checked += 1
+    print("%d frames inside guarded buffers: margins intact" % checked)
+
+
 def test_twenty_million_gaussians_through_the_same_path(tmp_path):
     """Sizes beyond the BASELINE configurations (a 288 GB part holds scenes of hundreds of millions of Gaussians; tools/big_scene.py
     ran 150M / 293M pairs against the whole C frame, profiles/r6_big_scenes.txt): 20M Gaussians at 1080p -- 19.8M kept, the
